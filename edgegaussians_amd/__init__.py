@@ -1,0 +1,10 @@
+"""edgegaussians_amd -- MI355X-native edge-Gaussian rasterizer (the hot path of
+kunalchelani/EdgeGaussians) behind the reference's own operator surface.
+
+    from edgegaussians_amd import rasterization      # == the reference's gsplat.rasterization call
+    from edgegaussians_amd import EdgeTrainer        # fused per-view training step (train_gaussians.py:71-106)
+"""
+from .rasterizer import rasterization  # noqa: F401
+from .trainer import EdgeTrainer, LRSchedule  # noqa: F401
+
+__all__ = ["rasterization", "EdgeTrainer", "LRSchedule"]

@@ -1,0 +1,115 @@
+"""ctypes binding of libedgegs.so (the C ABI declared in include/edgegs.h).
+
+There is NO fallback: if the shared library is missing or no gfx950 device is visible, the
+product raises.  (The CPU oracle under ``oracle/`` is test infrastructure and is never imported
+from here.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libedgegs.so")
+
+_vp = C.c_void_p
+_i32 = C.c_int32
+_i64 = C.c_int64
+_u32 = C.c_uint32
+_f = C.c_float
+
+FLAG_LOG_SCALES = 1
+FLAG_LOGIT_OPACITIES = 2
+FLAG_ANTIALIASED = 4
+
+
+class AdamHyper(C.Structure):
+    _fields_ = [("lr_means", C.c_double), ("lr_scales", C.c_double), ("lr_quats", C.c_double),
+                ("lr_opacities", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double),
+                ("eps", C.c_double), ("step", _i32)]
+
+
+class StepArgs(C.Structure):
+    _fields_ = [
+        ("means", _vp), ("quats", _vp), ("log_scales", _vp), ("logit_opacities", _vp),
+        ("adam_m", _vp), ("adam_v", _vp), ("absgrads", _vp), ("N", _i32),
+        ("viewmat", _vp), ("K", _vp), ("gt", _vp), ("wmap", _vp),
+        ("width", _i32), ("height", _i32), ("loss_scale", _f),
+        ("splat", _vp), ("g2d", _vp),
+        ("tile_counts", _vp), ("offsets", _vp), ("total", _vp),
+        ("keys", _vp), ("flatten_ids", _vp), ("capacity", _i64),
+        ("render", _vp), ("alphas", _vp), ("vpix", _vp), ("loss", _vp), ("last_ids", _vp),
+        ("v_means", _vp), ("v_quats", _vp), ("v_scales", _vp), ("v_opacities", _vp),
+        ("adam_host", C.POINTER(AdamHyper)),
+    ]
+
+
+# name -> argtypes; every entry returns int and ends with the stream
+_SIGS = {
+    "eg_project_fwd": [_vp] * 6 + [_i32, _i32, _i32, _f, _f, _f, _f, _u32] + [_vp] * 9 + [_vp],
+    "eg_tile_count": [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp],
+    "eg_tile_offsets": [_vp, _i32, _i64, _vp, _vp, _vp],
+    "eg_tile_emit": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _i64, _vp, _vp],
+    "eg_sort_pairs": [_vp, _vp, _i32, _i64, _vp, _vp, _vp],
+    "eg_composite_fwd": [_vp, _vp, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp],
+    "eg_composite_bwd": [_vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp],
+    "eg_composite_bwd_colors": [_vp, _vp, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "eg_project_bwd": [_vp] * 6 + [_i32, _i32, _i32, _f, _u32] + [_vp] * 9 + [_vp],
+    "eg_absgrad_accum": [_vp, _i32, _vp, _vp],
+    "eg_adam_multi": [_vp] * 10 + [_i32, AdamHyper, _vp],
+    "eg_project_bwd_adam": [_vp] * 6 + [_i32, _i32, _i32, _f, _u32] + [_vp] * 5 + [AdamHyper, _vp],
+    "eg_mask_scan": [_vp, _i32, _vp, _vp, _vp],
+    "eg_compact_rows": [_vp, _vp, _vp, _i32, _i32, _vp, _vp],
+    "eg_append_rows": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _f, _vp, _vp],
+    "eg_project_hits": [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _vp, _vp],
+    "eg_train_step": [C.POINTER(StepArgs), _vp],
+}
+EXPORTS = sorted(list(_SIGS) + ["eg_last_error_string", "eg_version", "eg_device_count"])
+
+_lib: Optional[C.CDLL] = None
+
+
+def load(require_device: bool = True) -> C.CDLL:
+    """Loads the library (once).  Raises RuntimeError when it is missing -- never falls back."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -m edgegaussians_amd.build` "
+                "(hipcc --offload-arch=gfx950).  There is no CPU fallback in the product path.")
+        lib = C.CDLL(LIB_PATH)
+        for name, args in _SIGS.items():
+            fn = getattr(lib, name)
+            fn.argtypes = args
+            fn.restype = C.c_int
+        lib.eg_last_error_string.restype = C.c_char_p
+        lib.eg_last_error_string.argtypes = []
+        lib.eg_version.restype = C.c_int
+        lib.eg_device_count.restype = C.c_int
+        _lib = lib
+    if require_device and not torch.cuda.is_available():
+        raise RuntimeError("edgegaussians_amd needs a gfx950 GPU (torch.cuda.is_available() is False); "
+                           "there is no CPU fallback in the product path")
+    return _lib
+
+
+def call(name: str, *args) -> None:
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise RuntimeError(f"{name} failed (code {rc}): {lib.eg_last_error_string().decode()}")
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    """Raw device pointer of a contiguous CUDA tensor (None -> NULL)."""
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous(), "libedgegs needs contiguous device tensors"
+    return t.data_ptr()
+
+
+def stream() -> int:
+    return torch.cuda.current_stream().cuda_stream

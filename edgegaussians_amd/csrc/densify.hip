@@ -1,0 +1,129 @@
+// a8-a10: densify / cull row movement and the not-projecting vote, on device.
+//
+// Replaces the torch boolean-index / cat / CPU loops of the reference:
+//   cull_gaussians + remove_from_optim   edge_gs.py:384-423  -> eg_mask_scan + eg_compact_rows
+//   dup_gaussians + dup_in_optim         edge_gs.py:431-474  -> eg_mask_scan + eg_append_rows
+//   cull_gaussians_not_projecting        edge_gs.py:578-601  -> eg_project_hits
+// All three are streaming passes (HBM bound); they run at 22 epoch boundaries out of 400 epochs.
+#include "common.h"
+
+namespace eg {
+
+// exclusive scan of a byte mask, single workgroup of 1024 threads (N <= a few million)
+__global__ void __launch_bounds__(1024)
+mask_scan_kernel(const uint8_t *__restrict__ keep, int N, int *__restrict__ positions, int *__restrict__ count) {
+  __shared__ int wave_sums[16];
+  __shared__ int carry;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  if (tid == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < N; base += 1024) {
+    const int i = base + tid;
+    const int c = (i < N && keep[i]) ? 1 : 0;
+    const unsigned long long bal = __ballot(c);
+    const int excl_w = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) wave_sums[wv] = __popcll(bal);
+    __syncthreads();
+    int pre = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+      const int s = wave_sums[w];
+      pre += (w < wv) ? s : 0;
+      tot += s;
+    }
+    if (i < N) positions[i] = carry + pre + excl_w;
+    __syncthreads();
+    if (tid == 0) carry += tot;
+    __syncthreads();
+  }
+  if (tid == 0) count[0] = carry;
+}
+
+__global__ void __launch_bounds__(256)
+compact_rows_kernel(const float *__restrict__ in, const uint8_t *__restrict__ keep,
+                    const int *__restrict__ positions, int N, int dim, float *__restrict__ out) {
+  const size_t total = (size_t)N * dim;
+  for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    const int r = (int)(e / dim), c = (int)(e - (size_t)r * dim);
+    if (keep[r]) out[(size_t)positions[r] * dim + c] = in[e];
+  }
+}
+
+__global__ void __launch_bounds__(256)
+append_rows_kernel(const float *__restrict__ in, const uint8_t *__restrict__ sel, const int *__restrict__ positions,
+                   int N, int n_sel, int dim, int copies, const float *__restrict__ noise, int fill_zero,
+                   float *__restrict__ out_tail) {
+  const size_t total = (size_t)N * dim;
+  for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    const int r = (int)(e / dim), c = (int)(e - (size_t)r * dim);
+    if (!sel[r]) continue;
+    const float v = fill_zero ? 0.f : in[e];
+    for (int k = 0; k < copies; ++k) {
+      const size_t o = ((size_t)k * n_sel + positions[r]) * dim + c;
+      out_tail[o] = noise ? v + noise[o] : v;
+    }
+  }
+}
+
+// one thread per Gaussian, loop over views: P = K [R|t] (3x4), round half to even like torch.round
+__global__ void __launch_bounds__(256)
+project_hits_kernel(const float *__restrict__ means, int N, const float *__restrict__ P, int V,
+                    const uint8_t *__restrict__ edge_masks, int width, int height, int *__restrict__ hits) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= N) return;
+  const float x = means[3 * g], y = means[3 * g + 1], z = means[3 * g + 2];
+  int h = 0;
+  for (int v = 0; v < V; ++v) {
+    const float *p = P + 12 * v;
+    // same association order as the reference's matmul of [x y z 1] with P^T (fp32)
+    const float a = p[0] * x + p[1] * y + p[2] * z + p[3];
+    const float b = p[4] * x + p[5] * y + p[6] * z + p[7];
+    const float c = p[8] * x + p[9] * y + p[10] * z + p[11];
+    const float u = rintf(a / c), w = rintf(b / c);
+    if (u >= 0.f && u < (float)width && w >= 0.f && w < (float)height)
+      h += edge_masks[((size_t)v * height + (int)w) * width + (int)u] ? 1 : 0;
+  }
+  hits[g] += h;
+}
+
+}  // namespace eg
+
+using namespace eg;
+
+extern "C" int eg_mask_scan(const uint8_t *keep, int32_t N, int32_t *positions, int32_t *count, eg_stream_t stream) {
+  EG_REQUIRE(N >= 0 && count, "bad arguments");
+  EG_REQUIRE(N == 0 || (keep && positions), "null pointer");
+  mask_scan_kernel<<<1, 1024, 0, as_stream(stream)>>>(keep, N, positions, count);
+  return check_launch("mask_scan");
+}
+
+extern "C" int eg_compact_rows(const float *in, const uint8_t *keep, const int32_t *positions, int32_t N,
+                               int32_t dim, float *out, eg_stream_t stream) {
+  EG_REQUIRE(N >= 0 && dim > 0, "bad sizes");
+  if (N == 0) return EG_OK;
+  EG_REQUIRE(in && keep && positions && out, "null pointer");
+  const int blocks = min(cdiv((int64_t)N * dim, 256), 2048);
+  compact_rows_kernel<<<blocks, 256, 0, as_stream(stream)>>>(in, keep, positions, N, dim, out);
+  return check_launch("compact_rows");
+}
+
+extern "C" int eg_append_rows(const float *in, const uint8_t *sel, const int32_t *positions, int32_t N,
+                              int32_t n_sel, int32_t dim, int32_t copies, const float *noise, float fill_zero,
+                              float *out_tail, eg_stream_t stream) {
+  EG_REQUIRE(N >= 0 && dim > 0 && copies >= 0 && n_sel >= 0, "bad sizes");
+  if (N == 0 || n_sel == 0 || copies == 0) return EG_OK;
+  EG_REQUIRE(in && sel && positions && out_tail, "null pointer");
+  const int blocks = min(cdiv((int64_t)N * dim, 256), 2048);
+  append_rows_kernel<<<blocks, 256, 0, as_stream(stream)>>>(in, sel, positions, N, n_sel, dim, copies, noise,
+                                                            fill_zero != 0.f, out_tail);
+  return check_launch("append_rows");
+}
+
+extern "C" int eg_project_hits(const float *means, int32_t N, const float *P, int32_t V, const uint8_t *edge_masks,
+                               int32_t width, int32_t height, int32_t *hits, eg_stream_t stream) {
+  EG_REQUIRE(N >= 0 && V >= 0 && width > 0 && height > 0, "bad sizes");
+  if (N == 0 || V == 0) return EG_OK;
+  EG_REQUIRE(means && P && edge_masks && hits, "null pointer");
+  project_hits_kernel<<<cdiv(N, 256), 256, 0, as_stream(stream)>>>(means, N, P, V, edge_masks, width, height, hits);
+  return check_launch("project_hits");
+}

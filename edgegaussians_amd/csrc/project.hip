@@ -1,0 +1,466 @@
+// G1 / G9: fully fused projection forward + backward, absgrad accumulation and Adam.
+//
+// Replaces gsplat 1.0.0 fully_fused_projection_{fwd,bwd} as reached from the reference call at
+// edgegaussians/models/edge_gs.py:250-268, the pre-activations at
+// edge_gs.py:253-254, update_absgrads (edge_gs.py:607-613) and the four Adam steps of
+// train_gaussians.py:104-106.  One thread per Gaussian: ~150 flops on 44 B in / 32 B out, so the
+// kernels are pure streaming passes (HBM/L2 bound); everything per-Gaussian is fused into these
+// two launches so the arrays are touched once per step.
+//
+// Math (written from the projection equations, not translated from the CUDA source):
+//   t = Rv mu + tv;  W = Rv R(q) diag(s);  P = J W (2x3);  cov2d = P P^T;  B = cov2d + eps I
+//   conic = B^-1;  comp = sqrt(max(0, det cov2d / det B));  o_eff = o * comp
+// and the reverse sweep through the same chain.
+#include "common.h"
+
+namespace eg {
+
+struct Cam {
+  float R[9], t[3], fx, fy, cx, cy;
+};
+
+__device__ __forceinline__ Cam load_cam(const float *__restrict__ vm, const float *__restrict__ K) {
+  Cam c;
+  c.R[0] = vm[0]; c.R[1] = vm[1]; c.R[2] = vm[2];  c.t[0] = vm[3];
+  c.R[3] = vm[4]; c.R[4] = vm[5]; c.R[5] = vm[6];  c.t[1] = vm[7];
+  c.R[6] = vm[8]; c.R[7] = vm[9]; c.R[8] = vm[10]; c.t[2] = vm[11];
+  c.fx = K[0]; c.cx = K[2]; c.fy = K[4]; c.cy = K[5];
+  return c;
+}
+
+// Everything the forward computes for one visible Gaussian; the backward re-derives it instead of
+// reading it back from memory (recompute is ~100 flops, a reload would be ~100 B).
+struct Fwd {
+  float x, y, z;            // camera-space mean
+  float qw, qx, qy, qz, qinv;  // normalised quaternion and 1/|q|
+  float s[3];               // scales (after exp)
+  float o;                  // opacity (after sigmoid)
+  float Rq[9];              // rotation of the Gaussian
+  float W[9];               // Rv * Rq * diag(s)
+  float rz, rz2, tx, ty;    // 1/z, 1/z^2, clamped x, y
+  bool in_x, in_y;          // fov clamp inactive
+  float J00, J02, J11, J12;
+  float p0[3], p1[3];
+  float c00, c01, c11, b00, b11, det0, det1;
+  float a, b, c, comp;      // conic, compensation
+  float u, v;               // mean2d
+};
+
+__device__ __forceinline__ bool forward_geom(const Cam &cam, const float *__restrict__ means,
+                                             const float *__restrict__ quats, const float *__restrict__ scales,
+                                             const float *__restrict__ opacities, int g, int width, int height,
+                                             float near_plane, float far_plane, float eps2d, uint32_t flags,
+                                             Fwd &f) {
+  const float mx = means[3 * g], my = means[3 * g + 1], mz = means[3 * g + 2];
+  f.x = cam.R[0] * mx + cam.R[1] * my + cam.R[2] * mz + cam.t[0];
+  f.y = cam.R[3] * mx + cam.R[4] * my + cam.R[5] * mz + cam.t[1];
+  f.z = cam.R[6] * mx + cam.R[7] * my + cam.R[8] * mz + cam.t[2];
+  if (f.z < near_plane || f.z > far_plane) return false;
+
+  float w = quats[4 * g], x = quats[4 * g + 1], y = quats[4 * g + 2], z = quats[4 * g + 3];
+  f.qinv = rsqrtf(w * w + x * x + y * y + z * z);
+  w *= f.qinv; x *= f.qinv; y *= f.qinv; z *= f.qinv;
+  f.qw = w; f.qx = x; f.qy = y; f.qz = z;
+  const float x2 = x * x, y2 = y * y, z2 = z * z, xy = x * y, xz = x * z, yz = y * z;
+  const float wx = w * x, wy = w * y, wz = w * z;
+  f.Rq[0] = 1.f - 2.f * (y2 + z2); f.Rq[1] = 2.f * (xy - wz);       f.Rq[2] = 2.f * (xz + wy);
+  f.Rq[3] = 2.f * (xy + wz);       f.Rq[4] = 1.f - 2.f * (x2 + z2); f.Rq[5] = 2.f * (yz - wx);
+  f.Rq[6] = 2.f * (xz - wy);       f.Rq[7] = 2.f * (yz + wx);       f.Rq[8] = 1.f - 2.f * (x2 + y2);
+
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const float sv = scales[3 * g + k];
+    f.s[k] = (flags & EG_FLAG_LOG_SCALES) ? expf(sv) : sv;
+  }
+  const float ov = opacities[g];
+  f.o = (flags & EG_FLAG_LOGIT_OPACITIES) ? 1.f / (1.f + expf(-ov)) : ov;
+
+  // W = Rv * (Rq * diag(s))
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      f.W[3 * i + k] =
+          (cam.R[3 * i] * f.Rq[k] + cam.R[3 * i + 1] * f.Rq[3 + k] + cam.R[3 * i + 2] * f.Rq[6 + k]) * f.s[k];
+
+  const float lim_x = kFovClamp * (0.5f * (float)width / cam.fx);
+  const float lim_y = kFovClamp * (0.5f * (float)height / cam.fy);
+  f.rz = 1.f / f.z;
+  f.rz2 = f.rz * f.rz;
+  const float xr = f.x * f.rz, yr = f.y * f.rz;
+  f.in_x = (xr <= lim_x) && (xr >= -lim_x);
+  f.in_y = (yr <= lim_y) && (yr >= -lim_y);
+  f.tx = f.z * fminf(lim_x, fmaxf(-lim_x, xr));
+  f.ty = f.z * fminf(lim_y, fmaxf(-lim_y, yr));
+  f.J00 = cam.fx * f.rz;
+  f.J11 = cam.fy * f.rz;
+  f.J02 = -cam.fx * f.tx * f.rz2;
+  f.J12 = -cam.fy * f.ty * f.rz2;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    f.p0[k] = f.J00 * f.W[k] + f.J02 * f.W[6 + k];
+    f.p1[k] = f.J11 * f.W[3 + k] + f.J12 * f.W[6 + k];
+  }
+  f.c00 = f.p0[0] * f.p0[0] + f.p0[1] * f.p0[1] + f.p0[2] * f.p0[2];
+  f.c01 = f.p0[0] * f.p1[0] + f.p0[1] * f.p1[1] + f.p0[2] * f.p1[2];
+  f.c11 = f.p1[0] * f.p1[0] + f.p1[1] * f.p1[1] + f.p1[2] * f.p1[2];
+  f.u = cam.fx * f.x * f.rz + cam.cx;
+  f.v = cam.fy * f.y * f.rz + cam.cy;
+
+  f.det0 = f.c00 * f.c11 - f.c01 * f.c01;
+  f.b00 = f.c00 + eps2d;
+  f.b11 = f.c11 + eps2d;
+  f.det1 = f.b00 * f.b11 - f.c01 * f.c01;
+  if (f.det1 <= 0.f) return false;
+  f.comp = sqrtf(fmaxf(0.f, f.det0 / f.det1));
+  const float inv = 1.f / f.det1;
+  f.a = f.b11 * inv;
+  f.b = -f.c01 * inv;
+  f.c = f.b00 * inv;
+  return true;
+}
+
+__device__ __forceinline__ int radius_of(const Fwd &f, int width, int height, float radius_clip) {
+  const float bh = 0.5f * (f.b00 + f.b11);
+  const float v1 = bh + sqrtf(fmaxf(0.01f, bh * bh - f.det1));
+  const float radius = ceilf(3.f * sqrtf(v1));
+  if (radius <= radius_clip) return 0;
+  if (f.u + radius <= 0.f || f.u - radius >= (float)width || f.v + radius <= 0.f ||
+      f.v - radius >= (float)height)
+    return 0;
+  return (int)radius;
+}
+
+__global__ void __launch_bounds__(256)
+project_fwd_kernel(const float *__restrict__ means, const float *__restrict__ quats,
+                   const float *__restrict__ scales, const float *__restrict__ opacities,
+                   const float *__restrict__ viewmat, const float *__restrict__ K, int N, int width, int height,
+                   float near_plane, float far_plane, float eps2d, float radius_clip, uint32_t flags,
+                   float4 *__restrict__ splat, int *__restrict__ radii, float *__restrict__ means2d,
+                   float *__restrict__ depths, float *__restrict__ conics, float *__restrict__ comps,
+                   int *__restrict__ tiles_per_gauss, int *__restrict__ tile_counts, float4 *__restrict__ g2d) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= N) return;
+  const Cam cam = load_cam(viewmat, K);
+  Fwd f;
+  int radius = 0;
+  if (forward_geom(cam, means, quats, scales, opacities, g, width, height, near_plane, far_plane, eps2d, flags, f))
+    radius = radius_of(f, width, height, radius_clip);
+
+  const bool aa = flags & EG_FLAG_ANTIALIASED;
+  float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+  if (radius > 0) {
+    s0 = make_float4(f.u, f.v, f.a, f.b);
+    s1 = make_float4(f.c, aa ? f.o * f.comp : f.o, f.z, __int_as_float(radius));
+  }
+  splat[2 * g] = s0;
+  splat[2 * g + 1] = s1;
+  if (radii) radii[g] = radius;
+  if (means2d) { means2d[2 * g] = s0.x; means2d[2 * g + 1] = s0.y; }
+  if (depths) depths[g] = s1.z;
+  if (conics) { conics[3 * g] = s0.z; conics[3 * g + 1] = s0.w; conics[3 * g + 2] = s1.x; }
+  if (comps) comps[g] = radius > 0 ? f.comp : 0.f;
+  if (g2d) { g2d[2 * g] = make_float4(0.f, 0.f, 0.f, 0.f); g2d[2 * g + 1] = make_float4(0.f, 0.f, 0.f, 0.f); }
+
+  if (tiles_per_gauss || tile_counts) {
+    int n = 0;
+    if (radius > 0) {
+      const int tw = (width + kTile - 1) / kTile, th = (height + kTile - 1) / kTile;
+      int x0, y0, x1, y1;
+      tile_box(s0.x, s0.y, radius, tw, th, x0, y0, x1, y1);
+      n = (y1 - y0) * (x1 - x0);
+      if (tile_counts)
+        for (int ty = y0; ty < y1; ++ty)
+          for (int tx = x0; tx < x1; ++tx) atomicAdd(&tile_counts[ty * tw + tx], 1);
+    }
+    if (tiles_per_gauss) tiles_per_gauss[g] = n;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+struct AdamK {
+  float step_size[4];  // lr_k / (1 - beta1^t), means | scales | quats | opacities
+  float bc2_sqrt;      // sqrt(1 - beta2^t)
+  float b1, omb1, b2, omb2, eps;
+};
+
+__device__ __forceinline__ void adam1(float &p, float g, float &m, float &v, float step_size, const AdamK &h) {
+  m = m * h.b1 + g * h.omb1;
+  v = v * h.b2 + (g * g) * h.omb2;
+  const float denom = sqrtf(v) / h.bc2_sqrt + h.eps;
+  p = p - step_size * (m / denom);
+}
+
+struct Grads {
+  float mean[3], quat[4], scale[3], opac;
+};
+
+__device__ __forceinline__ void backward_geom(const Cam &cam, const Fwd &f, float eps2d, uint32_t flags,
+                                              const float4 ga, const float4 gb, bool ext, float v_comp_ext,
+                                              float v_depth_ext, Grads &o) {
+  const float vx = ga.x, vy = ga.y;
+  const float va = gb.x, vb = gb.y, vc = gb.z, vo_eff = gb.w;
+  const bool aa = flags & EG_FLAG_ANTIALIASED;
+
+  // o_eff = o * comp (fused mode); in external mode the caller owns that product (gsplat layout:
+  // `opacities * compensations` is a torch op between the two autograd nodes)
+  float v_o = ext ? 0.f : (aa ? vo_eff * f.comp : vo_eff);
+  const float v_comp = ext ? v_comp_ext : (aa ? vo_eff * f.o : 0.f);
+
+  // conic = B^-1  =>  G = -A V A with V = [[va, vb/2],[vb/2, vc]] (b is stored once)
+  const float hb = 0.5f * vb;
+  const float av00 = f.a * va + f.b * hb, av01 = f.a * hb + f.b * vc;
+  const float av10 = f.b * va + f.c * hb, av11 = f.b * hb + f.c * vc;
+  float G00 = -(av00 * f.a + av01 * f.b);
+  float G01 = -(av00 * f.b + av01 * f.c);
+  float G11 = -(av10 * f.b + av11 * f.c);
+  if (aa) {
+    // d comp / d cov2d = (1/(2 comp)) * ((1 - comp^2) conic - eps det(conic) I); gsplat guards the
+    // division with +1e-6 and the oracle does the same
+    const float det_conic = f.a * f.c - f.b * f.b;
+    const float vs = v_comp * 0.5f / (f.comp + 1e-6f);
+    const float omc = 1.f - f.comp * f.comp;
+    G00 += vs * (omc * f.a - eps2d * det_conic);
+    G01 += vs * (omc * f.b);
+    G11 += vs * (omc * f.c - eps2d * det_conic);
+  }
+  // cov2d = P P^T  =>  v_P = 2 G P
+  float vp0[3], vp1[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    vp0[k] = 2.f * (G00 * f.p0[k] + G01 * f.p1[k]);
+    vp1[k] = 2.f * (G01 * f.p0[k] + G11 * f.p1[k]);
+  }
+  // P = J W
+  const float vJ00 = vp0[0] * f.W[0] + vp0[1] * f.W[1] + vp0[2] * f.W[2];
+  const float vJ02 = vp0[0] * f.W[6] + vp0[1] * f.W[7] + vp0[2] * f.W[8];
+  const float vJ11 = vp1[0] * f.W[3] + vp1[1] * f.W[4] + vp1[2] * f.W[5];
+  const float vJ12 = vp1[0] * f.W[6] + vp1[1] * f.W[7] + vp1[2] * f.W[8];
+  float vW[9];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    vW[k] = f.J00 * vp0[k];
+    vW[3 + k] = f.J11 * vp1[k];
+    vW[6 + k] = f.J02 * vp0[k] + f.J12 * vp1[k];
+  }
+  // camera-space mean: through mean2d and through J (fov clamp freezes tx = +-lim z)
+  const float rz3 = f.rz2 * f.rz;
+  float vtx = cam.fx * f.rz * vx;
+  float vty = cam.fy * f.rz * vy;
+  float vtz = -(cam.fx * f.x * vx + cam.fy * f.y * vy) * f.rz2 + v_depth_ext;
+  vtz += -cam.fx * f.rz2 * vJ00 - cam.fy * f.rz2 * vJ11;
+  if (f.in_x) { vtx += -cam.fx * f.rz2 * vJ02; vtz += 2.f * cam.fx * f.tx * rz3 * vJ02; }
+  else        { vtz += cam.fx * f.tx * rz3 * vJ02; }
+  if (f.in_y) { vty += -cam.fy * f.rz2 * vJ12; vtz += 2.f * cam.fy * f.ty * rz3 * vJ12; }
+  else        { vtz += cam.fy * f.ty * rz3 * vJ12; }
+  o.mean[0] = cam.R[0] * vtx + cam.R[3] * vty + cam.R[6] * vtz;
+  o.mean[1] = cam.R[1] * vtx + cam.R[4] * vty + cam.R[7] * vtz;
+  o.mean[2] = cam.R[2] * vtx + cam.R[5] * vty + cam.R[8] * vtz;
+
+  // W = Rv M, M = Rq diag(s)
+  float vR[9];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    float vs = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const float vM = cam.R[i] * vW[k] + cam.R[3 + i] * vW[3 + k] + cam.R[6 + i] * vW[6 + k];
+      vs += f.Rq[3 * i + k] * vM;
+      vR[3 * i + k] = vM * f.s[k];
+    }
+    o.scale[k] = (flags & EG_FLAG_LOG_SCALES) ? vs * f.s[k] : vs;
+  }
+  // rotation -> normalised quaternion -> raw quaternion
+  const float w = f.qw, x = f.qx, y = f.qy, z = f.qz;
+  const float nw = 2.f * (x * (vR[7] - vR[5]) + y * (vR[2] - vR[6]) + z * (vR[3] - vR[1]));
+  const float nx = 2.f * (-2.f * x * (vR[4] + vR[8]) + y * (vR[1] + vR[3]) + z * (vR[2] + vR[6]) + w * (vR[7] - vR[5]));
+  const float ny = 2.f * (x * (vR[1] + vR[3]) - 2.f * y * (vR[0] + vR[8]) + z * (vR[5] + vR[7]) + w * (vR[2] - vR[6]));
+  const float nz = 2.f * (x * (vR[2] + vR[6]) + y * (vR[5] + vR[7]) - 2.f * z * (vR[0] + vR[4]) + w * (vR[3] - vR[1]));
+  const float d = nw * w + nx * x + ny * y + nz * z;
+  o.quat[0] = (nw - d * w) * f.qinv;
+  o.quat[1] = (nx - d * x) * f.qinv;
+  o.quat[2] = (ny - d * y) * f.qinv;
+  o.quat[3] = (nz - d * z) * f.qinv;
+
+  if (flags & EG_FLAG_LOGIT_OPACITIES) v_o *= f.o * (1.f - f.o);
+  o.opac = v_o;
+}
+
+template <bool ADAM>
+__global__ void __launch_bounds__(256)
+project_bwd_kernel(float *__restrict__ means, float *__restrict__ quats, float *__restrict__ scales,
+                   float *__restrict__ opacities, const float *__restrict__ viewmat, const float *__restrict__ K,
+                   int N, int width, int height, float eps2d, uint32_t flags, const float4 *__restrict__ splat,
+                   const float4 *__restrict__ g2d, float *__restrict__ v_means, float *__restrict__ v_quats,
+                   float *__restrict__ v_scales, float *__restrict__ v_opacities, float *__restrict__ absgrads,
+                   const float *__restrict__ v_comps_ext, const float *__restrict__ v_depths_ext,
+                   float *__restrict__ am, float *__restrict__ av, AdamK hyper) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= N) return;
+  const Cam cam = load_cam(viewmat, K);
+  Grads gr;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) gr.mean[k] = gr.scale[k] = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) gr.quat[k] = 0.f;
+  gr.opac = 0.f;
+
+  const int radius = __float_as_int(splat[2 * g + 1].w);
+  if (radius > 0) {
+    const float4 ga = g2d[2 * g], gb = g2d[2 * g + 1];
+    Fwd f;
+    // near/far and det culls already passed in the forward (radius > 0), so pass open limits
+    forward_geom(cam, means, quats, scales, opacities, g, width, height, -3.0e38f, 3.0e38f, eps2d, flags, f);
+    backward_geom(cam, f, eps2d, flags, ga, gb, v_comps_ext != nullptr, v_comps_ext ? v_comps_ext[g] : 0.f,
+                  v_depths_ext ? v_depths_ext[g] : 0.f, gr);
+    if (absgrads) absgrads[g] += sqrtf(ga.z * ga.z + ga.w * ga.w);
+  }
+  if (!ADAM) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { v_means[3 * g + k] = gr.mean[k]; v_scales[3 * g + k] = gr.scale[k]; }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v_quats[4 * g + k] = gr.quat[k];
+    if (v_opacities) v_opacities[g] = gr.opac;
+  } else {
+    // moment layout: [means 3N | scales 3N | quats 4N | opacities N]
+    const size_t oM = 0, oS = 3 * (size_t)N, oQ = 6 * (size_t)N, oO = 10 * (size_t)N;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      float p = means[3 * g + k], m = am[oM + 3 * g + k], v = av[oM + 3 * g + k];
+      adam1(p, gr.mean[k], m, v, hyper.step_size[0], hyper);
+      means[3 * g + k] = p; am[oM + 3 * g + k] = m; av[oM + 3 * g + k] = v;
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      float p = scales[3 * g + k], m = am[oS + 3 * g + k], v = av[oS + 3 * g + k];
+      adam1(p, gr.scale[k], m, v, hyper.step_size[1], hyper);
+      scales[3 * g + k] = p; am[oS + 3 * g + k] = m; av[oS + 3 * g + k] = v;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float p = quats[4 * g + k], m = am[oQ + 4 * g + k], v = av[oQ + 4 * g + k];
+      adam1(p, gr.quat[k], m, v, hyper.step_size[2], hyper);
+      quats[4 * g + k] = p; am[oQ + 4 * g + k] = m; av[oQ + 4 * g + k] = v;
+    }
+    {
+      float p = opacities[g], m = am[oO + g], v = av[oO + g];
+      adam1(p, gr.opac, m, v, hyper.step_size[3], hyper);
+      opacities[g] = p; am[oO + g] = m; av[oO + g] = v;
+    }
+  }
+}
+
+// stand-alone Adam over the 11 N parameters (used after an RCCL gradient all-reduce)
+__global__ void __launch_bounds__(256)
+adam_multi_kernel(float *__restrict__ means, float *__restrict__ scales, float *__restrict__ quats,
+                  float *__restrict__ opacities, const float *__restrict__ g_means,
+                  const float *__restrict__ g_scales, const float *__restrict__ g_quats,
+                  const float *__restrict__ g_opacities, float *__restrict__ am, float *__restrict__ av, int N,
+                  AdamK hyper) {
+  const size_t total = 11 * (size_t)N;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    float *p; const float *g; int grp; size_t j;
+    if (i < 3 * (size_t)N) { p = means; g = g_means; grp = 0; j = i; }
+    else if (i < 6 * (size_t)N) { p = scales; g = g_scales; grp = 1; j = i - 3 * (size_t)N; }
+    else if (i < 10 * (size_t)N) { p = quats; g = g_quats; grp = 2; j = i - 6 * (size_t)N; }
+    else { p = opacities; g = g_opacities; grp = 3; j = i - 10 * (size_t)N; }
+    float pv = p[j], m = am[i], v = av[i];
+    adam1(pv, g[j], m, v, hyper.step_size[grp], hyper);
+    p[j] = pv; am[i] = m; av[i] = v;
+  }
+}
+
+__global__ void absgrad_accum_kernel(const float2 *__restrict__ ag, int N, float *__restrict__ absgrads) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= N) return;
+  const float2 a = ag[g];
+  absgrads[g] += sqrtf(a.x * a.x + a.y * a.y);
+}
+
+static AdamK make_adamk(const eg_adam_hyper &h) {
+  // host side in double, exactly how torch.optim.Adam forms its scalars before casting to fp32
+  AdamK k;
+  const double b1 = h.beta1, b2 = h.beta2;
+  const double bc1 = 1.0 - pow(b1, (double)h.step);
+  const double bc2 = 1.0 - pow(b2, (double)h.step);
+  const double lrs[4] = {h.lr_means, h.lr_scales, h.lr_quats, h.lr_opacities};
+  for (int i = 0; i < 4; ++i) k.step_size[i] = (float)(lrs[i] / bc1);
+  k.bc2_sqrt = (float)sqrt(bc2);
+  k.b1 = (float)b1; k.omb1 = (float)(1.0 - b1);
+  k.b2 = (float)b2; k.omb2 = (float)(1.0 - b2);
+  k.eps = (float)h.eps;
+  return k;
+}
+
+}  // namespace eg
+
+using namespace eg;
+
+extern "C" int eg_project_fwd(const float *means, const float *quats, const float *scales, const float *opacities,
+                              const float *viewmat, const float *K, int32_t N, int32_t width, int32_t height,
+                              float near_plane, float far_plane, float eps2d, float radius_clip, uint32_t flags,
+                              float *splat, int32_t *radii, float *means2d, float *depths, float *conics,
+                              float *compensations, int32_t *tiles_per_gauss, int32_t *tile_counts, float *g2d,
+                              eg_stream_t stream) {
+  EG_REQUIRE(N >= 0 && width > 0 && height > 0, "bad sizes");
+  if (N == 0) return EG_OK;
+  EG_REQUIRE(means && quats && scales && opacities && viewmat && K && splat, "null pointer");
+  project_fwd_kernel<<<cdiv(N, 256), 256, 0, as_stream(stream)>>>(
+      means, quats, scales, opacities, viewmat, K, N, width, height, near_plane, far_plane, eps2d, radius_clip,
+      flags, (float4 *)splat, radii, means2d, depths, conics, compensations, tiles_per_gauss, tile_counts,
+      (float4 *)g2d);
+  return check_launch("project_fwd");
+}
+
+extern "C" int eg_project_bwd(const float *means, const float *quats, const float *scales, const float *opacities,
+                              const float *viewmat, const float *K, int32_t N, int32_t width, int32_t height,
+                              float eps2d, uint32_t flags, const float *splat, const float *g2d,
+                              const float *v_comps_ext, const float *v_depths_ext, float *v_means,
+                              float *v_quats, float *v_scales, float *v_opacities, float *absgrads,
+                              eg_stream_t stream) {
+  EG_REQUIRE(N >= 0, "bad sizes");
+  if (N == 0) return EG_OK;
+  EG_REQUIRE(means && quats && scales && opacities && viewmat && K && splat && g2d, "null pointer");
+  EG_REQUIRE(v_means && v_quats && v_scales && (v_opacities || v_comps_ext), "null gradient output");
+  AdamK dummy = {};
+  project_bwd_kernel<false><<<cdiv(N, 256), 256, 0, as_stream(stream)>>>(
+      (float *)means, (float *)quats, (float *)scales, (float *)opacities, viewmat, K, N, width, height, eps2d,
+      flags, (const float4 *)splat, (const float4 *)g2d, v_means, v_quats, v_scales, v_opacities, absgrads,
+      v_comps_ext, v_depths_ext, nullptr, nullptr, dummy);
+  return check_launch("project_bwd");
+}
+
+extern "C" int eg_project_bwd_adam(float *means, float *quats, float *scales, float *opacities,
+                                   const float *viewmat, const float *K, int32_t N, int32_t width, int32_t height,
+                                   float eps2d, uint32_t flags, const float *splat, const float *g2d, float *m,
+                                   float *v, float *absgrads, eg_adam_hyper hyper, eg_stream_t stream) {
+  EG_REQUIRE(N >= 0 && hyper.step >= 1, "bad sizes / step");
+  if (N == 0) return EG_OK;
+  EG_REQUIRE(means && quats && scales && opacities && viewmat && K && splat && g2d && m && v, "null pointer");
+  project_bwd_kernel<true><<<cdiv(N, 256), 256, 0, as_stream(stream)>>>(
+      means, quats, scales, opacities, viewmat, K, N, width, height, eps2d, flags, (const float4 *)splat,
+      (const float4 *)g2d, nullptr, nullptr, nullptr, nullptr, absgrads, nullptr, nullptr, m, v,
+      make_adamk(hyper));
+  return check_launch("project_bwd_adam");
+}
+
+extern "C" int eg_adam_multi(float *means, float *scales, float *quats, float *opacities, const float *g_means,
+                             const float *g_scales, const float *g_quats, const float *g_opacities, float *m,
+                             float *v, int32_t N, eg_adam_hyper hyper, eg_stream_t stream) {
+  EG_REQUIRE(N >= 0 && hyper.step >= 1, "bad sizes / step");
+  if (N == 0) return EG_OK;
+  EG_REQUIRE(means && scales && quats && opacities && g_means && g_scales && g_quats && g_opacities && m && v,
+             "null pointer");
+  const int blocks = min(cdiv(11 * (int64_t)N, 256), 2048);
+  adam_multi_kernel<<<blocks, 256, 0, as_stream(stream)>>>(means, scales, quats, opacities, g_means, g_scales,
+                                                          g_quats, g_opacities, m, v, N, make_adamk(hyper));
+  return check_launch("adam_multi");
+}
+
+extern "C" int eg_absgrad_accum(const float *means2d_absgrad, int32_t N, float *absgrads, eg_stream_t stream) {
+  EG_REQUIRE(N >= 0, "bad sizes");
+  if (N == 0) return EG_OK;
+  EG_REQUIRE(means2d_absgrad && absgrads, "null pointer");
+  absgrad_accum_kernel<<<cdiv(N, 256), 256, 0, as_stream(stream)>>>((const float2 *)means2d_absgrad, N, absgrads);
+  return check_launch("absgrad_accum");
+}

@@ -1,0 +1,361 @@
+"""EdgeTrainer -- the reference's per-view training step as ONE natively sequenced enqueue.
+
+Host-side mirror of the hot loop ``train_epoch`` body, ``/root/reference/train_gaussians.py:71-106``
+and of the model methods it drives (``edgegaussians/models/edge_gs.py``):
+
+    output = model(idx)                       edge_gs.py:617-623,197-286
+    loss = model.compute_projection_loss(..)  edge_gs.py:288-324   (weight-map form)
+    (lambda * loss).backward()                train_gaussians.py:98,101
+    model.update_absgrads()                   edge_gs.py:607-613
+    for opt in 4 Adams: step(); zero_grad()   train_gaussians.py:104-106, train_utils.py:50-60
+
+and of the epoch-boundary events: ``duplicate_high_pos_gradients`` (edge_gs.py:544-576),
+``cull_gaussians_opacity`` (:477-488), ``cull_gaussians_not_projecting`` (:578-601).
+
+Differences from the reference that are deliberate (documented in DESIGN.md):
+  * GT images, weight maps and cameras are device-resident; no per-step H2D, no ``.item()``
+    syncs (the loss accumulates in a device scalar that is read when the caller asks);
+  * the RNG-dependent ``bg_edge_ratio`` sample mask is an INPUT (a per-pixel weight map built by
+    the caller, e.g. ``synth.weight_map``), because the reference draws it with the CPU generator;
+  * M (tile intersections) never crosses to the host inside a step: the isect buffers have a
+    capacity sized from a count-only sweep over all views, and an overflow flag is checked lazily.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional
+
+import torch
+from torch import Tensor
+
+from . import _lib
+from ._lib import AdamHyper, StepArgs, call, ptr, stream
+
+TILE = 16
+
+
+@dataclass
+class LRSchedule:
+    """Per-epoch learning rates of ``train_utils.get_optimizers_schedulers`` (train_utils.py:48-65):
+    MultiStepLR for means, 'zero until start_at_epoch, then constant' for the other three."""
+    means_lr: float = 2e-3
+    means_milestones: List[int] = field(default_factory=lambda: [10, 20, 30, 40, 50])
+    means_gamma: float = 0.75
+    scales_lr: float = 1e-4
+    scales_start: int = 30
+    quats_lr: float = 1e-3
+    quats_start: int = 30
+    opacities_lr: float = 0.03
+    opacities_start: int = 20
+
+    @classmethod
+    def from_config(cls, optim_cfg: Dict) -> "LRSchedule":
+        m, s, q, o = optim_cfg["means"], optim_cfg["scales"], optim_cfg["quats"], optim_cfg["opacities"]
+        return cls(m["start_lr"], list(m["milestones"]), m["gamma"], s["start_lr"], s["start_at_epoch"],
+                   q["start_lr"], q["start_at_epoch"], o["start_lr"], o["start_at_epoch"])
+
+    def at(self, epoch: int) -> Dict[str, float]:
+        k = sum(1 for ms in self.means_milestones if ms <= epoch)
+        return {
+            "means": self.means_lr * (self.means_gamma ** k),
+            "scales": 0.0 if epoch < self.scales_start else self.scales_lr,
+            "quats": 0.0 if epoch < self.quats_start else self.quats_lr,
+            "opacities": 0.0 if epoch < self.opacities_start else self.opacities_lr,
+        }
+
+
+class EdgeTrainer:
+    """Device-resident training state + fused step.  One instance per GPU (one process per GPU)."""
+
+    def __init__(self, means: Tensor, log_scales: Tensor, quats: Tensor, logit_opacities: Tensor,
+                 viewmats: Tensor, Ks: Tensor, gt: Tensor, width: int, height: int,
+                 device: str = "cuda", schedule: Optional[LRSchedule] = None,
+                 betas=(0.9, 0.999), eps: float = 1e-8):
+        _lib.load()
+        self.dev = torch.device(device)
+        f = dict(device=self.dev, dtype=torch.float32)
+        self.means = means.detach().to(**f).contiguous().clone()
+        self.log_scales = log_scales.detach().to(**f).contiguous().clone()
+        self.quats = quats.detach().to(**f).contiguous().clone()
+        self.logit_opacities = logit_opacities.detach().to(**f).reshape(-1).contiguous().clone()
+        self.viewmats = viewmats.to(**f).contiguous()
+        self.Ks = Ks.to(**f).contiguous()
+        self.gt = gt.to(**f).contiguous()  # [V,H,W] in [0,1]
+        self.width, self.height = int(width), int(height)
+        self.tw, self.th = math.ceil(width / TILE), math.ceil(height / TILE)
+        self.T = self.tw * self.th
+        self.V = self.viewmats.shape[0]
+        self.schedule = schedule or LRSchedule()
+        self.betas, self.eps = betas, eps
+        self.adam_step = 0  # shared step count of the four optimizers
+        self.step = 0       # model.step (edge_gs.py:621)
+        self.epoch = 0
+        self.loss_scale = 1.0  # lambda_projection (train_gaussians.py:98; constant 1 in every config)
+        self.capacity = 0
+        self._hyper = AdamHyper()
+        self._alloc_state()
+        self._alloc_pixels()
+
+    # ------------------------------------------------------------------ allocation
+    @property
+    def N(self) -> int:
+        return self.means.shape[0]
+
+    def _alloc_state(self):
+        N, d = self.N, self.dev
+        self.adam_m = torch.zeros(11 * N, device=d)
+        self.adam_v = torch.zeros(11 * N, device=d)
+        self.absgrads = torch.zeros(N, device=d)
+        self.absgrads_normalize_factor = 1.0  # edge_gs.py:89,605
+        self._alloc_per_gaussian()
+
+    def _alloc_per_gaussian(self):
+        N, d = self.N, self.dev
+        self.splat = torch.empty(N, 8, device=d)
+        self.g2d = torch.zeros(N, 8, device=d)
+        self.grads = torch.zeros(N, 12, device=d)  # [means3|quats4|scales3|opac1|absgrad-inc1] for all-reduce
+        self._args_cache: Dict = {}
+
+    def _alloc_pixels(self):
+        H, W, d = self.height, self.width, self.dev
+        self.tile_counts = torch.zeros(self.T, dtype=torch.int32, device=d)
+        self.offsets = torch.zeros(self.T + 1, dtype=torch.int32, device=d)
+        self.total = torch.zeros(2, dtype=torch.int32, device=d)
+        self.render = torch.zeros(H, W, device=d)
+        self.alphas = torch.zeros(H, W, device=d)
+        self.vpix = torch.zeros(H, W, device=d)
+        self.last_ids = torch.zeros(H, W, dtype=torch.int32, device=d)
+        self.loss_acc = torch.zeros(1, device=d)
+
+    def _alloc_isect(self, capacity: int):
+        self.capacity = int(capacity)
+        self.keys = torch.empty(self.capacity, dtype=torch.int64, device=self.dev)
+        self.flatten_ids = torch.empty(self.capacity, dtype=torch.int32, device=self.dev)
+        self._args_cache = {}
+
+    # ------------------------------------------------------------------ capacity
+    def count_intersections(self, view: int) -> int:
+        """M for one view (count-only pass: projection + per-tile counts + scan).  Host sync."""
+        call("eg_project_fwd", ptr(self.means), ptr(self.quats), ptr(self.log_scales), ptr(self.logit_opacities),
+             ptr(self.viewmats[view]), ptr(self.Ks[view]), self.N, self.width, self.height, 0.01, 1e10, 0.3, 0.0,
+             _lib.FLAG_LOG_SCALES | _lib.FLAG_LOGIT_OPACITIES | _lib.FLAG_ANTIALIASED, ptr(self.splat),
+             None, None, None, None, None, None, ptr(self.tile_counts), None, stream())
+        call("eg_tile_offsets", ptr(self.tile_counts), self.T, 1 << 40, ptr(self.offsets), ptr(self.total), stream())
+        m = int(self.total[0].item())
+        self.tile_counts.zero_()
+        return m
+
+    def ensure_capacity(self, slack: float = 1.3, views: Optional[List[int]] = None) -> int:
+        """Sizes the isect buffers from a count-only sweep (called at start and after every
+        densify / cull event, i.e. whenever N changes -- 22 times in a 400-epoch ABC run)."""
+        views = list(range(self.V)) if views is None else views
+        m_max = max(self.count_intersections(v) for v in views)
+        need = int(m_max * slack) + 4096
+        if need > self.capacity:
+            self._alloc_isect(need)
+        self.m_max_seen = m_max
+        return m_max
+
+    # ------------------------------------------------------------------ the step
+    def _args(self, view: int, wmap: Tensor, fused_adam: bool) -> StepArgs:
+        a = self._args_cache.get("sa")
+        if a is None:  # rebuilt only when a buffer was re-allocated (N or capacity changed)
+            a = StepArgs()
+            a.means, a.quats = ptr(self.means), ptr(self.quats)
+            a.log_scales, a.logit_opacities = ptr(self.log_scales), ptr(self.logit_opacities)
+            a.adam_m, a.adam_v = ptr(self.adam_m), ptr(self.adam_v)
+            a.N = self.N
+            a.width, a.height = self.width, self.height
+            a.splat, a.g2d = ptr(self.splat), ptr(self.g2d)
+            a.tile_counts, a.offsets, a.total = ptr(self.tile_counts), ptr(self.offsets), ptr(self.total)
+            a.keys, a.flatten_ids, a.capacity = ptr(self.keys), ptr(self.flatten_ids), self.capacity
+            a.render, a.alphas, a.vpix = ptr(self.render), ptr(self.alphas), ptr(self.vpix)
+            a.loss, a.last_ids = ptr(self.loss_acc), ptr(self.last_ids)
+            g0 = self.grads.data_ptr()
+            a.v_means, a.v_quats = g0, g0 + 4 * 3 * self.N
+            a.v_scales, a.v_opacities = g0 + 4 * 7 * self.N, g0 + 4 * 10 * self.N
+            self._args_cache["sa"] = a
+            self._args_cache["hyper_ptr"] = C.pointer(self._hyper)
+            self._args_cache["null_hyper"] = C.POINTER(AdamHyper)()
+        assert wmap.is_cuda and wmap.is_contiguous() and wmap.shape == (self.height, self.width)
+        a.viewmat = self.viewmats.data_ptr() + 64 * view
+        a.K = self.Ks.data_ptr() + 36 * view
+        a.gt = self.gt.data_ptr() + 4 * self.height * self.width * view
+        a.wmap = wmap.data_ptr()
+        a.loss_scale = self.loss_scale
+        if fused_adam:
+            a.absgrads = ptr(self.absgrads)
+            a.adam_host = self._args_cache["hyper_ptr"]
+        else:  # data-parallel: the absgrad increment of this view goes to block 11 of `grads`
+            a.absgrads = self.grads.data_ptr() + 4 * 11 * self.N
+            a.adam_host = self._args_cache["null_hyper"]
+        return a
+
+    def _set_hyper(self):
+        lr = self.schedule.at(self.epoch)
+        h = self._hyper
+        h.lr_means, h.lr_scales, h.lr_quats, h.lr_opacities = lr["means"], lr["scales"], lr["quats"], lr["opacities"]
+        h.beta1, h.beta2, h.eps = self.betas[0], self.betas[1], self.eps
+        h.step = self.adam_step
+
+    def train_step(self, view: int, wmap: Tensor) -> None:
+        """One reference iteration (train_gaussians.py:81-106) for `view`, fully asynchronous.
+        `wmap` [H,W]: the per-pixel loss weights of the strategy chosen for this step."""
+        if self.capacity == 0:
+            self.ensure_capacity()
+        self.adam_step += 1
+        self._set_hyper()
+        call("eg_train_step", C.byref(self._args(view, wmap, True)), stream())
+        self.absgrads_normalize_factor += 1  # edge_gs.py:613
+        self.step += 1
+
+    def grad_step(self, view: int, wmap: Tensor) -> Tensor:
+        """Forward + loss + backward only: leaves dL/d{means,quats,log_scales,logit_opacities} in
+        ``self.grads`` ([means 3N | quats 4N | scales 3N | opac N | absgrad increment N] flat
+        blocks) for the data-parallel driver, which all-reduces them and then calls ``apply_adam``."""
+        if self.capacity == 0:
+            self.ensure_capacity()
+        self.grads.view(-1)[11 * self.N:].zero_()
+        call("eg_train_step", C.byref(self._args(view, wmap, False)), stream())
+        self.step += 1
+        return self.grads
+
+    def grad_views(self):
+        N, g = self.N, self.grads.view(-1)
+        return (g[:3 * N].view(N, 3), g[3 * N:7 * N].view(N, 4), g[7 * N:10 * N].view(N, 3), g[10 * N:11 * N])
+
+    def apply_adam(self) -> None:
+        self.adam_step += 1
+        self._set_hyper()
+        gm, gq, gs, go = self.grad_views()
+        call("eg_adam_multi", ptr(self.means), ptr(self.log_scales), ptr(self.quats), ptr(self.logit_opacities),
+             ptr(gm), ptr(gs), ptr(gq), ptr(go), ptr(self.adam_m), ptr(self.adam_v), self.N, self._hyper, stream())
+        self.absgrads += self.grads.view(-1)[11 * self.N:]  # summed over the ranks' views by the all-reduce
+        self.absgrads_normalize_factor += 1
+
+    # ------------------------------------------------------------------ read-backs (these sync)
+    def pop_loss(self) -> float:
+        """Sum of the projection losses since the last call (the reference's avg_loss numerator,
+        train_gaussians.py:99) -- ONE device sync for many steps instead of two per step."""
+        v = float(self.loss_acc.item())
+        self.loss_acc.zero_()
+        return v
+
+    def overflowed(self) -> bool:
+        return bool(self.total[1].item() != 0)
+
+    def last_m(self) -> int:
+        return int(self.total[0].item())
+
+    # ------------------------------------------------------------------ densify / cull
+    def _moment_views(self, t: Tensor):
+        N = self.N
+        return {"means": t[:3 * N].view(N, 3), "scales": t[3 * N:6 * N].view(N, 3),
+                "quats": t[6 * N:10 * N].view(N, 4), "opacities": t[10 * N:11 * N].view(N, 1)}
+
+    def _params(self):
+        return {"means": self.means, "scales": self.log_scales, "quats": self.quats,
+                "opacities": self.logit_opacities.view(-1, 1)}
+
+    def _scan(self, mask_u8: Tensor):
+        pos = torch.empty(self.N, dtype=torch.int32, device=self.dev)
+        cnt = torch.empty(1, dtype=torch.int32, device=self.dev)
+        call("eg_mask_scan", ptr(mask_u8), self.N, ptr(pos), ptr(cnt), stream())
+        return pos, int(cnt.item())
+
+    def cull(self, cull_mask: Tensor, reset_opacity_value: float = 0.08) -> int:
+        """cull_gaussians (edge_gs.py:412-429) + remove_from_all_optim (:384-409): rows of the 4
+        params, 8 moment tensors and absgrads where ~cull_mask, then the reference's opacity clamp
+        (a probability-space constant applied in LOGIT space -- kept, it is what the reference does)."""
+        keep = (~cull_mask.to(self.dev).bool()).to(torch.uint8).contiguous()
+        pos, n_keep = self._scan(keep)
+        N = self.N
+        m_old, v_old = self._moment_views(self.adam_m), self._moment_views(self.adam_v)
+        new_m = torch.zeros(11 * n_keep, device=self.dev)
+        new_v = torch.zeros(11 * n_keep, device=self.dev)
+        new_p = {}
+        off = 0
+        for name, p in self._params().items():
+            d = p.shape[1]
+            out = torch.empty(n_keep, d, device=self.dev)
+            call("eg_compact_rows", ptr(p), ptr(keep), ptr(pos), N, d, ptr(out), stream())
+            new_p[name] = out
+            for old, new in ((m_old[name], new_m), (v_old[name], new_v)):
+                dst = new[off:off + n_keep * d].view(n_keep, d)
+                call("eg_compact_rows", ptr(old.contiguous()), ptr(keep), ptr(pos), N, d, ptr(dst), stream())
+            off += n_keep * d
+        ag = torch.empty(n_keep, 1, device=self.dev)
+        call("eg_compact_rows", ptr(self.absgrads.view(-1, 1)), ptr(keep), ptr(pos), N, 1, ptr(ag), stream())
+        self.means, self.log_scales, self.quats = new_p["means"], new_p["scales"], new_p["quats"]
+        self.logit_opacities = new_p["opacities"].view(-1).clamp_(max=reset_opacity_value)
+        self.adam_m, self.adam_v, self.absgrads = new_m, new_v, ag.view(-1)
+        self._alloc_per_gaussian()
+        return N - n_keep
+
+    def cull_opacity(self, value: float = 0.05) -> int:
+        """cull_gaussians_opacity, 'absolute' (edge_gs.py:477-488; every shipped config)."""
+        return self.cull(torch.sigmoid(self.logit_opacities) < value)
+
+    def duplicate(self, dup_mask: Tensor, dup_factor: int = 3, noise_scale: float = 0.05,
+                  noise: Optional[Tensor] = None) -> int:
+        """dup_gaussians (edge_gs.py:460-474) + dup_in_all_optim (:431-457): append dup_factor-1
+        copies of the masked rows; means get N(0, noise_scale^2) noise, moments of new rows are 0."""
+        sel = dup_mask.to(self.dev).bool().to(torch.uint8).contiguous()
+        pos, n_sel = self._scan(sel)
+        copies = dup_factor - 1
+        N, n_new = self.N, self.N + copies * n_sel
+        if noise is None:
+            noise = torch.randn(copies * n_sel, 3, device=self.dev)
+        noise = (noise.to(self.dev) * noise_scale).contiguous()
+        m_old, v_old = self._moment_views(self.adam_m), self._moment_views(self.adam_v)
+        new_m = torch.zeros(11 * n_new, device=self.dev)
+        new_v = torch.zeros(11 * n_new, device=self.dev)
+        new_p = {}
+        off = 0
+        for name, p in self._params().items():
+            d = p.shape[1]
+            out = torch.empty(n_new, d, device=self.dev)
+            out[:N] = p
+            if n_sel:
+                call("eg_append_rows", ptr(p.contiguous()), ptr(sel), ptr(pos), N, n_sel, d, copies,
+                     ptr(noise) if name == "means" else None, 0.0, ptr(out[N:]), stream())
+            new_p[name] = out
+            new_m[off:off + N * d] = m_old[name].reshape(-1)
+            new_v[off:off + N * d] = v_old[name].reshape(-1)
+            off += n_new * d
+        self.means, self.log_scales, self.quats = new_p["means"], new_p["scales"], new_p["quats"]
+        self.logit_opacities = new_p["opacities"].view(-1)
+        self.adam_m, self.adam_v = new_m, new_v
+        self.reset_absgrads()
+        self._alloc_per_gaussian()
+        return n_sel
+
+    def duplicate_high_pos_gradients(self, threshold: float = 0.5, dup_factor: int = 3,
+                                     noise_scale: float = 0.05, noise: Optional[Tensor] = None) -> int:
+        """'absolute' branch of edge_gs.py:544-576: min-max normalised mean absgrad > threshold."""
+        g = self.absgrads / self.absgrads_normalize_factor
+        gn = (g - g.min()) / (g.max() - g.min())
+        return self.duplicate(gn > threshold, dup_factor, noise_scale, noise)
+
+    def reset_absgrads(self):
+        self.absgrads = torch.zeros(self.means.shape[0], device=self.dev)
+        self.absgrads_normalize_factor = 1
+
+    def cull_not_projecting(self, edge_masks_u8: Tensor, min_projecting_fraction: float = 0.1) -> int:
+        """cull_gaussians_not_projecting (edge_gs.py:578-601) as one N x V device kernel.
+        edge_masks_u8: [V,H,W] uint8 (gt >= 0.5)."""
+        P = torch.bmm(self.Ks, self.viewmats[:, :3, :4]).contiguous()  # K @ viewmat[:3,:4]
+        hits = torch.zeros(self.N, dtype=torch.int32, device=self.dev)
+        call("eg_project_hits", ptr(self.means), self.N, ptr(P), self.V, ptr(edge_masks_u8.contiguous()),
+             self.width, self.height, ptr(hits), stream())
+        frac = hits.float() / float(self.V)
+        return self.cull(frac < min_projecting_fraction)
+
+    # ------------------------------------------------------------------ hand-off
+    def state_dict(self) -> Dict[str, Tensor]:
+        """Same keys / shapes as the reference's checkpoint (edge_gs.py:625-633)."""
+        return {"gauss_params.means": self.means.clone(), "gauss_params.scales": self.log_scales.clone(),
+                "gauss_params.quats": self.quats.clone(),
+                "gauss_params.opacities": self.logit_opacities.view(-1, 1).clone()}

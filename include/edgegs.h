@@ -1,0 +1,204 @@
+/*
+ * edgegs.h -- C ABI of libedgegs.so, the MI355X (gfx950) edge-Gaussian rasterizer.
+ *
+ * This is the drop-in boundary for the ONE hot path of kunalchelani/EdgeGaussians: the call
+ *     render, alpha, info = gsplat.rasterization(...)      reference edgegaussians/models/edge_gs.py:250-268
+ * and its autograd backward (train_gaussians.py:101), plus the per-step glue around it
+ * (edge_gs.py:278-324 loss, :603-613 absgrad, train_gaussians.py:104-106 Adam,
+ * edge_gs.py:384-488,544-601 densify/cull).  The reference binds that path through Python
+ * (`from gsplat import rasterization`, edge_gs.py:8); the binding a maintainer adds is the
+ * ctypes stub in INTEGRATION.md (shipped as edgegaussians_amd/_lib.py + gsplat/__init__.py).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in _host; plain pointers + sizes,
+ *     no torch types; the library allocates nothing and keeps no state between calls
+ *   - all work is enqueued asynchronously on `stream` (a hipStream_t); no call synchronises
+ *   - return 0 on success, a negative EG_ERR_* code otherwise (eg_last_error_string() explains)
+ *   - fp32 arithmetic; indices int32; sort keys uint64 = (depth_bits << 32) | gaussian_id within
+ *     a tile segment; isect ids int64 = (tile_id << 32) | depth_bits exactly as gsplat 1.0.0
+ *   - N Gaussians, M tile intersections, T = tiles_x * tiles_y tiles of 16x16 pixels, one camera
+ *     per call (the reference always passes C = 1, edge_gs.py:235-236; C > 1 is looped above)
+ *
+ * Packed per-Gaussian screen record ("splat", 8 floats, 32 B, one L2 sector pair):
+ *     [0] x  [1] y  [2] conic a  [3] conic b  [4] conic c  [5] opacity*compensation
+ *     [6] depth (fp32)  [7] radius (int32 bits; 0 = culled)
+ * Packed per-Gaussian 2D gradient accumulator ("g2d", 8 floats, 32 B):
+ *     [0] v_x [1] v_y [2] |v_x| [3] |v_y| [4] v_a [5] v_b [6] v_c [7] v_opacity_eff
+ */
+#ifndef EDGEGS_H
+#define EDGEGS_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void *eg_stream_t; /* hipStream_t */
+
+#define EG_OK 0
+#define EG_ERR_ARG (-1)     /* bad argument (null pointer, negative size, unsupported channel count) */
+#define EG_ERR_LAUNCH (-2)  /* hipGetLastError() after a launch */
+#define EG_ERR_NODEVICE (-3)
+
+#define EG_TILE 16
+#define EG_FLAG_LOG_SCALES 1u      /* `scales` holds log-scales: exp() fused (edge_gs.py:253) */
+#define EG_FLAG_LOGIT_OPACITIES 2u /* `opacities` holds logits: sigmoid() fused (edge_gs.py:254) */
+#define EG_FLAG_ANTIALIASED 4u     /* rasterize_mode="antialiased" (edge_gs.py:50,266) */
+
+const char *eg_last_error_string(void);
+int eg_version(void);
+/* number of gfx950 devices visible; <= 0 means the library cannot run (callers must fail loudly) */
+int eg_device_count(void);
+
+/* ---- G1: fully fused projection forward (replaces gsplat fully_fused_projection fwd)
+ * Optional outputs may be NULL.  When tile_counts != NULL the per-tile intersection counts are
+ * accumulated too (gsplat isect_tiles pass 1) -- tile_counts must be zeroed by the
+ * caller once (eg_tile_emit returns it to zero every step).  g2d, when non-NULL, is zeroed for the
+ * backward pass of this step. */
+int eg_project_fwd(const float *means, const float *quats, const float *scales, const float *opacities,
+                   const float *viewmat /*[16] row-major world->cam*/, const float *K /*[9]*/,
+                   int32_t N, int32_t width, int32_t height, float near_plane, float far_plane,
+                   float eps2d, float radius_clip, uint32_t flags,
+                   float *splat /*[N,8]*/, int32_t *radii /*[N]|NULL*/, float *means2d /*[N,2]|NULL*/,
+                   float *depths /*[N]|NULL*/, float *conics /*[N,3]|NULL*/, float *compensations /*[N]|NULL*/,
+                   int32_t *tiles_per_gauss /*[N]|NULL*/, int32_t *tile_counts /*[T]|NULL*/,
+                   float *g2d /*[N,8]|NULL*/, eg_stream_t stream);
+
+/* ---- G2 (per-Gaussian part) on caller-supplied screen data: tiles_per_gauss + tile_counts from
+ * (means2d, radii).  Used when projection ran elsewhere (parity tests feed oracle floats). */
+int eg_tile_count(const float *means2d, const int32_t *radii, int32_t N, int32_t width, int32_t height,
+                  int32_t *tiles_per_gauss /*[N]|NULL*/, int32_t *tile_counts /*[T]*/, eg_stream_t stream);
+
+/* ---- G3+G6: exclusive scan of the per-tile counts -> isect_offsets[T+1] (offsets[T] = M), which is
+ * gsplat's isect_offset_encode result.  Also writes total[0] = M, total[1] = 1 if
+ * M > capacity (overflow).  tile_counts is left intact: eg_tile_emit counts it back down to zero. */
+int eg_tile_offsets(const int32_t *tile_counts /*[T]*/, int32_t T, int64_t capacity,
+                    int32_t *offsets /*[T+1]*/, int32_t *total /*[2]*/, eg_stream_t stream);
+
+/* ---- G4: emit one (depth_bits<<32 | gaussian_id) key per (Gaussian, tile) into that tile's
+ * segment [offsets[t], offsets[t+1]) (order inside a segment arbitrary; eg_sort_pairs fixes it). */
+int eg_tile_emit(const float *means2d_or_null, const int32_t *radii_or_null, const float *depths_or_null,
+                 const float *splat_or_null, int32_t N, int32_t width, int32_t height,
+                 const int32_t *offsets /*[T+1]*/, int32_t *tile_counts /*[T]: counts on entry, zero on exit*/,
+                 int64_t capacity, uint64_t *keys /*[capacity]*/, eg_stream_t stream);
+
+/* ---- G5: segmented sort -- every tile segment ascending by (depth bits, gaussian id), which equals
+ * gsplat's stable radix sort on (tile, depth) of index-ordered emissions.  Writes the sorted
+ * Gaussian ids (gsplat flatten_ids) and optionally the int64 isect ids (tile<<32 | depth_bits). */
+int eg_sort_pairs(uint64_t *keys /*[capacity] in/out*/, const int32_t *offsets /*[T+1]*/, int32_t T,
+                  int64_t capacity, int32_t *flatten_ids /*[capacity]*/, int64_t *isect_ids /*[capacity]|NULL*/,
+                  eg_stream_t stream);
+
+/* ---- G7: alpha compositing forward (replaces gsplat rasterize_to_pixels fwd).
+ * channels = 1 or 3.  colors == NULL means "all ones" (the reference's colours, edge_gs.py:247).
+ * Fused weighted-L1 (edge_gs.py:279,288-324 in weight-map form): when wmap != NULL,
+ * channel 0 is clamped to [0,1], loss_out[0] += sum_p wmap_p*|c0_p - gt_p| and
+ * vpix[p] = loss_scale * wmap_p * sign(c0_p - gt_p) (the upstream gradient of eg_composite_bwd). */
+int eg_composite_fwd(const float *splat, const float *colors /*[N,channels]|NULL*/, int32_t channels,
+                     const int32_t *offsets, const int32_t *flatten_ids, int32_t width, int32_t height,
+                     float *render /*[H,W,channels]*/, float *alphas /*[H,W]*/, int32_t *last_ids /*[H,W]*/,
+                     const float *gt /*[H,W]|NULL*/, const float *wmap /*[H,W]|NULL*/, float loss_scale,
+                     float *vpix /*[H,W]|NULL*/, float *loss_out /*[1]|NULL*/, eg_stream_t stream);
+
+/* ---- G8: compositing backward for unit colours (replaces gsplat rasterize_to_pixels bwd for the
+ * reference's call).  vpix[p] = sum_k dL/drender[p,k] + dL/dalpha[p].  Accumulates
+ * into g2d with float atomics. */
+int eg_composite_bwd(const float *splat, const int32_t *offsets, const int32_t *flatten_ids,
+                     int32_t width, int32_t height, const float *alphas, const int32_t *last_ids,
+                     const float *vpix, float *g2d /*[N,8] accumulated*/, eg_stream_t stream);
+
+/* ---- G8 (general colours): order-dependent backward with per-Gaussian colours, channels = 3.
+ * v_colors may be NULL. */
+int eg_composite_bwd_colors(const float *splat, const float *colors, int32_t channels,
+                            const int32_t *offsets, const int32_t *flatten_ids, int32_t width, int32_t height,
+                            const float *alphas, const int32_t *last_ids, const float *v_render,
+                            const float *v_alphas, float *g2d, float *v_colors /*[N,channels]|NULL*/,
+                            eg_stream_t stream);
+
+/* ---- G9: fully fused projection backward (replaces gsplat fully_fused_projection bwd).
+ * Consumes g2d; writes (not accumulates) gradients w.r.t. the SAME representation the forward
+ * took (flags): v_means[N,3], v_quats[N,4], v_scales[N,3], v_opacities[N].
+ * absgrads (edge_gs.py:603-613), when non-NULL: absgrads[g] += hypot(g2d[g][2], g2d[g][3]).
+ * External mode (v_comps_ext != NULL; gsplat's autograd layout, where `opacities * compensations`
+ * is a torch op between projection and compositing): dL/dcompensation is read from v_comps_ext[N],
+ * g2d[.][7] is ignored and v_opacities may be NULL.  v_depths_ext[N] (may be NULL) adds dL/ddepth. */
+int eg_project_bwd(const float *means, const float *quats, const float *scales, const float *opacities,
+                   const float *viewmat, const float *K, int32_t N, int32_t width, int32_t height,
+                   float eps2d, uint32_t flags, const float *splat, const float *g2d,
+                   const float *v_comps_ext, const float *v_depths_ext,
+                   float *v_means, float *v_quats, float *v_scales, float *v_opacities,
+                   float *absgrads /*[N]|NULL*/, eg_stream_t stream);
+
+/* ---- a6: absgrad accumulate on its own (edge_gs.py:607-613): absgrads += ||means2d.absgrad||_2 */
+int eg_absgrad_accum(const float *means2d_absgrad /*[N,2]*/, int32_t N, float *absgrads, eg_stream_t stream);
+
+/* ---- a7: the four torch.optim.Adam steps of train_gaussians.py:104-106 in one launch
+ * (train_utils.py:50-60: betas 0.9/0.999, eps 1e-8, no weight decay, no amsgrad; torch 1.13
+ * update order).  `step` is the 1-based step count shared by the four optimizers. */
+typedef struct {
+  double lr_means, lr_scales, lr_quats, lr_opacities; /* doubles: the bias-corrected scalars are */
+  double beta1, beta2, eps;                            /* formed in double like torch does, then cast */
+  int32_t step;
+} eg_adam_hyper;
+
+int eg_adam_multi(float *means, float *scales, float *quats, float *opacities,
+                  const float *g_means, const float *g_scales, const float *g_quats, const float *g_opacities,
+                  float *m /*[N,11]: means3|scales3|quats4|opac1 blocks of N*dim*/, float *v /*same*/,
+                  int32_t N, eg_adam_hyper hyper, eg_stream_t stream);
+
+/* ---- fused G9 + absgrad + Adam: single-GPU training step tail (no gradient exchange needed). */
+int eg_project_bwd_adam(float *means, float *quats, float *scales, float *opacities,
+                        const float *viewmat, const float *K, int32_t N, int32_t width, int32_t height,
+                        float eps2d, uint32_t flags, const float *splat, const float *g2d,
+                        float *m, float *v, float *absgrads, eg_adam_hyper hyper, eg_stream_t stream);
+
+/* ---- a8/a9: densify / cull row movement (edge_gs.py:384-488,544-576).
+ * eg_compact: out[j] = in[i] for the j-th row i with keep[i] != 0 (stable); rows of `dim` floats.
+ * `positions` is an exclusive scan of keep (int32[N]) computed by eg_mask_scan; returns nothing on host.
+ * eg_append: out[n_old + k*n_sel + j] = in[sel_j] (+ noise) for copies k = 0..copies-1. */
+int eg_mask_scan(const uint8_t *keep /*[N]*/, int32_t N, int32_t *positions /*[N]*/, int32_t *count /*[1]*/,
+                 eg_stream_t stream);
+int eg_compact_rows(const float *in, const uint8_t *keep, const int32_t *positions, int32_t N, int32_t dim,
+                    float *out, eg_stream_t stream);
+int eg_append_rows(const float *in, const uint8_t *sel, const int32_t *positions, int32_t N, int32_t n_sel,
+                   int32_t dim, int32_t copies, const float *noise /*[copies*n_sel,dim]|NULL*/, float fill_zero,
+                   float *out_tail /*[copies*n_sel, dim]*/, eg_stream_t stream);
+
+/* ---- a10: cull_gaussians_not_projecting (edge_gs.py:578-601): hits[g] += 1 for every view whose
+ * rounded projection of means[g] lands inside the image on an edge pixel. */
+int eg_project_hits(const float *means, int32_t N, const float *P /*[V,3,4] = K @ viewmat[:3]*/, int32_t V,
+                    const uint8_t *edge_masks /*[V,H,W]*/, int32_t width, int32_t height,
+                    int32_t *hits /*[N] zeroed by caller*/, eg_stream_t stream);
+
+/* ---- whole training step for one view, enqueued from native code (train_gaussians.py:81-106):
+ * project+count -> offsets -> emit -> sort -> composite+loss -> composite bwd -> project bwd
+ * (+absgrad, +Adam when hyper != NULL).  All buffers caller-owned. */
+typedef struct {
+  /* trainable state, raw representation (log-scales, logit-opacities) */
+  float *means, *quats, *log_scales, *logit_opacities;
+  float *adam_m, *adam_v, *absgrads;
+  int32_t N;
+  /* view */
+  const float *viewmat, *K, *gt, *wmap;
+  int32_t width, height;
+  float loss_scale; /* lambda_projection (train_gaussians.py:98) */
+  /* workspace */
+  float *splat, *g2d;
+  int32_t *tile_counts, *offsets, *total; /* [T], [T+1], [2] */
+  uint64_t *keys;
+  int32_t *flatten_ids;
+  int64_t capacity;
+  float *render, *alphas, *vpix, *loss; /* [H,W], [H,W], [H,W], [1] accumulated */
+  int32_t *last_ids;
+  /* gradient outputs (used when adam == NULL, e.g. before an RCCL all-reduce) */
+  float *v_means, *v_quats, *v_scales, *v_opacities;
+  const eg_adam_hyper *adam_host; /* NULL = write gradients instead of stepping */
+} eg_step_args;
+
+int eg_train_step(const eg_step_args *args_host, eg_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EDGEGS_H */

@@ -1,0 +1,413 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on identical inputs.
+
+Tolerances (BASELINE.json north_star): floats 1e-4 relative; tile / pixel indexing bit-exact
+(on identical float inputs -- the binning tests feed the ORACLE's floats to the HIP kernels).
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from tests.util import assert_close, rel_err, to_np
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    from edgegaussians_amd import _lib
+    _lib.load()  # raises if the .so or the GPU is missing: no fallback
+    from edgegaussians_amd import synth
+    from oracle import ref_torch as O
+    return _lib, synth, O
+
+
+def _scene(synth, n=3000, w=200, h=136, seed=0, scale=0.02, views=2, aniso=5.0):
+    return synth.make_scene(n, views, w, h, seed=seed, spread_opacity=True, scale=scale, anisotropy=aniso)
+
+
+def _dev(*ts):
+    return [t.cuda().contiguous() for t in ts]
+
+
+# ------------------------------------------------------------------ G1
+def test_projection_forward(env):
+    _lib, synth, O = env
+    from edgegaussians_amd._lib import call, ptr, stream
+    sc = _scene(synth)
+    # put some Gaussians behind the camera and some far off-screen to exercise the culls
+    R, t = sc.viewmats[0, :3, :3], sc.viewmats[0, :3, 3]
+    cam_c = -R.T @ t
+    sc.means[:30] = cam_c - 2.0 * R[2] + 0.1 * sc.means[:30]
+    sc.means[30:50] = cam_c + 2.0 * R[2] + 40.0 * R[0]
+    scales = torch.exp(sc.log_scales)
+    op = torch.sigmoid(sc.logit_opacities).squeeze(-1)
+    N, W, H = sc.means.shape[0], sc.width, sc.height
+    radii_o, m2d_o, dep_o, con_o, comp_o = O.project(sc.means, sc.quats, scales, sc.viewmats[0], sc.Ks[0], W, H)
+    means, quats, scl, opd, vm, K = _dev(sc.means, sc.quats, scales, op, sc.viewmats[0], sc.Ks[0])
+    splat = torch.empty(N, 8, device="cuda")
+    radii = torch.empty(N, dtype=torch.int32, device="cuda")
+    m2d = torch.empty(N, 2, device="cuda")
+    dep = torch.empty(N, device="cuda")
+    con = torch.empty(N, 3, device="cuda")
+    comp = torch.empty(N, device="cuda")
+    call("eg_project_fwd", ptr(means), ptr(quats), ptr(scl), ptr(opd), ptr(vm), ptr(K), N, W, H, 0.01, 1e10, 0.3,
+         0.0, _lib.FLAG_ANTIALIASED, ptr(splat), ptr(radii), ptr(m2d), ptr(dep), ptr(con), ptr(comp), None, None,
+         None, stream())
+    torch.cuda.synchronize()
+    r = to_np(radii)
+    ro = to_np(radii_o)
+    assert ((r > 0) == (ro > 0)).mean() > 0.999
+    both = (r > 0) & (ro > 0)
+    assert both.sum() > 1000 and (ro == 0).sum() >= 50
+    # radius = ceil(3 sqrt(lambda)): identical except where 3 sqrt(lambda) sits within an ulp of an integer
+    assert (r[both] != ro[both]).mean() < 2e-3 and np.abs(r[both] - ro[both]).max() <= 1
+    sel = torch.from_numpy(both)
+    assert_close(m2d.cpu()[sel], m2d_o[sel], name="means2d")
+    assert_close(dep.cpu()[sel], dep_o[sel], name="depths")
+    assert_close(con.cpu()[sel], con_o[sel], name="conics")
+    assert_close(comp.cpu()[sel], comp_o[sel], name="compensations")
+    # packed record agrees with the separate outputs
+    sp = splat.cpu()
+    assert torch.equal(sp[:, 0:2], m2d.cpu()) and torch.equal(sp[:, 2:5], con.cpu())
+    assert torch.equal(sp[:, 7].view(torch.int32), radii.cpu())
+    assert_close(sp[:, 5][sel], (op * comp_o)[sel], name="opacity*comp")
+
+
+# ------------------------------------------------------------------ G2-G6 (bit exact on oracle floats)
+def _bin_on_device(means2d, radii, depths, W, H):
+    from edgegaussians_amd._lib import call, ptr, stream
+    from edgegaussians_amd.rasterizer import isect_tiles_and_sort
+    N = means2d.shape[0]
+    tw, th = math.ceil(W / 16), math.ceil(H / 16)
+    m, r, d = _dev(means2d, radii, depths)
+    tpg = torch.empty(N, dtype=torch.int32, device="cuda")
+    counts = torch.zeros(tw * th, dtype=torch.int32, device="cuda")
+    call("eg_tile_count", ptr(m), ptr(r), N, W, H, ptr(tpg), ptr(counts), stream())
+    counts_copy = counts.clone()
+    offsets, flat, ids, M = isect_tiles_and_sort(m, r, d, counts, W, H)
+    torch.cuda.synchronize()
+    assert int(counts.abs().sum()) == 0, "emit must return the tile counters to zero"
+    return to_np(tpg), to_np(ids), to_np(flat), to_np(offsets), M, to_np(counts_copy)
+
+
+@pytest.mark.parametrize("case", ["scene", "ties", "huge_tile", "empty"])
+def test_binning_bit_exact(env, case):
+    _lib, synth, O = env
+    W, H = 200, 136
+    tw, th = math.ceil(W / 16), math.ceil(H / 16)
+    g = torch.Generator().manual_seed(3)
+    if case == "scene":
+        sc = _scene(synth, n=4000)
+        radii, m2d, dep, _, _ = O.project(sc.means, sc.quats, torch.exp(sc.log_scales), sc.viewmats[1], sc.Ks[1], W, H)
+    elif case == "ties":  # many equal depths: order must fall back to the Gaussian index
+        n = 3000
+        m2d = torch.rand(n, 2, generator=g) * torch.tensor([W, H])
+        radii = torch.randint(1, 30, (n,), generator=g, dtype=torch.int32)
+        dep = torch.randint(1, 5, (n,), generator=g).float()
+    elif case == "huge_tile":  # > 4096 entries in one tile: the global/LDS hybrid sort path
+        n = 11000
+        m2d = torch.rand(n, 2, generator=g) * 10 + torch.tensor([40.0, 40.0])
+        radii = torch.randint(1, 4, (n,), generator=g, dtype=torch.int32)
+        dep = torch.rand(n, generator=g) * 5 + 0.5
+        dep[::7] = dep[0]
+    else:
+        n = 64
+        m2d = torch.zeros(n, 2)
+        radii = torch.zeros(n, dtype=torch.int32)
+        dep = torch.zeros(n)
+    tpg_o, ids_o, flat_o = O.isect_tiles(to_np(m2d), to_np(radii), to_np(dep), 16, tw, th)
+    offs_o = O.isect_offset_encode(ids_o, tw, th).reshape(-1)
+    tpg, ids, flat, offsets, M, counts = _bin_on_device(m2d, radii, dep, W, H)
+    assert M == len(ids_o)
+    if case == "huge_tile":
+        assert counts.max() > 4096
+    assert np.array_equal(tpg, tpg_o)
+    assert np.array_equal(offsets[:-1], offs_o) and offsets[-1] == M
+    assert np.array_equal(ids, ids_o)
+    assert np.array_equal(flat, flat_o)
+
+
+# ------------------------------------------------------------------ full boundary call
+def _run_pair(env, sc, view=0, colors=None, absgrad=True, mode="antialiased", loss_fn=None):
+    _lib, synth, O = env
+    from edgegaussians_amd import rasterization
+    N = sc.means.shape[0]
+    outs = []
+    for dev in ("cpu", "cuda"):
+        means = sc.means.clone().to(dev).requires_grad_(True)
+        ls = sc.log_scales.clone().to(dev).requires_grad_(True)
+        q = sc.quats.clone().to(dev).requires_grad_(True)
+        lo = sc.logit_opacities.clone().to(dev).requires_grad_(True)
+        col = (torch.ones(N, 3) if colors is None else colors.clone()).to(dev)
+        if colors is not None:
+            col.requires_grad_(True)
+        fn = O.rasterization if dev == "cpu" else rasterization
+        render, alpha, info = fn(
+            means=means, quats=q, scales=torch.exp(ls), opacities=torch.sigmoid(lo).squeeze(-1), colors=col,
+            viewmats=sc.viewmats[view:view + 1].to(dev), Ks=sc.Ks[view:view + 1].to(dev), width=sc.width,
+            height=sc.height, tile_size=16, packed=False, near_plane=0.01, far_plane=1e10, render_mode="RGB",
+            sparse_grad=False, absgrad=absgrad, rasterize_mode=mode)
+        assert info["means2d"].requires_grad and not info["means2d"].is_leaf
+        info["means2d"].retain_grad()
+        loss = loss_fn(render, alpha, dev)
+        loss.backward()
+        outs.append(dict(render=render, alpha=alpha, info=info, means=means, ls=ls, q=q, lo=lo, col=col,
+                         loss=loss))
+    return outs
+
+
+def _l1_loss(sc, synth, view, strategy):
+    w = synth.weight_map(strategy, sc.gt[view], ratio=1.0, generator=torch.Generator().manual_seed(5))
+
+    def fn(render, alpha, dev):
+        rgb = torch.clamp(render[0, ..., :3], 0.0, 1.0)  # edge_gs.py:278-279
+        return (w.to(dev) * (rgb[:, :, 0] - sc.gt[view].to(dev)).abs()).sum()  # train_gaussians.py:84-94
+    return fn
+
+
+@pytest.mark.parametrize("strategy,mode", [("weighted", "antialiased"), ("whole", "antialiased"),
+                                           ("bg_edge_ratio", "antialiased"), ("weighted", "classic")])
+def test_rasterization_matches_oracle(env, strategy, mode):
+    _lib, synth, O = env
+    sc = _scene(synth, n=3000)
+    cpu, gpu = _run_pair(env, sc, view=0, mode=mode, loss_fn=_l1_loss(sc, synth, 0, strategy))
+    io, ig = cpu["info"], gpu["info"]
+    # integer outputs: identical wherever the float inputs of the integer decisions agree
+    ro, rg = to_np(io["radii"]), to_np(ig["radii"])
+    assert (ro != rg).mean() < 2e-3
+    same_bins = np.array_equal(ro, rg) and np.array_equal(to_np(io["flatten_ids"]), to_np(ig["flatten_ids"]))
+    assert np.array_equal(to_np(io["tiles_per_gauss"])[ro == rg], to_np(ig["tiles_per_gauss"])[ro == rg])
+    if same_bins:
+        assert np.array_equal(to_np(io["isect_offsets"]), to_np(ig["isect_offsets"]))
+        assert (to_np(io["last_ids"]) != to_np(ig["last_ids"])).mean() < 1e-3
+    # float outputs
+    assert cpu["render"].shape == gpu["render"].shape == (1, sc.height, sc.width, 3)
+    assert_close(gpu["render"], cpu["render"], max_bad=2e-3, name="render")
+    assert_close(gpu["alpha"], cpu["alpha"], max_bad=2e-3, name="alpha")
+    assert np.abs(to_np(gpu["render"]) - to_np(cpu["render"])).max() < 1.2 / 255
+    assert abs(float(gpu["loss"]) - float(cpu["loss"])) <= 1e-4 * abs(float(cpu["loss"]))
+    for k in ("means", "q", "ls", "lo"):
+        assert_close(gpu[k].grad, cpu[k].grad, max_bad=5e-3, name=f"grad {k}")
+        assert rel_err(gpu[k].grad, cpu[k].grad) < 2e-3, k
+    assert_close(ig["means2d"].grad, io["means2d"].grad, max_bad=5e-3, name="v_means2d")
+    assert ig["means2d"].absgrad.shape == (1, sc.means.shape[0], 2)
+    assert_close(ig["means2d"].absgrad, io["means2d"].absgrad, max_bad=5e-3, name="absgrad")
+
+
+def test_rasterization_general_colors(env):
+    _lib, synth, O = env
+    sc = _scene(synth, n=1500, w=96, h=80)
+    colors = torch.rand(1500, 3, generator=torch.Generator().manual_seed(9))
+    wr = torch.rand(80, 96, 3, generator=torch.Generator().manual_seed(10))
+
+    def fn(render, alpha, dev):
+        return (render[0] * wr.to(dev)).sum() * 1e-3 + (alpha[0, ..., 0] ** 2).sum() * 1e-3
+    cpu, gpu = _run_pair(env, sc, colors=colors, loss_fn=fn)
+    assert_close(gpu["render"], cpu["render"], max_bad=2e-3, name="render")
+    for k in ("means", "q", "ls", "lo", "col"):
+        assert_close(gpu[k].grad, cpu[k].grad, max_bad=5e-3, name=f"grad {k}")
+    assert_close(gpu["info"]["means2d"].absgrad, cpu["info"]["means2d"].absgrad, max_bad=5e-3, name="absgrad")
+
+
+def test_boundary_protocol(env, golden_dir):
+    """The exact payload the reference's model class passes / reads back (boundary_trace.json,
+    recorded by tests/golden/make_golden.py from edge_gs.py:250-275,607-613)."""
+    import json
+    import os
+    _lib, synth, O = env
+    from gsplat import rasterization  # the name the reference imports (edge_gs.py:8)
+    tr = json.load(open(os.path.join(golden_dir, "boundary_trace.json")))
+    kw = tr["kwargs"]
+    cams = np.load(os.path.join(golden_dir, "cameras_00004926.npz"))
+    N = kw["means"]["shape"][0]
+    g = torch.Generator().manual_seed(1)
+    args = dict(
+        means=(1.1 * torch.rand(N, 3, generator=g) - 0.05).cuda().requires_grad_(True),
+        quats=synth.random_quats(N, g).cuda().requires_grad_(True),
+        scales=torch.full((N, 3), 0.004).cuda().requires_grad_(True),
+        opacities=torch.full((N,), 0.08).cuda().requires_grad_(True),
+        colors=torch.ones(N, 3).cuda(),
+        viewmats=torch.from_numpy(cams["viewmats"][:1]).cuda(), Ks=torch.from_numpy(cams["Ks"][:1]).cuda())
+    for k, v in kw.items():
+        if isinstance(v, dict):
+            assert list(args[k].shape) == v["shape"] and args[k].requires_grad == v["requires_grad"]
+        else:
+            args[k] = v
+    render, alpha, info = rasterization(**args)
+    assert list(render.shape) == [1, kw["height"], kw["width"], 3] and list(alpha.shape) == [1, kw["height"], kw["width"], 1]
+    info["means2d"].retain_grad()
+    xys, radii = info["means2d"], info["radii"][0]
+    assert list(radii.shape) == tr["reads_back"]["info['radii'][0]"] and radii.dtype == torch.int32
+    torch.clamp(render[0, ..., :3], 0, 1)[:, :, 0].mean().backward()
+    absgrads = torch.zeros(N, device="cuda") + xys.absgrad[0].norm(dim=-1)  # update_absgrads
+    assert absgrads.shape == (N,) and float(absgrads.max()) > 0
+    assert args["means"].grad is not None and float(args["means"].grad.abs().max()) > 0
+
+
+# ------------------------------------------------------------------ fused step
+def test_adam_matches_torch(env):
+    _lib, synth, O = env
+    from edgegaussians_amd._lib import AdamHyper, call, ptr, stream
+    N = 1000
+    g = torch.Generator().manual_seed(2)
+    shapes = {"means": 3, "scales": 3, "quats": 4, "opacities": 1}
+    lrs = {"means": 2e-3, "scales": 1e-4, "quats": 1e-3, "opacities": 0.03}
+    ps = {k: torch.randn(N, d, generator=g) for k, d in shapes.items()}
+    ref = {k: torch.nn.Parameter(v.clone()) for k, v in ps.items()}
+    opts = {k: torch.optim.Adam([ref[k]], lr=lrs[k]) for k in ref}
+    dev = {k: v.clone().cuda() for k, v in ps.items()}
+    m = torch.zeros(11 * N, device="cuda")
+    v = torch.zeros(11 * N, device="cuda")
+    for step in range(1, 6):
+        grads = {k: torch.randn(N, d, generator=g) * 10 ** float(torch.randint(-6, 0, (1,), generator=g))
+                 for k, d in shapes.items()}
+        if step == 3:
+            grads["quats"].zero_()  # zero gradients still move the parameter through the moments
+        for k in ref:
+            ref[k].grad = grads[k].clone()
+            opts[k].step()
+        gd = {k: t.cuda().contiguous() for k, t in grads.items()}
+        h = AdamHyper(lrs["means"], lrs["scales"], lrs["quats"], lrs["opacities"], 0.9, 0.999, 1e-8, step)
+        call("eg_adam_multi", ptr(dev["means"]), ptr(dev["scales"]), ptr(dev["quats"]), ptr(dev["opacities"]),
+             ptr(gd["means"]), ptr(gd["scales"]), ptr(gd["quats"]), ptr(gd["opacities"]), ptr(m), ptr(v), N, h,
+             stream())
+    for k in ref:
+        assert_close(dev[k], ref[k].data, rtol=1e-5, name=f"adam {k}")
+
+
+def _reference_steps_cpu(O, synth, sc, views, strategies, lrs, n_steps):
+    """K iterations of the reference protocol (train_gaussians.py:81-106) on the CPU oracle."""
+    N = sc.means.shape[0]
+    P = {"means": torch.nn.Parameter(sc.means.clone()), "scales": torch.nn.Parameter(sc.log_scales.clone()),
+         "quats": torch.nn.Parameter(sc.quats.clone()), "opacities": torch.nn.Parameter(sc.logit_opacities.clone())}
+    opts = {k: torch.optim.Adam([P[k]], lr=lrs[k]) for k in P}
+    absgrads = torch.zeros(N)
+    losses = []
+    for s in range(n_steps):
+        v = views[s]
+        render, alpha, info = O.rasterization(
+            means=P["means"], quats=P["quats"], scales=torch.exp(P["scales"]),
+            opacities=torch.sigmoid(P["opacities"]).squeeze(-1), colors=torch.ones(N, 3),
+            viewmats=sc.viewmats[v:v + 1], Ks=sc.Ks[v:v + 1], width=sc.width, height=sc.height, tile_size=16,
+            packed=False, absgrad=True, rasterize_mode="antialiased")
+        info["means2d"].retain_grad()
+        w = synth.weight_map(strategies[s], sc.gt[v], generator=torch.Generator().manual_seed(100 + s))
+        loss = O.edge_step_loss(render[0, ..., 0], sc.gt[v], w)
+        losses.append(float(loss))
+        loss.backward()
+        absgrads += info["means2d"].absgrad[0].norm(dim=-1)
+        for o in opts.values():
+            o.step()
+            o.zero_grad()
+    return P, absgrads, losses
+
+
+def test_fused_train_step_matches_reference_protocol(env):
+    _lib, synth, O = env
+    from edgegaussians_amd import EdgeTrainer, LRSchedule
+    sc = _scene(synth, n=2000, w=128, h=96, views=3)
+    views = [0, 2, 1, 0]
+    strategies = ["weighted", "bg_edge_ratio", "whole", "weighted"]
+    sched = LRSchedule(scales_start=0, quats_start=0, opacities_start=0)
+    lrs = sched.at(0)
+    P, absgrads, losses = _reference_steps_cpu(O, synth, sc, views, strategies, lrs, len(views))
+    tr = EdgeTrainer(sc.means, sc.log_scales, sc.quats, sc.logit_opacities, sc.viewmats, sc.Ks, sc.gt,
+                     sc.width, sc.height, schedule=sched)
+    tr.ensure_capacity()
+    got = []
+    for s, v in enumerate(views):
+        w = synth.weight_map(strategies[s], sc.gt[v], generator=torch.Generator().manual_seed(100 + s)).cuda()
+        tr.train_step(v, w)
+        got.append(tr.pop_loss())
+    assert not tr.overflowed()
+    for a, b in zip(got, losses):
+        assert abs(a - b) <= 2e-4 * abs(b), (got, losses)
+    # Adam normalises the update, so the first steps move every parameter by ~lr regardless of the
+    # gradient scale: compare the parameter DELTAS with a tolerance that admits sign-borderline noise
+    for name, mine in (("means", tr.means), ("scales", tr.log_scales), ("quats", tr.quats),
+                       ("opacities", tr.logit_opacities.view(-1, 1))):
+        init = {"means": sc.means, "scales": sc.log_scales, "quats": sc.quats, "opacities": sc.logit_opacities}[name]
+        d_ref = P[name].data - init
+        d_got = mine.cpu() - init
+        assert_close(d_got, d_ref, rtol=2e-3, max_bad=2e-2, name=f"delta {name}")
+    assert_close(tr.absgrads, absgrads, max_bad=5e-3, name="absgrads")
+    assert tr.absgrads_normalize_factor == 1 + len(views)
+
+
+def test_grad_step_equals_autograd_path(env):
+    """eg_train_step without Adam (the data-parallel leg) == rasterization() + torch autograd."""
+    _lib, synth, O = env
+    from edgegaussians_amd import EdgeTrainer, rasterization
+    sc = _scene(synth, n=2500, w=160, h=112, views=2)
+    tr = EdgeTrainer(sc.means, sc.log_scales, sc.quats, sc.logit_opacities, sc.viewmats, sc.Ks, sc.gt,
+                     sc.width, sc.height)
+    tr.ensure_capacity()
+    w = synth.weight_map("weighted", sc.gt[1]).cuda()
+    tr.grad_step(1, w)
+    gm, gq, gs, go = [t.clone() for t in tr.grad_views()]
+    N = sc.means.shape[0]
+    means = sc.means.clone().cuda().requires_grad_(True)
+    ls = sc.log_scales.clone().cuda().requires_grad_(True)
+    q = sc.quats.clone().cuda().requires_grad_(True)
+    lo = sc.logit_opacities.clone().cuda().requires_grad_(True)
+    render, alpha, info = rasterization(means, q, torch.exp(ls), torch.sigmoid(lo).squeeze(-1),
+                                        torch.ones(N, 3, device="cuda"), sc.viewmats[1:2].cuda(), sc.Ks[1:2].cuda(),
+                                        sc.width, sc.height, packed=False, absgrad=True, rasterize_mode="antialiased")
+    loss = (w * (torch.clamp(render[0, ..., 0], 0, 1) - sc.gt[1].cuda()).abs()).sum()
+    loss.backward()
+    assert abs(tr.pop_loss() - float(loss)) <= 1e-5 * abs(float(loss))
+    assert_close(gm, means.grad, rtol=1e-4, max_bad=1e-3, name="means")
+    assert_close(gq, q.grad, rtol=1e-4, max_bad=1e-3, name="quats")
+    assert_close(gs, ls.grad, rtol=1e-4, max_bad=1e-3, name="scales")
+    assert_close(go, lo.grad.view(-1), rtol=1e-4, max_bad=1e-3, name="opacities")
+    inc = tr.grads.view(-1)[11 * N:]
+    assert_close(inc, info["means2d"].absgrad[0].norm(dim=-1), rtol=1e-4, max_bad=1e-3, name="absgrad inc")
+
+
+# ------------------------------------------------------------------ densify / cull vs the reference's own outputs
+def test_densify_cull_golden(env, golden_dir):
+    import os
+    _lib, synth, O = env
+    from edgegaussians_amd import EdgeTrainer
+    d = np.load(os.path.join(golden_dir, "densify_cull.npz"))
+    cams = np.load(os.path.join(golden_dir, "cameras_00004926.npz"))
+    edges = np.load(os.path.join(golden_dir, "edges_00004926.npz"))
+    keep_views = list(edges["views"])
+    H, W = int(cams["height"]), int(cams["width"])
+    T = lambda k: torch.from_numpy(d[k])  # noqa: E731
+    gt = torch.zeros(len(keep_views), H, W)
+    for i, k in enumerate(keep_views):
+        gt[i].view(-1)[torch.from_numpy(edges[f"idx_{k}"]).long()] = torch.from_numpy(edges[f"val_{k}"]).float() / 255.0
+    tr = EdgeTrainer(T("before_means"), T("before_scales"), T("before_quats"), T("before_opacities"),
+                     torch.from_numpy(cams["viewmats"][keep_views]), torch.from_numpy(cams["Ks"][keep_views]), gt, W, H)
+    N = tr.N
+    for t, key in ((tr.adam_m, "exp_avg"), (tr.adam_v, "exp_avg_sq")):
+        off = 0
+        for name, dim in (("means", 3), ("scales", 3), ("quats", 4), ("opacities", 1)):
+            t[off:off + N * dim] = T(f"before_{name}_{key}").reshape(-1).cuda()
+            off += N * dim
+    tr.absgrads = T("absgrads").cuda()
+    tr.absgrads_normalize_factor = float(d["absgrads_factor"])
+    # duplicate_high_pos_gradients ('absolute', 0.5, dup_factor 3, noise 0.05: configs/ABC_DexiNed.json)
+    n_sel = tr.duplicate_high_pos_gradients(0.5, 3, 0.05, noise=T("dup_noise"))
+    assert tr.N == d["dup_means"].shape[0] and n_sel * 2 == tr.N - N
+    for name, p in tr._params().items():
+        assert_close(p, T(f"dup_{name}"), rtol=1e-6, name=f"dup {name}")
+        assert_close(tr._moment_views(tr.adam_m)[name], T(f"dup_{name}_exp_avg"), rtol=1e-6, name=f"dup m {name}")
+        assert_close(tr._moment_views(tr.adam_v)[name], T(f"dup_{name}_exp_avg_sq"), rtol=1e-6, name=f"dup v {name}")
+    assert tr.absgrads.shape[0] == int(d["dup_absgrads_len"]) and float(tr.absgrads.abs().sum()) == 0
+    assert tr.absgrads_normalize_factor == float(d["dup_factor_after"])
+    # cull_gaussians_opacity (absolute 0.05)
+    tr.absgrads = torch.arange(tr.N, device="cuda").float()
+    tr.cull_opacity(0.05)
+    for name, p in tr._params().items():
+        assert_close(p, T(f"cull_{name}"), rtol=1e-6, name=f"cull {name}")
+        assert_close(tr._moment_views(tr.adam_m)[name], T(f"cull_{name}_exp_avg"), rtol=1e-6, name=f"cull m {name}")
+    assert np.array_equal(to_np(tr.absgrads), d["cull_absgrads"])
+    # cull_gaussians_not_projecting over the 4 fixture views
+    assert_close(tr.means, T("np_means_before"), rtol=1e-6, name="np means")
+    tr.absgrads = torch.arange(tr.N, device="cuda").float()
+    tr.cull_not_projecting((gt >= 0.5).to(torch.uint8).cuda(), 0.1)
+    assert np.array_equal(to_np(tr.absgrads).astype(np.int64), d["np_kept_index"])
