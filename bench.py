@@ -1,0 +1,223 @@
+#!/usr/bin/env python3
+"""bench.py -- train-step Gaussians*views/sec of the edge-Gaussian hot path on N MI355X.
+
+    python bench.py --gpus 1 --steps 200 --warmup 20
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
+        --master-port 29500 bench.py --gpus 8 --steps 200 --warmup 20
+
+One "step" = one pass of the hot path over one view per GPU: project -> tile-bin -> sort ->
+alpha-composite -> weighted-L1 -> backward -> absgrad -> Adam on all 11 floats/Gaussian
+(train_gaussians.py:81-106 of the reference).  N GPUs = N views per step (weak scaling), one
+RCCL all-reduce of the fused [N,12] gradient buffer per step.  Inputs are resident in HBM before
+the timed region starts.  Prints ONE JSON line on rank 0.
+
+Workload (BASELINE.json): default = configs[1], "ABC-NEF 00004926, 100k Gaussians after densify,
+50 views @512x512, 1xMI355X" -- synthetic Gaussians of that shape (edgegaussians_amd/synth.py),
+loss strategy alternating like configs/ABC_DexiNed.json:85-92 after epoch 50 (bg_edge_ratio on
+every 5th step, whole otherwise).
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CONFIGS = {
+    # name: (n_gauss, n_views, width, height)
+    "config1": (30_000, 50, 512, 512),
+    "config2": (100_000, 50, 512, 512),
+    "config3": (200_000, 49, 1600, 1200),
+    "config4": (500_000, 200, 1200, 680),
+}
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (~6.3 TB/s achievable)
+
+
+def algorithmic_bytes(n, m, hw):
+    """B = 626 N + 100 M + 40 HW per view-step, split over the kernels of THIS
+    design (DESIGN.md 'algorithmic bytes'); the 8 B/isect of gsplat's offset-encode pass has no
+    counterpart here (offsets come from the per-tile scan)."""
+    return {
+        "project_fwd": 108 * n,            # G1 80 + per-Gaussian binning 28
+        "tile_offsets": 0,
+        "tile_emit": 12 * m,
+        "tile_sort": 24 * m,
+        "composite_fwd": 28 * m + 20 * hw,
+        "composite_bwd": 28 * m + 20 * hw + 64 * n,
+        "project_bwd_adam": 454 * n,       # G9 130 + absgrad 16 + Adam 308
+        "step_total": 626 * n + 100 * m + 40 * hw,
+    }
+
+
+def build_trainer(cfg, seed, device):
+    from edgegaussians_amd import EdgeTrainer, LRSchedule, synth
+    n, v, w, h = cfg
+    sc = synth.make_scene(n, v, w, h, seed=seed, anisotropy=5.0, spread_opacity=False)
+    # all four learning rates live (as after epoch 30 of the reference schedule)
+    sched = LRSchedule(scales_start=0, quats_start=0, opacities_start=0)
+    tr = EdgeTrainer(sc.means, sc.log_scales, sc.quats, sc.logit_opacities, sc.viewmats, sc.Ks, sc.gt,
+                     w, h, device=device, schedule=sched)
+    g = torch.Generator().manual_seed(seed + 1)
+    whole = synth.weight_map("whole", sc.gt[0]).to(device).contiguous()
+    ratio = [synth.weight_map("bg_edge_ratio", sc.gt[i], 1.0, g).to(device).contiguous() for i in range(v)]
+    return tr, sc, whole, ratio
+
+
+def cpu_baseline(sc, budget_s=25.0):
+    """The CPU oracle (oracle/ref_torch.py: dense PyTorch restatement, autograd backward, torch
+    Adam) timed on this host on a bounded sample of the SAME workload: whole view-steps until
+    ~budget_s of CPU time is spent (at least one)."""
+    from oracle import ref_torch as O
+    from edgegaussians_amd import synth
+    n = sc.means.shape[0]
+    P = {"means": torch.nn.Parameter(sc.means.clone()), "scales": torch.nn.Parameter(sc.log_scales.clone()),
+         "quats": torch.nn.Parameter(sc.quats.clone()), "opacities": torch.nn.Parameter(sc.logit_opacities.clone())}
+    lrs = {"means": 2e-3, "scales": 1e-4, "quats": 1e-3, "opacities": 0.03}
+    opts = [torch.optim.Adam([P[k]], lr=lrs[k]) for k in P]
+    absgrads = torch.zeros(n)
+    colors = torch.ones(n, 3)
+    steps, t0 = 0, time.perf_counter()
+    while True:
+        v = steps % sc.viewmats.shape[0]
+        render, _, info = O.rasterization(
+            means=P["means"], quats=P["quats"], scales=torch.exp(P["scales"]),
+            opacities=torch.sigmoid(P["opacities"]).squeeze(-1), colors=colors, viewmats=sc.viewmats[v:v + 1],
+            Ks=sc.Ks[v:v + 1], width=sc.width, height=sc.height, tile_size=16, packed=False, absgrad=True,
+            rasterize_mode="antialiased")
+        info["means2d"].retain_grad()
+        w = synth.weight_map("whole", sc.gt[v])
+        O.edge_step_loss(render[0, ..., 0], sc.gt[v], w).backward()
+        absgrads += info["means2d"].absgrad[0].norm(dim=-1)
+        for o in opts:
+            o.step()
+            o.zero_grad()
+        steps += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or el + el / steps > 1.6 * budget_s:
+            break
+    return {"value": n * steps / el, "unit": "Gaussians*views/s", "cores": torch.get_num_threads(),
+            "kind": "port", "ms_per_step": 1e3 * el / steps,
+            "sample": f"{steps} view-step(s) of the same workload (N={n}, {sc.width}x{sc.height}), "
+                      f"oracle/ref_torch.py on {torch.get_num_threads()} torch threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", default="config2", choices=sorted(CONFIGS))
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=25.0)
+    ap.add_argument("--profile-only", action="store_true",
+                    help="run only warmup+steps of the fused step (for rocprofv3), skip stage timing/CPU leg")
+    args = ap.parse_args()
+
+    from edgegaussians_amd import dist as egdist
+    rank, local, world = egdist.init_from_env("nccl")
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    torch.cuda.set_device(local)
+    device = f"cuda:{local}"
+    import torch.distributed as dist
+
+    cfg = CONFIGS[args.config]
+    n, n_views, w, h = cfg
+    tr, sc, whole, ratio = build_trainer(cfg, args.seed, device)
+    m_max = tr.ensure_capacity()
+    dp = egdist.DataParallelStep(tr) if world > 1 else None
+
+    def wmap_for(step, view):
+        return ratio[view] if step % 5 == 0 else whole  # configs/ABC_DexiNed.json:85-92
+
+    def run(k, step0):
+        for s in range(step0, step0 + k):
+            if dp is None:
+                v = s % n_views
+                tr.train_step(v, wmap_for(s, v))
+            else:
+                v = egdist.view_for(s, rank, world, n_views)
+                dp.step(v, wmap_for(s, v))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    run(args.warmup, 0)
+    barrier()
+    t0 = time.perf_counter()
+    run(args.steps, args.warmup)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    loss_sum = tr.pop_loss()
+    if tr.overflowed() or not math.isfinite(loss_sum):
+        raise SystemExit(f"invalid run: overflow={tr.overflowed()} loss={loss_sum}")
+    m_last = tr.last_m()
+
+    out = {
+        "metric": "train-step Gaussians*views/sec",
+        "value": n * args.steps * world / dt,
+        "unit": "Gaussians*views/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * dt / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{args.config}: {n} Gaussians (5:1 anisotropic, scale 0.004, opacity 0.08), "
+                               f"{n_views} views @{w}x{h}, loss whole/bg_edge_ratio 4:1",
+                   "n_gaussians": n, "views": n_views, "width": w, "height": h,
+                   "tile_intersections_M": m_last, "views_per_step": world,
+                   "parallelism": f"dp{world} (views sharded, RCCL all-reduce of [N,12] grads)" if world > 1 else "single GPU"},
+        "mean_loss": loss_sum / (args.warmup + args.steps),
+    }
+
+    if rank == 0 and world == 1 and not args.profile_only:
+        # ---- per-stage durations with HIP events on the launch stream (torch's current stream)
+        k = min(args.steps, 100)
+        names = ["project_fwd", "tile_offsets", "tile_emit", "tile_sort", "composite_fwd", "composite_bwd",
+                 "project_bwd_adam"]
+        evs = [[torch.cuda.Event(enable_timing=True) for _ in range(len(names) + 1)] for _ in range(k)]
+        for s in range(k):
+            it = iter(evs[s])
+            v = s % n_views
+            tr.train_step_staged(v, wmap_for(s, v), mark=lambda name, it=it: next(it).record())
+        torch.cuda.synchronize()
+        stage_us = {nm: 1e3 * sum(evs[s][i].elapsed_time(evs[s][i + 1]) for s in range(k)) / k
+                    for i, nm in enumerate(names)}
+        tr.pop_loss()
+        ab = algorithmic_bytes(n, m_last, w * h)
+        dom = max(stage_us, key=stage_us.get)
+        achieved = ab[dom] / (stage_us[dom] * 1e-6) / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", f"r01_pmc_{args.config}.json")
+        if os.path.exists(pmc):
+            traffic = json.load(open(pmc)).get(dom, {}).get("hbm_bytes_per_launch")
+        out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
+                           "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                           "algorithmic_bytes_per_launch": ab[dom], "avg_launch_us": stage_us[dom]}
+        out["stages_us"] = stage_us
+        out["step_roofline"] = {"algorithmic_bytes_per_step": ab["step_total"],
+                                "achieved_GBps": ab["step_total"] / (dt / args.steps) / 1e9,
+                                "frac": ab["step_total"] / (dt / args.steps) / 1e9 / HBM_PEAK_GBS}
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(sc, args.cpu_budget)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -211,6 +211,46 @@ class EdgeTrainer:
         self.absgrads_normalize_factor += 1  # edge_gs.py:613
         self.step += 1
 
+    def train_step_staged(self, view: int, wmap: Tensor, mark=None) -> None:
+        """The same step as ``train_step`` but sequenced from Python, one C-ABI call per stage, with
+        ``mark(stage_name)`` called after each enqueue -- bench.py brackets the stages with HIP
+        events through it.  Results are identical to ``train_step`` (same kernels, same order)."""
+        if self.capacity == 0:
+            self.ensure_capacity()
+        mark = mark or (lambda name: None)
+        self.adam_step += 1
+        self._set_hyper()
+        fl = _lib.FLAG_LOG_SCALES | _lib.FLAG_LOGIT_OPACITIES | _lib.FLAG_ANTIALIASED
+        st = stream()
+        vm, K = ptr(self.viewmats[view]), ptr(self.Ks[view])
+        N, W, H = self.N, self.width, self.height
+        mark("start")
+        call("eg_project_fwd", ptr(self.means), ptr(self.quats), ptr(self.log_scales), ptr(self.logit_opacities),
+             vm, K, N, W, H, 0.01, 1e10, 0.3, 0.0, fl, ptr(self.splat), None, None, None, None, None, None,
+             ptr(self.tile_counts), ptr(self.g2d), st)
+        mark("project_fwd")
+        call("eg_tile_offsets", ptr(self.tile_counts), self.T, self.capacity, ptr(self.offsets), ptr(self.total), st)
+        mark("tile_offsets")
+        call("eg_tile_emit", None, None, None, ptr(self.splat), N, W, H, ptr(self.offsets), ptr(self.tile_counts),
+             self.capacity, ptr(self.keys), st)
+        mark("tile_emit")
+        call("eg_sort_pairs", ptr(self.keys), ptr(self.offsets), self.T, self.capacity, ptr(self.flatten_ids),
+             None, st)
+        mark("tile_sort")
+        call("eg_composite_fwd", ptr(self.splat), None, 1, ptr(self.offsets), ptr(self.flatten_ids), W, H,
+             ptr(self.render), ptr(self.alphas), ptr(self.last_ids), ptr(self.gt[view]), ptr(wmap),
+             self.loss_scale, ptr(self.vpix), ptr(self.loss_acc), st)
+        mark("composite_fwd")
+        call("eg_composite_bwd", ptr(self.splat), ptr(self.offsets), ptr(self.flatten_ids), W, H, ptr(self.alphas),
+             ptr(self.last_ids), ptr(self.vpix), ptr(self.g2d), st)
+        mark("composite_bwd")
+        call("eg_project_bwd_adam", ptr(self.means), ptr(self.quats), ptr(self.log_scales),
+             ptr(self.logit_opacities), vm, K, N, W, H, 0.3, fl, ptr(self.splat), ptr(self.g2d), ptr(self.adam_m),
+             ptr(self.adam_v), ptr(self.absgrads), self._hyper, st)
+        mark("project_bwd_adam")
+        self.absgrads_normalize_factor += 1
+        self.step += 1
+
     def grad_step(self, view: int, wmap: Tensor) -> Tensor:
         """Forward + loss + backward only: leaves dL/d{means,quats,log_scales,logit_opacities} in
         ``self.grads`` ([means 3N | quats 4N | scales 3N | opac N | absgrad increment N] flat
