@@ -24,6 +24,7 @@ _f = C.c_float
 FLAG_LOG_SCALES = 1
 FLAG_LOGIT_OPACITIES = 2
 FLAG_ANTIALIASED = 4
+FLAG_TIGHT_TILES = 8
 
 
 class AdamHyper(C.Structure):
@@ -39,9 +40,11 @@ class StepArgs(C.Structure):
         ("viewmat", _vp), ("K", _vp), ("gt", _vp), ("wmap", _vp),
         ("width", _i32), ("height", _i32), ("loss_scale", _f),
         ("splat", _vp), ("g2d", _vp),
-        ("tile_counts", _vp), ("offsets", _vp), ("total", _vp),
+        ("tile_counts", _vp), ("offsets", _vp), ("item_offsets", _vp), ("total", _vp),
+        ("workspace", _vp), ("max_items", _i64),
         ("keys", _vp), ("flatten_ids", _vp), ("capacity", _i64),
-        ("render", _vp), ("alphas", _vp), ("vpix", _vp), ("loss", _vp), ("last_ids", _vp),
+        ("render", _vp), ("alphas", _vp), ("vpix", _vp), ("loss", _vp), ("gtstop", _vp), ("big_list", _vp),
+        ("parity", _i32), ("last_ids", _vp),
         ("v_means", _vp), ("v_quats", _vp), ("v_scales", _vp), ("v_opacities", _vp),
         ("adam_host", C.POINTER(AdamHyper)),
     ]
@@ -51,14 +54,18 @@ class StepArgs(C.Structure):
 _SIGS = {
     "eg_project_fwd": [_vp] * 6 + [_i32, _i32, _i32, _f, _f, _f, _f, _u32] + [_vp] * 9 + [_vp],
     "eg_tile_count": [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp],
-    "eg_tile_offsets": [_vp, _i32, _i64, _vp, _vp, _vp],
-    "eg_tile_emit": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _i64, _vp, _vp],
+    "eg_tile_offsets": [_vp, _i32, _i64, _vp, _vp, _vp, _vp],
+    "eg_tile_emit": [_vp, _vp, _vp, _vp, _u32, _i32, _i32, _i32, _vp, _vp, _i64, _vp, _vp],
     "eg_sort_pairs": [_vp, _vp, _i32, _i64, _vp, _vp, _vp],
-    "eg_composite_fwd": [_vp, _vp, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp],
-    "eg_composite_bwd": [_vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp],
+    "eg_composite_fwd": [_vp, _vp, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp,
+                         _vp, _vp, _i64, _vp, _vp, _vp],
+    "eg_composite_bwd": [_vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp],
     "eg_composite_bwd_colors": [_vp, _vp, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "eg_project_bwd": [_vp] * 6 + [_i32, _i32, _i32, _f, _u32] + [_vp] * 9 + [_vp],
     "eg_absgrad_accum": [_vp, _i32, _vp, _vp],
+    "eg_composite_bwd_footprint": [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _vp],
+    "eg_backward_fused": [_vp] * 6 + [_i32, _i32, _i32, _f, _u32] + [_vp] * 10 + [C.POINTER(AdamHyper), _vp, _i32,
+                                                                                 _vp],
     "eg_adam_multi": [_vp] * 10 + [_i32, AdamHyper, _vp],
     "eg_project_bwd_adam": [_vp] * 6 + [_i32, _i32, _i32, _f, _u32] + [_vp] * 5 + [AdamHyper, _vp],
     "eg_mask_scan": [_vp, _i32, _vp, _vp, _vp],
@@ -67,7 +74,9 @@ _SIGS = {
     "eg_project_hits": [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _vp, _vp],
     "eg_train_step": [C.POINTER(StepArgs), _vp],
 }
-EXPORTS = sorted(list(_SIGS) + ["eg_last_error_string", "eg_version", "eg_device_count"])
+EXPORTS = sorted(list(_SIGS) + ["eg_last_error_string", "eg_version", "eg_device_count",
+                                 "eg_composite_workspace_bytes", "eg_timing_begin", "eg_timing_end",
+                                 "eg_timing_stage_count", "eg_timing_stage_name"])
 
 _lib: Optional[C.CDLL] = None
 
@@ -89,6 +98,12 @@ def load(require_device: bool = True) -> C.CDLL:
         lib.eg_last_error_string.argtypes = []
         lib.eg_version.restype = C.c_int
         lib.eg_device_count.restype = C.c_int
+        lib.eg_timing_begin.argtypes = [_i32]
+        lib.eg_timing_end.argtypes = [C.POINTER(C.c_float), C.POINTER(_i32)]
+        lib.eg_timing_stage_name.argtypes = [_i32]
+        lib.eg_timing_stage_name.restype = C.c_char_p
+        lib.eg_composite_workspace_bytes.restype = _i64
+        lib.eg_composite_workspace_bytes.argtypes = [_i64]
         _lib = lib
     if require_device and not torch.cuda.is_available():
         raise RuntimeError("edgegaussians_amd needs a gfx950 GPU (torch.cuda.is_available() is False); "

@@ -12,7 +12,8 @@
 //   3. emit: each (Gaussian, tile) claims a slot in its tile's segment with a returning atomic that
 //      counts the tile's counter back DOWN (so the counters are zero again for the next step) and
 //      writes key = depth_bits << 32 | gaussian_id                            -> keys[M]
-//   4. one workgroup per tile sorts its segment in LDS (bitonic network on unique 64-bit keys)
+//   4. one workgroup per tile sorts its segment in LDS (bucket + rank on unique 64-bit keys;
+//      bitonic network as the fallback)
 // The result is bit-identical to gsplat's stable sort: inside a tile the order is by depth bits with
 // ties broken by Gaussian id, which is exactly what a stable sort of index-ordered emissions gives.
 // Segments larger than the LDS capacity fall back to a hybrid global/LDS bitonic sort by the
@@ -21,127 +22,211 @@
 
 namespace eg {
 
-__global__ void __launch_bounds__(256)
+// Per-tile counting with LDS privatisation.  All of a view's hot tile counters sit in a handful of
+// cache lines (the object covers ~13x13 central tiles), so per-intersection global atomics serialise
+// on those lines (measured: 250 us for 480k atomics).  Each 512-thread workgroup histograms its
+// Gaussians into LDS first and flushes one global atomic per touched tile.
+constexpr int kBinThreads = 512;
+constexpr int kMaxLdsTiles = 16384;  // 64 KiB of counters; larger grids use the direct-atomic path
+
+template <bool LDS>
+__global__ void __launch_bounds__(kBinThreads)
 tile_count_kernel(const float2 *__restrict__ means2d, const int *__restrict__ radii, int N, int width,
                   int height, int *__restrict__ tiles_per_gauss, int *__restrict__ tile_counts) {
-  const int g = blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= N) return;
-  const int radius = radii[g];
-  int n = 0;
-  if (radius > 0) {
-    const int tw = (width + kTile - 1) / kTile, th = (height + kTile - 1) / kTile;
-    const float2 m = means2d[g];
-    int x0, y0, x1, y1;
-    tile_box(m.x, m.y, radius, tw, th, x0, y0, x1, y1);
-    n = (y1 - y0) * (x1 - x0);
-    for (int ty = y0; ty < y1; ++ty)
-      for (int tx = x0; tx < x1; ++tx) atomicAdd(&tile_counts[ty * tw + tx], 1);
+  extern __shared__ __attribute__((aligned(16))) int s_hist[];
+  const int tw = (width + kTile - 1) / kTile, th = (height + kTile - 1) / kTile, T = tw * th;
+  if (LDS) {
+    for (int t = threadIdx.x; t < T; t += kBinThreads) s_hist[t] = 0;
+    __syncthreads();
   }
-  if (tiles_per_gauss) tiles_per_gauss[g] = n;
+  const int g = blockIdx.x * kBinThreads + threadIdx.x;
+  if (g < N) {
+    const int radius = radii[g];
+    int n = 0;
+    if (radius > 0) {
+      const float2 m = means2d[g];
+      int x0, y0, x1, y1;
+      tile_box(m.x, m.y, radius, tw, th, x0, y0, x1, y1);
+      n = (y1 - y0) * (x1 - x0);
+      for (int ty = y0; ty < y1; ++ty)
+        for (int tx = x0; tx < x1; ++tx) atomicAdd(LDS ? &s_hist[ty * tw + tx] : &tile_counts[ty * tw + tx], 1);
+    }
+    if (tiles_per_gauss) tiles_per_gauss[g] = n;
+  }
+  if (LDS) {
+    __syncthreads();
+    for (int t = threadIdx.x; t < T; t += kBinThreads) {
+      const int c = s_hist[t];
+      if (c) atomicAdd(&tile_counts[t], c);
+    }
+  }
 }
 
 // single workgroup, 1024 threads: exclusive scan of counts[T] -> offsets[T+1]; counts stay intact
-// (the emit pass counts them back down to zero, so no memset is ever needed between steps)
+// (the emit pass counts them back down to zero, so no memset is ever needed between steps).
+// Also scans the per-tile SLICE counts ceil(n_t / 256) -> item_offsets[T+1]: the compositing kernels
+// run one workgroup per (tile, 256-Gaussian slice) "item", so a tile holding thousands of Gaussians
+// is spread over many CUs instead of serialising on one.
+__device__ __forceinline__ int block_excl_scan_1024(int c, int *wave_sums, int &block_total) {
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  int s = c;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int o = __shfl_up(s, d, 64);
+    if (lane >= d) s += o;
+  }
+  if (lane == 63) wave_sums[wv] = s;
+  __syncthreads();
+  if (wv == 0) {
+    int ws = (lane < 16) ? wave_sums[lane] : 0;
+#pragma unroll
+    for (int d = 1; d < 16; d <<= 1) {
+      const int o = __shfl_up(ws, d, 64);
+      if (lane >= d) ws += o;
+    }
+    if (lane < 16) wave_sums[lane] = ws;  // inclusive over waves
+  }
+  __syncthreads();
+  const int wave_excl = (wv == 0) ? 0 : wave_sums[wv - 1];
+  block_total = wave_sums[15];
+  const int r = wave_excl + (s - c);
+  __syncthreads();
+  return r;
+}
+
 __global__ void __launch_bounds__(1024)
 tile_offsets_kernel(const int *__restrict__ counts, int T, long long capacity, int *__restrict__ offsets,
-                    int *__restrict__ total) {
+                    int *__restrict__ item_offsets, int *__restrict__ total) {
   __shared__ int wave_sums[16];
-  __shared__ int carry;
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  if (tid == 0) carry = 0;
-  __syncthreads();
+  const int tid = threadIdx.x;
+  int carry = 0, icarry = 0, cmax = 0;
   for (int base = 0; base < T; base += 1024) {
     const int i = base + tid;
     const int c = (i < T) ? counts[i] : 0;
-    // inclusive scan inside the wave
-    int s = c;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const int o = __shfl_up(s, d, 64);
-      if (lane >= d) s += o;
+    const int it = (c + 255) >> 8;
+    int tot, itot;
+    const int e = block_excl_scan_1024(c, wave_sums, tot);
+    const int ie = block_excl_scan_1024(it, wave_sums, itot);
+    if (i < T) {
+      // clamped to the buffer capacity: on overflow (flagged in total[1]) every downstream range stays
+      // inside the isect buffers instead of faulting
+      offsets[i] = (int)min((long long)(carry + e), capacity);
+      if (item_offsets) item_offsets[i] = icarry + ie;
     }
-    if (lane == 63) wave_sums[wv] = s;
-    __syncthreads();
-    if (wv == 0) {
-      int ws = (lane < 16) ? wave_sums[lane] : 0;
-#pragma unroll
-      for (int d = 1; d < 16; d <<= 1) {
-        const int o = __shfl_up(ws, d, 64);
-        if (lane >= d) ws += o;
-      }
-      if (lane < 16) wave_sums[lane] = ws;  // inclusive over waves
-    }
-    __syncthreads();
-    const int wave_excl = (wv == 0) ? 0 : wave_sums[wv - 1];
-    const int excl = carry + wave_excl + (s - c);
-    if (i < T) offsets[i] = excl;
-    __syncthreads();
-    if (tid == 1023) carry = excl + c;
-    __syncthreads();
+    carry += tot;
+    icarry += itot;
+    cmax = max(cmax, c);
   }
+  // max tile population (sizes the sort variant that has to run)
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) cmax = max(cmax, __shfl_xor(cmax, d, 64));
+  if ((tid & 63) == 0) wave_sums[tid >> 6] = cmax;
+  __syncthreads();
   if (tid == 0) {
-    offsets[T] = carry;
+    for (int w = 1; w < 16; ++w) cmax = max(cmax, wave_sums[w]);
+    offsets[T] = (int)min((long long)carry, capacity);
+    if (item_offsets) item_offsets[T] = icarry;
     if (total) {
       total[0] = carry;
       total[1] = ((long long)carry > capacity) ? 1 : 0;
+      total[2] = icarry;
+      total[3] = cmax;
     }
   }
 }
 
-__global__ void __launch_bounds__(256)
+// emit: block-local histogram in LDS -> ONE returning global atomic per (block, touched tile) reserves
+// a run of slots in the tile's segment -> block-local LDS cursors hand out the slots.
+template <bool LDS>
+__global__ void __launch_bounds__(kBinThreads)
 tile_emit_kernel(const float2 *__restrict__ means2d, const int *__restrict__ radii,
-                 const float *__restrict__ depths, const float4 *__restrict__ splat, int N, int width,
-                 int height, const int *__restrict__ offsets, int *__restrict__ cursor, long long capacity,
-                 unsigned long long *__restrict__ keys) {
-  const int g = blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= N) return;
-  float x, y, depth;
-  int radius;
-  if (splat) {
-    const float4 s0 = splat[2 * g], s1 = splat[2 * g + 1];
-    x = s0.x; y = s0.y; depth = s1.z; radius = __float_as_int(s1.w);
-  } else {
-    const float2 m = means2d[g];
-    x = m.x; y = m.y; depth = depths[g]; radius = radii[g];
+                 const float *__restrict__ depths, const float4 *__restrict__ splat, unsigned flags, int N,
+                 int width, int height, const int *__restrict__ offsets, int *__restrict__ cursor,
+                 long long capacity, unsigned long long *__restrict__ keys) {
+  extern __shared__ __attribute__((aligned(16))) int s_mem[];
+  const int tw = (width + kTile - 1) / kTile, th = (height + kTile - 1) / kTile, T = tw * th;
+  int *s_hist = s_mem, *s_base = s_mem + T;
+  if (LDS) {
+    for (int t = threadIdx.x; t < T; t += kBinThreads) s_hist[t] = 0;
+    __syncthreads();
   }
-  if (radius <= 0) return;
-  const int tw = (width + kTile - 1) / kTile, th = (height + kTile - 1) / kTile;
-  int x0, y0, x1, y1;
-  tile_box(x, y, radius, tw, th, x0, y0, x1, y1);
+  const int g = blockIdx.x * kBinThreads + threadIdx.x;
+  float x = 0.f, y = 0.f, depth = 0.f;
+  float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+  int radius = 0;
+  if (g < N) {
+    if (splat) {
+      s0 = splat[2 * g]; s1 = splat[2 * g + 1];
+      x = s0.x; y = s0.y; depth = s1.z; radius = __float_as_int(s1.w);
+    } else {
+      const float2 m = means2d[g];
+      x = m.x; y = m.y; depth = depths[g]; radius = radii[g];
+    }
+  }
+  int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
+  if (radius > 0) {
+    if (splat && (flags & EG_FLAG_TIGHT_TILES)) tile_box_tight(x, y, radius, s0.z, s0.w, s1.x, s1.y, tw, th, x0, y0, x1, y1);
+    else tile_box(x, y, radius, tw, th, x0, y0, x1, y1);
+  }
   const unsigned long long key = ((unsigned long long)(unsigned)__float_as_int(depth) << 32) | (unsigned)g;
+  if (!LDS) {
+    for (int ty = y0; ty < y1; ++ty)
+      for (int tx = x0; tx < x1; ++tx) {
+        const int t = ty * tw + tx;
+        const long long idx = (long long)offsets[t] + (atomicSub(&cursor[t], 1) - 1);
+        if (idx < capacity) keys[idx] = key;
+      }
+    return;
+  }
+  for (int ty = y0; ty < y1; ++ty)
+    for (int tx = x0; tx < x1; ++tx) atomicAdd(&s_hist[ty * tw + tx], 1);
+  __syncthreads();
+  for (int t = threadIdx.x; t < T; t += kBinThreads) {
+    const int c = s_hist[t];
+    if (c) {
+      s_base[t] = offsets[t] + (atomicSub(&cursor[t], c) - c);  // slots [base, base + c)
+      s_hist[t] = 0;
+    }
+  }
+  __syncthreads();
   for (int ty = y0; ty < y1; ++ty)
     for (int tx = x0; tx < x1; ++tx) {
       const int t = ty * tw + tx;
-      const long long idx = (long long)offsets[t] + (atomicSub(&cursor[t], 1) - 1);
+      const long long idx = (long long)s_base[t] + atomicAdd(&s_hist[t], 1);
       if (idx < capacity) keys[idx] = key;
     }
 }
 
 // ---------------------------------------------------------------------------------------------
-// segmented sort: one 256-thread workgroup per tile
-constexpr int kSortCap = 4096;  // keys per LDS pass (32 KiB)
-
-__device__ __forceinline__ void ce(unsigned long long &a, unsigned long long &b) {
-  if (a > b) { const unsigned long long t = a; a = b; b = t; }
-}
+// segmented sort: one workgroup per tile on unique 64-bit keys in LDS.
+// Two variants are launched back to back; each tile is handled by exactly one of them:
+//   small: 256 threads,  2 x 2048 keys (34 KiB LDS)  -- tiles with n <= 2048
+//   large: 1024 threads, 2 x 8192 keys (136 KiB LDS) -- tiles with n > 2048; bucket+rank up to 8192
+//          keys, in-LDS bitonic network up to 16384, hybrid global/LDS network beyond (any n, slow)
 
 // all compare-exchanges of bitonic stages k = k_lo .. k_hi restricted to strides < P, on s[0..P)
 // (ascending-only network: first substage of each k mirrors inside the k-block, then half-cleaners)
+template <int THREADS>
 __device__ __forceinline__ void bitonic_lds(unsigned long long *s, int P, int k_lo, int k_hi, int tid) {
+  // every size is a power of two: index math by shifts and masks (a runtime integer division costs
+  // more than the compare-exchange it addresses)
   for (int k = k_lo; k <= k_hi; k <<= 1) {
     if (k <= P) {
-      const int hk = k >> 1;
-      for (int i = tid; i < (P >> 1); i += 256) {
-        const int blk = i / hk, off = i - blk * hk;
-        const int lo = blk * k + off, hi = blk * k + k - 1 - off;
+      const int lhk = 31 - __clz(k) - 1;  // log2(k/2)
+      const int mk = (1 << lhk) - 1;
+      for (int i = tid; i < (P >> 1); i += THREADS) {
+        const int blk = i >> lhk, off = i & mk;
+        const int base = blk << (lhk + 1);
+        const int lo = base + off, hi = base + k - 1 - off;
         unsigned long long a = s[lo], b = s[hi];
         if (a > b) { s[lo] = b; s[hi] = a; }
       }
       __syncthreads();
     }
     for (int j = min(k >> 2, P >> 1); j >= 1; j >>= 1) {
-      for (int i = tid; i < (P >> 1); i += 256) {
-        const int lo = ((i / j) * (j << 1)) + (i % j), hi = lo + j;
+      const int lj = 31 - __clz(j);
+      for (int i = tid; i < (P >> 1); i += THREADS) {
+        const int lo = ((i >> lj) << (lj + 1)) + (i & (j - 1)), hi = lo + j;
         unsigned long long a = s[lo], b = s[hi];
         if (a > b) { s[lo] = b; s[hi] = a; }
       }
@@ -150,50 +235,177 @@ __device__ __forceinline__ void bitonic_lds(unsigned long long *s, int P, int k_
   }
 }
 
-__global__ void __launch_bounds__(256)
+// Bucket + rank sort (the fast path).  Keys inside one tile are spread over a narrow depth range, so
+// a monotone map depth -> bucket (uniform over the tile's own [min, max] depth bits, THREADS buckets)
+// followed by an exact rank inside each small bucket sorts the segment in O(n) LDS operations instead
+// of the bitonic network's O(n log^2 n) barrier-separated stages:
+//   load keys -> min/max -> LDS histogram -> block scan -> scatter by bucket -> rank inside bucket
+// Keys are unique 64-bit values, so the rank (number of smaller keys in the bucket) is the final
+// position: the result equals the stable (tile, depth) sort bit for bit.  A bucket that is too full
+// (many equal depths) falls back to the bitonic network for that tile.
+template <int THREADS>
+__device__ __forceinline__ int block_excl_scan(int c, int *wave_tmp, int &block_total) {
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  constexpr int NW = THREADS / 64;
+  int s = c;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int o = __shfl_up(s, d, 64);
+    if (lane >= d) s += o;
+  }
+  if (lane == 63) wave_tmp[wv] = s;
+  __syncthreads();
+  int pre = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) {
+    const int v = wave_tmp[w];
+    pre += (w < wv) ? v : 0;
+    tot += v;
+  }
+  block_total = tot;
+  __syncthreads();
+  return pre + (s - c);
+}
+
+template <int THREADS>
+__device__ __forceinline__ unsigned block_reduce_u32(unsigned v, bool take_max, unsigned *wave_tmp) {
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  constexpr int NW = THREADS / 64;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    const unsigned o = __shfl_xor(v, d, 64);
+    v = take_max ? max(v, o) : min(v, o);
+  }
+  if (lane == 0) wave_tmp[wv] = v;
+  __syncthreads();
+  unsigned r = wave_tmp[0];
+#pragma unroll
+  for (int w = 1; w < NW; ++w) r = take_max ? max(r, wave_tmp[w]) : min(r, wave_tmp[w]);
+  __syncthreads();
+  return r;
+}
+
+constexpr int kMaxBucketFill = 96;  // beyond this a bucket's rank pass degenerates: use the network
+
+// THREADS = number of buckets; CAP = keys per buffer (two buffers).  n_lo < n handled here.
+template <int THREADS, int CAP, bool LARGE>
+__global__ void __launch_bounds__(THREADS)
 tile_sort_kernel(unsigned long long *__restrict__ keys, const int *__restrict__ offsets, int T,
-                 long long capacity, int *__restrict__ flatten_ids, long long *__restrict__ isect_ids) {
-  __shared__ unsigned long long s[kSortCap];
-  const int tile = blockIdx.x, tid = threadIdx.x;
+                 long long capacity, int small_cap, int *__restrict__ flatten_ids,
+                 long long *__restrict__ isect_ids) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long s[];
+  unsigned long long *kin = s, *kout = s + CAP;
+  int *hist = (int *)(s + 2 * CAP);  // [THREADS] counts -> exclusive starts
+  int *cursor = hist + THREADS;      // [THREADS]
+  __shared__ unsigned wave_tmp[16];
+
+  const int tid = threadIdx.x;
+  // the large variant runs a small grid (<= 256 workgroups of 136 KiB LDS) striding over the tiles
+  for (int tile = blockIdx.x; tile < T; tile += gridDim.x) {
+  __syncthreads();
   const long long start = offsets[tile];
   long long end = offsets[tile + 1];
   if (end > capacity) end = capacity;
   const int n = (int)(end - start);
-  if (n <= 0) return;
+  if (n <= 0) continue;
+  if (LARGE ? (n <= small_cap) : (n > small_cap)) continue;  // the other variant owns this tile
   unsigned long long *seg = keys + start;
   const unsigned long long kInf = ~0ull;
 
-  if (n <= kSortCap) {
+  if (n <= CAP) {
+    // ---- bucket + rank
+    unsigned dmin = 0xffffffffu, dmax = 0u;
+    for (int i = tid; i < n; i += THREADS) {
+      const unsigned long long k = seg[i];
+      kin[i] = k;
+      const unsigned d = (unsigned)(k >> 32);
+      dmin = min(dmin, d);
+      dmax = max(dmax, d);
+    }
+    hist[tid] = 0;
+    cursor[tid] = 0;
+    dmin = block_reduce_u32<THREADS>(dmin, false, wave_tmp);
+    dmax = block_reduce_u32<THREADS>(dmax, true, wave_tmp);
+    const float scale = (float)THREADS / ((float)(dmax - dmin) + 1.f);
+    for (int i = tid; i < n; i += THREADS) {
+      const unsigned d = (unsigned)(kin[i] >> 32);
+      const int bk = min(THREADS - 1, (int)((float)(d - dmin) * scale));
+      atomicAdd(&hist[bk], 1);
+    }
+    __syncthreads();
+    const int cnt = hist[tid];
+    const unsigned fill = block_reduce_u32<THREADS>((unsigned)cnt, true, wave_tmp);
+    if (fill <= (unsigned)kMaxBucketFill) {
+      int tot;
+      const int excl = block_excl_scan<THREADS>(cnt, (int *)wave_tmp, tot);
+      hist[tid] = excl;
+      __syncthreads();
+      for (int i = tid; i < n; i += THREADS) {
+        const unsigned long long k = kin[i];
+        const unsigned d = (unsigned)(k >> 32);
+        const int bk = min(THREADS - 1, (int)((float)(d - dmin) * scale));
+        kout[hist[bk] + atomicAdd(&cursor[bk], 1)] = k;
+      }
+      __syncthreads();
+      for (int i = tid; i < n; i += THREADS) {
+        const unsigned long long k = kout[i];
+        const unsigned d = (unsigned)(k >> 32);
+        const int bk = min(THREADS - 1, (int)((float)(d - dmin) * scale));
+        const int b0 = hist[bk], b1 = b0 + cursor[bk];
+        int rank = 0;
+        for (int q = b0; q < b1; ++q) rank += (kout[q] < k) ? 1 : 0;
+        const long long o = start + b0 + rank;
+        flatten_ids[o] = (int)(unsigned)(k & 0xffffffffull);
+        if (isect_ids) isect_ids[o] = ((long long)tile << 32) | (long long)(k >> 32);
+      }
+      continue;
+    }
+    // degenerate depth distribution: bitonic network on kin
     int P = 1;
     while (P < n) P <<= 1;
-    for (int i = tid; i < P; i += 256) s[i] = (i < n) ? seg[i] : kInf;
+    for (int i = n + tid; i < P; i += THREADS) kin[i] = kInf;
     __syncthreads();
-    bitonic_lds(s, P, 2, P, tid);
-    for (int i = tid; i < n; i += 256) {
+    bitonic_lds<THREADS>(kin, P, 2, P, tid);
+    for (int i = tid; i < n; i += THREADS) {
+      const unsigned long long key = kin[i];
+      flatten_ids[start + i] = (int)(unsigned)(key & 0xffffffffull);
+      if (isect_ids) isect_ids[start + i] = ((long long)tile << 32) | (long long)(key >> 32);
+    }
+    continue;
+  }
+
+  // ---- oversized segment (n > CAP): bitonic network over both buffers (2 CAP keys) in LDS, and the
+  // hybrid global/LDS network beyond that.  Virtual size P (power of two), indices >= n behave as
+  // +inf and never move (the network only ever moves larger keys to higher indices).
+  constexpr int BCAP = 2 * CAP;
+  if (n <= BCAP) {
+    int P = 1;
+    while (P < n) P <<= 1;
+    for (int i = tid; i < P; i += THREADS) s[i] = (i < n) ? seg[i] : kInf;
+    __syncthreads();
+    bitonic_lds<THREADS>(s, P, 2, P, tid);
+    for (int i = tid; i < n; i += THREADS) {
       const unsigned long long key = s[i];
       flatten_ids[start + i] = (int)(unsigned)(key & 0xffffffffull);
       if (isect_ids) isect_ids[start + i] = ((long long)tile << 32) | (long long)(key >> 32);
     }
-    return;
+    continue;
   }
-
-  // ---- slow path: segment larger than one LDS pass.  Virtual size P (power of two), indices >= n
-  // behave as +inf and never move (the network only ever moves larger keys to higher indices).
-  long long P = kSortCap;
+  long long P = BCAP;
   while (P < n) P <<= 1;
-  // (a) sort every kSortCap chunk completely
-  for (long long c0 = 0; c0 < n; c0 += kSortCap) {
-    for (int i = tid; i < kSortCap; i += 256) s[i] = (c0 + i < n) ? seg[c0 + i] : kInf;
+  // (a) sort every BCAP chunk completely
+  for (long long c0 = 0; c0 < n; c0 += BCAP) {
+    for (int i = tid; i < BCAP; i += THREADS) s[i] = (c0 + i < n) ? seg[c0 + i] : kInf;
     __syncthreads();
-    bitonic_lds(s, kSortCap, 2, kSortCap, tid);
-    for (int i = tid; i < kSortCap; i += 256)
+    bitonic_lds<THREADS>(s, BCAP, 2, BCAP, tid);
+    for (int i = tid; i < BCAP; i += THREADS)
       if (c0 + i < n) seg[c0 + i] = s[i];
     __syncthreads();
   }
-  // (b) merges for k > kSortCap: long strides in global memory, the tail (j <= kSortCap/2) in LDS
-  for (long long k = 2 * (long long)kSortCap; k <= P; k <<= 1) {
+  // (b) merges for k > BCAP: long strides in global memory, the tail (j <= BCAP/2) in LDS
+  for (long long k = 2 * (long long)BCAP; k <= P; k <<= 1) {
     const long long hk = k >> 1;
-    for (long long i = tid; i < (P >> 1); i += 256) {
+    for (long long i = tid; i < (P >> 1); i += THREADS) {
       const long long blk = i / hk, off = i - blk * hk;
       const long long lo = blk * k + off, hi = blk * k + k - 1 - off;
       if (hi < n) {
@@ -202,8 +414,8 @@ tile_sort_kernel(unsigned long long *__restrict__ keys, const int *__restrict__ 
       }
     }
     __syncthreads();
-    for (long long j = k >> 2; j >= kSortCap; j >>= 1) {
-      for (long long i = tid; i < (P >> 1); i += 256) {
+    for (long long j = k >> 2; j >= BCAP; j >>= 1) {
+      for (long long i = tid; i < (P >> 1); i += THREADS) {
         const long long lo = ((i / j) * (j << 1)) + (i % j), hi = lo + j;
         if (hi < n) {
           unsigned long long a = seg[lo], b = seg[hi];
@@ -212,21 +424,22 @@ tile_sort_kernel(unsigned long long *__restrict__ keys, const int *__restrict__ 
       }
       __syncthreads();
     }
-    for (long long c0 = 0; c0 < n; c0 += kSortCap) {
-      for (int i = tid; i < kSortCap; i += 256) s[i] = (c0 + i < n) ? seg[c0 + i] : kInf;
+    for (long long c0 = 0; c0 < n; c0 += BCAP) {
+      for (int i = tid; i < BCAP; i += THREADS) s[i] = (c0 + i < n) ? seg[c0 + i] : kInf;
       __syncthreads();
-      // only the half-cleaner substages j = kSortCap/2 .. 1 (k_lo = k_hi = 2*kSortCap > P skips the mirror)
-      bitonic_lds(s, kSortCap, 2 * kSortCap, 2 * kSortCap, tid);
-      for (int i = tid; i < kSortCap; i += 256)
+      // only the half-cleaner substages j = BCAP/2 .. 1 (k_lo = k_hi = 2*BCAP > P skips the mirror)
+      bitonic_lds<THREADS>(s, BCAP, 2 * BCAP, 2 * BCAP, tid);
+      for (int i = tid; i < BCAP; i += THREADS)
         if (c0 + i < n) seg[c0 + i] = s[i];
       __syncthreads();
     }
   }
-  for (int i = tid; i < n; i += 256) {
+  for (int i = tid; i < n; i += THREADS) {
     const unsigned long long key = seg[i];
     flatten_ids[start + i] = (int)(unsigned)(key & 0xffffffffull);
     if (isect_ids) isect_ids[start + i] = ((long long)tile << 32) | (long long)(key >> 32);
   }
+  }  // tile loop
 }
 
 }  // namespace eg
@@ -238,37 +451,61 @@ extern "C" int eg_tile_count(const float *means2d, const int32_t *radii, int32_t
   EG_REQUIRE(N >= 0 && width > 0 && height > 0, "bad sizes");
   if (N == 0) return EG_OK;
   EG_REQUIRE(means2d && radii && tile_counts, "null pointer");
-  tile_count_kernel<<<cdiv(N, 256), 256, 0, as_stream(stream)>>>((const float2 *)means2d, radii, N, width, height,
-                                                                tiles_per_gauss, tile_counts);
+  const int T = cdiv(width, kTile) * cdiv(height, kTile);
+  if (T <= kMaxLdsTiles)
+    tile_count_kernel<true><<<cdiv(N, kBinThreads), kBinThreads, sizeof(int) * T, as_stream(stream)>>>(
+        (const float2 *)means2d, radii, N, width, height, tiles_per_gauss, tile_counts);
+  else
+    tile_count_kernel<false><<<cdiv(N, kBinThreads), kBinThreads, 0, as_stream(stream)>>>(
+        (const float2 *)means2d, radii, N, width, height, tiles_per_gauss, tile_counts);
   return check_launch("tile_count");
 }
 
-extern "C" int eg_tile_offsets(const int32_t *tile_counts, int32_t T, int64_t capacity, int32_t *offsets, int32_t *total,
-                               eg_stream_t stream) {
+extern "C" int eg_tile_offsets(const int32_t *tile_counts, int32_t T, int64_t capacity, int32_t *offsets,
+                               int32_t *item_offsets, int32_t *total, eg_stream_t stream) {
   EG_REQUIRE(T > 0 && tile_counts && offsets, "bad arguments");
-  tile_offsets_kernel<<<1, 1024, 0, as_stream(stream)>>>(tile_counts, T, (long long)capacity, offsets, total);
+  tile_offsets_kernel<<<1, 1024, 0, as_stream(stream)>>>(tile_counts, T, (long long)capacity, offsets, item_offsets,
+                                                        total);
   return check_launch("tile_offsets");
 }
 
 extern "C" int eg_tile_emit(const float *means2d, const int32_t *radii, const float *depths, const float *splat,
-                            int32_t N, int32_t width, int32_t height, const int32_t *offsets, int32_t *tile_cursor,
+                            uint32_t flags, int32_t N, int32_t width, int32_t height, const int32_t *offsets, int32_t *tile_cursor,
                             int64_t capacity, uint64_t *keys, eg_stream_t stream) {
   EG_REQUIRE(N >= 0 && width > 0 && height > 0 && capacity >= 0, "bad sizes");
   if (N == 0) return EG_OK;
   EG_REQUIRE(offsets && tile_cursor && (keys || capacity == 0), "null pointer");
   EG_REQUIRE(splat || (means2d && radii && depths), "need splat or (means2d, radii, depths)");
-  tile_emit_kernel<<<cdiv(N, 256), 256, 0, as_stream(stream)>>>(
-      (const float2 *)means2d, radii, depths, (const float4 *)splat, N, width, height, offsets, tile_cursor,
-      (long long)capacity, (unsigned long long *)keys);
+  const int T = cdiv(width, kTile) * cdiv(height, kTile);
+  if (2 * T <= kMaxLdsTiles)
+    tile_emit_kernel<true><<<cdiv(N, kBinThreads), kBinThreads, sizeof(int) * 2 * T, as_stream(stream)>>>(
+        (const float2 *)means2d, radii, depths, (const float4 *)splat, flags, N, width, height, offsets,
+        tile_cursor, (long long)capacity, (unsigned long long *)keys);
+  else
+    tile_emit_kernel<false><<<cdiv(N, kBinThreads), kBinThreads, 0, as_stream(stream)>>>(
+        (const float2 *)means2d, radii, depths, (const float4 *)splat, flags, N, width, height, offsets,
+        tile_cursor, (long long)capacity, (unsigned long long *)keys);
   return check_launch("tile_emit");
 }
+
+static bool g_sort_attr_set = false;
 
 extern "C" int eg_sort_pairs(uint64_t *keys, const int32_t *offsets, int32_t T, int64_t capacity,
                              int32_t *flatten_ids, int64_t *isect_ids, eg_stream_t stream) {
   EG_REQUIRE(T > 0 && offsets, "bad arguments");
   if (capacity == 0) return EG_OK;
   EG_REQUIRE(keys && flatten_ids, "null pointer");
-  tile_sort_kernel<<<T, 256, 0, as_stream(stream)>>>((unsigned long long *)keys, offsets, T, (long long)capacity,
-                                                    flatten_ids, (long long *)isect_ids);
+  // small: 256 threads / buckets, 2 x 2048 keys; large: 1024 threads / buckets, 2 x 8192 keys
+  constexpr int kSmall = 2048, kLarge = 8192;
+  constexpr size_t kSmallLds = 2 * kSmall * 8 + 2 * 256 * 4, kLargeLds = 2 * kLarge * 8 + 2 * 1024 * 4;
+  if (!g_sort_attr_set) {
+    (void)hipFuncSetAttribute((const void *)tile_sort_kernel<1024, kLarge, true>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLargeLds);
+    g_sort_attr_set = true;
+  }
+  tile_sort_kernel<256, kSmall, false><<<T, 256, kSmallLds, as_stream(stream)>>>(
+      (unsigned long long *)keys, offsets, T, (long long)capacity, kSmall, flatten_ids, (long long *)isect_ids);
+  tile_sort_kernel<1024, kLarge, true><<<min(T, 256), 1024, kLargeLds, as_stream(stream)>>>(
+      (unsigned long long *)keys, offsets, T, (long long)capacity, kSmall, flatten_ids, (long long *)isect_ids);
   return check_launch("tile_sort");
 }

@@ -43,6 +43,32 @@ __device__ __forceinline__ void tile_box(float x, float y, int radius, int tw, i
   y1 = min(max((int)ceilf(ty + tr), 0), th);
 }
 
+// Opacity-aware tight tile box (fused training path only; the gsplat-compatible API keeps the
+// 3-sigma square box so that info["tiles_per_gauss"/"flatten_ids"] stay bit-identical).
+// A pixel can only pass alpha = o * exp(-sigma) >= 1/255 inside the ellipse sigma <= ln(255 o);
+// its axis-aligned extent is ex = sqrt(2 thr c / det), ey = sqrt(2 thr a / det) for conic
+// [[a,b],[b,c]].  The box is the INTERSECTION of gsplat's box with the tiles that hold a pixel
+// centre inside that extent, so every dropped (Gaussian, tile) pair contributes exactly nothing and
+// rendered values / gradients are unchanged.  `thr` must be the compositing kernels' threshold.
+constexpr float kThrMargin = 1e-3f;
+
+__device__ __forceinline__ void tile_box_tight(float x, float y, int radius, float a, float b, float c, float o,
+                                               int tw, int th, int &x0, int &y0, int &x1, int &y1) {
+  tile_box(x, y, radius, tw, th, x0, y0, x1, y1);
+  const float thr = __logf(255.f * o) + kThrMargin;
+  const float det = a * c - b * b;
+  if (!(thr > 0.f) || !(det > 0.f)) { x1 = x0; y1 = y0; return; }
+  const float ex = sqrtf(2.f * thr * c / det) * 1.001f + 0.01f;
+  const float ey = sqrtf(2.f * thr * a / det) * 1.001f + 0.01f;
+  // tile t holds pixel centres 16 t + 0.5 .. 16 t + 15.5
+  const float ts = (float)kTile;
+  x0 = max(x0, (int)ceilf((x - ex - 15.5f) / ts));
+  y0 = max(y0, (int)ceilf((y - ey - 15.5f) / ts));
+  x1 = min(x1, (int)floorf((x + ex - 0.5f) / ts) + 1);
+  y1 = min(y1, (int)floorf((y + ey - 0.5f) / ts) + 1);
+  if (x1 <= x0 || y1 <= y0) { x1 = x0; y1 = y0; }
+}
+
 }  // namespace eg
 
 #define EG_REQUIRE(cond, msg)                         \

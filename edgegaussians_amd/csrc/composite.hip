@@ -5,10 +5,23 @@
 // (edge_gs.py:279) and projection loss (edge_gs.py:288-324, losses.py:5-11, in weight-map form)
 // fused into the forward epilogue.
 //
-// Forward: one 256-thread workgroup (4 wavefronts x 64 lanes; wave w owns rows 4w..4w+3) per
-// 16x16 tile, Gaussians staged through LDS in chunks of 256 packed 32-byte records; the inner
-// loop reads them as two broadcast ds_read_b128.  A conservative sigma-threshold (ln(255 o) +
-// margin) skips the exp for pairs that cannot reach alpha >= 1/255; the exact test follows.
+// Work decomposition: the reference's scenes put nearly all Gaussians into the ~13x13 central tiles
+// (the object spans ~200 px), so "one workgroup per tile" leaves >80 % of the 256 CUs idle while a
+// few workgroups walk thousands of Gaussians serially (measured: 1.2 ms).  Both passes therefore
+// run one 256-thread workgroup per ITEM = (tile, slice of <= 256 depth-sorted Gaussians); the item
+// table is the second scan produced by eg_tile_offsets.
+//
+// Forward (unit colours), two kernels:
+//   slice  : item -> per-pixel product P = prod(1 - alpha) over the slice and the index of the last
+//            contributing Gaussian; Gaussians staged through LDS as packed 32-byte records, inner loop
+//            = two broadcast ds_read_b128 + ~15 VALU; a conservative sigma threshold (ln(255 o) +
+//            margin) skips the exp for pairs that cannot reach alpha >= 1/255, the exact test follows
+//   combine: tile -> T = prod over its slices in depth order; the transmittance stop (T <= 1e-4) is
+//            detected on the slice products and resolved exactly by re-walking only the slice in
+//            which it happens; fused clamp + weighted L1 + upstream gradient
+// (front-to-back compositing is associative: (C1,T1) o (C2,T2) = (C1 + T1 C2, T1 T2); with unit
+// colours C = 1 - T, so only T travels).  General colours use the classic one-workgroup-per-tile
+// kernel below.
 //
 // Backward (unit colours -- the reference passes colours == 1, edge_gs.py:247): with c == 1 and no
 // background, pix = 1 - T_final, hence dpix/dalpha_i = T_final / (1 - alpha_i) for EVERY contributing
@@ -26,7 +39,6 @@
 
 namespace eg {
 
-constexpr float kThrMargin = 1e-3f;
 
 template <int CH, bool UNIT>
 __global__ void __launch_bounds__(256)
@@ -232,6 +244,490 @@ composite_bwd_unit_kernel(const float4 *__restrict__ splat, const int *__restric
 }
 
 // ---------------------------------------------------------------------------------------------
+// item helpers
+constexpr int kSlice = 256;
+
+// largest t with item_offsets[t] <= b (item_offsets[T] = n_items > b): the tile owning item b
+__device__ __forceinline__ int item_tile(const int *__restrict__ item_offsets, int T, int b) {
+  int lo = 0, hi = T;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (item_offsets[mid] <= b) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+// pixel of thread `tid` in the slice-parallel kernels: wave w owns the 8x8 quadrant (w & 1, w >> 1)
+// of the tile, lane l the pixel (l & 7, l >> 3) inside it (a compact 8x8 block culls far better
+// against thin ellipses than a 4x16 strip)
+__device__ __forceinline__ void quad_pixel(int tid, int &di, int &dj) {
+  const int w = tid >> 6, l = tid & 63;
+  di = ((w >> 1) << 3) + (l >> 3);
+  dj = ((w & 1) << 3) + (l & 7);
+}
+
+// forward phase A: per (tile, slice) transmittance products.
+// Staging: thread t fetches Gaussian t of the slice, computes its conservative alpha >= 1/255 extent
+// (ex, ey) and appends the packed record to the list of every quadrant it can touch (ballot +
+// popcount compaction, 4 lists x 256 records in LDS).  Each wave then walks only ITS list.
+__global__ void __launch_bounds__(256)
+composite_slice_fwd_kernel(const float4 *__restrict__ splat, const int *__restrict__ offsets,
+                           const int *__restrict__ item_offsets, const int *__restrict__ total,
+                           const int *__restrict__ flat, int tw, int th, float *__restrict__ sliceP,
+                           int *__restrict__ sliceL) {
+  __shared__ float4 sA[4][kSlice + 2];  // x, y, a, b
+  __shared__ float4 sB[4][kSlice + 2];  // c, o, sigma threshold, slice-local index (int bits)
+  __shared__ int sCnt[4][4];            // [quadrant][source wave]
+  const int b = blockIdx.x;
+  if (b >= total[2]) return;
+  const int tile = item_tile(item_offsets, tw * th, b);
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int ty = tile / tw, tx = tile - ty * tw;
+  int di, dj;
+  quad_pixel(tid, di, dj);
+  const float px = (float)(tx * kTile + dj) + 0.5f, py = (float)(ty * kTile + di) + 0.5f;
+  const int start = offsets[tile] + (b - item_offsets[tile]) * kSlice;
+  const int end = min(offsets[tile + 1], start + kSlice);
+  const int idx = start + tid;
+
+  float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), rB = s0;
+  bool hitq[4] = {false, false, false, false};
+  if (idx < end) {
+    const int g = flat[idx];
+    s0 = splat[2 * g];
+    const float4 s1 = splat[2 * g + 1];
+    const float thr = __logf(255.f * s1.y) + kThrMargin;
+    rB = make_float4(s1.x, s1.y, thr, __int_as_float(tid));
+    const float det = s0.z * s1.x - s0.w * s0.w;
+    if (thr > 0.f && det > 0.f) {
+      const float ex = sqrtf(2.f * thr * s1.x / det) * 1.001f + 0.01f;
+      const float ey = sqrtf(2.f * thr * s0.z / det) * 1.001f + 0.01f;
+      const float X0 = (float)(tx * kTile), Y0 = (float)(ty * kTile);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float qx = X0 + (float)((q & 1) << 3), qy = Y0 + (float)((q >> 1) << 3);
+        // pixel centres of the quadrant span [q + 0.5, q + 7.5]
+        hitq[q] = (s0.x - ex <= qx + 7.5f) && (s0.x + ex >= qx + 0.5f) && (s0.y - ey <= qy + 7.5f) &&
+                  (s0.y + ey >= qy + 0.5f);
+      }
+    }
+  }
+  unsigned long long bal[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    bal[q] = __ballot(hitq[q]);
+    if (lane == 0) sCnt[q][wv] = __popcll(bal[q]);
+  }
+  __syncthreads();
+  int n_mine = 0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const int c = sCnt[q][w];
+      base += (w < wv) ? c : 0;
+      tot += c;
+    }
+    if (hitq[q]) {
+      const int pos = base + __popcll(bal[q] & ((1ull << lane) - 1ull));
+      sA[q][pos] = s0;
+      sB[q][pos] = rB;
+    }
+    if (q == wv) n_mine = tot;
+    // two sentinels (threshold < 0 => rejected) so the 2-way unrolled walk may read past the end
+    if (tid == q) {
+      sB[q][tot] = make_float4(0.f, 0.f, -1.f, 0.f);
+      sB[q][tot + 1] = make_float4(0.f, 0.f, -1.f, 0.f);
+      sA[q][tot] = make_float4(0.f, 0.f, 0.f, 0.f);
+      sA[q][tot + 1] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  __syncthreads();
+
+  const float4 *lA = sA[wv], *lB = sB[wv];
+  float P = 1.f;
+  int L = -1;
+  for (int t = 0; t < n_mine; t += 2) {
+    const float4 A0 = lA[t], B0 = lB[t], A1 = lA[t + 1], B1 = lB[t + 1];
+    {
+      const float dx = A0.x - px, dy = A0.y - py;
+      const float sigma = 0.5f * (A0.z * dx * dx + B0.x * dy * dy) + A0.w * dx * dy;
+      if (sigma >= 0.f && sigma <= B0.z) {
+        const float alpha = fminf(kAlphaMax, B0.y * __expf(-sigma));
+        if (alpha >= kAlphaMin) { P *= (1.f - alpha); L = start + __float_as_int(B0.w); }
+      }
+    }
+    {
+      const float dx = A1.x - px, dy = A1.y - py;
+      const float sigma = 0.5f * (A1.z * dx * dx + B1.x * dy * dy) + A1.w * dx * dy;
+      if (sigma >= 0.f && sigma <= B1.z) {
+        const float alpha = fminf(kAlphaMax, B1.y * __expf(-sigma));
+        if (alpha >= kAlphaMin) { P *= (1.f - alpha); L = start + __float_as_int(B1.w); }
+      }
+    }
+  }
+  sliceP[(size_t)b * kSlice + tid] = P;
+  sliceL[(size_t)b * kSlice + tid] = L;
+}
+
+// forward phase B: per tile, combine the slices in depth order (+ exact stop, + fused loss)
+template <int CH>
+__global__ void __launch_bounds__(256)
+composite_combine_fwd_kernel(const float4 *__restrict__ splat, const int *__restrict__ offsets,
+                             const int *__restrict__ item_offsets, const int *__restrict__ flat, int width,
+                             int height, int tw, int th, const float *__restrict__ sliceP,
+                             const int *__restrict__ sliceL, float *__restrict__ render,
+                             float *__restrict__ alphas, int *__restrict__ last_ids,
+                             const float *__restrict__ gt, const float *__restrict__ wmap, float loss_scale,
+                             float *__restrict__ vpix, float *__restrict__ loss_out,
+                             float2 *__restrict__ gtstop) {
+  __shared__ float sRed[4];
+  const int tile = blockIdx.x, tid = threadIdx.x;
+  const int ty = tile / tw, tx = tile - ty * tw;
+  int di, dj;
+  quad_pixel(tid, di, dj);  // same thread -> pixel map as the slice kernel
+  const int i = ty * kTile + di, j = tx * kTile + dj;
+  const bool inside = (i < height) && (j < width);
+  const float px = (float)j + 0.5f, py = (float)i + 0.5f;
+  const int i0 = item_offsets[tile], ns = item_offsets[tile + 1] - i0;
+  const int seg0 = offsets[tile], seg1 = offsets[tile + 1];
+
+  float T = 1.f;
+  int last = 0;
+  bool stopped = false;
+  for (int s = 0; s < ns; ++s) {
+    const float P = sliceP[(size_t)(i0 + s) * kSlice + tid];
+    const int L = sliceL[(size_t)(i0 + s) * kSlice + tid];
+    const float nT = T * P;
+    const bool need = !stopped && (L >= 0) && (nT <= kTStop);
+    if (__any(need)) {
+      // the stop falls inside this slice for some lanes: re-walk it sequentially for those lanes
+      const int a0 = seg0 + s * kSlice, a1 = min(seg1, a0 + kSlice);
+      float Tw = T;
+      int lw = last;
+      bool found = false;
+      for (int idx = a0; idx < a1; ++idx) {
+        const int g = flat[idx];
+        const float4 s0 = splat[2 * g], s1 = splat[2 * g + 1];
+        if (need && !found) {
+          const float dx = s0.x - px, dy = s0.y - py;
+          const float sigma = 0.5f * (s0.z * dx * dx + s1.x * dy * dy) + s0.w * dx * dy;
+          const float alpha = fminf(kAlphaMax, s1.y * __expf(-sigma));
+          if (sigma >= 0.f && alpha >= kAlphaMin) {
+            const float next_T = Tw * (1.f - alpha);
+            if (next_T <= kTStop) found = true;
+            else { Tw = next_T; lw = idx; }
+          }
+        }
+      }
+      if (need) { T = Tw; last = lw; stopped = found; }
+      else if (!stopped && L >= 0) { T = nT; last = L; }
+    } else if (!stopped && L >= 0) {
+      T = nT;
+      last = L;
+    }
+  }
+
+  float l = 0.f;
+  if (inside) {
+    const int p = i * width + j;
+    const float pix = 1.f - T;  // unit colours, no background: sum_i alpha_i T_i == 1 - T_final
+    alphas[p] = pix;
+    last_ids[p] = last;
+#pragma unroll
+    for (int k = 0; k < CH; ++k) render[(size_t)p * CH + k] = pix;
+    if (wmap) {
+      const float w = wmap[p];
+      const float c0 = fminf(fmaxf(pix, 0.f), 1.f);
+      const float d = c0 - gt[p];
+      l = w * fabsf(d);
+      const float sgn = (d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f);
+      const float v = loss_scale * w * sgn;  // pix is in [0,1): the clamp always passes the gradient
+      if (vpix) vpix[p] = v;
+      if (gtstop) {
+        // what the footprint backward needs per pixel: v * T_final, and -- only for pixels whose walk
+        // stopped on the transmittance rule -- the id of the last contributing Gaussian
+        const int stop_id = stopped ? flat[last] : -1;
+        gtstop[p] = make_float2((T < 1.f) ? v * T : 0.f, __int_as_float(stop_id));
+      }
+    }
+  }
+  if (wmap && loss_out) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) l += __shfl_xor(l, d, 64);
+    if ((tid & 63) == 0) sRed[tid >> 6] = l;
+    __syncthreads();
+    if (tid == 0) {
+      const float s = sRed[0] + sRed[1] + sRed[2] + sRed[3];
+      if (s != 0.f) unsafeAtomicAdd(loss_out, s);
+    }
+  }
+}
+
+// backward, unit colours, one workgroup per item: lane = Gaussian of the slice, loop = active pixels
+__global__ void __launch_bounds__(256)
+composite_bwd_item_kernel(const float4 *__restrict__ splat, const int *__restrict__ offsets,
+                          const int *__restrict__ item_offsets, const int *__restrict__ total,
+                          const int *__restrict__ flat, int width, int height, int tw, int th,
+                          const float *__restrict__ alphas, const int *__restrict__ last_ids,
+                          const float *__restrict__ vpix, float *__restrict__ g2d) {
+  __shared__ float4 sP[kTilePix];  // px, py, v*T_final, last id (int bits) -- compacted
+  __shared__ int sCnt[4];
+  __shared__ int sMaxLast[4];
+  const int b = blockIdx.x;
+  if (b >= total[2]) return;
+  const int tile = item_tile(item_offsets, tw * th, b);
+  const int start = offsets[tile] + (b - item_offsets[tile]) * kSlice;
+  const int end = min(offsets[tile + 1], start + kSlice);
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int ty = tile / tw, tx = tile - ty * tw;
+  const int i = ty * kTile + (tid >> 4), j = tx * kTile + (tid & 15);
+  const bool inside = (i < height) && (j < width);
+  float gT = 0.f;
+  int last = -1;
+  if (inside) {
+    const int p = i * width + j;
+    const float a = alphas[p];
+    const float v = vpix[p];
+    if (a > 0.f && v != 0.f) {  // a > 0 <=> at least one Gaussian contributed to this pixel
+      const int l = last_ids[p];
+      if (l >= start) { gT = v * (1.f - a); last = l; }  // nothing of this slice contributes otherwise
+    }
+  }
+  const bool active = (last >= 0) && (gT != 0.f);
+  const unsigned long long bal = __ballot(active);
+  const int rank = __popcll(bal & ((1ull << lane) - 1ull));
+  int wmax = last;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) wmax = max(wmax, __shfl_xor(wmax, d, 64));
+  if (lane == 0) { sCnt[wv] = __popcll(bal); sMaxLast[wv] = wmax; }
+  __syncthreads();
+  int pre = 0;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) pre += (w < wv) ? sCnt[w] : 0;
+  const int n_act = sCnt[0] + sCnt[1] + sCnt[2] + sCnt[3];
+  const int max_last = max(max(sMaxLast[0], sMaxLast[1]), max(sMaxLast[2], sMaxLast[3]));
+  if (n_act == 0) return;
+  if (active) sP[pre + rank] = make_float4((float)j + 0.5f, (float)i + 0.5f, gT, __int_as_float(last));
+  __syncthreads();
+
+  const int n_live = min(end, max_last + 1) - start;  // Gaussians past every pixel's stop are dead
+  if (n_live <= 0) return;
+  const int n_chunks = (n_live + 63) >> 6;
+  const int splits = (n_chunks >= 4) ? 1 : ((n_chunks == 2) ? 2 : 4);
+  const int n_items = n_chunks * splits;
+  for (int item = wv; item < n_items; item += 4) {
+    const int chunk = item / splits, sp = item - chunk * splits;
+    const int q0 = (n_act * sp) / splits, q1 = (n_act * (sp + 1)) / splits;
+    const int idx = start + (chunk << 6) + lane;
+    const bool have = idx < start + n_live;
+    int g = 0;
+    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+    if (have) {
+      g = flat[idx];
+      s0 = splat[2 * g];
+      s1 = splat[2 * g + 1];
+    }
+    const float x = s0.x, y = s0.y, ca = s0.z, cb = s0.w, cc = s1.x, o = s1.y;
+    const float thr = have ? __logf(255.f * o) + kThrMargin : -1.f;
+    float ax = 0.f, ay = 0.f, aax = 0.f, aay = 0.f, aa = 0.f, ab = 0.f, ac = 0.f, ao = 0.f;
+    bool hit = false;
+    for (int q = q0; q < q1; ++q) {
+      const float4 P = sP[q];
+      const float dx = x - P.x, dy = y - P.y;
+      const float sigma = 0.5f * (ca * dx * dx + cc * dy * dy) + cb * dx * dy;
+      bool valid = (idx <= __float_as_int(P.w)) && (sigma >= 0.f) && (sigma <= thr);
+      if (!__any(valid)) continue;
+      const float vis = __expf(-sigma);
+      const float araw = o * vis;
+      const float alpha = fminf(kAlphaMax, araw);
+      valid = valid && (alpha >= kAlphaMin);
+      if (valid) {
+        hit = true;
+        const float v_alpha = P.z * __frcp_rn(1.f - alpha);  // dL/dalpha = v * T_final / (1 - alpha)
+        if (araw <= kAlphaMax) {
+          const float v_sigma = -araw * v_alpha;
+          const float gx = v_sigma * (ca * dx + cb * dy);
+          const float gy = v_sigma * (cb * dx + cc * dy);
+          ax += gx; ay += gy;
+          aax += fabsf(gx); aay += fabsf(gy);
+          aa += 0.5f * v_sigma * dx * dx;
+          ab += v_sigma * dx * dy;
+          ac += 0.5f * v_sigma * dy * dy;
+          ao += vis * v_alpha;
+        }
+      }
+    }
+    if (hit) {
+      float *dst = g2d + (size_t)g * 8;
+      unsafeAtomicAdd(dst + 0, ax);
+      unsafeAtomicAdd(dst + 1, ay);
+      unsafeAtomicAdd(dst + 2, aax);
+      unsafeAtomicAdd(dst + 3, aay);
+      unsafeAtomicAdd(dst + 4, aa);
+      unsafeAtomicAdd(dst + 5, ab);
+      unsafeAtomicAdd(dst + 6, ac);
+      unsafeAtomicAdd(dst + 7, ao);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Footprint backward for unit colours (the fused training path): no tile lists, no atomics.
+//
+// With colours == 1 and no background dL/dalpha_i = v_p T_final,p / (1 - alpha_i) for every Gaussian
+// that contributed to pixel p, independent of the depth order.  So a Gaussian's whole 2D gradient is
+// a sum over ITS OWN footprint: the pixels of gsplat's tile box that lie inside the ellipse
+// sigma <= ln(255 o) (outside it alpha < 1/255 and the forward skipped the pair).  8 lanes share one
+// Gaussian (8 Gaussians per wavefront): each lane takes every 8th column of the footprint, so a
+// wave reads 64-byte row segments of the packed {v * T_final, stop id} image written by the forward;
+// a 3-step butterfly over the 8 lanes leaves the 8 partial derivatives in all of them and lane c
+// stores component c -- one coalesced 32-byte store per Gaussian into g2d, which needs no zeroing.
+// The transmittance stop (pixels whose front-to-back walk ended on T <= 1e-4) is the only
+// order-dependent part: for those pixels the forward records the id of the last contributing
+// Gaussian and a candidate contributes iff its (depth bits, id) <= that Gaussian's.
+// Footprints above kBigFootprint pixels are deferred to a wavefront-per-Gaussian kernel.
+constexpr int kBigFootprint = 8192;
+constexpr int kLanesPerGauss = 8;
+
+struct Footprint {
+  int i0, i1, j0, j1;  // inclusive pixel bounds; empty if i1 < i0 or j1 < j0
+  float thr;
+};
+
+__device__ __forceinline__ Footprint footprint_of(const float4 s0, const float4 s1, int width, int height) {
+  Footprint f;
+  f.i0 = f.j0 = 0;
+  f.i1 = f.j1 = -1;
+  const int radius = __float_as_int(s1.w);
+  f.thr = __logf(255.f * s1.y) + kThrMargin;
+  const float det = s0.z * s1.x - s0.w * s0.w;
+  if (radius <= 0 || !(f.thr > 0.f) || !(det > 0.f)) return f;
+  const int tw = (width + kTile - 1) / kTile, th = (height + kTile - 1) / kTile;
+  int x0, y0, x1, y1;
+  tile_box(s0.x, s0.y, radius, tw, th, x0, y0, x1, y1);  // pixels outside gsplat's box never see it
+  const float ex = sqrtf(2.f * f.thr * s1.x / det) * 1.001f + 0.01f;
+  const float ey = sqrtf(2.f * f.thr * s0.z / det) * 1.001f + 0.01f;
+  f.j0 = max(x0 * kTile, (int)ceilf(s0.x - ex - 0.5f));
+  f.j1 = min(min(x1 * kTile, width) - 1, (int)floorf(s0.x + ex - 0.5f));
+  f.i0 = max(y0 * kTile, (int)ceilf(s0.y - ey - 0.5f));
+  f.i1 = min(min(y1 * kTile, height) - 1, (int)floorf(s0.y + ey - 0.5f));
+  return f;
+}
+
+struct Acc8 {
+  float v[8];  // vx, vy, |vx|, |vy|, va, vb, vc, vo  (the g2d record)
+};
+
+__device__ __forceinline__ void footprint_pixel(const float4 s0, const float4 s1, float thr, int g, int i, int j,
+                                                const float2 rec, const float4 *__restrict__ splat, Acc8 &a) {
+  const float gT = rec.x;
+  if (gT == 0.f) return;
+  const float dx = s0.x - ((float)j + 0.5f), dy = s0.y - ((float)i + 0.5f);
+  const float sigma = 0.5f * (s0.z * dx * dx + s1.x * dy * dy) + s0.w * dx * dy;
+  if (sigma < 0.f || sigma > thr) return;
+  const float vis = __expf(-sigma);
+  const float araw = s1.y * vis;
+  const float alpha = fminf(kAlphaMax, araw);
+  if (alpha < kAlphaMin) return;
+  const int stop_id = __float_as_int(rec.y);
+  if (stop_id >= 0 && stop_id != g) {
+    // the walk of this pixel stopped: only Gaussians at or before the last contributor count
+    const unsigned dl = (unsigned)__float_as_int(splat[2 * stop_id + 1].z), dg = (unsigned)__float_as_int(s1.z);
+    if (dg > dl || (dg == dl && g > stop_id)) return;
+  }
+  const float v_alpha = gT * __frcp_rn(1.f - alpha);
+  if (araw <= kAlphaMax) {
+    const float v_sigma = -araw * v_alpha;
+    const float gx = v_sigma * (s0.z * dx + s0.w * dy);
+    const float gy = v_sigma * (s0.w * dx + s1.x * dy);
+    a.v[0] += gx; a.v[1] += gy;
+    a.v[2] += fabsf(gx); a.v[3] += fabsf(gy);
+    a.v[4] += 0.5f * v_sigma * dx * dx;
+    a.v[5] += v_sigma * dx * dy;
+    a.v[6] += 0.5f * v_sigma * dy * dy;
+    a.v[7] += vis * v_alpha;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+footprint_bwd_kernel(const float4 *__restrict__ splat, int N, int width, int height,
+                     const float2 *__restrict__ gtstop, float *__restrict__ g2d, int *__restrict__ big_list,
+                     int parity) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int g = t >> 3, c = t & 7;
+  if (t == 0) big_list[parity ^ 1] = 0;  // the NEXT call's counter (this call's is zero on entry)
+  if (g >= N) return;  // whole 8-lane groups leave together
+  const float4 s0 = splat[2 * g], s1 = splat[2 * g + 1];
+  const Footprint fp = footprint_of(s0, s1, width, height);
+  const int fw = fp.j1 - fp.j0 + 1, fh = fp.i1 - fp.i0 + 1;
+  Acc8 a;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) a.v[k] = 0.f;
+  if (fw > 0 && fh > 0) {
+    if (fw * fh > kBigFootprint) {
+      if (c == 0) big_list[2 + atomicAdd(&big_list[parity], 1)] = g;  // a whole wavefront takes it
+      return;
+    }
+    for (int i = fp.i0; i <= fp.i1; ++i) {
+      const float2 *row = gtstop + (size_t)i * width;
+      for (int j = fp.j0 + c; j <= fp.j1; j += kLanesPerGauss)
+        footprint_pixel(s0, s1, fp.thr, g, i, j, row[j], splat, a);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    float v = a.v[k];
+    v += __shfl_xor(v, 1, 64);
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 4, 64);
+    a.v[k] = v;
+  }
+  float out = a.v[0];
+#pragma unroll
+  for (int k = 1; k < 8; ++k) out = (c == k) ? a.v[k] : out;
+  g2d[(size_t)g * 8 + c] = out;
+}
+
+// one wavefront per big-footprint Gaussian: lanes stride over the footprint, full butterfly
+__global__ void __launch_bounds__(256)
+footprint_big_kernel(const float4 *__restrict__ splat, int width, int height, const float2 *__restrict__ gtstop,
+                     float *__restrict__ g2d, const int *__restrict__ big_list, int parity) {
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
+  const int n_big = big_list[parity];
+  for (int b = wave; b < n_big; b += n_waves) {
+    const int g = big_list[2 + b];
+    const float4 s0 = splat[2 * g], s1 = splat[2 * g + 1];
+    const Footprint fp = footprint_of(s0, s1, width, height);
+    const int fw = fp.j1 - fp.j0 + 1, fh = fp.i1 - fp.i0 + 1;
+    Acc8 a;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a.v[k] = 0.f;
+    const int area = fw * fh;
+    for (int q = lane; q < area; q += 64) {
+      const int i = fp.i0 + q / fw, j = fp.j0 + q % fw;
+      footprint_pixel(s0, s1, fp.thr, g, i, j, gtstop[(size_t)i * width + j], splat, a);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      float v = a.v[k];
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+      a.v[k] = v;
+    }
+    if (lane < 8) {
+      float out = a.v[0];
+#pragma unroll
+      for (int k = 1; k < 8; ++k) out = (lane == k) ? a.v[k] : out;
+      g2d[(size_t)g * 8 + lane] = out;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // backward, general colours: lane = pixel, back to front, wave64 butterfly reductions
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -358,16 +854,42 @@ composite_bwd_colors_kernel(const float4 *__restrict__ splat, const float *__res
 
 using namespace eg;
 
+extern "C" int64_t eg_composite_workspace_bytes(int64_t max_items) {
+  return max_items < 0 ? 0 : max_items * kSlice * (int64_t)(sizeof(float) + sizeof(int32_t));
+}
+
 extern "C" int eg_composite_fwd(const float *splat, const float *colors, int32_t channels, const int32_t *offsets,
                                 const int32_t *flatten_ids, int32_t width, int32_t height, float *render,
                                 float *alphas, int32_t *last_ids, const float *gt, const float *wmap,
-                                float loss_scale, float *vpix, float *loss_out, eg_stream_t stream) {
+                                float loss_scale, float *vpix, float *loss_out, const int32_t *item_offsets,
+                                const int32_t *total, int64_t max_items, void *workspace, float *gtstop,
+                                eg_stream_t stream) {
   EG_REQUIRE(width > 0 && height > 0, "bad sizes");
   EG_REQUIRE(channels == 1 || channels == 3, "channels must be 1 or 3");
   EG_REQUIRE(splat && offsets && render && alphas && last_ids, "null pointer");
   EG_REQUIRE(!wmap || gt, "wmap needs gt");
+  EG_REQUIRE(!gtstop || (wmap && !colors && item_offsets && total && workspace && max_items > 0),
+             "gtstop needs the fused loss and the slice-parallel unit-colour mode");
   const int tw = cdiv(width, kTile), th = cdiv(height, kTile);
   hipStream_t s = as_stream(stream);
+  if (!colors && item_offsets && total && workspace && max_items > 0) {
+    // unit colours: slice-parallel two-kernel forward
+    float *sliceP = (float *)workspace;
+    int *sliceL = (int *)(sliceP + (size_t)max_items * kSlice);
+    composite_slice_fwd_kernel<<<(unsigned)max_items, 256, 0, s>>>((const float4 *)splat, offsets, item_offsets,
+                                                                  total, flatten_ids, tw, th, sliceP, sliceL);
+    if (channels == 1)
+      composite_combine_fwd_kernel<1><<<tw * th, 256, 0, s>>>((const float4 *)splat, offsets, item_offsets,
+                                                             flatten_ids, width, height, tw, th, sliceP, sliceL,
+                                                             render, alphas, last_ids, gt, wmap, loss_scale, vpix,
+                                                             loss_out, (float2 *)gtstop);
+    else
+      composite_combine_fwd_kernel<3><<<tw * th, 256, 0, s>>>((const float4 *)splat, offsets, item_offsets,
+                                                             flatten_ids, width, height, tw, th, sliceP, sliceL,
+                                                             render, alphas, last_ids, gt, wmap, loss_scale, vpix,
+                                                             loss_out, (float2 *)gtstop);
+    return check_launch("composite_fwd(sliced)");
+  }
 #define EG_LAUNCH_FWD(CH, UNIT)                                                                              \
   composite_fwd_kernel<CH, UNIT><<<tw * th, 256, 0, s>>>((const float4 *)splat, colors, offsets, flatten_ids, \
                                                         width, height, tw, th, render, alphas, last_ids, gt,  \
@@ -380,14 +902,34 @@ extern "C" int eg_composite_fwd(const float *splat, const float *colors, int32_t
 
 extern "C" int eg_composite_bwd(const float *splat, const int32_t *offsets, const int32_t *flatten_ids,
                                 int32_t width, int32_t height, const float *alphas, const int32_t *last_ids,
-                                const float *vpix, float *g2d, eg_stream_t stream) {
+                                const float *vpix, float *g2d, const int32_t *item_offsets, const int32_t *total,
+                                int64_t max_items, eg_stream_t stream) {
   EG_REQUIRE(width > 0 && height > 0, "bad sizes");
   EG_REQUIRE(splat && offsets && alphas && last_ids && vpix && g2d, "null pointer");
   const int tw = cdiv(width, kTile), th = cdiv(height, kTile);
-  composite_bwd_unit_kernel<<<tw * th, 256, 0, as_stream(stream)>>>((const float4 *)splat, offsets, flatten_ids,
-                                                                    width, height, tw, th, alphas, last_ids, vpix,
-                                                                    g2d);
+  if (item_offsets && total && max_items > 0)
+    composite_bwd_item_kernel<<<(unsigned)max_items, 256, 0, as_stream(stream)>>>(
+        (const float4 *)splat, offsets, item_offsets, total, flatten_ids, width, height, tw, th, alphas, last_ids,
+        vpix, g2d);
+  else
+    composite_bwd_unit_kernel<<<tw * th, 256, 0, as_stream(stream)>>>((const float4 *)splat, offsets, flatten_ids,
+                                                                      width, height, tw, th, alphas, last_ids,
+                                                                      vpix, g2d);
   return check_launch("composite_bwd");
+}
+
+extern "C" int eg_composite_bwd_footprint(const float *splat, int32_t N, int32_t width, int32_t height,
+                                          const float *gtstop, float *g2d, int32_t *big_list, int32_t parity,
+                                          eg_stream_t stream) {
+  EG_REQUIRE(N >= 0 && width > 0 && height > 0 && (parity == 0 || parity == 1), "bad sizes / parity");
+  if (N == 0) return EG_OK;
+  EG_REQUIRE(splat && gtstop && g2d && big_list, "null pointer");
+  hipStream_t st = as_stream(stream);
+  footprint_bwd_kernel<<<cdiv((int64_t)N * kLanesPerGauss, 256), 256, 0, st>>>(
+      (const float4 *)splat, N, width, height, (const float2 *)gtstop, g2d, big_list, parity);
+  footprint_big_kernel<<<64, 256, 0, st>>>((const float4 *)splat, width, height, (const float2 *)gtstop, g2d,
+                                          big_list, parity);
+  return check_launch("composite_bwd_footprint");
 }
 
 extern "C" int eg_composite_bwd_colors(const float *splat, const float *colors, int32_t channels,

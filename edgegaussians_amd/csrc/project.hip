@@ -131,6 +131,9 @@ __device__ __forceinline__ int radius_of(const Fwd &f, int width, int height, fl
   return (int)radius;
 }
 
+// The per-tile counters are privatised in LDS (one global atomic per workgroup per touched tile):
+// the hot counters of a view share a dozen cache lines and direct atomics serialise on them.
+template <bool LDS_COUNT>
 __global__ void __launch_bounds__(256)
 project_fwd_kernel(const float *__restrict__ means, const float *__restrict__ quats,
                    const float *__restrict__ scales, const float *__restrict__ opacities,
@@ -139,12 +142,19 @@ project_fwd_kernel(const float *__restrict__ means, const float *__restrict__ qu
                    float4 *__restrict__ splat, int *__restrict__ radii, float *__restrict__ means2d,
                    float *__restrict__ depths, float *__restrict__ conics, float *__restrict__ comps,
                    int *__restrict__ tiles_per_gauss, int *__restrict__ tile_counts, float4 *__restrict__ g2d) {
+  extern __shared__ __attribute__((aligned(16))) int s_hist[];
+  const int tw = (width + kTile - 1) / kTile, th = (height + kTile - 1) / kTile, T = tw * th;
+  if (LDS_COUNT) {
+    for (int t = threadIdx.x; t < T; t += 256) s_hist[t] = 0;
+    __syncthreads();
+  }
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= N) return;
+  const bool live = g < N;
   const Cam cam = load_cam(viewmat, K);
   Fwd f;
   int radius = 0;
-  if (forward_geom(cam, means, quats, scales, opacities, g, width, height, near_plane, far_plane, eps2d, flags, f))
+  if (live &&
+      forward_geom(cam, means, quats, scales, opacities, g, width, height, near_plane, far_plane, eps2d, flags, f))
     radius = radius_of(f, width, height, radius_clip);
 
   const bool aa = flags & EG_FLAG_ANTIALIASED;
@@ -153,27 +163,37 @@ project_fwd_kernel(const float *__restrict__ means, const float *__restrict__ qu
     s0 = make_float4(f.u, f.v, f.a, f.b);
     s1 = make_float4(f.c, aa ? f.o * f.comp : f.o, f.z, __int_as_float(radius));
   }
-  splat[2 * g] = s0;
-  splat[2 * g + 1] = s1;
-  if (radii) radii[g] = radius;
-  if (means2d) { means2d[2 * g] = s0.x; means2d[2 * g + 1] = s0.y; }
-  if (depths) depths[g] = s1.z;
-  if (conics) { conics[3 * g] = s0.z; conics[3 * g + 1] = s0.w; conics[3 * g + 2] = s1.x; }
-  if (comps) comps[g] = radius > 0 ? f.comp : 0.f;
-  if (g2d) { g2d[2 * g] = make_float4(0.f, 0.f, 0.f, 0.f); g2d[2 * g + 1] = make_float4(0.f, 0.f, 0.f, 0.f); }
+  if (live) {
+    splat[2 * g] = s0;
+    splat[2 * g + 1] = s1;
+    if (radii) radii[g] = radius;
+    if (means2d) { means2d[2 * g] = s0.x; means2d[2 * g + 1] = s0.y; }
+    if (depths) depths[g] = s1.z;
+    if (conics) { conics[3 * g] = s0.z; conics[3 * g + 1] = s0.w; conics[3 * g + 2] = s1.x; }
+    if (comps) comps[g] = radius > 0 ? f.comp : 0.f;
+    if (g2d) { g2d[2 * g] = make_float4(0.f, 0.f, 0.f, 0.f); g2d[2 * g + 1] = make_float4(0.f, 0.f, 0.f, 0.f); }
+  }
 
   if (tiles_per_gauss || tile_counts) {
     int n = 0;
     if (radius > 0) {
-      const int tw = (width + kTile - 1) / kTile, th = (height + kTile - 1) / kTile;
       int x0, y0, x1, y1;
-      tile_box(s0.x, s0.y, radius, tw, th, x0, y0, x1, y1);
+      if (flags & EG_FLAG_TIGHT_TILES) tile_box_tight(s0.x, s0.y, radius, s0.z, s0.w, s1.x, s1.y, tw, th, x0, y0, x1, y1);
+      else tile_box(s0.x, s0.y, radius, tw, th, x0, y0, x1, y1);
       n = (y1 - y0) * (x1 - x0);
       if (tile_counts)
         for (int ty = y0; ty < y1; ++ty)
-          for (int tx = x0; tx < x1; ++tx) atomicAdd(&tile_counts[ty * tw + tx], 1);
+          for (int tx = x0; tx < x1; ++tx)
+            atomicAdd(LDS_COUNT ? &s_hist[ty * tw + tx] : &tile_counts[ty * tw + tx], 1);
     }
-    if (tiles_per_gauss) tiles_per_gauss[g] = n;
+    if (live && tiles_per_gauss) tiles_per_gauss[g] = n;
+  }
+  if (LDS_COUNT && tile_counts) {
+    __syncthreads();
+    for (int t = threadIdx.x; t < T; t += 256) {
+      const int c = s_hist[t];
+      if (c) atomicAdd(&tile_counts[t], c);
+    }
   }
 }
 
@@ -405,10 +425,17 @@ extern "C" int eg_project_fwd(const float *means, const float *quats, const floa
   EG_REQUIRE(N >= 0 && width > 0 && height > 0, "bad sizes");
   if (N == 0) return EG_OK;
   EG_REQUIRE(means && quats && scales && opacities && viewmat && K && splat, "null pointer");
-  project_fwd_kernel<<<cdiv(N, 256), 256, 0, as_stream(stream)>>>(
-      means, quats, scales, opacities, viewmat, K, N, width, height, near_plane, far_plane, eps2d, radius_clip,
-      flags, (float4 *)splat, radii, means2d, depths, conics, compensations, tiles_per_gauss, tile_counts,
-      (float4 *)g2d);
+  const int T = cdiv(width, kTile) * cdiv(height, kTile);
+  if (tile_counts && T <= 16384)
+    project_fwd_kernel<true><<<cdiv(N, 256), 256, sizeof(int) * T, as_stream(stream)>>>(
+        means, quats, scales, opacities, viewmat, K, N, width, height, near_plane, far_plane, eps2d, radius_clip,
+        flags, (float4 *)splat, radii, means2d, depths, conics, compensations, tiles_per_gauss, tile_counts,
+        (float4 *)g2d);
+  else
+    project_fwd_kernel<false><<<cdiv(N, 256), 256, 0, as_stream(stream)>>>(
+        means, quats, scales, opacities, viewmat, K, N, width, height, near_plane, far_plane, eps2d, radius_clip,
+        flags, (float4 *)splat, radii, means2d, depths, conics, compensations, tiles_per_gauss, tile_counts,
+        (float4 *)g2d);
   return check_launch("project_fwd");
 }
 
@@ -442,6 +469,25 @@ extern "C" int eg_project_bwd_adam(float *means, float *quats, float *scales, fl
       (const float4 *)g2d, nullptr, nullptr, nullptr, nullptr, absgrads, nullptr, nullptr, m, v,
       make_adamk(hyper));
   return check_launch("project_bwd_adam");
+}
+
+extern "C" int eg_backward_fused(float *means, float *quats, float *scales, float *opacities,
+                                 const float *viewmat, const float *K, int32_t N, int32_t width, int32_t height,
+                                 float eps2d, uint32_t flags, const float *splat, const float *gtstop, float *g2d,
+                                 float *v_means, float *v_quats, float *v_scales, float *v_opacities,
+                                 float *absgrads, float *m, float *v, const eg_adam_hyper *hyper_host,
+                                 int32_t *big_list, int32_t parity, eg_stream_t stream) {
+  EG_REQUIRE(N >= 0 && width > 0 && height > 0, "bad sizes");
+  if (N == 0) return EG_OK;
+  EG_REQUIRE(means && quats && scales && opacities && viewmat && K && splat && gtstop && g2d && big_list,
+             "null pointer");
+  int rc = eg_composite_bwd_footprint(splat, N, width, height, gtstop, g2d, big_list, parity, stream);
+  if (rc) return rc;
+  if (hyper_host)
+    return eg_project_bwd_adam(means, quats, scales, opacities, viewmat, K, N, width, height, eps2d, flags, splat,
+                               g2d, m, v, absgrads, *hyper_host, stream);
+  return eg_project_bwd(means, quats, scales, opacities, viewmat, K, N, width, height, eps2d, flags, splat, g2d,
+                        nullptr, nullptr, v_means, v_quats, v_scales, v_opacities, absgrads, stream);
 }
 
 extern "C" int eg_adam_multi(float *means, float *scales, float *quats, float *opacities, const float *g_means,

@@ -4,11 +4,11 @@
 // protocol of the reference's train_epoch body (train_gaussians.py:81-106):
 //   model(idx)                 -> project(+exp/sigmoid, +tile counts) / offsets / emit / sort / composite
 //   compute_projection_loss    -> fused in the compositing epilogue (weight-map form)
-//   backward()                 -> composite bwd / project bwd
-//   update_absgrads()          -> fused in project bwd
-//   4x Adam.step(), zero_grad  -> fused in project bwd (single-GPU) or left to eg_adam_multi after
+//   backward()                 -> footprint compositing VJP (no lists, no atomics) + projection VJP
+//   update_absgrads()          -> fused in the projection VJP
+//   4x Adam.step(), zero_grad  -> fused in the projection VJP (single-GPU) or left to eg_adam_multi after
 //                                 the RCCL all-reduce (multi-GPU)
-// 7 launches per step instead of ~60 (torch glue + gsplat + CUB passes + 4 unfused Adams).
+// 10 launches per step instead of ~60 (torch glue + gsplat + CUB passes + 4 unfused Adams).
 #include <cstdarg>
 #include <cstdio>
 
@@ -50,39 +50,110 @@ extern "C" int eg_device_count(void) {
   return n;
 }
 
+// ---- optional per-stage timing: HIP events recorded by this library between the stages of
+// eg_train_step, on the launch stream, for a window of steps; one synchronisation at the end.
+// (Driving the stages from Python to time them measures the Python call overhead instead: a
+// 20-argument ctypes call costs ~100 us, the kernels 5-50 us.)
+namespace eg {
+constexpr int kStages = 7;
+static const char *kStageNames[kStages] = {"project_fwd", "tile_offsets", "tile_emit", "tile_sort",
+                                           "composite_fwd", "composite_bwd_footprint", "project_bwd_adam"};
+static hipEvent_t *g_ev = nullptr;  // [(kStages + 1) * g_ev_steps]
+static int g_ev_steps = 0, g_ev_next = 0;
+}  // namespace eg
+
+extern "C" int eg_timing_begin(int32_t n_steps) {
+  EG_REQUIRE(n_steps > 0 && n_steps <= 4096, "n_steps out of range");
+  if (g_ev) {
+    for (int i = 0; i < (kStages + 1) * g_ev_steps; ++i) (void)hipEventDestroy(g_ev[i]);
+    delete[] g_ev;
+  }
+  g_ev = new hipEvent_t[(kStages + 1) * n_steps];
+  for (int i = 0; i < (kStages + 1) * n_steps; ++i)
+    if (hipEventCreate(&g_ev[i]) != hipSuccess) {
+      set_error("eg_timing_begin: hipEventCreate failed");
+      return EG_ERR_LAUNCH;
+    }
+  g_ev_steps = n_steps;
+  g_ev_next = 0;
+  return EG_OK;
+}
+
+extern "C" const char *eg_timing_stage_name(int32_t i) { return (i >= 0 && i < kStages) ? kStageNames[i] : ""; }
+extern "C" int eg_timing_stage_count(void) { return kStages; }
+
+// average microseconds per stage over the recorded steps; stops the timing window
+extern "C" int eg_timing_end(float *stage_us /*[kStages] host*/, int32_t *n_steps_out /*host|NULL*/) {
+  EG_REQUIRE(g_ev && stage_us, "no timing window open");
+  const int n = g_ev_next;
+  for (int k = 0; k < kStages; ++k) stage_us[k] = 0.f;
+  if (n > 0) {
+    if (hipEventSynchronize(g_ev[(kStages + 1) * (n - 1) + kStages]) != hipSuccess) {
+      set_error("eg_timing_end: hipEventSynchronize failed");
+      return EG_ERR_LAUNCH;
+    }
+    for (int s = 0; s < n; ++s)
+      for (int k = 0; k < kStages; ++k) {
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, g_ev[(kStages + 1) * s + k], g_ev[(kStages + 1) * s + k + 1]);
+        stage_us[k] += 1e3f * ms / (float)n;
+      }
+  }
+  if (n_steps_out) *n_steps_out = n;
+  for (int i = 0; i < (kStages + 1) * g_ev_steps; ++i) (void)hipEventDestroy(g_ev[i]);
+  delete[] g_ev;
+  g_ev = nullptr;
+  g_ev_steps = g_ev_next = 0;
+  return EG_OK;
+}
+
 extern "C" int eg_train_step(const eg_step_args *a, eg_stream_t stream) {
   EG_REQUIRE(a != nullptr, "null args");
   EG_REQUIRE(a->N > 0 && a->width > 0 && a->height > 0 && a->capacity > 0, "bad sizes");
   const int tw = cdiv(a->width, kTile), th = cdiv(a->height, kTile), T = tw * th;
-  const uint32_t flags = EG_FLAG_LOG_SCALES | EG_FLAG_LOGIT_OPACITIES | EG_FLAG_ANTIALIASED;
+  const uint32_t flags = EG_FLAG_LOG_SCALES | EG_FLAG_LOGIT_OPACITIES | EG_FLAG_ANTIALIASED | EG_FLAG_TIGHT_TILES;
+  hipEvent_t *ev = (g_ev && g_ev_next < g_ev_steps) ? &g_ev[(kStages + 1) * g_ev_next] : nullptr;
+  hipStream_t st = as_stream(stream);
+#define EG_MARK(k) do { if (ev) (void)hipEventRecord(ev[k], st); } while (0)
   int rc;
+  EG_MARK(0);
   // tile_counts is zero on entry (caller zero-initialises it once): the projection counts it up,
   // the emit pass counts it back down to zero.
   rc = eg_project_fwd(a->means, a->quats, a->log_scales, a->logit_opacities, a->viewmat, a->K, a->N, a->width,
                       a->height, 0.01f, 1e10f, 0.3f, 0.0f, flags, a->splat, nullptr, nullptr, nullptr, nullptr,
-                      nullptr, nullptr, a->tile_counts, a->g2d, stream);
+                      nullptr, nullptr, a->tile_counts, nullptr, stream);
   if (rc) return rc;
-  rc = eg_tile_offsets(a->tile_counts, T, a->capacity, a->offsets, a->total, stream);
+  EG_MARK(1);
+  rc = eg_tile_offsets(a->tile_counts, T, a->capacity, a->offsets, a->item_offsets, a->total, stream);
   if (rc) return rc;
-  rc = eg_tile_emit(nullptr, nullptr, nullptr, a->splat, a->N, a->width, a->height, a->offsets, a->tile_counts,
-                    a->capacity, a->keys, stream);
+  EG_MARK(2);
+  rc = eg_tile_emit(nullptr, nullptr, nullptr, a->splat, flags, a->N, a->width, a->height, a->offsets,
+                    a->tile_counts, a->capacity, a->keys, stream);
   if (rc) return rc;
+  EG_MARK(3);
   rc = eg_sort_pairs(a->keys, a->offsets, T, a->capacity, a->flatten_ids, nullptr, stream);
   if (rc) return rc;
+  EG_MARK(4);
   rc = eg_composite_fwd(a->splat, nullptr, 1, a->offsets, a->flatten_ids, a->width, a->height, a->render,
-                        a->alphas, a->last_ids, a->gt, a->wmap, a->loss_scale, a->vpix, a->loss, stream);
+                        a->alphas, a->last_ids, a->gt, a->wmap, a->loss_scale, a->vpix, a->loss, a->item_offsets,
+                        a->total, a->max_items, a->workspace, a->gtstop, stream);
   if (rc) return rc;
-  rc = eg_composite_bwd(a->splat, a->offsets, a->flatten_ids, a->width, a->height, a->alphas, a->last_ids,
-                        a->vpix, a->g2d, stream);
+  EG_MARK(5);
+  // backward: footprint compositing VJP, then projection VJP + absgrad (+ Adam)
+  rc = eg_composite_bwd_footprint(a->splat, a->N, a->width, a->height, a->gtstop, a->g2d, a->big_list, a->parity,
+                                  stream);
   if (rc) return rc;
-  if (a->adam_host) {
+  EG_MARK(6);
+  if (a->adam_host)
     rc = eg_project_bwd_adam(a->means, a->quats, a->log_scales, a->logit_opacities, a->viewmat, a->K, a->N,
-                             a->width, a->height, 0.3f, flags, a->splat, a->g2d, a->adam_m, a->adam_v,
-                             a->absgrads, *a->adam_host, stream);
-  } else {
+                             a->width, a->height, 0.3f, flags, a->splat, a->g2d, a->adam_m, a->adam_v, a->absgrads,
+                             *a->adam_host, stream);
+  else
     rc = eg_project_bwd(a->means, a->quats, a->log_scales, a->logit_opacities, a->viewmat, a->K, a->N, a->width,
-                        a->height, 0.3f, flags, a->splat, a->g2d, nullptr, nullptr, a->v_means, a->v_quats, a->v_scales,
-                        a->v_opacities, a->absgrads, stream);
-  }
+                        a->height, 0.3f, flags, a->splat, a->g2d, nullptr, nullptr, a->v_means, a->v_quats,
+                        a->v_scales, a->v_opacities, a->absgrads, stream);
+  EG_MARK(7);
+#undef EG_MARK
+  if (ev) ++g_ev_next;
   return rc;
 }

@@ -101,7 +101,7 @@ class _Compositing(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, means2d, conics, colors, opacities, width, height, offsets, flatten_ids, absgrad,
-                unit_colors):
+                unit_colors, item_offsets, totals, n_items):
         Cn, N = means2d.shape[0], means2d.shape[1]
         dev = means2d.device
         D = colors.shape[-1]
@@ -113,19 +113,27 @@ class _Compositing(torch.autograd.Function):
         last_ids = torch.empty(Cn, height, width, dtype=torch.int32, device=dev)
         for c in range(Cn):
             col = None if unit_colors else ptr(colors_c[c] if colors_c.dim() == 3 else colors_c)
+            ws = None
+            if unit_colors and n_items[c] > 0:  # slice-parallel forward needs its scratch
+                nbytes = _lib.load().eg_composite_workspace_bytes(n_items[c])
+                ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
             call("eg_composite_fwd", ptr(splat[c]), col, D, ptr(offsets[c]), ptr(flatten_ids[c]), width, height,
-                 ptr(render[c]), ptr(alphas[c]), ptr(last_ids[c]), None, None, 1.0, None, None, stream())
-        ctx.save_for_backward(means2d, splat, colors_c, alphas, last_ids, *offsets, *flatten_ids)
-        ctx.cfg = (width, height, absgrad, unit_colors, Cn)
+                 ptr(render[c]), ptr(alphas[c]), ptr(last_ids[c]), None, None, 1.0, None, None,
+                 ptr(item_offsets[c]) if ws is not None else None, ptr(totals[c]) if ws is not None else None,
+                 n_items[c], ptr(ws), None, stream())
+        ctx.save_for_backward(means2d, splat, colors_c, alphas, last_ids, *offsets, *flatten_ids, *item_offsets,
+                              *totals)
+        ctx.cfg = (width, height, absgrad, unit_colors, Cn, tuple(n_items))
         ctx.mark_non_differentiable(last_ids)
         return render, alphas, last_ids
 
     @staticmethod
     def backward(ctx, v_render, v_alphas, _v_last):
-        width, height, absgrad, unit_colors, Cn = ctx.cfg
+        width, height, absgrad, unit_colors, Cn, n_items = ctx.cfg
         saved = ctx.saved_tensors
         means2d, splat, colors, alphas, last_ids = saved[:5]
         offsets, flatten_ids = saved[5:5 + Cn], saved[5 + Cn:5 + 2 * Cn]
+        item_offsets, totals = saved[5 + 2 * Cn:5 + 3 * Cn], saved[5 + 3 * Cn:5 + 4 * Cn]
         N, D = means2d.shape[1], colors.shape[-1]
         dev = means2d.device
         g2d = torch.zeros(Cn, N, 8, device=dev)
@@ -137,7 +145,8 @@ class _Compositing(torch.autograd.Function):
             vpix = (v_render.sum(-1) + v_alphas[..., 0]).contiguous()
             for c in range(Cn):
                 call("eg_composite_bwd", ptr(splat[c]), ptr(offsets[c]), ptr(flatten_ids[c]), width, height,
-                     ptr(alphas[c]), ptr(last_ids[c]), ptr(vpix[c]), ptr(g2d[c]), stream())
+                     ptr(alphas[c]), ptr(last_ids[c]), ptr(vpix[c]), ptr(g2d[c]),
+                     ptr(item_offsets[c]), ptr(totals[c]), n_items[c], stream())
         else:
             per_cam = colors.dim() == 3
             v_colors = torch.zeros(Cn, N, D, device=dev) if need_vcol else None
@@ -151,12 +160,12 @@ class _Compositing(torch.autograd.Function):
         if absgrad:
             means2d.absgrad = g2d[..., 2:4].contiguous()
         return (g2d[..., 0:2].contiguous(), g2d[..., 4:7].contiguous(), v_colors, g2d[..., 7].contiguous(),
-                None, None, None, None, None, None)
+                None, None, None, None, None, None, None, None, None)
 
 
 def isect_tiles_and_sort(means2d: Tensor, radii: Tensor, depths: Tensor, counts: Tensor, width: int,
                          height: int, want_isect_ids: bool = True
-                         ) -> Tuple[Tensor, Tensor, Optional[Tensor], int]:
+                         ) -> Tuple[Tensor, Tensor, Optional[Tensor], int, Tensor, Tensor, int]:
     """Per camera: offsets[T+1] (scan of `counts`), keys -> sorted flatten_ids (+ int64 isect ids).
 
     `counts` holds the per-tile counts on entry and is returned to zero.  One host sync (the read
@@ -165,17 +174,18 @@ def isect_tiles_and_sort(means2d: Tensor, radii: Tensor, depths: Tensor, counts:
     N = means2d.shape[0]
     T = counts.shape[0]
     offsets = torch.empty(T + 1, dtype=torch.int32, device=dev)
-    total = torch.empty(2, dtype=torch.int32, device=dev)
-    call("eg_tile_offsets", ptr(counts), T, 1 << 40, ptr(offsets), ptr(total), stream())
-    M = int(total[0].item())
+    item_offsets = torch.empty(T + 1, dtype=torch.int32, device=dev)
+    total = torch.empty(4, dtype=torch.int32, device=dev)
+    call("eg_tile_offsets", ptr(counts), T, 1 << 40, ptr(offsets), ptr(item_offsets), ptr(total), stream())
+    M, _ovf, n_items, _nmax = (int(v) for v in total.tolist())
     keys = torch.empty(max(M, 1), dtype=torch.int64, device=dev)
     flat = torch.empty(max(M, 1), dtype=torch.int32, device=dev)
     ids = torch.empty(max(M, 1), dtype=torch.int64, device=dev) if want_isect_ids else None
-    call("eg_tile_emit", ptr(means2d), ptr(radii), ptr(depths), None, N, width, height, ptr(offsets),
+    call("eg_tile_emit", ptr(means2d), ptr(radii), ptr(depths), None, 0, N, width, height, ptr(offsets),
          ptr(counts), M, ptr(keys), stream())
     call("eg_sort_pairs", ptr(keys), ptr(offsets), T, M, ptr(flat), ptr(ids) if ids is not None else None,
          stream())
-    return offsets, flat[:M], (ids[:M] if ids is not None else None), M
+    return offsets, flat[:M], (ids[:M] if ids is not None else None), M, item_offsets, total, n_items
 
 
 def rasterization(
@@ -226,12 +236,16 @@ def rasterization(
 
     tw, th = math.ceil(width / TILE), math.ceil(height / TILE)
     tile_bits = int(math.floor(math.log2(tw * th))) + 1
-    offs_l, flat_l, ids_l = [], [], []
+    offs_l, flat_l, ids_l, item_l, tot_l, nit_l = [], [], [], [], [], []
     m_base = 0
     info_offsets = []
     with torch.no_grad():
         for c in range(Cn):
-            offsets, flat, ids, M = isect_tiles_and_sort(means2d[c], radii[c], depths[c], counts[c], width, height)
+            offsets, flat, ids, M, item_offsets, total, n_items = isect_tiles_and_sort(
+                means2d[c], radii[c], depths[c], counts[c], width, height)
+            item_l.append(item_offsets)
+            tot_l.append(total)
+            nit_l.append(n_items)
             offs_l.append(offsets)
             flat_l.append(flat if M > 0 else torch.zeros(1, dtype=torch.int32, device=means.device))
             ids_l.append((ids | (c << (32 + tile_bits)), flat + c * N, M))
@@ -243,7 +257,7 @@ def rasterization(
     unit = (not colors.requires_grad) and bool((colors == 1).all().item())
     render, alphas, last_ids = _Compositing.apply(
         means2d, conics, colors, opac.contiguous(), width, height, tuple(offs_l), tuple(flat_l), bool(absgrad),
-        unit)
+        unit, tuple(item_l), tuple(tot_l), tuple(nit_l))
 
     info = {
         "camera_ids": None, "gaussian_ids": None,

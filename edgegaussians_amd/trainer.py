@@ -114,7 +114,9 @@ class EdgeTrainer:
     def _alloc_per_gaussian(self):
         N, d = self.N, self.dev
         self.splat = torch.empty(N, 8, device=d)
-        self.g2d = torch.zeros(N, 8, device=d)
+        self.g2d = torch.empty(N, 8, device=d)  # written (not accumulated) by the footprint backward
+        self.big_list = torch.zeros(2 + N, dtype=torch.int32, device=d)  # big-footprint work list
+        self._parity = 0
         self.grads = torch.zeros(N, 12, device=d)  # [means3|quats4|scales3|opac1|absgrad-inc1] for all-reduce
         self._args_cache: Dict = {}
 
@@ -122,10 +124,12 @@ class EdgeTrainer:
         H, W, d = self.height, self.width, self.dev
         self.tile_counts = torch.zeros(self.T, dtype=torch.int32, device=d)
         self.offsets = torch.zeros(self.T + 1, dtype=torch.int32, device=d)
-        self.total = torch.zeros(2, dtype=torch.int32, device=d)
+        self.item_offsets = torch.zeros(self.T + 1, dtype=torch.int32, device=d)
+        self.total = torch.zeros(4, dtype=torch.int32, device=d)  # M, overflow, items, largest tile
         self.render = torch.zeros(H, W, device=d)
         self.alphas = torch.zeros(H, W, device=d)
         self.vpix = torch.zeros(H, W, device=d)
+        self.gtstop = torch.zeros(H, W, 2, device=d)  # {vpix * T_final, stop id} for the fused backward
         self.last_ids = torch.zeros(H, W, dtype=torch.int32, device=d)
         self.loss_acc = torch.zeros(1, device=d)
 
@@ -133,6 +137,9 @@ class EdgeTrainer:
         self.capacity = int(capacity)
         self.keys = torch.empty(self.capacity, dtype=torch.int64, device=self.dev)
         self.flatten_ids = torch.empty(self.capacity, dtype=torch.int32, device=self.dev)
+        self.max_items = (self.capacity + 255) // 256 + self.T
+        self.workspace = torch.empty(_lib.load().eg_composite_workspace_bytes(self.max_items), dtype=torch.uint8,
+                                     device=self.dev)
         self._args_cache = {}
 
     # ------------------------------------------------------------------ capacity
@@ -140,9 +147,11 @@ class EdgeTrainer:
         """M for one view (count-only pass: projection + per-tile counts + scan).  Host sync."""
         call("eg_project_fwd", ptr(self.means), ptr(self.quats), ptr(self.log_scales), ptr(self.logit_opacities),
              ptr(self.viewmats[view]), ptr(self.Ks[view]), self.N, self.width, self.height, 0.01, 1e10, 0.3, 0.0,
-             _lib.FLAG_LOG_SCALES | _lib.FLAG_LOGIT_OPACITIES | _lib.FLAG_ANTIALIASED, ptr(self.splat),
+             _lib.FLAG_LOG_SCALES | _lib.FLAG_LOGIT_OPACITIES | _lib.FLAG_ANTIALIASED | _lib.FLAG_TIGHT_TILES,
+             ptr(self.splat),
              None, None, None, None, None, None, ptr(self.tile_counts), None, stream())
-        call("eg_tile_offsets", ptr(self.tile_counts), self.T, 1 << 40, ptr(self.offsets), ptr(self.total), stream())
+        call("eg_tile_offsets", ptr(self.tile_counts), self.T, 1 << 40, ptr(self.offsets), ptr(self.item_offsets),
+             ptr(self.total), stream())
         m = int(self.total[0].item())
         self.tile_counts.zero_()
         return m
@@ -169,7 +178,9 @@ class EdgeTrainer:
             a.N = self.N
             a.width, a.height = self.width, self.height
             a.splat, a.g2d = ptr(self.splat), ptr(self.g2d)
+            a.gtstop, a.big_list = ptr(self.gtstop), ptr(self.big_list)
             a.tile_counts, a.offsets, a.total = ptr(self.tile_counts), ptr(self.offsets), ptr(self.total)
+            a.item_offsets, a.workspace, a.max_items = ptr(self.item_offsets), ptr(self.workspace), self.max_items
             a.keys, a.flatten_ids, a.capacity = ptr(self.keys), ptr(self.flatten_ids), self.capacity
             a.render, a.alphas, a.vpix = ptr(self.render), ptr(self.alphas), ptr(self.vpix)
             a.loss, a.last_ids = ptr(self.loss_acc), ptr(self.last_ids)
@@ -185,6 +196,8 @@ class EdgeTrainer:
         a.gt = self.gt.data_ptr() + 4 * self.height * self.width * view
         a.wmap = wmap.data_ptr()
         a.loss_scale = self.loss_scale
+        a.parity = self._parity
+        self._parity ^= 1
         if fused_adam:
             a.absgrads = ptr(self.absgrads)
             a.adam_host = self._args_cache["hyper_ptr"]
@@ -220,18 +233,20 @@ class EdgeTrainer:
         mark = mark or (lambda name: None)
         self.adam_step += 1
         self._set_hyper()
-        fl = _lib.FLAG_LOG_SCALES | _lib.FLAG_LOGIT_OPACITIES | _lib.FLAG_ANTIALIASED
+        fl = (_lib.FLAG_LOG_SCALES | _lib.FLAG_LOGIT_OPACITIES | _lib.FLAG_ANTIALIASED |
+              _lib.FLAG_TIGHT_TILES)
         st = stream()
         vm, K = ptr(self.viewmats[view]), ptr(self.Ks[view])
         N, W, H = self.N, self.width, self.height
         mark("start")
         call("eg_project_fwd", ptr(self.means), ptr(self.quats), ptr(self.log_scales), ptr(self.logit_opacities),
              vm, K, N, W, H, 0.01, 1e10, 0.3, 0.0, fl, ptr(self.splat), None, None, None, None, None, None,
-             ptr(self.tile_counts), ptr(self.g2d), st)
+             ptr(self.tile_counts), None, st)
         mark("project_fwd")
-        call("eg_tile_offsets", ptr(self.tile_counts), self.T, self.capacity, ptr(self.offsets), ptr(self.total), st)
+        call("eg_tile_offsets", ptr(self.tile_counts), self.T, self.capacity, ptr(self.offsets),
+             ptr(self.item_offsets), ptr(self.total), st)
         mark("tile_offsets")
-        call("eg_tile_emit", None, None, None, ptr(self.splat), N, W, H, ptr(self.offsets), ptr(self.tile_counts),
+        call("eg_tile_emit", None, None, None, ptr(self.splat), fl, N, W, H, ptr(self.offsets), ptr(self.tile_counts),
              self.capacity, ptr(self.keys), st)
         mark("tile_emit")
         call("eg_sort_pairs", ptr(self.keys), ptr(self.offsets), self.T, self.capacity, ptr(self.flatten_ids),
@@ -239,17 +254,37 @@ class EdgeTrainer:
         mark("tile_sort")
         call("eg_composite_fwd", ptr(self.splat), None, 1, ptr(self.offsets), ptr(self.flatten_ids), W, H,
              ptr(self.render), ptr(self.alphas), ptr(self.last_ids), ptr(self.gt[view]), ptr(wmap),
-             self.loss_scale, ptr(self.vpix), ptr(self.loss_acc), st)
+             self.loss_scale, ptr(self.vpix), ptr(self.loss_acc), ptr(self.item_offsets), ptr(self.total),
+             self.max_items, ptr(self.workspace), ptr(self.gtstop), st)
         mark("composite_fwd")
-        call("eg_composite_bwd", ptr(self.splat), ptr(self.offsets), ptr(self.flatten_ids), W, H, ptr(self.alphas),
-             ptr(self.last_ids), ptr(self.vpix), ptr(self.g2d), st)
-        mark("composite_bwd")
-        call("eg_project_bwd_adam", ptr(self.means), ptr(self.quats), ptr(self.log_scales),
-             ptr(self.logit_opacities), vm, K, N, W, H, 0.3, fl, ptr(self.splat), ptr(self.g2d), ptr(self.adam_m),
-             ptr(self.adam_v), ptr(self.absgrads), self._hyper, st)
-        mark("project_bwd_adam")
+        call("eg_backward_fused", ptr(self.means), ptr(self.quats), ptr(self.log_scales),
+             ptr(self.logit_opacities), vm, K, N, W, H, 0.3, fl, ptr(self.splat), ptr(self.gtstop), ptr(self.g2d),
+             None, None, None, None, ptr(self.absgrads), ptr(self.adam_m), ptr(self.adam_v), C.byref(self._hyper),
+             ptr(self.big_list), self._parity, st)
+        self._parity ^= 1
+        mark("backward_fused")
         self.absgrads_normalize_factor += 1
         self.step += 1
+
+    @staticmethod
+    def timing_begin(n_steps: int) -> None:
+        """The next `n_steps` train_step / grad_step calls record HIP events between their stages
+        (natively, on the launch stream)."""
+        rc = _lib.load().eg_timing_begin(n_steps)
+        if rc != 0:
+            raise RuntimeError(_lib.load().eg_last_error_string().decode())
+
+    @staticmethod
+    def timing_end() -> Dict[str, float]:
+        """Synchronises once; average launch duration in microseconds per stage."""
+        lib = _lib.load()
+        k = lib.eg_timing_stage_count()
+        buf = (C.c_float * k)()
+        n = C.c_int32(0)
+        rc = lib.eg_timing_end(buf, C.byref(n))
+        if rc != 0:
+            raise RuntimeError(lib.eg_last_error_string().decode())
+        return {lib.eg_timing_stage_name(i).decode(): float(buf[i]) for i in range(k)}
 
     def grad_step(self, view: int, wmap: Tensor) -> Tensor:
         """Forward + loss + backward only: leaves dL/d{means,quats,log_scales,logit_opacities} in

@@ -45,6 +45,8 @@ typedef void *eg_stream_t; /* hipStream_t */
 #define EG_FLAG_LOG_SCALES 1u      /* `scales` holds log-scales: exp() fused (edge_gs.py:253) */
 #define EG_FLAG_LOGIT_OPACITIES 2u /* `opacities` holds logits: sigmoid() fused (edge_gs.py:254) */
 #define EG_FLAG_ANTIALIASED 4u     /* rasterize_mode="antialiased" (edge_gs.py:50,266) */
+#define EG_FLAG_TIGHT_TILES 8u     /* bin with the opacity-aware tile box (subset of gsplat's box that \
+                                      drops only (Gaussian, tile) pairs contributing exactly nothing) */
 
 const char *eg_last_error_string(void);
 int eg_version(void);
@@ -71,15 +73,19 @@ int eg_tile_count(const float *means2d, const int32_t *radii, int32_t N, int32_t
                   int32_t *tiles_per_gauss /*[N]|NULL*/, int32_t *tile_counts /*[T]*/, eg_stream_t stream);
 
 /* ---- G3+G6: exclusive scan of the per-tile counts -> isect_offsets[T+1] (offsets[T] = M), which is
- * gsplat's isect_offset_encode result.  Also writes total[0] = M, total[1] = 1 if
- * M > capacity (overflow).  tile_counts is left intact: eg_tile_emit counts it back down to zero. */
+ * gsplat's isect_offset_encode result.  tile_counts is left intact: eg_tile_emit
+ * counts it back down to zero.  item_offsets[T+1] (may be NULL) is the exclusive scan of
+ * ceil(count/256): the (tile, 256-Gaussian slice) work items of the compositing kernels.
+ * total[4] = { M, overflow flag (M > capacity), number of items, largest tile population }. */
 int eg_tile_offsets(const int32_t *tile_counts /*[T]*/, int32_t T, int64_t capacity,
-                    int32_t *offsets /*[T+1]*/, int32_t *total /*[2]*/, eg_stream_t stream);
+                    int32_t *offsets /*[T+1]*/, int32_t *item_offsets /*[T+1]|NULL*/, int32_t *total /*[4]*/,
+                    eg_stream_t stream);
 
 /* ---- G4: emit one (depth_bits<<32 | gaussian_id) key per (Gaussian, tile) into that tile's
  * segment [offsets[t], offsets[t+1]) (order inside a segment arbitrary; eg_sort_pairs fixes it). */
 int eg_tile_emit(const float *means2d_or_null, const int32_t *radii_or_null, const float *depths_or_null,
-                 const float *splat_or_null, int32_t N, int32_t width, int32_t height,
+                 const float *splat_or_null, uint32_t flags /*EG_FLAG_TIGHT_TILES needs splat*/,
+                 int32_t N, int32_t width, int32_t height,
                  const int32_t *offsets /*[T+1]*/, int32_t *tile_counts /*[T]: counts on entry, zero on exit*/,
                  int64_t capacity, uint64_t *keys /*[capacity]*/, eg_stream_t stream);
 
@@ -94,19 +100,31 @@ int eg_sort_pairs(uint64_t *keys /*[capacity] in/out*/, const int32_t *offsets /
  * channels = 1 or 3.  colors == NULL means "all ones" (the reference's colours, edge_gs.py:247).
  * Fused weighted-L1 (edge_gs.py:279,288-324 in weight-map form): when wmap != NULL,
  * channel 0 is clamped to [0,1], loss_out[0] += sum_p wmap_p*|c0_p - gt_p| and
- * vpix[p] = loss_scale * wmap_p * sign(c0_p - gt_p) (the upstream gradient of eg_composite_bwd). */
+ * vpix[p] = loss_scale * wmap_p * sign(c0_p - gt_p) (the upstream gradient of eg_composite_bwd).
+ * Slice-parallel mode (unit colours only): pass item_offsets + total from eg_tile_offsets, an upper
+ * bound max_items >= total[2] (e.g. ceil(capacity/256) + T) and a workspace of
+ * eg_composite_workspace_bytes(max_items) bytes; one workgroup runs per (tile, 256-Gaussian slice).
+ * With item_offsets == NULL (or per-Gaussian colours) one workgroup walks each tile. */
+int64_t eg_composite_workspace_bytes(int64_t max_items);
 int eg_composite_fwd(const float *splat, const float *colors /*[N,channels]|NULL*/, int32_t channels,
                      const int32_t *offsets, const int32_t *flatten_ids, int32_t width, int32_t height,
                      float *render /*[H,W,channels]*/, float *alphas /*[H,W]*/, int32_t *last_ids /*[H,W]*/,
                      const float *gt /*[H,W]|NULL*/, const float *wmap /*[H,W]|NULL*/, float loss_scale,
-                     float *vpix /*[H,W]|NULL*/, float *loss_out /*[1]|NULL*/, eg_stream_t stream);
+                     float *vpix /*[H,W]|NULL*/, float *loss_out /*[1]|NULL*/,
+                     const int32_t *item_offsets /*[T+1]|NULL*/, const int32_t *total /*[4]|NULL*/,
+                     int64_t max_items, void *workspace,
+                     float *gtstop /*[H,W,2]|NULL: {vpix * T_final, id of the last contributor if the
+                                     pixel's walk stopped on T <= 1e-4 else -1} for eg_backward_fused*/,
+                     eg_stream_t stream);
 
 /* ---- G8: compositing backward for unit colours (replaces gsplat rasterize_to_pixels bwd for the
  * reference's call).  vpix[p] = sum_k dL/drender[p,k] + dL/dalpha[p].  Accumulates
  * into g2d with float atomics. */
 int eg_composite_bwd(const float *splat, const int32_t *offsets, const int32_t *flatten_ids,
                      int32_t width, int32_t height, const float *alphas, const int32_t *last_ids,
-                     const float *vpix, float *g2d /*[N,8] accumulated*/, eg_stream_t stream);
+                     const float *vpix, float *g2d /*[N,8] accumulated*/,
+                     const int32_t *item_offsets /*[T+1]|NULL*/, const int32_t *total /*[4]|NULL*/,
+                     int64_t max_items, eg_stream_t stream);
 
 /* ---- G8 (general colours): order-dependent backward with per-Gaussian colours, channels = 3.
  * v_colors may be NULL. */
@@ -130,17 +148,41 @@ int eg_project_bwd(const float *means, const float *quats, const float *scales, 
                    float *v_means, float *v_quats, float *v_scales, float *v_opacities,
                    float *absgrads /*[N]|NULL*/, eg_stream_t stream);
 
+/* hyper-parameters of the four torch.optim.Adam instances (train_utils.py:50-60) */
+typedef struct {
+  double lr_means, lr_scales, lr_quats, lr_opacities; /* doubles: the bias-corrected scalars are */
+  double beta1, beta2, eps;                            /* formed in double like torch does, then cast */
+  int32_t step;
+} eg_adam_hyper;
+
+/* ---- G8, footprint form (unit colours, fused path): 8 lanes per Gaussian walk the Gaussian's own
+ * footprint in the gtstop image written by eg_composite_fwd (the unit-colour backward is
+ * order-independent), and WRITE its g2d record -- no tile lists, no atomics, no zeroing of g2d.
+ * big_list: int32[2 + N] scratch, zero-initialised ONCE by the caller (footprints above 8192 px are
+ * queued there and handled by a wavefront each).  `parity` (0/1) must alternate between consecutive
+ * calls on the same big_list: call k uses counter big_list[parity] and clears the other one for
+ * call k+1, which saves a memset node per step. */
+int eg_composite_bwd_footprint(const float *splat, int32_t N, int32_t width, int32_t height,
+                               const float *gtstop /*[H,W,2]*/, float *g2d /*[N,8] written*/,
+                               int32_t *big_list, int32_t parity, eg_stream_t stream);
+
+/* ---- whole backward of the fused path: eg_composite_bwd_footprint, then eg_project_bwd_adam
+ * (hyper_host != NULL: absgrads accumulated, Adam applied) or eg_project_bwd (hyper_host == NULL:
+ * gradients written to v_*, absgrads[g] += increment). */
+int eg_backward_fused(float *means, float *quats, float *scales, float *opacities,
+                      const float *viewmat, const float *K, int32_t N, int32_t width, int32_t height,
+                      float eps2d, uint32_t flags, const float *splat, const float *gtstop, float *g2d,
+                      float *v_means, float *v_quats, float *v_scales, float *v_opacities,
+                      float *absgrads /*[N]|NULL*/, float *m, float *v,
+                      const eg_adam_hyper *hyper_host /*NULL = write gradients*/, int32_t *big_list,
+                      int32_t parity, eg_stream_t stream);
+
 /* ---- a6: absgrad accumulate on its own (edge_gs.py:607-613): absgrads += ||means2d.absgrad||_2 */
 int eg_absgrad_accum(const float *means2d_absgrad /*[N,2]*/, int32_t N, float *absgrads, eg_stream_t stream);
 
 /* ---- a7: the four torch.optim.Adam steps of train_gaussians.py:104-106 in one launch
  * (train_utils.py:50-60: betas 0.9/0.999, eps 1e-8, no weight decay, no amsgrad; torch 1.13
  * update order).  `step` is the 1-based step count shared by the four optimizers. */
-typedef struct {
-  double lr_means, lr_scales, lr_quats, lr_opacities; /* doubles: the bias-corrected scalars are */
-  double beta1, beta2, eps;                            /* formed in double like torch does, then cast */
-  int32_t step;
-} eg_adam_hyper;
 
 int eg_adam_multi(float *means, float *scales, float *quats, float *opacities,
                   const float *g_means, const float *g_scales, const float *g_quats, const float *g_opacities,
@@ -185,11 +227,16 @@ typedef struct {
   float loss_scale; /* lambda_projection (train_gaussians.py:98) */
   /* workspace */
   float *splat, *g2d;
-  int32_t *tile_counts, *offsets, *total; /* [T], [T+1], [2] */
+  int32_t *tile_counts, *offsets, *item_offsets, *total; /* [T], [T+1], [T+1], [4] */
+  void *workspace;   /* eg_composite_workspace_bytes(max_items) bytes */
+  int64_t max_items; /* >= ceil(capacity/256) + T */
   uint64_t *keys;
   int32_t *flatten_ids;
   int64_t capacity;
   float *render, *alphas, *vpix, *loss; /* [H,W], [H,W], [H,W], [1] accumulated */
+  float *gtstop;                        /* [H,W,2] */
+  int32_t *big_list;                    /* [2 + N], zero-initialised once */
+  int32_t parity;                       /* 0/1, alternates every step (see eg_composite_bwd_footprint) */
   int32_t *last_ids;
   /* gradient outputs (used when adam == NULL, e.g. before an RCCL all-reduce) */
   float *v_means, *v_quats, *v_scales, *v_opacities;
@@ -197,6 +244,15 @@ typedef struct {
 } eg_step_args;
 
 int eg_train_step(const eg_step_args *args_host, eg_stream_t stream);
+
+/* ---- measurement aid: between eg_timing_begin(n) and eg_timing_end(), the next n eg_train_step
+ * calls record HIP events between their stages on the launch stream; eg_timing_end synchronises
+ * once and returns the average microseconds per stage (eg_timing_stage_count() entries, names by
+ * eg_timing_stage_name(i)).  Not thread safe; one window at a time. */
+int eg_timing_begin(int32_t n_steps);
+int eg_timing_end(float *stage_us_host, int32_t *n_steps_out_host);
+int eg_timing_stage_count(void);
+const char *eg_timing_stage_name(int32_t i);
 
 #ifdef __cplusplus
 }

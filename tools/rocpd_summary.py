@@ -41,5 +41,23 @@ def main():
         open(sys.argv[2], "w").write(out + "\n")
 
 
+
+
+def tail_dispatches(path, n=200):
+    """Debug helper: the last n kernel dispatches in order (name, duration us, gap to previous us)."""
+    db = sqlite3.connect(path)
+    cur = db.cursor()
+    rows = cur.execute("select name, start, end from kernels order by start").fetchall()[-n:]
+    prev = None
+    for name, s, e in rows:
+        short = name.split("(")[0].replace("void ", "").replace("eg::", "")[:50]
+        gap = (s - prev) / 1e3 if prev else 0.0
+        print(f"{short:52s} {(e - s) / 1e3:9.2f} {gap:9.2f}")
+        prev = e
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 2 and sys.argv[2] == "--tail":
+        tail_dispatches(sys.argv[1], int(sys.argv[3]) if len(sys.argv) > 3 else 200)
+    else:
+        main()
