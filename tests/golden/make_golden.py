@@ -116,6 +116,8 @@ def lr_table():
             opts[n].step()
             scheds[n].step()
     np.savez(os.path.join(OUT, "lr_table.npz"), names=np.array(names), lr=np.array(rows, dtype=np.float64))
+    # the optimiser section of the config the table was produced from (values only)
+    json.dump(CFG["training"]["optim"], open(os.path.join(OUT, "abc_optim_config.json"), "w"), indent=1)
 
 
 def _make_model(views, n=96, seed=5):
