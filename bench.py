@@ -145,7 +145,10 @@ def main():
     # device pre-warm, not part of --warmup: a fresh box needs ~0.1 s of work before clocks and page
     # tables settle (first-run outliers of 2x were measured without it)
     for s in range(300):
-        tr.train_step(s % n_views, whole)
+        if dp is None:
+            tr.train_step(s % n_views, whole)
+        else:  # keep the replicas identical: the pre-warm goes through the all-reduce as well
+            dp.step(egdist.view_for(s, rank, world, n_views), whole)
     torch.cuda.synchronize()
     tr.pop_loss()
 
