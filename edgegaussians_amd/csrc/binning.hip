@@ -64,8 +64,8 @@ tile_count_kernel(const float2 *__restrict__ means2d, const int *__restrict__ ra
 
 // single workgroup, 1024 threads: exclusive scan of counts[T] -> offsets[T+1]; counts stay intact
 // (the emit pass counts them back down to zero, so no memset is ever needed between steps).
-// Also scans the per-tile SLICE counts ceil(n_t / 256) -> item_offsets[T+1]: the compositing kernels
-// run one workgroup per (tile, 256-Gaussian slice) "item", so a tile holding thousands of Gaussians
+// Also scans the per-tile SLICE counts ceil(n_t / 128) -> item_offsets[T+1]: the compositing kernels
+// run one workgroup per (tile, 128-Gaussian slice) "item", so a tile holding thousands of Gaussians
 // is spread over many CUs instead of serialising on one.
 __device__ __forceinline__ int block_excl_scan_1024(int c, int *wave_sums, int &block_total) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -103,7 +103,7 @@ tile_offsets_kernel(const int *__restrict__ counts, int T, long long capacity, i
   for (int base = 0; base < T; base += 1024) {
     const int i = base + tid;
     const int c = (i < T) ? counts[i] : 0;
-    const int it = (c + 255) >> 8;
+    const int it = (c + 127) >> 7;  // 128-Gaussian slices (kSlice in composite.hip)
     int tot, itot;
     const int e = block_excl_scan_1024(c, wave_sums, tot);
     const int ie = block_excl_scan_1024(it, wave_sums, itot);

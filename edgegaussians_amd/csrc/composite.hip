@@ -215,7 +215,7 @@ composite_bwd_unit_kernel(const float4 *__restrict__ splat, const int *__restric
       valid = valid && (alpha >= kAlphaMin);
       if (valid) {
         hit = true;
-        const float v_alpha = P.z * __frcp_rn(1.f - alpha);  // dL/dalpha = v * T_final / (1 - alpha)
+        const float v_alpha = P.z * __builtin_amdgcn_rcpf(1.f - alpha);  // dL/dalpha = v * T_final / (1 - alpha)
         if (araw <= kAlphaMax) {
           const float v_sigma = -araw * v_alpha;
           const float gx = v_sigma * (ca * dx + cb * dy);
@@ -245,7 +245,7 @@ composite_bwd_unit_kernel(const float4 *__restrict__ splat, const int *__restric
 
 // ---------------------------------------------------------------------------------------------
 // item helpers
-constexpr int kSlice = 256;
+constexpr int kSlice = 128;  // Gaussians per item (half the LDS of 256 => 8 workgroups/CU, 2x the items)
 
 // largest t with item_offsets[t] <= b (item_offsets[T] = n_items > b): the tile owning item b
 __device__ __forceinline__ int item_tile(const int *__restrict__ item_offsets, int T, int b) {
@@ -277,6 +277,7 @@ composite_slice_fwd_kernel(const float4 *__restrict__ splat, const int *__restri
                            int *__restrict__ sliceL) {
   __shared__ float4 sA[4][kSlice + 2];  // x, y, a, b
   __shared__ float4 sB[4][kSlice + 2];  // c, o, sigma threshold, slice-local index (int bits)
+  static_assert(kSlice <= kTilePix, "one staging thread per Gaussian of the slice");
   __shared__ int sCnt[4][4];            // [quadrant][source wave]
   const int b = blockIdx.x;
   if (b >= total[2]) return;
@@ -367,8 +368,8 @@ composite_slice_fwd_kernel(const float4 *__restrict__ splat, const int *__restri
       }
     }
   }
-  sliceP[(size_t)b * kSlice + tid] = P;
-  sliceL[(size_t)b * kSlice + tid] = L;
+  sliceP[(size_t)b * kTilePix + tid] = P;
+  sliceL[(size_t)b * kTilePix + tid] = L;
 }
 
 // forward phase B: per tile, combine the slices in depth order (+ exact stop, + fused loss)
@@ -397,8 +398,8 @@ composite_combine_fwd_kernel(const float4 *__restrict__ splat, const int *__rest
   int last = 0;
   bool stopped = false;
   for (int s = 0; s < ns; ++s) {
-    const float P = sliceP[(size_t)(i0 + s) * kSlice + tid];
-    const int L = sliceL[(size_t)(i0 + s) * kSlice + tid];
+    const float P = sliceP[(size_t)(i0 + s) * kTilePix + tid];
+    const int L = sliceL[(size_t)(i0 + s) * kTilePix + tid];
     const float nT = T * P;
     const bool need = !stopped && (L >= 0) && (nT <= kTStop);
     if (__any(need)) {
@@ -546,7 +547,7 @@ composite_bwd_item_kernel(const float4 *__restrict__ splat, const int *__restric
       valid = valid && (alpha >= kAlphaMin);
       if (valid) {
         hit = true;
-        const float v_alpha = P.z * __frcp_rn(1.f - alpha);  // dL/dalpha = v * T_final / (1 - alpha)
+        const float v_alpha = P.z * __builtin_amdgcn_rcpf(1.f - alpha);  // dL/dalpha = v * T_final / (1 - alpha)
         if (araw <= kAlphaMax) {
           const float v_sigma = -araw * v_alpha;
           const float gx = v_sigma * (ca * dx + cb * dy);
@@ -638,7 +639,7 @@ __device__ __forceinline__ void footprint_pixel(const float4 s0, const float4 s1
     const unsigned dl = (unsigned)__float_as_int(splat[2 * stop_id + 1].z), dg = (unsigned)__float_as_int(s1.z);
     if (dg > dl || (dg == dl && g > stop_id)) return;
   }
-  const float v_alpha = gT * __frcp_rn(1.f - alpha);
+  const float v_alpha = gT * __builtin_amdgcn_rcpf(1.f - alpha);
   if (araw <= kAlphaMax) {
     const float v_sigma = -araw * v_alpha;
     const float gx = v_sigma * (s0.z * dx + s0.w * dy);
@@ -671,10 +672,20 @@ footprint_bwd_kernel(const float4 *__restrict__ splat, int N, int width, int hei
       if (c == 0) big_list[2 + atomicAdd(&big_list[parity], 1)] = g;  // a whole wavefront takes it
       return;
     }
-    for (int i = fp.i0; i <= fp.i1; ++i) {
-      const float2 *row = gtstop + (size_t)i * width;
-      for (int j = fp.j0 + c; j <= fp.j1; j += kLanesPerGauss)
-        footprint_pixel(s0, s1, fp.thr, g, i, j, row[j], splat, a);
+    // software-pipelined walk: the record of the NEXT pixel is in flight while this one is
+    // evaluated (the loop is latency-bound on these L2-resident gathers otherwise)
+    int i = fp.i0, j = fp.j0 + c;
+    bool more = j <= fp.j1;
+    float2 nxt = make_float2(0.f, 0.f);
+    if (more) nxt = gtstop[i * width + j];
+    while (more) {
+      const float2 rec = nxt;
+      const int ci = i, cj = j;
+      j += kLanesPerGauss;
+      if (j > fp.j1) { j = fp.j0 + c; ++i; }
+      more = i <= fp.i1;
+      if (more) nxt = gtstop[i * width + j];
+      footprint_pixel(s0, s1, fp.thr, g, ci, cj, rec, splat, a);
     }
   }
 #pragma unroll
@@ -855,7 +866,7 @@ composite_bwd_colors_kernel(const float4 *__restrict__ splat, const float *__res
 using namespace eg;
 
 extern "C" int64_t eg_composite_workspace_bytes(int64_t max_items) {
-  return max_items < 0 ? 0 : max_items * kSlice * (int64_t)(sizeof(float) + sizeof(int32_t));
+  return max_items < 0 ? 0 : max_items * kTilePix * (int64_t)(sizeof(float) + sizeof(int32_t));
 }
 
 extern "C" int eg_composite_fwd(const float *splat, const float *colors, int32_t channels, const int32_t *offsets,
@@ -875,7 +886,7 @@ extern "C" int eg_composite_fwd(const float *splat, const float *colors, int32_t
   if (!colors && item_offsets && total && workspace && max_items > 0) {
     // unit colours: slice-parallel two-kernel forward
     float *sliceP = (float *)workspace;
-    int *sliceL = (int *)(sliceP + (size_t)max_items * kSlice);
+    int *sliceL = (int *)(sliceP + (size_t)max_items * kTilePix);
     composite_slice_fwd_kernel<<<(unsigned)max_items, 256, 0, s>>>((const float4 *)splat, offsets, item_offsets,
                                                                   total, flatten_ids, tw, th, sliceP, sliceL);
     if (channels == 1)

@@ -75,7 +75,7 @@ int eg_tile_count(const float *means2d, const int32_t *radii, int32_t N, int32_t
 /* ---- G3+G6: exclusive scan of the per-tile counts -> isect_offsets[T+1] (offsets[T] = M), which is
  * gsplat's isect_offset_encode result.  tile_counts is left intact: eg_tile_emit
  * counts it back down to zero.  item_offsets[T+1] (may be NULL) is the exclusive scan of
- * ceil(count/256): the (tile, 256-Gaussian slice) work items of the compositing kernels.
+ * ceil(count/128): the (tile, 128-Gaussian slice) work items of the compositing kernels.
  * total[4] = { M, overflow flag (M > capacity), number of items, largest tile population }. */
 int eg_tile_offsets(const int32_t *tile_counts /*[T]*/, int32_t T, int64_t capacity,
                     int32_t *offsets /*[T+1]*/, int32_t *item_offsets /*[T+1]|NULL*/, int32_t *total /*[4]*/,
@@ -102,8 +102,8 @@ int eg_sort_pairs(uint64_t *keys /*[capacity] in/out*/, const int32_t *offsets /
  * channel 0 is clamped to [0,1], loss_out[0] += sum_p wmap_p*|c0_p - gt_p| and
  * vpix[p] = loss_scale * wmap_p * sign(c0_p - gt_p) (the upstream gradient of eg_composite_bwd).
  * Slice-parallel mode (unit colours only): pass item_offsets + total from eg_tile_offsets, an upper
- * bound max_items >= total[2] (e.g. ceil(capacity/256) + T) and a workspace of
- * eg_composite_workspace_bytes(max_items) bytes; one workgroup runs per (tile, 256-Gaussian slice).
+ * bound max_items >= total[2] (e.g. ceil(capacity/128) + T) and a workspace of
+ * eg_composite_workspace_bytes(max_items) bytes; one workgroup runs per (tile, 128-Gaussian slice).
  * With item_offsets == NULL (or per-Gaussian colours) one workgroup walks each tile. */
 int64_t eg_composite_workspace_bytes(int64_t max_items);
 int eg_composite_fwd(const float *splat, const float *colors /*[N,channels]|NULL*/, int32_t channels,
@@ -229,7 +229,7 @@ typedef struct {
   float *splat, *g2d;
   int32_t *tile_counts, *offsets, *item_offsets, *total; /* [T], [T+1], [T+1], [4] */
   void *workspace;   /* eg_composite_workspace_bytes(max_items) bytes */
-  int64_t max_items; /* >= ceil(capacity/256) + T */
+  int64_t max_items; /* >= ceil(capacity/128) + T */
   uint64_t *keys;
   int32_t *flatten_ids;
   int64_t capacity;
