@@ -653,6 +653,7 @@ __device__ __forceinline__ void footprint_pixel(const float4 s0, const float4 s1
   }
 }
 
+template <bool ROWSPAN>
 __global__ void __launch_bounds__(256)
 footprint_bwd_kernel(const float4 *__restrict__ splat, int N, int width, int height,
                      const float2 *__restrict__ gtstop, float *__restrict__ g2d, int *__restrict__ big_list,
@@ -672,20 +673,54 @@ footprint_bwd_kernel(const float4 *__restrict__ splat, int N, int width, int hei
       if (c == 0) big_list[2 + atomicAdd(&big_list[parity], 1)] = g;  // a whole wavefront takes it
       return;
     }
-    // software-pipelined walk: the record of the NEXT pixel is in flight while this one is
-    // evaluated (the loop is latency-bound on these L2-resident gathers otherwise)
-    int i = fp.i0, j = fp.j0 + c;
-    bool more = j <= fp.j1;
-    float2 nxt = make_float2(0.f, 0.f);
-    if (more) nxt = gtstop[i * width + j];
-    while (more) {
-      const float2 rec = nxt;
-      const int ci = i, cj = j;
-      j += kLanesPerGauss;
-      if (j > fp.j1) { j = fp.j0 + c; ++i; }
-      more = i <= fp.i1;
+    if (!ROWSPAN) {
+      // small footprints: plain AABB walk, software-pipelined (the record of the NEXT pixel is in
+      // flight while this one is evaluated)
+      int i = fp.i0, j = fp.j0 + c;
+      bool more = j <= fp.j1;
+      float2 nxt = make_float2(0.f, 0.f);
       if (more) nxt = gtstop[i * width + j];
-      footprint_pixel(s0, s1, fp.thr, g, ci, cj, rec, splat, a);
+      while (more) {
+        const float2 rec = nxt;
+        const int ci = i, cj = j;
+        j += kLanesPerGauss;
+        if (j > fp.j1) { j = fp.j0 + c; ++i; }
+        more = i <= fp.i1;
+        if (more) nxt = gtstop[i * width + j];
+        footprint_pixel(s0, s1, fp.thr, g, ci, cj, rec, splat, a);
+      }
+    } else {
+      // Row-span walk: on pixel row i the ellipse sigma <= thr is the interval
+      //   px in x + (b dy -/+ sqrt(2 a thr - det dy^2)) / a,   dy = y - (i + 0.5)
+      // (thin diagonal edge Gaussians fill a small fraction of their AABB).  Two rows are processed per
+      // iteration so that two independent gathers are in flight per lane.
+      const float ca = s0.z, cb = s0.w, cc = s1.x;
+      const float det = ca * cc - cb * cb, inv_a = 1.f / ca, two_a_thr = 2.f * ca * fp.thr;
+      for (int i = fp.i0; i <= fp.i1; i += 2) {
+        int jl[2], jr[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          const float dy = s0.y - ((float)(i + r) + 0.5f);
+          const float disc = two_a_thr - det * dy * dy;
+          jl[r] = 1; jr[r] = 0;
+          if (i + r <= fp.i1 && disc >= 0.f) {
+            const float sq = sqrtf(disc) * 1.001f + 0.01f * ca;  // same inflation as the AABB
+            const float lo = s0.x + (cb * dy - sq) * inv_a, hi = s0.x + (cb * dy + sq) * inv_a;
+            jl[r] = max(fp.j0, (int)ceilf(lo - 0.5f));
+            jr[r] = min(fp.j1, (int)floorf(hi - 0.5f));
+          }
+        }
+        for (int k = c;; k += kLanesPerGauss) {
+          const int ja = jl[0] + k, jb = jl[1] + k;
+          const bool va = ja <= jr[0], vb = jb <= jr[1];
+          if (!va && !vb) break;
+          float2 ra = make_float2(0.f, 0.f), rb = ra;
+          if (va) ra = gtstop[i * width + ja];
+          if (vb) rb = gtstop[(i + 1) * width + jb];
+          if (va) footprint_pixel(s0, s1, fp.thr, g, i, ja, ra, splat, a);
+          if (vb) footprint_pixel(s0, s1, fp.thr, g, i + 1, jb, rb, splat, a);
+        }
+      }
     }
   }
 #pragma unroll
@@ -931,13 +966,17 @@ extern "C" int eg_composite_bwd(const float *splat, const int32_t *offsets, cons
 
 extern "C" int eg_composite_bwd_footprint(const float *splat, int32_t N, int32_t width, int32_t height,
                                           const float *gtstop, float *g2d, int32_t *big_list, int32_t parity,
-                                          eg_stream_t stream) {
+                                          int32_t row_span, eg_stream_t stream) {
   EG_REQUIRE(N >= 0 && width > 0 && height > 0 && (parity == 0 || parity == 1), "bad sizes / parity");
   if (N == 0) return EG_OK;
   EG_REQUIRE(splat && gtstop && g2d && big_list, "null pointer");
   hipStream_t st = as_stream(stream);
-  footprint_bwd_kernel<<<cdiv((int64_t)N * kLanesPerGauss, 256), 256, 0, st>>>(
-      (const float4 *)splat, N, width, height, (const float2 *)gtstop, g2d, big_list, parity);
+  if (row_span)
+    footprint_bwd_kernel<true><<<cdiv((int64_t)N * kLanesPerGauss, 256), 256, 0, st>>>(
+        (const float4 *)splat, N, width, height, (const float2 *)gtstop, g2d, big_list, parity);
+  else
+    footprint_bwd_kernel<false><<<cdiv((int64_t)N * kLanesPerGauss, 256), 256, 0, st>>>(
+        (const float4 *)splat, N, width, height, (const float2 *)gtstop, g2d, big_list, parity);
   footprint_big_kernel<<<64, 256, 0, st>>>((const float4 *)splat, width, height, (const float2 *)gtstop, g2d,
                                           big_list, parity);
   return check_launch("composite_bwd_footprint");

@@ -141,7 +141,7 @@ extern "C" int eg_train_step(const eg_step_args *a, eg_stream_t stream) {
   EG_MARK(5);
   // backward: footprint compositing VJP, then projection VJP + absgrad (+ Adam)
   rc = eg_composite_bwd_footprint(a->splat, a->N, a->width, a->height, a->gtstop, a->g2d, a->big_list, a->parity,
-                                  stream);
+                                  a->row_span, stream);
   if (rc) return rc;
   EG_MARK(6);
   if (a->adam_host)

@@ -94,6 +94,7 @@ class EdgeTrainer:
         self.epoch = 0
         self.loss_scale = 1.0  # lambda_projection (train_gaussians.py:98; constant 1 in every config)
         self.capacity = 0
+        self.row_span = 0
         self._hyper = AdamHyper()
         self._alloc_state()
         self._alloc_pixels()
@@ -165,6 +166,10 @@ class EdgeTrainer:
         if need > self.capacity:
             self._alloc_isect(need)
         self.m_max_seen = m_max
+        # tuning hint for the footprint backward: large footprints (many tiles per Gaussian) favour the
+        # per-row ellipse-span walk, small ones the plain AABB walk (identical results either way)
+        self.row_span = 1 if m_max > 4 * self.N else 0
+        self._args_cache = {}
         return m_max
 
     # ------------------------------------------------------------------ the step
@@ -179,6 +184,7 @@ class EdgeTrainer:
             a.width, a.height = self.width, self.height
             a.splat, a.g2d = ptr(self.splat), ptr(self.g2d)
             a.gtstop, a.big_list = ptr(self.gtstop), ptr(self.big_list)
+            a.row_span = self.row_span
             a.tile_counts, a.offsets, a.total = ptr(self.tile_counts), ptr(self.offsets), ptr(self.total)
             a.item_offsets, a.workspace, a.max_items = ptr(self.item_offsets), ptr(self.workspace), self.max_items
             a.keys, a.flatten_ids, a.capacity = ptr(self.keys), ptr(self.flatten_ids), self.capacity
@@ -260,7 +266,7 @@ class EdgeTrainer:
         call("eg_backward_fused", ptr(self.means), ptr(self.quats), ptr(self.log_scales),
              ptr(self.logit_opacities), vm, K, N, W, H, 0.3, fl, ptr(self.splat), ptr(self.gtstop), ptr(self.g2d),
              None, None, None, None, ptr(self.absgrads), ptr(self.adam_m), ptr(self.adam_v), C.byref(self._hyper),
-             ptr(self.big_list), self._parity, st)
+             ptr(self.big_list), self._parity, self.row_span, st)
         self._parity ^= 1
         mark("backward_fused")
         self.absgrads_normalize_factor += 1

@@ -161,10 +161,11 @@ typedef struct {
  * big_list: int32[2 + N] scratch, zero-initialised ONCE by the caller (footprints above 8192 px are
  * queued there and handled by a wavefront each).  `parity` (0/1) must alternate between consecutive
  * calls on the same big_list: call k uses counter big_list[parity] and clears the other one for
- * call k+1, which saves a memset node per step. */
+ * call k+1, which saves a memset node per step.  row_span != 0 selects the per-row ellipse-span
+ * walk (pays off when footprints are large, i.e. M/N above ~4); 0 the AABB walk.  Same results. */
 int eg_composite_bwd_footprint(const float *splat, int32_t N, int32_t width, int32_t height,
                                const float *gtstop /*[H,W,2]*/, float *g2d /*[N,8] written*/,
-                               int32_t *big_list, int32_t parity, eg_stream_t stream);
+                               int32_t *big_list, int32_t parity, int32_t row_span, eg_stream_t stream);
 
 /* ---- whole backward of the fused path: eg_composite_bwd_footprint, then eg_project_bwd_adam
  * (hyper_host != NULL: absgrads accumulated, Adam applied) or eg_project_bwd (hyper_host == NULL:
@@ -175,7 +176,7 @@ int eg_backward_fused(float *means, float *quats, float *scales, float *opacitie
                       float *v_means, float *v_quats, float *v_scales, float *v_opacities,
                       float *absgrads /*[N]|NULL*/, float *m, float *v,
                       const eg_adam_hyper *hyper_host /*NULL = write gradients*/, int32_t *big_list,
-                      int32_t parity, eg_stream_t stream);
+                      int32_t parity, int32_t row_span, eg_stream_t stream);
 
 /* ---- a6: absgrad accumulate on its own (edge_gs.py:607-613): absgrads += ||means2d.absgrad||_2 */
 int eg_absgrad_accum(const float *means2d_absgrad /*[N,2]*/, int32_t N, float *absgrads, eg_stream_t stream);
@@ -237,6 +238,7 @@ typedef struct {
   float *gtstop;                        /* [H,W,2] */
   int32_t *big_list;                    /* [2 + N], zero-initialised once */
   int32_t parity;                       /* 0/1, alternates every step (see eg_composite_bwd_footprint) */
+  int32_t row_span;                     /* tuning hint of eg_composite_bwd_footprint */
   int32_t *last_ids;
   /* gradient outputs (used when adam == NULL, e.g. before an RCCL all-reduce) */
   float *v_means, *v_quats, *v_scales, *v_opacities;

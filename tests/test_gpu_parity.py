@@ -422,6 +422,47 @@ def test_fused_step_with_transmittance_stops(env):
         assert_close(a, b, rtol=1e-3, max_bad=2e-2, name=name)
 
 
+def test_data_parallel_leg_on_gpu_single_rank(env):
+    """The multi-GPU code path (grad_step -> RCCL all-reduce of the fused [N,12] buffer -> eg_adam_multi)
+    on one rank must reproduce the fused single-GPU step: same gradients, same Adam arithmetic."""
+    import os
+    import socket
+    import torch.distributed as dist
+    _lib, synth, O = env
+    from edgegaussians_amd import EdgeTrainer, LRSchedule
+    from edgegaussians_amd import dist as egdist
+    sc = _scene(synth, n=2500, w=160, h=112, views=3)
+    sched = LRSchedule(scales_start=0, quats_start=0, opacities_start=0)
+    mk = lambda: EdgeTrainer(sc.means, sc.log_scales, sc.quats, sc.logit_opacities, sc.viewmats, sc.Ks, sc.gt,  # noqa: E731
+                             sc.width, sc.height, schedule=sched)
+    a, b = mk(), mk()
+    a.ensure_capacity()
+    b.ensure_capacity()
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        dp = egdist.DataParallelStep(b)
+        dp.world = 2  # force the collective even with one rank
+        for s, v in enumerate([0, 2, 1]):
+            w = synth.weight_map("weighted" if s != 1 else "bg_edge_ratio", sc.gt[v],
+                                 generator=torch.Generator().manual_seed(s)).cuda()
+            a.train_step(v, w)
+            dp.step(v, w)
+        torch.cuda.synchronize()
+    finally:
+        dist.destroy_process_group()
+    for x, y, name in ((a.means, b.means, "means"), (a.log_scales, b.log_scales, "scales"), (a.quats, b.quats, "quats"),
+                       (a.logit_opacities, b.logit_opacities, "opac"), (a.absgrads, b.absgrads, "absgrads"),
+                       (a.adam_m, b.adam_m, "m"), (a.adam_v, b.adam_v, "v")):
+        assert_close(x, y, rtol=1e-6, name=name)
+    assert a.absgrads_normalize_factor == b.absgrads_normalize_factor == 4
+    assert abs(a.pop_loss() - b.pop_loss()) < 1e-6
+
+
 # ------------------------------------------------------------------ densify / cull vs the reference's own outputs
 def test_densify_cull_golden(env, golden_dir):
     import os
