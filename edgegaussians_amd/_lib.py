@@ -103,7 +103,7 @@ def load(require_device: bool = True) -> C.CDLL:
         lib.eg_timing_stage_name.argtypes = [_i32]
         lib.eg_timing_stage_name.restype = C.c_char_p
         lib.eg_composite_workspace_bytes.restype = _i64
-        lib.eg_composite_workspace_bytes.argtypes = [_i64]
+        lib.eg_composite_workspace_bytes.argtypes = [_i64, _i64]
         _lib = lib
     if require_device and not torch.cuda.is_available():
         raise RuntimeError("edgegaussians_amd needs a gfx950 GPU (torch.cuda.is_available() is False); "

@@ -372,13 +372,66 @@ composite_slice_fwd_kernel(const float4 *__restrict__ splat, const int *__restri
   sliceL[(size_t)b * kTilePix + tid] = L;
 }
 
-// forward phase B: per tile, combine the slices in depth order (+ exact stop, + fused loss)
+// per-pixel epilogue shared by the combine and re-walk kernels: outputs, fused clamp + weighted L1
+// (edge_gs.py:279,288-324) and the packed record the footprint backward reads.  Returns the loss term.
+template <int CH>
+__device__ __forceinline__ float finalize_pixel(int p, float T, int last, bool stopped, const int *__restrict__ flat,
+                                                float *__restrict__ render, float *__restrict__ alphas,
+                                                int *__restrict__ last_ids, const float *__restrict__ gt,
+                                                const float *__restrict__ wmap, float loss_scale,
+                                                float *__restrict__ vpix, float2 *__restrict__ gtstop) {
+  const float pix = 1.f - T;  // unit colours, no background: sum_i alpha_i T_i == 1 - T_final
+  alphas[p] = pix;
+  last_ids[p] = last;
+#pragma unroll
+  for (int k = 0; k < CH; ++k) render[(size_t)p * CH + k] = pix;
+  float l = 0.f;
+  if (wmap) {
+    const float w = wmap[p];
+    const float c0 = fminf(fmaxf(pix, 0.f), 1.f);
+    const float d = c0 - gt[p];
+    l = w * fabsf(d);
+    const float sgn = (d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f);
+    const float v = loss_scale * w * sgn;  // pix is in [0,1): the clamp always passes the gradient
+    if (vpix) vpix[p] = v;
+    if (gtstop) {
+      // v * T_final, and -- only for pixels whose walk stopped on the transmittance rule -- the id of
+      // the last contributing Gaussian
+      const int stop_id = stopped ? flat[last] : -1;
+      gtstop[p] = make_float2((T < 1.f) ? v * T : 0.f, __int_as_float(stop_id));
+    }
+  }
+  return l;
+}
+
+__device__ __forceinline__ void block_loss_add(float l, float *sRed, float *__restrict__ loss_out) {
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) l += __shfl_xor(l, d, 64);
+  if ((tid & 63) == 0) sRed[tid >> 6] = l;
+  __syncthreads();
+  if (tid == 0) {
+    const float s = sRed[0] + sRed[1] + sRed[2] + sRed[3];
+    if (s != 0.f) unsafeAtomicAdd(loss_out, s);
+  }
+}
+
+// per-pixel hand-off from combine to re-walk: the slice in which the stop falls and the state before it
+struct StopInfo {
+  int slice;     // tile-local slice index, -1 = this pixel is final
+  float T;       // transmittance before that slice
+  int last;      // last contributor before that slice
+};
+
+// forward phase B: per tile, T = product of the slice products in depth order.  A pixel whose running
+// T * P_s drops to <= 1e-4 has its transmittance stop INSIDE slice s: it is handed to the re-walk
+// kernel (item flag + StopInfo); every other pixel is finalised here.
 template <int CH>
 __global__ void __launch_bounds__(256)
-composite_combine_fwd_kernel(const float4 *__restrict__ splat, const int *__restrict__ offsets,
-                             const int *__restrict__ item_offsets, const int *__restrict__ flat, int width,
+composite_combine_fwd_kernel(const int *__restrict__ item_offsets, const int *__restrict__ flat, int width,
                              int height, int tw, int th, const float *__restrict__ sliceP,
-                             const int *__restrict__ sliceL, float *__restrict__ render,
+                             const int *__restrict__ sliceL, int *__restrict__ item_flags,
+                             StopInfo *__restrict__ stopinfo, float *__restrict__ render,
                              float *__restrict__ alphas, int *__restrict__ last_ids,
                              const float *__restrict__ gt, const float *__restrict__ wmap, float loss_scale,
                              float *__restrict__ vpix, float *__restrict__ loss_out,
@@ -390,80 +443,104 @@ composite_combine_fwd_kernel(const float4 *__restrict__ splat, const int *__rest
   quad_pixel(tid, di, dj);  // same thread -> pixel map as the slice kernel
   const int i = ty * kTile + di, j = tx * kTile + dj;
   const bool inside = (i < height) && (j < width);
-  const float px = (float)j + 0.5f, py = (float)i + 0.5f;
   const int i0 = item_offsets[tile], ns = item_offsets[tile + 1] - i0;
-  const int seg0 = offsets[tile], seg1 = offsets[tile + 1];
+  for (int s = tid; s < ns; s += 256) item_flags[i0 + s] = 0;
+  __syncthreads();
 
   float T = 1.f;
-  int last = 0;
-  bool stopped = false;
+  int last = 0, stop_slice = -1;
   for (int s = 0; s < ns; ++s) {
     const float P = sliceP[(size_t)(i0 + s) * kTilePix + tid];
     const int L = sliceL[(size_t)(i0 + s) * kTilePix + tid];
+    if (L < 0) continue;
     const float nT = T * P;
-    const bool need = !stopped && (L >= 0) && (nT <= kTStop);
-    if (__any(need)) {
-      // the stop falls inside this slice for some lanes: re-walk it sequentially for those lanes
-      const int a0 = seg0 + s * kSlice, a1 = min(seg1, a0 + kSlice);
-      float Tw = T;
-      int lw = last;
-      bool found = false;
-      for (int idx = a0; idx < a1; ++idx) {
-        const int g = flat[idx];
-        const float4 s0 = splat[2 * g], s1 = splat[2 * g + 1];
-        if (need && !found) {
-          const float dx = s0.x - px, dy = s0.y - py;
-          const float sigma = 0.5f * (s0.z * dx * dx + s1.x * dy * dy) + s0.w * dx * dy;
-          const float alpha = fminf(kAlphaMax, s1.y * __expf(-sigma));
-          if (sigma >= 0.f && alpha >= kAlphaMin) {
-            const float next_T = Tw * (1.f - alpha);
-            if (next_T <= kTStop) found = true;
-            else { Tw = next_T; lw = idx; }
-          }
-        }
-      }
-      if (need) { T = Tw; last = lw; stopped = found; }
-      else if (!stopped && L >= 0) { T = nT; last = L; }
-    } else if (!stopped && L >= 0) {
-      T = nT;
-      last = L;
-    }
+    if (nT <= kTStop) { stop_slice = s; break; }
+    T = nT;
+    last = L;
+  }
+  StopInfo si;
+  si.slice = inside ? stop_slice : -1;
+  si.T = T;
+  si.last = last;
+  if (__syncthreads_or(si.slice >= 0)) {  // only tiles that hand pixels over need the per-pixel records
+    stopinfo[(size_t)tile * kTilePix + tid] = si;
+    if (si.slice >= 0) item_flags[i0 + si.slice] = 1;  // benign race: every writer stores 1
   }
 
   float l = 0.f;
-  if (inside) {
-    const int p = i * width + j;
-    const float pix = 1.f - T;  // unit colours, no background: sum_i alpha_i T_i == 1 - T_final
-    alphas[p] = pix;
-    last_ids[p] = last;
-#pragma unroll
-    for (int k = 0; k < CH; ++k) render[(size_t)p * CH + k] = pix;
-    if (wmap) {
-      const float w = wmap[p];
-      const float c0 = fminf(fmaxf(pix, 0.f), 1.f);
-      const float d = c0 - gt[p];
-      l = w * fabsf(d);
-      const float sgn = (d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f);
-      const float v = loss_scale * w * sgn;  // pix is in [0,1): the clamp always passes the gradient
-      if (vpix) vpix[p] = v;
-      if (gtstop) {
-        // what the footprint backward needs per pixel: v * T_final, and -- only for pixels whose walk
-        // stopped on the transmittance rule -- the id of the last contributing Gaussian
-        const int stop_id = stopped ? flat[last] : -1;
-        gtstop[p] = make_float2((T < 1.f) ? v * T : 0.f, __int_as_float(stop_id));
+  if (inside && stop_slice < 0)
+    l = finalize_pixel<CH>(i * width + j, T, last, false, flat, render, alphas, last_ids, gt, wmap, loss_scale, vpix,
+                           gtstop);
+  if (wmap && loss_out) block_loss_add(l, sRed, loss_out);
+}
+
+// forward phase C: exact transmittance stop.  One workgroup per flagged (tile, slice) item: the slice's
+// records are staged through LDS once and the pixels whose stop falls in this slice walk it
+// sequentially from their known T; should float rounding move the crossing past the slice end, the
+// same lanes carry on through the following slices.
+template <int CH>
+__global__ void __launch_bounds__(256)
+composite_rewalk_fwd_kernel(const float4 *__restrict__ splat, const int *__restrict__ offsets,
+                            const int *__restrict__ item_offsets, const int *__restrict__ total,
+                            const int *__restrict__ flat, int width, int height, int tw, int th,
+                            const int *__restrict__ item_flags, const StopInfo *__restrict__ stopinfo,
+                            float *__restrict__ render, float *__restrict__ alphas, int *__restrict__ last_ids,
+                            const float *__restrict__ gt, const float *__restrict__ wmap, float loss_scale,
+                            float *__restrict__ vpix, float *__restrict__ loss_out, float2 *__restrict__ gtstop) {
+  __shared__ float4 sA[kSlice];
+  __shared__ float4 sB[kSlice];
+  __shared__ float sRed[4];
+  // a fixed small grid strides over the items: in scenes without stops this whole launch is a scan of
+  // the flag array
+  const int tid = threadIdx.x;
+  int di, dj;
+  quad_pixel(tid, di, dj);
+  const int n_items = total[2];
+  for (int b = blockIdx.x; b < n_items; b += gridDim.x) {
+  if (item_flags[b] == 0) continue;
+  __syncthreads();
+  const int tile = item_tile(item_offsets, tw * th, b);
+  const int ty = tile / tw, tx = tile - ty * tw;
+  const int i = ty * kTile + di, j = tx * kTile + dj;
+  const float px = (float)j + 0.5f, py = (float)i + 0.5f;
+  const int s0 = b - item_offsets[tile], ns = item_offsets[tile + 1] - item_offsets[tile];
+  const StopInfo si = stopinfo[(size_t)tile * kTilePix + tid];
+  const bool mine = si.slice == s0;
+  float T = si.T;
+  int last = si.last;
+  bool found = false;
+  for (int s = s0; s < ns; ++s) {
+    if (!__syncthreads_or(mine && !found)) break;
+    const int start = offsets[tile] + s * kSlice, end = min(offsets[tile + 1], start + kSlice);
+    if (start + tid < end) {
+      const int g = flat[start + tid];
+      const float4 r0 = splat[2 * g], r1 = splat[2 * g + 1];
+      sA[tid] = r0;
+      sB[tid] = make_float4(r1.x, r1.y, __logf(255.f * r1.y) + kThrMargin, 0.f);
+    }
+    __syncthreads();
+    if (mine && !found) {
+      const int n = end - start;
+      for (int t = 0; t < n; ++t) {
+        const float4 A = sA[t], B = sB[t];
+        const float dx = A.x - px, dy = A.y - py;
+        const float sigma = 0.5f * (A.z * dx * dx + B.x * dy * dy) + A.w * dx * dy;
+        if (sigma < 0.f || sigma > B.z) continue;
+        const float alpha = fminf(kAlphaMax, B.y * __expf(-sigma));
+        if (alpha < kAlphaMin) continue;
+        const float next_T = T * (1.f - alpha);
+        if (next_T <= kTStop) { found = true; break; }
+        T = next_T;
+        last = start + t;
       }
     }
   }
-  if (wmap && loss_out) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) l += __shfl_xor(l, d, 64);
-    if ((tid & 63) == 0) sRed[tid >> 6] = l;
-    __syncthreads();
-    if (tid == 0) {
-      const float s = sRed[0] + sRed[1] + sRed[2] + sRed[3];
-      if (s != 0.f) unsafeAtomicAdd(loss_out, s);
-    }
-  }
+  float l = 0.f;
+  if (mine)
+    l = finalize_pixel<CH>(i * width + j, T, last, found, flat, render, alphas, last_ids, gt, wmap, loss_scale, vpix,
+                           gtstop);
+  if (wmap && loss_out) block_loss_add(l, sRed, loss_out);
+  }  // item loop
 }
 
 // backward, unit colours, one workgroup per item: lane = Gaussian of the slice, loop = active pixels
@@ -900,8 +977,12 @@ composite_bwd_colors_kernel(const float4 *__restrict__ splat, const float *__res
 
 using namespace eg;
 
-extern "C" int64_t eg_composite_workspace_bytes(int64_t max_items) {
-  return max_items < 0 ? 0 : max_items * kTilePix * (int64_t)(sizeof(float) + sizeof(int32_t));
+// workspace layout: sliceP f32[max_items][256] | sliceL i32[max_items][256] | item_flags i32[max_items]
+//                   | stopinfo {i32,f32,i32}[T][256]
+extern "C" int64_t eg_composite_workspace_bytes(int64_t max_items, int64_t n_tiles) {
+  if (max_items < 0 || n_tiles < 0) return 0;
+  return max_items * kTilePix * (int64_t)(sizeof(float) + sizeof(int32_t)) + max_items * (int64_t)sizeof(int32_t) +
+         n_tiles * kTilePix * (int64_t)sizeof(StopInfo);
 }
 
 extern "C" int eg_composite_fwd(const float *splat, const float *colors, int32_t channels, const int32_t *offsets,
@@ -919,21 +1000,25 @@ extern "C" int eg_composite_fwd(const float *splat, const float *colors, int32_t
   const int tw = cdiv(width, kTile), th = cdiv(height, kTile);
   hipStream_t s = as_stream(stream);
   if (!colors && item_offsets && total && workspace && max_items > 0) {
-    // unit colours: slice-parallel two-kernel forward
+    // unit colours: slice-parallel forward (slice products -> combine -> exact-stop re-walk)
     float *sliceP = (float *)workspace;
     int *sliceL = (int *)(sliceP + (size_t)max_items * kTilePix);
+    int *item_flags = sliceL + (size_t)max_items * kTilePix;
+    StopInfo *stopinfo = (StopInfo *)(item_flags + max_items);
     composite_slice_fwd_kernel<<<(unsigned)max_items, 256, 0, s>>>((const float4 *)splat, offsets, item_offsets,
                                                                   total, flatten_ids, tw, th, sliceP, sliceL);
-    if (channels == 1)
-      composite_combine_fwd_kernel<1><<<tw * th, 256, 0, s>>>((const float4 *)splat, offsets, item_offsets,
-                                                             flatten_ids, width, height, tw, th, sliceP, sliceL,
-                                                             render, alphas, last_ids, gt, wmap, loss_scale, vpix,
-                                                             loss_out, (float2 *)gtstop);
-    else
-      composite_combine_fwd_kernel<3><<<tw * th, 256, 0, s>>>((const float4 *)splat, offsets, item_offsets,
-                                                             flatten_ids, width, height, tw, th, sliceP, sliceL,
-                                                             render, alphas, last_ids, gt, wmap, loss_scale, vpix,
-                                                             loss_out, (float2 *)gtstop);
+#define EG_LAUNCH_CB(CH)                                                                                          \
+  do {                                                                                                            \
+    composite_combine_fwd_kernel<CH><<<tw * th, 256, 0, s>>>(item_offsets, flatten_ids, width, height, tw, th,    \
+                                                            sliceP, sliceL, item_flags, stopinfo, render, alphas,\
+                                                            last_ids, gt, wmap, loss_scale, vpix, loss_out,       \
+                                                            (float2 *)gtstop);                                    \
+    composite_rewalk_fwd_kernel<CH><<<(unsigned)max_items, 256, 0, s>>>(                                          \
+        (const float4 *)splat, offsets, item_offsets, total, flatten_ids, width, height, tw, th, item_flags,      \
+        stopinfo, render, alphas, last_ids, gt, wmap, loss_scale, vpix, loss_out, (float2 *)gtstop);              \
+  } while (0)
+    if (channels == 1) EG_LAUNCH_CB(1); else EG_LAUNCH_CB(3);
+#undef EG_LAUNCH_CB
     return check_launch("composite_fwd(sliced)");
   }
 #define EG_LAUNCH_FWD(CH, UNIT)                                                                              \

@@ -139,7 +139,7 @@ class EdgeTrainer:
         self.keys = torch.empty(self.capacity, dtype=torch.int64, device=self.dev)
         self.flatten_ids = torch.empty(self.capacity, dtype=torch.int32, device=self.dev)
         self.max_items = (self.capacity + 127) // 128 + self.T
-        self.workspace = torch.empty(_lib.load().eg_composite_workspace_bytes(self.max_items), dtype=torch.uint8,
+        self.workspace = torch.empty(_lib.load().eg_composite_workspace_bytes(self.max_items, self.T), dtype=torch.uint8,
                                      device=self.dev)
         self._args_cache = {}
 

@@ -103,9 +103,9 @@ int eg_sort_pairs(uint64_t *keys /*[capacity] in/out*/, const int32_t *offsets /
  * vpix[p] = loss_scale * wmap_p * sign(c0_p - gt_p) (the upstream gradient of eg_composite_bwd).
  * Slice-parallel mode (unit colours only): pass item_offsets + total from eg_tile_offsets, an upper
  * bound max_items >= total[2] (e.g. ceil(capacity/128) + T) and a workspace of
- * eg_composite_workspace_bytes(max_items) bytes; one workgroup runs per (tile, 128-Gaussian slice).
+ * eg_composite_workspace_bytes(max_items, T) bytes; one workgroup runs per (tile, 128-Gaussian slice).
  * With item_offsets == NULL (or per-Gaussian colours) one workgroup walks each tile. */
-int64_t eg_composite_workspace_bytes(int64_t max_items);
+int64_t eg_composite_workspace_bytes(int64_t max_items, int64_t n_tiles);
 int eg_composite_fwd(const float *splat, const float *colors /*[N,channels]|NULL*/, int32_t channels,
                      const int32_t *offsets, const int32_t *flatten_ids, int32_t width, int32_t height,
                      float *render /*[H,W,channels]*/, float *alphas /*[H,W]*/, int32_t *last_ids /*[H,W]*/,
@@ -229,7 +229,7 @@ typedef struct {
   /* workspace */
   float *splat, *g2d;
   int32_t *tile_counts, *offsets, *item_offsets, *total; /* [T], [T+1], [T+1], [4] */
-  void *workspace;   /* eg_composite_workspace_bytes(max_items) bytes */
+  void *workspace;   /* eg_composite_workspace_bytes(max_items, T) bytes */
   int64_t max_items; /* >= ceil(capacity/128) + T */
   uint64_t *keys;
   int32_t *flatten_ids;
