@@ -435,6 +435,22 @@ class EdgeTrainer:
         return self.cull(frac < min_projecting_fraction)
 
     # ------------------------------------------------------------------ hand-off
+    def export_as_ply(self, ply_path: str) -> None:
+        """`EdgeGaussianSplatting.export_as_ply` (edge_gs.py:635-642): same file, no plyfile needed."""
+        from . import io as egio
+        egio.export_as_ply(self.state_dict(), ply_path)
+
+    def load_state_dict(self, state: Dict[str, Tensor]) -> None:
+        """Weights only, like the reference's `--ckpt_path` (edge_gs.py:625-633): Adam moments and
+        absgrads restart from zero."""
+        f = dict(device=self.dev, dtype=torch.float32)
+        self.means = state["gauss_params.means"].detach().to(**f).contiguous().clone()
+        self.log_scales = state["gauss_params.scales"].detach().to(**f).contiguous().clone()
+        self.quats = state["gauss_params.quats"].detach().to(**f).contiguous().clone()
+        self.logit_opacities = state["gauss_params.opacities"].detach().to(**f).reshape(-1).contiguous().clone()
+        self._alloc_state()
+        self.capacity = 0
+
     def state_dict(self) -> Dict[str, Tensor]:
         """Same keys / shapes as the reference's checkpoint (edge_gs.py:625-633)."""
         return {"gauss_params.means": self.means.clone(), "gauss_params.scales": self.log_scales.clone(),
