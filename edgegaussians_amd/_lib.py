@@ -30,7 +30,7 @@ FLAG_TIGHT_TILES = 8
 class AdamHyper(C.Structure):
     _fields_ = [("lr_means", C.c_double), ("lr_scales", C.c_double), ("lr_quats", C.c_double),
                 ("lr_opacities", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double),
-                ("eps", C.c_double), ("step", _i32)]
+                ("eps", C.c_double), ("step", _i32), ("group_steps", _i32 * 4)]
 
 
 class StepArgs(C.Structure):
@@ -72,6 +72,9 @@ _SIGS = {
     "eg_compact_rows": [_vp, _vp, _vp, _i32, _i32, _vp, _vp],
     "eg_append_rows": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _f, _vp, _vp],
     "eg_project_hits": [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _vp, _vp],
+    "eg_knn": [_vp, _i32, _i32, C.POINTER(_f), _f, C.POINTER(_i32), _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "eg_direction_loss": [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp],
+    "eg_ratio_loss": [_vp, _i32, _vp, _vp, _vp],
     "eg_train_step": [C.POINTER(StepArgs), _vp],
 }
 EXPORTS = sorted(list(_SIGS) + ["eg_last_error_string", "eg_version", "eg_device_count",

@@ -18,7 +18,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libedgegs.so")
 OBJ = os.path.join(HERE, "csrc", "_obj")
-SOURCES = ["project.hip", "binning.hip", "composite.hip", "densify.hip", "step.hip"]
+SOURCES = ["project.hip", "binning.hip", "composite.hip", "densify.hip", "knn.hip", "step.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
          "-Wall", "-Wno-unused-function"]
 

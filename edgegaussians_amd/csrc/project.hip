@@ -199,16 +199,18 @@ project_fwd_kernel(const float *__restrict__ means, const float *__restrict__ qu
 
 // ---------------------------------------------------------------------------------------------
 struct AdamK {
-  float step_size[4];  // lr_k / (1 - beta1^t), means | scales | quats | opacities
-  float bc2_sqrt;      // sqrt(1 - beta2^t)
+  float step_size[4];  // lr_k / (1 - beta1^t_k), means | scales | quats | opacities
+  float bc2_sqrt[4];   // sqrt(1 - beta2^t_k)   (each optimizer has its own step count t_k)
+  int active[4];       // 0 = this optimizer does not step in this call
   float b1, omb1, b2, omb2, eps;
 };
 
-__device__ __forceinline__ void adam1(float &p, float g, float &m, float &v, float step_size, const AdamK &h) {
+__device__ __forceinline__ void adam1(float &p, float g, float &m, float &v, int grp, const AdamK &h) {
+  if (!h.active[grp]) return;
   m = m * h.b1 + g * h.omb1;
   v = v * h.b2 + (g * g) * h.omb2;
-  const float denom = sqrtf(v) / h.bc2_sqrt + h.eps;
-  p = p - step_size * (m / denom);
+  const float denom = sqrtf(v) / h.bc2_sqrt[grp] + h.eps;
+  p = p - h.step_size[grp] * (m / denom);
 }
 
 struct Grads {
@@ -347,24 +349,24 @@ project_bwd_kernel(float *__restrict__ means, float *__restrict__ quats, float *
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       float p = means[3 * g + k], m = am[oM + 3 * g + k], v = av[oM + 3 * g + k];
-      adam1(p, gr.mean[k], m, v, hyper.step_size[0], hyper);
+      adam1(p, gr.mean[k], m, v, 0, hyper);
       means[3 * g + k] = p; am[oM + 3 * g + k] = m; av[oM + 3 * g + k] = v;
     }
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       float p = scales[3 * g + k], m = am[oS + 3 * g + k], v = av[oS + 3 * g + k];
-      adam1(p, gr.scale[k], m, v, hyper.step_size[1], hyper);
+      adam1(p, gr.scale[k], m, v, 1, hyper);
       scales[3 * g + k] = p; am[oS + 3 * g + k] = m; av[oS + 3 * g + k] = v;
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       float p = quats[4 * g + k], m = am[oQ + 4 * g + k], v = av[oQ + 4 * g + k];
-      adam1(p, gr.quat[k], m, v, hyper.step_size[2], hyper);
+      adam1(p, gr.quat[k], m, v, 2, hyper);
       quats[4 * g + k] = p; am[oQ + 4 * g + k] = m; av[oQ + 4 * g + k] = v;
     }
     {
       float p = opacities[g], m = am[oO + g], v = av[oO + g];
-      adam1(p, gr.opac, m, v, hyper.step_size[3], hyper);
+      adam1(p, gr.opac, m, v, 3, hyper);
       opacities[g] = p; am[oO + g] = m; av[oO + g] = v;
     }
   }
@@ -385,7 +387,7 @@ adam_multi_kernel(float *__restrict__ means, float *__restrict__ scales, float *
     else if (i < 10 * (size_t)N) { p = quats; g = g_quats; grp = 2; j = i - 6 * (size_t)N; }
     else { p = opacities; g = g_opacities; grp = 3; j = i - 10 * (size_t)N; }
     float pv = p[j], m = am[i], v = av[i];
-    adam1(pv, g[j], m, v, hyper.step_size[grp], hyper);
+    adam1(pv, g[j], m, v, grp, hyper);
     p[j] = pv; am[i] = m; av[i] = v;
   }
 }
@@ -401,11 +403,14 @@ static AdamK make_adamk(const eg_adam_hyper &h) {
   // host side in double, exactly how torch.optim.Adam forms its scalars before casting to fp32
   AdamK k;
   const double b1 = h.beta1, b2 = h.beta2;
-  const double bc1 = 1.0 - pow(b1, (double)h.step);
-  const double bc2 = 1.0 - pow(b2, (double)h.step);
   const double lrs[4] = {h.lr_means, h.lr_scales, h.lr_quats, h.lr_opacities};
-  for (int i = 0; i < 4; ++i) k.step_size[i] = (float)(lrs[i] / bc1);
-  k.bc2_sqrt = (float)sqrt(bc2);
+  for (int i = 0; i < 4; ++i) {
+    const int t = h.group_steps[i] == 0 ? h.step : h.group_steps[i];  // 0: shared count, < 0: skip
+    k.active[i] = t > 0;
+    const double tt = t > 0 ? (double)t : 1.0;
+    k.step_size[i] = (float)(lrs[i] / (1.0 - pow(b1, tt)));
+    k.bc2_sqrt[i] = (float)sqrt(1.0 - pow(b2, tt));
+  }
   k.b1 = (float)b1; k.omb1 = (float)(1.0 - b1);
   k.b2 = (float)b2; k.omb2 = (float)(1.0 - b2);
   k.eps = (float)h.eps;

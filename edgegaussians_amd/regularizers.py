@@ -1,0 +1,75 @@
+"""Nearest neighbours + the two orientation regularisers on device.
+
+Host-side mirror of `EdgeGaussianSplatting.k_nearest_sklearn` / `update_nearest_neighbors`
+(edge_gs.py:135-151,326-344), `compute_direction_loss` (:346-373) and `compute_ratio_loss`
+(:375-380).  The reference builds a CPU KD-tree over all means (D2H copy included) every 5th step of
+the last 150 epochs; here the search is a uniform-grid kernel on the GPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Tuple
+
+import torch
+from torch import Tensor
+
+from ._lib import call, ptr, stream
+
+
+def knn(points: Tensor, k: int, want_dist: bool = False) -> Tuple[Tensor, Tensor]:
+    """Indices [N,k] (int32, ascending distance, self excluded) and, optionally, distances [N,k].
+    One host sync (the bounding box), where the reference had a full D2H copy + CPU tree build."""
+    assert points.is_cuda and points.dtype == torch.float32 and points.dim() == 2 and points.shape[1] == 3
+    assert 1 <= k <= 16
+    pts = points.detach().contiguous()
+    N = pts.shape[0]
+    dev = pts.device
+    lo = pts.min(dim=0).values
+    hi = pts.max(dim=0).values
+    lo_h, hi_h = lo.tolist(), hi.tolist()
+    ext = [max(h - l, 1e-6) for l, h in zip(lo_h, hi_h)]
+    vol = ext[0] * ext[1] * ext[2]
+    cell = max((vol * 2.0 / max(N, 1)) ** (1.0 / 3.0), max(ext) / 512.0)  # ~2 points per cell, <= 512^3 cells
+    dims = [max(1, min(512, int(math.ceil(e / cell)))) for e in ext]
+    ncell = dims[0] * dims[1] * dims[2]
+    cell_of = torch.empty(N, dtype=torch.int32, device=dev)
+    counts = torch.zeros(ncell, dtype=torch.int32, device=dev)
+    start = torch.empty(ncell + 1, dtype=torch.int32, device=dev)
+    order = torch.empty(N, dtype=torch.int32, device=dev)
+    idx = torch.empty(N, k, dtype=torch.int32, device=dev)
+    d2 = torch.empty(N, k, device=dev) if want_dist else None
+    origin = (C.c_float * 3)(*lo_h)
+    cdims = (C.c_int32 * 3)(*dims)
+    call("eg_knn", ptr(pts), N, k, origin, float(cell), cdims, ptr(cell_of), ptr(counts), ptr(start), ptr(order),
+         ptr(idx), ptr(d2) if d2 is not None else None, stream())
+    return idx, (d2.sqrt() if d2 is not None else None)
+
+
+def reference_nn_indices(points: Tensor, dir_loss_num_nn: int) -> Tensor:
+    """`update_nearest_neighbors` for every enforce method but 'enforce_half' (edge_gs.py:326-344):
+    k_nearest_sklearn(points, k+1) already drops the point itself, and `indices[:, 1:]` then drops the
+    NEAREST neighbour as well -- the reference aligns with neighbours 2 .. k+1.  Kept as is."""
+    idx, _ = knn(points, dir_loss_num_nn + 1)
+    return idx[:, 1:].contiguous()
+
+
+def direction_loss(means: Tensor, quats: Tensor, log_scales: Tensor, nn_idx: Tensor):
+    """Returns (loss [device scalar], dloss/dmeans [N,3], dloss/dquats [N,4]) of edge_gs.py:346-373."""
+    N, K = nn_idx.shape
+    g_means = torch.zeros(N, 3, device=means.device)
+    g_quats = torch.empty(N, 4, device=means.device)
+    s = torch.zeros(1, device=means.device)
+    call("eg_direction_loss", ptr(means.contiguous()), ptr(quats.contiguous()), ptr(log_scales.contiguous()),
+         ptr(nn_idx.contiguous()), N, K, ptr(g_means), ptr(g_quats), ptr(s), stream())
+    w = -1.0 / (N * K)
+    return 1.0 + w * s[0], g_means * w, g_quats * w
+
+
+def ratio_loss(log_scales: Tensor):
+    """Returns (loss [device scalar], dloss/dlog_scales [N,3]) of edge_gs.py:375-380."""
+    N = log_scales.shape[0]
+    g = torch.empty(N, 3, device=log_scales.device)
+    s = torch.zeros(1, device=log_scales.device)
+    call("eg_ratio_loss", ptr(log_scales.contiguous()), N, ptr(g), ptr(s), stream())
+    return s[0] / N, g / N

@@ -89,7 +89,8 @@ class EdgeTrainer:
         self.V = self.viewmats.shape[0]
         self.schedule = schedule or LRSchedule()
         self.betas, self.eps = betas, eps
-        self.adam_step = 0  # shared step count of the four optimizers
+        self.adam_step = 0  # step count of the opacity optimizer (== all four until a regulariser steps)
+        self.group_steps = [0, 0, 0, 0]  # per-optimizer counts: means, scales, quats, opacities
         self.step = 0       # model.step (edge_gs.py:621)
         self.epoch = 0
         self.loss_scale = 1.0  # lambda_projection (train_gaussians.py:98; constant 1 in every config)
@@ -212,19 +213,25 @@ class EdgeTrainer:
             a.adam_host = self._args_cache["null_hyper"]
         return a
 
+    def _advance_all(self):
+        self.adam_step += 1
+        self.group_steps = [t + 1 for t in self.group_steps]
+
     def _set_hyper(self):
         lr = self.schedule.at(self.epoch)
         h = self._hyper
         h.lr_means, h.lr_scales, h.lr_quats, h.lr_opacities = lr["means"], lr["scales"], lr["quats"], lr["opacities"]
         h.beta1, h.beta2, h.eps = self.betas[0], self.betas[1], self.eps
-        h.step = self.adam_step
+        h.step = max(self.adam_step, 1)
+        for i in range(4):
+            h.group_steps[i] = self.group_steps[i]
 
     def train_step(self, view: int, wmap: Tensor) -> None:
         """One reference iteration (train_gaussians.py:81-106) for `view`, fully asynchronous.
         `wmap` [H,W]: the per-pixel loss weights of the strategy chosen for this step."""
         if self.capacity == 0:
             self.ensure_capacity()
-        self.adam_step += 1
+        self._advance_all()
         self._set_hyper()
         call("eg_train_step", C.byref(self._args(view, wmap, True)), stream())
         self.absgrads_normalize_factor += 1  # edge_gs.py:613
@@ -237,7 +244,7 @@ class EdgeTrainer:
         if self.capacity == 0:
             self.ensure_capacity()
         mark = mark or (lambda name: None)
-        self.adam_step += 1
+        self._advance_all()
         self._set_hyper()
         fl = (_lib.FLAG_LOG_SCALES | _lib.FLAG_LOGIT_OPACITIES | _lib.FLAG_ANTIALIASED |
               _lib.FLAG_TIGHT_TILES)
@@ -308,13 +315,55 @@ class EdgeTrainer:
         return (g[:3 * N].view(N, 3), g[3 * N:7 * N].view(N, 4), g[7 * N:10 * N].view(N, 3), g[10 * N:11 * N])
 
     def apply_adam(self) -> None:
-        self.adam_step += 1
+        self._advance_all()
         self._set_hyper()
         gm, gq, gs, go = self.grad_views()
         call("eg_adam_multi", ptr(self.means), ptr(self.log_scales), ptr(self.quats), ptr(self.logit_opacities),
              ptr(gm), ptr(gs), ptr(gq), ptr(go), ptr(self.adam_m), ptr(self.adam_v), self.N, self._hyper, stream())
         self.absgrads += self.grads.view(-1)[11 * self.N:]  # summed over the ranks' views by the all-reduce
         self.absgrads_normalize_factor += 1
+
+    # ------------------------------------------------------------------ orientation regularisers (8f)
+    def update_nearest_neighbors(self, dir_loss_num_nn: int = 5) -> Tensor:
+        """`update_nearest_neighbors` (edge_gs.py:326-344) on device; keeps the reference's quirk of
+        skipping the nearest neighbour (see regularizers.reference_nn_indices)."""
+        from . import regularizers as R
+        self.nn_indices = R.reference_nn_indices(self.means, dir_loss_num_nn)
+        return self.nn_indices
+
+    def regulariser_step(self, kind: str, avg_loss_sum: float, scale_factor: float,
+                         dir_loss_num_nn: int = 5) -> float:
+        """One regulariser iteration of train_gaussians.py:108-131 ('direction' or 'ratio'):
+        loss -> lambda = avg_loss_sum * scale_factor / loss.item() -> backward -> Adam step of the
+        means / scales / quats optimizers only (their step counts advance, the opacity optimizer's does
+        not).  With the reference's torch 1.13 `zero_grad()` (zeroed, not None) the optimizers whose
+        parameter is outside the loss still step on a zero gradient; that is reproduced.  Returns the
+        loss value (one host sync, where the reference has `.item()`)."""
+        from . import regularizers as R
+        N = self.N
+        gm, gq, gs, go = self.grad_views()
+        self.grads.zero_()
+        if kind == "direction":
+            self.update_nearest_neighbors(dir_loss_num_nn)
+            loss, dm, dq = R.direction_loss(self.means, self.quats, self.log_scales, self.nn_indices)
+            val = float(loss)
+            lam = avg_loss_sum * scale_factor / val
+            gm.copy_(dm * lam)
+            gq.copy_(dq * lam)
+        elif kind == "ratio":
+            loss, ds = R.ratio_loss(self.log_scales)
+            val = float(loss)
+            lam = avg_loss_sum * scale_factor / val
+            gs.copy_(ds * lam)
+        else:
+            raise ValueError(f"unknown regulariser: {kind}")
+        self.group_steps = [self.group_steps[0] + 1, self.group_steps[1] + 1, self.group_steps[2] + 1,
+                            self.group_steps[3]]
+        self._set_hyper()
+        self._hyper.group_steps[3] = -1  # the opacity optimizer does not step here (train_gaussians.py:116-119)
+        call("eg_adam_multi", ptr(self.means), ptr(self.log_scales), ptr(self.quats), ptr(self.logit_opacities),
+             ptr(gm), ptr(gs), ptr(gq), ptr(go), ptr(self.adam_m), ptr(self.adam_v), N, self._hyper, stream())
+        return val
 
     # ------------------------------------------------------------------ read-backs (these sync)
     def pop_loss(self) -> float:

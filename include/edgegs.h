@@ -152,7 +152,11 @@ int eg_project_bwd(const float *means, const float *quats, const float *scales, 
 typedef struct {
   double lr_means, lr_scales, lr_quats, lr_opacities; /* doubles: the bias-corrected scalars are */
   double beta1, beta2, eps;                            /* formed in double like torch does, then cast */
-  int32_t step;
+  int32_t step;           /* 1-based step count shared by the four optimizers ... */
+  int32_t group_steps[4]; /* ... unless overridden per optimizer (means, scales, quats, opacities):
+                             0 = use `step`, > 0 = that optimizer's own count, < 0 = it does not step in
+                             this call (the regulariser steps of train_gaussians.py:108-131 advance only
+                             means / scales / quats, so the counts drift apart) */
 } eg_adam_hyper;
 
 /* ---- G8, footprint form (unit colours, fused path): 8 lanes per Gaussian walk the Gaussian's own
@@ -213,6 +217,27 @@ int eg_append_rows(const float *in, const uint8_t *sel, const int32_t *positions
 int eg_project_hits(const float *means, int32_t N, const float *P /*[V,3,4] = K @ viewmat[:3]*/, int32_t V,
                     const uint8_t *edge_masks /*[V,H,W]*/, int32_t width, int32_t height,
                     int32_t *hits /*[N] zeroed by caller*/, eg_stream_t stream);
+
+/* ---- nearest neighbours + orientation regularisers (train_gaussians.py:108-131).
+ * eg_knn: exact K <= 16 nearest neighbours (self excluded, ascending distance, ties by index) of N 3D
+ * points on a uniform grid: origin/cell/dims chosen by the caller (bounding box of the points, ~2
+ * points per cell).  Scratch: cell_of[N], cell_counts[C] (zero on entry, returned to zero),
+ * cell_start[C+1], sorted[N] with C = dims[0]*dims[1]*dims[2].  Replaces k_nearest_sklearn
+ * (edge_gs.py:135-151). */
+int eg_knn(const float *points /*[N,3]*/, int32_t N, int32_t K, const float *origin_host /*[3]*/, float cell,
+           const int32_t *dims_host /*[3]*/, int32_t *cell_of, int32_t *cell_counts, int32_t *cell_start,
+           int32_t *sorted, int32_t *out_idx /*[N,K]*/, float *out_d2 /*[N,K]|NULL squared distances*/,
+           eg_stream_t stream);
+/* compute_direction_loss (edge_gs.py:346-373, every method but 'enforce_half'): sum_out[0] += sum over
+ * (i,k) of |m_i . unit(mu_i - mu_nn(i,k))| (loss = 1 - sum/(N K)); g_means += and g_quats = the
+ * gradient of that SUM (the caller scales by -lambda/(N K)). */
+int eg_direction_loss(const float *means, const float *quats, const float *log_scales,
+                      const int32_t *nn_idx /*[N,K]*/, int32_t N, int32_t K, float *g_means /*[N,3] accumulated*/,
+                      float *g_quats /*[N,4] written*/, float *sum_out, eg_stream_t stream);
+/* compute_ratio_loss (edge_gs.py:375-380): sum_out[0] += sum_i second/largest scale (loss = sum/N);
+ * g_scales = gradient of the sum w.r.t. the log-scales. */
+int eg_ratio_loss(const float *log_scales, int32_t N, float *g_scales /*[N,3] written*/, float *sum_out,
+                  eg_stream_t stream);
 
 /* ---- whole training step for one view, enqueued from native code (train_gaussians.py:81-106):
  * project+count -> offsets -> emit -> sort -> composite+loss -> composite bwd -> project bwd
