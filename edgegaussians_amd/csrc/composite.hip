@@ -275,8 +275,8 @@ composite_slice_fwd_kernel(const float4 *__restrict__ splat, const int *__restri
                            const int *__restrict__ item_offsets, const int *__restrict__ total,
                            const int *__restrict__ flat, int tw, int th, float *__restrict__ sliceP,
                            int *__restrict__ sliceL) {
-  __shared__ float4 sA[4][kSlice + 2];  // x, y, a, b
-  __shared__ float4 sB[4][kSlice + 2];  // c, o, sigma threshold, slice-local index (int bits)
+  __shared__ float4 sA[4][kSlice + 4];  // x, y, a, b
+  __shared__ float4 sB[4][kSlice + 4];  // c, o, sigma threshold, slice-local index (int bits)
   static_assert(kSlice <= kTilePix, "one staging thread per Gaussian of the slice");
   __shared__ int sCnt[4][4];            // [quadrant][source wave]
   const int b = blockIdx.x;
@@ -336,12 +336,11 @@ composite_slice_fwd_kernel(const float4 *__restrict__ splat, const int *__restri
       sB[q][pos] = rB;
     }
     if (q == wv) n_mine = tot;
-    // two sentinels (threshold < 0 => rejected) so the 2-way unrolled walk may read past the end
-    if (tid == q) {
-      sB[q][tot] = make_float4(0.f, 0.f, -1.f, 0.f);
-      sB[q][tot + 1] = make_float4(0.f, 0.f, -1.f, 0.f);
-      sA[q][tot] = make_float4(0.f, 0.f, 0.f, 0.f);
-      sA[q][tot + 1] = make_float4(0.f, 0.f, 0.f, 0.f);
+    // sentinels (threshold < 0 => rejected) so the 4-way unrolled walk may read past the end
+    if (tid >= 64 * q && tid < 64 * q + 3) {
+      const int e = tot + (tid - 64 * q);
+      sB[q][e] = make_float4(0.f, 0.f, -1.f, 0.f);
+      sA[q][e] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
   }
   __syncthreads();
@@ -349,22 +348,19 @@ composite_slice_fwd_kernel(const float4 *__restrict__ splat, const int *__restri
   const float4 *lA = sA[wv], *lB = sB[wv];
   float P = 1.f;
   int L = -1;
-  for (int t = 0; t < n_mine; t += 2) {
-    const float4 A0 = lA[t], B0 = lB[t], A1 = lA[t + 1], B1 = lB[t + 1];
-    {
-      const float dx = A0.x - px, dy = A0.y - py;
-      const float sigma = 0.5f * (A0.z * dx * dx + B0.x * dy * dy) + A0.w * dx * dy;
-      if (sigma >= 0.f && sigma <= B0.z) {
-        const float alpha = fminf(kAlphaMax, B0.y * __expf(-sigma));
-        if (alpha >= kAlphaMin) { P *= (1.f - alpha); L = start + __float_as_int(B0.w); }
-      }
-    }
-    {
-      const float dx = A1.x - px, dy = A1.y - py;
-      const float sigma = 0.5f * (A1.z * dx * dx + B1.x * dy * dy) + A1.w * dx * dy;
-      if (sigma >= 0.f && sigma <= B1.z) {
-        const float alpha = fminf(kAlphaMax, B1.y * __expf(-sigma));
-        if (alpha >= kAlphaMin) { P *= (1.f - alpha); L = start + __float_as_int(B1.w); }
+  // 4-way unrolled walk: the eight LDS reads of a group are issued before the first use, so one
+  // lgkmcnt wait covers four Gaussians (the loop is latency-bound, not issue-bound)
+  for (int t = 0; t < n_mine; t += 4) {
+    float4 A[4], B[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { A[u] = lA[t + u]; B[u] = lB[t + u]; }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float dx = A[u].x - px, dy = A[u].y - py;
+      const float sigma = 0.5f * (A[u].z * dx * dx + B[u].x * dy * dy) + A[u].w * dx * dy;
+      if (sigma >= 0.f && sigma <= B[u].z) {
+        const float alpha = fminf(kAlphaMax, B[u].y * __expf(-sigma));
+        if (alpha >= kAlphaMin) { P *= (1.f - alpha); L = start + __float_as_int(B[u].w); }
       }
     }
   }
