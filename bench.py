@@ -126,6 +126,9 @@ def main():
     ap.add_argument("--spread-opacity", action="store_true",
                     help="opacities U(0.05,0.9) instead of the reference's init 0.08: a 'trained-like' scene in "
                          "which many pixels hit the transmittance stop (robustness check, not the headline)")
+    ap.add_argument("--force-dp", action="store_true",
+                    help="run the data-parallel code path (grad_step -> all-reduce -> eg_adam_multi) even with one "
+                         "rank: measures the path's overhead without the communication")
     ap.add_argument("--profile-only", action="store_true",
                     help="run only warmup+steps of the fused step (for rocprofv3), skip stage timing/CPU leg")
     args = ap.parse_args()
@@ -144,7 +147,12 @@ def main():
     n, n_views, w, h = cfg
     tr, sc, whole, ratio = build_trainer(cfg, args.seed, device, args.spread_opacity)
     m_max = tr.ensure_capacity()
-    dp = egdist.DataParallelStep(tr) if world > 1 else None
+    dp = egdist.DataParallelStep(tr) if (world > 1 or args.force_dp) else None
+    if args.force_dp and world == 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=0, world_size=1)
+        dp.world = 2  # issue the collective
     # device pre-warm, not part of --warmup: a fresh box needs ~0.1 s of work before clocks and page
     # tables settle (first-run outliers of 2x were measured without it)
     for s in range(300):
@@ -206,7 +214,7 @@ def main():
         "host_enqueue_ms_per_step": 1e3 * t_enq / args.steps,
     }
 
-    if rank == 0 and world == 1 and not args.profile_only:
+    if rank == 0 and world == 1 and not args.profile_only and dp is None:
         # ---- per-stage launch durations: HIP events recorded natively between the stages of
         # eg_train_step on the launch stream, over a second window of the same steps (one sync)
         k = min(args.steps, 200)
@@ -230,10 +238,11 @@ def main():
                                 "frac": ab["step_total"] / (dt / args.steps) / 1e9 / HBM_PEAK_GBS}
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sc, args.cpu_budget)
-    if rank == 0:
-        print(json.dumps(out))
-    if world > 1:
+    if world > 1 or args.force_dp:
         dist.destroy_process_group()
+    if rank == 0:  # last thing on stdout: the one JSON line
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -335,7 +335,10 @@ project_bwd_kernel(float *__restrict__ means, float *__restrict__ quats, float *
     forward_geom(cam, means, quats, scales, opacities, g, width, height, -3.0e38f, 3.0e38f, eps2d, flags, f);
     backward_geom(cam, f, eps2d, flags, ga, gb, v_comps_ext != nullptr, v_comps_ext ? v_comps_ext[g] : 0.f,
                   v_depths_ext ? v_depths_ext[g] : 0.f, gr);
-    if (absgrads) absgrads[g] += sqrtf(ga.z * ga.z + ga.w * ga.w);
+    if (absgrads && !(flags & EG_FLAG_ABSGRAD_WRITE)) absgrads[g] += sqrtf(ga.z * ga.z + ga.w * ga.w);
+    if (absgrads && (flags & EG_FLAG_ABSGRAD_WRITE)) absgrads[g] = sqrtf(ga.z * ga.z + ga.w * ga.w);
+  } else if (absgrads && (flags & EG_FLAG_ABSGRAD_WRITE)) {
+    absgrads[g] = 0.f;
   }
   if (!ADAM) {
 #pragma unroll
@@ -378,7 +381,10 @@ adam_multi_kernel(float *__restrict__ means, float *__restrict__ scales, float *
                   float *__restrict__ opacities, const float *__restrict__ g_means,
                   const float *__restrict__ g_scales, const float *__restrict__ g_quats,
                   const float *__restrict__ g_opacities, float *__restrict__ am, float *__restrict__ av, int N,
-                  AdamK hyper) {
+                  AdamK hyper, const float *__restrict__ absgrad_inc, float *__restrict__ absgrads) {
+  if (absgrads)
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < (size_t)N; i += (size_t)gridDim.x * blockDim.x)
+      absgrads[i] += absgrad_inc[i];
   const size_t total = 11 * (size_t)N;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     float *p; const float *g; int grp; size_t j;
@@ -497,14 +503,17 @@ extern "C" int eg_backward_fused(float *means, float *quats, float *scales, floa
 
 extern "C" int eg_adam_multi(float *means, float *scales, float *quats, float *opacities, const float *g_means,
                              const float *g_scales, const float *g_quats, const float *g_opacities, float *m,
-                             float *v, int32_t N, eg_adam_hyper hyper, eg_stream_t stream) {
+                             float *v, int32_t N, eg_adam_hyper hyper, const float *absgrad_inc, float *absgrads,
+                             eg_stream_t stream) {
   EG_REQUIRE(N >= 0 && hyper.step >= 1, "bad sizes / step");
   if (N == 0) return EG_OK;
   EG_REQUIRE(means && scales && quats && opacities && g_means && g_scales && g_quats && g_opacities && m && v,
              "null pointer");
+  EG_REQUIRE(!absgrads || absgrad_inc, "absgrads needs absgrad_inc");
   const int blocks = min(cdiv(11 * (int64_t)N, 256), 2048);
   adam_multi_kernel<<<blocks, 256, 0, as_stream(stream)>>>(means, scales, quats, opacities, g_means, g_scales,
-                                                          g_quats, g_opacities, m, v, N, make_adamk(hyper));
+                                                          g_quats, g_opacities, m, v, N, make_adamk(hyper),
+                                                          absgrad_inc, absgrads);
   return check_launch("adam_multi");
 }
 

@@ -150,7 +150,7 @@ extern "C" int eg_train_step(const eg_step_args *a, eg_stream_t stream) {
                              *a->adam_host, stream);
   else
     rc = eg_project_bwd(a->means, a->quats, a->log_scales, a->logit_opacities, a->viewmat, a->K, a->N, a->width,
-                        a->height, 0.3f, flags, a->splat, a->g2d, nullptr, nullptr, a->v_means, a->v_quats,
+                        a->height, 0.3f, flags | EG_FLAG_ABSGRAD_WRITE, a->splat, a->g2d, nullptr, nullptr, a->v_means, a->v_quats,
                         a->v_scales, a->v_opacities, a->absgrads, stream);
   EG_MARK(7);
 #undef EG_MARK

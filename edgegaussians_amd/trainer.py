@@ -305,7 +305,6 @@ class EdgeTrainer:
         blocks) for the data-parallel driver, which all-reduces them and then calls ``apply_adam``."""
         if self.capacity == 0:
             self.ensure_capacity()
-        self.grads.view(-1)[11 * self.N:].zero_()
         call("eg_train_step", C.byref(self._args(view, wmap, False)), stream())
         self.step += 1
         return self.grads
@@ -319,8 +318,8 @@ class EdgeTrainer:
         self._set_hyper()
         gm, gq, gs, go = self.grad_views()
         call("eg_adam_multi", ptr(self.means), ptr(self.log_scales), ptr(self.quats), ptr(self.logit_opacities),
-             ptr(gm), ptr(gs), ptr(gq), ptr(go), ptr(self.adam_m), ptr(self.adam_v), self.N, self._hyper, stream())
-        self.absgrads += self.grads.view(-1)[11 * self.N:]  # summed over the ranks' views by the all-reduce
+             ptr(gm), ptr(gs), ptr(gq), ptr(go), ptr(self.adam_m), ptr(self.adam_v), self.N, self._hyper,
+             self.grads.data_ptr() + 4 * 11 * self.N, ptr(self.absgrads), stream())  # += all-reduced absgrad block
         self.absgrads_normalize_factor += 1
 
     # ------------------------------------------------------------------ orientation regularisers (8f)
@@ -362,7 +361,8 @@ class EdgeTrainer:
         self._set_hyper()
         self._hyper.group_steps[3] = -1  # the opacity optimizer does not step here (train_gaussians.py:116-119)
         call("eg_adam_multi", ptr(self.means), ptr(self.log_scales), ptr(self.quats), ptr(self.logit_opacities),
-             ptr(gm), ptr(gs), ptr(gq), ptr(go), ptr(self.adam_m), ptr(self.adam_v), N, self._hyper, stream())
+             ptr(gm), ptr(gs), ptr(gq), ptr(go), ptr(self.adam_m), ptr(self.adam_v), N, self._hyper, None, None,
+             stream())
         return val
 
     # ------------------------------------------------------------------ read-backs (these sync)

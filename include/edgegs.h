@@ -45,6 +45,7 @@ typedef void *eg_stream_t; /* hipStream_t */
 #define EG_FLAG_LOG_SCALES 1u      /* `scales` holds log-scales: exp() fused (edge_gs.py:253) */
 #define EG_FLAG_LOGIT_OPACITIES 2u /* `opacities` holds logits: sigmoid() fused (edge_gs.py:254) */
 #define EG_FLAG_ANTIALIASED 4u     /* rasterize_mode="antialiased" (edge_gs.py:50,266) */
+#define EG_FLAG_ABSGRAD_WRITE 16u   /* eg_project_bwd: absgrads[g] = increment instead of += (data-parallel leg) */
 #define EG_FLAG_TIGHT_TILES 8u     /* bin with the opacity-aware tile box (subset of gsplat's box that \
                                       drops only (Gaussian, tile) pairs contributing exactly nothing) */
 
@@ -192,7 +193,10 @@ int eg_absgrad_accum(const float *means2d_absgrad /*[N,2]*/, int32_t N, float *a
 int eg_adam_multi(float *means, float *scales, float *quats, float *opacities,
                   const float *g_means, const float *g_scales, const float *g_quats, const float *g_opacities,
                   float *m /*[N,11]: means3|scales3|quats4|opac1 blocks of N*dim*/, float *v /*same*/,
-                  int32_t N, eg_adam_hyper hyper, eg_stream_t stream);
+                  int32_t N, eg_adam_hyper hyper,
+                  const float *absgrad_inc /*[N]|NULL*/, float *absgrads /*[N]|NULL: += absgrad_inc (the
+                                             all-reduced increment of the data-parallel leg)*/,
+                  eg_stream_t stream);
 
 /* ---- fused G9 + absgrad + Adam: single-GPU training step tail (no gradient exchange needed). */
 int eg_project_bwd_adam(float *means, float *quats, float *scales, float *opacities,
