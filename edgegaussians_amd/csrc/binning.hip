@@ -169,9 +169,12 @@ tile_emit_kernel(const float2 *__restrict__ means2d, const int *__restrict__ rad
     else tile_box(x, y, radius, tw, th, x0, y0, x1, y1);
   }
   const unsigned long long key = ((unsigned long long)(unsigned)__float_as_int(depth) << 32) | (unsigned)g;
+  const bool exact = splat && (flags & EG_FLAG_TIGHT_TILES);  // must mirror the counting pass exactly
+#define EG_TILE_OK(tx, ty) (!exact || splat_hits_tile(x, y, s0.z, s0.w, s1.x, s1.y, tx, ty))
   if (!LDS) {
     for (int ty = y0; ty < y1; ++ty)
       for (int tx = x0; tx < x1; ++tx) {
+        if (!EG_TILE_OK(tx, ty)) continue;
         const int t = ty * tw + tx;
         const long long idx = (long long)offsets[t] + (atomicSub(&cursor[t], 1) - 1);
         if (idx < capacity) keys[idx] = key;
@@ -179,7 +182,8 @@ tile_emit_kernel(const float2 *__restrict__ means2d, const int *__restrict__ rad
     return;
   }
   for (int ty = y0; ty < y1; ++ty)
-    for (int tx = x0; tx < x1; ++tx) atomicAdd(&s_hist[ty * tw + tx], 1);
+    for (int tx = x0; tx < x1; ++tx)
+      if (EG_TILE_OK(tx, ty)) atomicAdd(&s_hist[ty * tw + tx], 1);
   __syncthreads();
   for (int t = threadIdx.x; t < T; t += kBinThreads) {
     const int c = s_hist[t];
@@ -191,10 +195,12 @@ tile_emit_kernel(const float2 *__restrict__ means2d, const int *__restrict__ rad
   __syncthreads();
   for (int ty = y0; ty < y1; ++ty)
     for (int tx = x0; tx < x1; ++tx) {
+      if (!EG_TILE_OK(tx, ty)) continue;
       const int t = ty * tw + tx;
       const long long idx = (long long)s_base[t] + atomicAdd(&s_hist[t], 1);
       if (idx < capacity) keys[idx] = key;
     }
+#undef EG_TILE_OK
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -69,6 +69,41 @@ __device__ __forceinline__ void tile_box_tight(float x, float y, int radius, flo
   if (x1 <= x0 || y1 <= y0) { x1 = x0; y1 = y0; }
 }
 
+// Exact refinement of the tight box: does the ellipse sigma(p) <= thr reach any point of the tile's
+// pixel-centre rectangle [X0+0.5, X0+15.5] x [Y0+0.5, Y0+15.5]?  sigma is a convex quadratic, so its
+// minimum over the rectangle is 0 if the centre is inside, else it lies on one of the four edges, where
+// it is a 1-D quadratic minimised in closed form (clamped to the edge).  Thin diagonal edge Gaussians
+// miss many of the tiles their AABB touches.  A small relative slack keeps the test conservative.
+__device__ __forceinline__ float sigma_at(float a, float b, float c, float dx, float dy) {
+  return 0.5f * (a * dx * dx + c * dy * dy) + b * dx * dy;
+}
+
+__device__ __forceinline__ bool ellipse_hits_rect(float x, float y, float a, float b, float c, float thr,
+                                                  float rx0, float ry0, float rx1, float ry1) {
+  // offsets of the rectangle relative to the centre (dx = x - px as in the kernels; sign is irrelevant
+  // for a centred quadratic, so use p - centre)
+  const float u0 = rx0 - x, u1 = rx1 - x, v0 = ry0 - y, v1 = ry1 - y;
+  if (u0 <= 0.f && u1 >= 0.f && v0 <= 0.f && v1 >= 0.f) return true;
+  float best = 3.0e38f;
+  // edges v = v0 and v = v1: minimise over u in [u0,u1]: u* = -b v / a
+  {
+    const float us0 = fminf(fmaxf(-b * v0 / a, u0), u1), us1 = fminf(fmaxf(-b * v1 / a, u0), u1);
+    best = fminf(best, fminf(sigma_at(a, b, c, us0, v0), sigma_at(a, b, c, us1, v1)));
+  }
+  // edges u = u0 and u = u1: v* = -b u / c
+  {
+    const float vs0 = fminf(fmaxf(-b * u0 / c, v0), v1), vs1 = fminf(fmaxf(-b * u1 / c, v0), v1);
+    best = fminf(best, fminf(sigma_at(a, b, c, u0, vs0), sigma_at(a, b, c, u1, vs1)));
+  }
+  return best <= thr * 1.001f + 1e-3f;
+}
+
+__device__ __forceinline__ bool splat_hits_tile(float x, float y, float a, float b, float c, float o, int tx, int ty) {
+  const float thr = __logf(255.f * o) + kThrMargin;
+  const float X0 = (float)(tx * kTile), Y0 = (float)(ty * kTile);
+  return ellipse_hits_rect(x, y, a, b, c, thr, X0 + 0.5f, Y0 + 0.5f, X0 + 15.5f, Y0 + 15.5f);
+}
+
 }  // namespace eg
 
 #define EG_REQUIRE(cond, msg)                         \

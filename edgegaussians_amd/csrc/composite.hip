@@ -307,9 +307,11 @@ composite_slice_fwd_kernel(const float4 *__restrict__ splat, const int *__restri
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const float qx = X0 + (float)((q & 1) << 3), qy = Y0 + (float)((q >> 1) << 3);
-        // pixel centres of the quadrant span [q + 0.5, q + 7.5]
+        // pixel centres of the quadrant span [q + 0.5, q + 7.5]: AABB reject, then the exact
+        // ellipse-vs-rectangle test (thin diagonal ellipses miss most of their AABB)
         hitq[q] = (s0.x - ex <= qx + 7.5f) && (s0.x + ex >= qx + 0.5f) && (s0.y - ey <= qy + 7.5f) &&
-                  (s0.y + ey >= qy + 0.5f);
+                  (s0.y + ey >= qy + 0.5f) &&
+                  ellipse_hits_rect(s0.x, s0.y, s0.z, s0.w, s1.x, thr, qx + 0.5f, qy + 0.5f, qx + 7.5f, qy + 7.5f);
       }
     }
   }
@@ -445,14 +447,24 @@ composite_combine_fwd_kernel(const int *__restrict__ item_offsets, const int *__
 
   float T = 1.f;
   int last = 0, stop_slice = -1;
-  for (int s = 0; s < ns; ++s) {
-    const float P = sliceP[(size_t)(i0 + s) * kTilePix + tid];
-    const int L = sliceL[(size_t)(i0 + s) * kTilePix + tid];
-    if (L < 0) continue;
-    const float nT = T * P;
-    if (nT <= kTStop) { stop_slice = s; break; }
-    T = nT;
-    last = L;
+  for (int s4 = 0; s4 < ns && stop_slice < 0; s4 += 4) {
+    // four slices' records in flight per wait (the walk over a tile's ~20 slices is latency-bound)
+    float P[4];
+    int L[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const bool ok = s4 + u < ns;
+      P[u] = ok ? sliceP[(size_t)(i0 + s4 + u) * kTilePix + tid] : 1.f;
+      L[u] = ok ? sliceL[(size_t)(i0 + s4 + u) * kTilePix + tid] : -1;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (L[u] < 0 || stop_slice >= 0) continue;
+      const float nT = T * P[u];
+      if (nT <= kTStop) { stop_slice = s4 + u; continue; }
+      T = nT;
+      last = L[u];
+    }
   }
   StopInfo si;
   si.slice = inside ? stop_slice : -1;

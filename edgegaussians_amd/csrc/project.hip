@@ -180,11 +180,15 @@ project_fwd_kernel(const float *__restrict__ means, const float *__restrict__ qu
       int x0, y0, x1, y1;
       if (flags & EG_FLAG_TIGHT_TILES) tile_box_tight(s0.x, s0.y, radius, s0.z, s0.w, s1.x, s1.y, tw, th, x0, y0, x1, y1);
       else tile_box(s0.x, s0.y, radius, tw, th, x0, y0, x1, y1);
-      n = (y1 - y0) * (x1 - x0);
-      if (tile_counts)
+      const bool exact = flags & EG_FLAG_TIGHT_TILES;  // drop tiles the ellipse itself does not reach
+      n = exact ? 0 : (y1 - y0) * (x1 - x0);
+      if (tile_counts || exact)
         for (int ty = y0; ty < y1; ++ty)
-          for (int tx = x0; tx < x1; ++tx)
-            atomicAdd(LDS_COUNT ? &s_hist[ty * tw + tx] : &tile_counts[ty * tw + tx], 1);
+          for (int tx = x0; tx < x1; ++tx) {
+            if (exact && !splat_hits_tile(s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, tx, ty)) continue;
+            if (exact) ++n;
+            if (tile_counts) atomicAdd(LDS_COUNT ? &s_hist[ty * tw + tx] : &tile_counts[ty * tw + tx], 1);
+          }
     }
     if (live && tiles_per_gauss) tiles_per_gauss[g] = n;
   }
