@@ -6,5 +6,6 @@ kunalchelani/EdgeGaussians) behind the reference's own operator surface.
 """
 from .rasterizer import rasterization  # noqa: F401
 from .trainer import EdgeTrainer, LRSchedule  # noqa: F401
+from .train_loop import train, train_epoch  # noqa: F401
 
-__all__ = ["rasterization", "EdgeTrainer", "LRSchedule"]
+__all__ = ["rasterization", "EdgeTrainer", "LRSchedule", "train", "train_epoch"]

@@ -1,0 +1,111 @@
+"""The reference's epoch / iteration protocol, driven on the fused device step.
+
+Host-side mirror of `train()` and `train_epoch()` (`/root/reference/train_gaussians.py:17-222`): same
+config dictionaries (the `model` and `training` sections of `configs/*.json`), same calendar, same
+quirks -- but every iteration is one `EdgeTrainer.train_step` enqueue and the only host syncs are the
+ones the semantics require (the regulariser lambda needs the loss values, train_gaussians.py:113,125;
+densify/cull events change N).
+
+Line map:
+    bg_edge_pixel_ratio / lambda_projection annealing   train_utils.py:28-45, train_gaussians.py:29-34
+    strategy alternation (model.step % ratio)           train_gaussians.py:59-77
+    per-view iteration                                  :81-106      -> EdgeTrainer.train_step
+    direction / ratio regulariser every 5th step        :108-131     -> EdgeTrainer.regulariser_step
+    schedulers step once per epoch                      :183-184     -> LRSchedule.at(epoch)
+    duplicate / cull calendar, absgrad reset            :186-219     -> EdgeTrainer.duplicate*/cull*
+The view order is the caller's (`view_order(epoch) -> iterable of view indices`): the reference uses
+`DataLoader(shuffle=True)` on the default CPU generator (train_gaussians.py:311).
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, Iterable, List, Optional
+
+import torch
+
+from .trainer import EdgeTrainer, LRSchedule
+
+
+def _anneal(cfg: Dict, key: str, step: int, max_steps: int) -> float:
+    kind = cfg[f"{key}_annealing"]
+    if kind == "constant":
+        return cfg[f"{key}_start"]
+    if kind == "linear":
+        return cfg[f"{key}_start"] + (cfg[f"{key}_end"] - cfg[f"{key}_start"]) * step / max_steps
+    raise ValueError(f"Unsupported {key}_annealing: {kind}")
+
+
+def train_epoch(tr: EdgeTrainer, views: Iterable[int], epoch: int, num_epochs: int, projection_cfg: Dict,
+                orientation_cfg: Dict, edge_threshold: float = 0.5,
+                generator: Optional[torch.Generator] = None) -> float:
+    """train_gaussians.py:17-141 for one epoch; returns the average projection loss."""
+    ratio = _anneal(projection_cfg, "bg_edge_pixel_ratio", epoch, num_epochs)
+    tr.loss_scale = float(_anneal({"lambda_annealing": projection_cfg["lambda_annealing"],
+                                   "lambda_start": projection_cfg["lambda_start"],
+                                   "lambda_end": projection_cfg["lambda_end"]}, "lambda", epoch, num_epochs))
+    tr.epoch = epoch
+    alternate = epoch > projection_cfg["start_alternating_at_epoch"]
+    strategy = projection_cfg["loss_before_alternating"]
+    apply_dir = epoch > orientation_cfg["start_dir_loss_at_epoch"]
+    apply_ratio = epoch > orientation_cfg["start_ratio_loss_at_epoch"]
+    period = projection_cfg["sampling_whole_num_epochs_ratio"]
+    loss_sum, n = 0.0, 0
+    for idx in views:
+        if alternate:
+            strategy = projection_cfg["less_freq_loss"] if tr.step % period == 0 else projection_cfg["more_freq_loss"]
+        tr.train_step(idx, tr.weight_map(idx, strategy, ratio, generator, edge_threshold))
+        n += 1
+        if (apply_dir or apply_ratio) and tr.step % 5 == 0:
+            # the regulariser weights are data-dependent: lambda = running loss sum * factor / loss
+            loss_sum += tr.pop_loss()  # the device accumulator holds the UNSCALED losses (train_gaussians.py:99)
+            if apply_dir:
+                tr.regulariser_step("direction", loss_sum, orientation_cfg["dir_loss_scale_factor"],
+                                    orientation_cfg["dir_loss_num_nn"])
+            if apply_ratio:
+                tr.regulariser_step("ratio", loss_sum, orientation_cfg["ratio_loss_scale_factor"])
+    loss_sum += tr.pop_loss()
+    return loss_sum / max(n, 1)
+
+
+def train(tr: EdgeTrainer, model_cfg: Dict, training_cfg: Dict, view_order: Callable[[int], Iterable[int]],
+          edge_masks_u8: Optional[torch.Tensor] = None, on_epoch: Optional[Callable[[int, float, int], None]] = None,
+          generator: Optional[torch.Generator] = None, num_epochs: Optional[int] = None) -> List[float]:
+    """train_gaussians.py:144-222.  `model_cfg` / `training_cfg` are the reference's JSON sections;
+    `edge_masks_u8` [V,H,W] (gt >= threshold) is needed only for the not-projecting cull."""
+    loss_cfg = training_cfg["loss"]
+    proj_cfg, orient_cfg = loss_cfg["projection_losses"], loss_cfg["orientation_losses"]
+    num_epochs = training_cfg["num_epochs"] if num_epochs is None else num_epochs
+    tr.schedule = LRSchedule.from_config(training_cfg["optim"])
+    get = model_cfg.get
+    thr = get("edge_detection_threshold", 0.5)
+    if tr.capacity == 0:
+        tr.ensure_capacity()
+    history = []
+    for epoch in range(num_epochs):
+        avg = train_epoch(tr, view_order(epoch), epoch, num_epochs, proj_cfg, orient_cfg, thr, generator)
+        history.append(avg)
+        changed = False
+        if get("if_duplicate_high_pos_grad", True) and epoch in get("dup_high_pos_grads_at_epoch", []):
+            if get("dup_threshold_type", "percentile") == "absolute":  # the only branch the reference executes
+                tr.duplicate_high_pos_gradients(get("dup_threshold_value", 0.95), get("dup_factor", 2),
+                                                get("init_dup_rand_noise_scale", 0.05))
+                changed = True
+        if get("if_cull_gaussians_not_projecting", True) and epoch in get("cull_gaussians_not_projecting_at_epoch", []):
+            if edge_masks_u8 is None:
+                edge_masks_u8 = (tr.gt >= thr).to(torch.uint8)
+            tr.cull_not_projecting(edge_masks_u8, get("cull_gaussians_not_projecting_threshold", 0.35))
+            changed = True
+        if get("if_cull_low_opacity", True) and epoch in get("cull_opacity_at_epoch", []):
+            if get("cull_opacity_type", "absolute") == "absolute":
+                tr.cull_opacity(get("cull_opacity_value", 0.05))
+            else:
+                q = torch.quantile(torch.sigmoid(tr.logit_opacities), get("cull_opacity_value", 0.05))
+                tr.cull(torch.sigmoid(tr.logit_opacities) < q)
+            changed = True
+        # cull_wayward computes a mask and never applies it (edge_gs.py:498-542): a no-op, skipped
+        # "if reset_opacity" (with a space) never matches the dataclass field (configs/*.json:37): always False
+        if changed:
+            tr.reset_absgrads()          # train_gaussians.py:218-219
+            tr.ensure_capacity()         # N changed: re-size the isect buffers (one count-only sweep)
+        if on_epoch:
+            on_epoch(epoch, avg, tr.N)
+    return history

@@ -144,6 +144,43 @@ class EdgeTrainer:
                                      device=self.dev)
         self._args_cache = {}
 
+    # ------------------------------------------------------------------ loss weight maps
+    def weight_map(self, view: int, strategy: str, ratio: float = 1.0,
+                   generator: Optional[torch.Generator] = None, threshold: float = 0.5) -> Tensor:
+        """Per-pixel weights w with  loss = sum_p w_p |render_p - gt_p|  for the reference's three
+        strategies (edge_gs.py:288-324).  'whole' / 'weighted' are cached on the device; the
+        'bg_edge_ratio' sample is drawn per call -- on the device by default, or on the host from
+        `generator` exactly like the reference (CPU randperm, edge_gs.py:306) when one is given."""
+        from . import synth
+        cache = self.__dict__.setdefault("_wmaps", {})
+        H, W = self.height, self.width
+        hw = H * W
+        if strategy == "whole":
+            if "whole" not in cache:
+                cache["whole"] = torch.full((H, W), 1.0 / hw, device=self.dev)
+            return cache["whole"]
+        key = ("edge", view, threshold)
+        if key not in cache:
+            edge = (self.gt[view] >= threshold)
+            cache[key] = (edge, int(edge.sum().item()))
+        edge, n_e = cache[key]
+        if strategy == "weighted":
+            k2 = ("weighted", view, threshold)
+            if k2 not in cache:
+                n_b = hw - n_e
+                cache[k2] = (torch.where(edge, n_b / hw, n_e / hw).float() / hw).contiguous()
+            return cache[k2]
+        if strategy == "bg_edge_ratio":
+            if generator is not None:
+                return synth.weight_map(strategy, self.gt[view].cpu(), ratio, generator, threshold).to(self.dev)
+            n_sel = int(ratio * n_e)
+            perm = torch.randperm(hw - n_e, device=self.dev)[:n_sel] % hw
+            sel = torch.zeros(hw, device=self.dev)
+            sel[perm] = 1.0
+            w = edge.reshape(-1).float() / max(n_e, 1) + sel / max(float(sel.sum().item()), 1.0)
+            return w.reshape(H, W).contiguous()
+        raise ValueError(f"Unknown projection loss strategy: {strategy}")
+
     # ------------------------------------------------------------------ capacity
     def count_intersections(self, view: int) -> int:
         """M for one view (count-only pass: projection + per-tile counts + scan).  Host sync."""

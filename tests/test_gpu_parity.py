@@ -658,6 +658,58 @@ def test_regulariser_step_advances_only_three_optimizers(env):
         assert_close(mine.cpu() - init, P[name].data.cpu() - init, rtol=2e-3, max_bad=2e-2, name=f"delta {name}")
 
 
+# ------------------------------------------------------------------ the reference's loop, end to end
+def test_training_loop_on_real_edge_maps(env, golden_dir):
+    """`train()` (train_gaussians.py:144-222) with the reference's own ABC config sections on the four
+    real DexiNed views of scan 00004926 (fixtures): alternating loss strategies, LR schedule, both
+    regularisers, duplicate / opacity-cull / not-projecting-cull events.  Checks that the loop runs
+    through every branch, that N follows the calendar and that the projection loss falls."""
+    import json
+    import os
+    _lib, synth, O = env
+    from edgegaussians_amd import EdgeTrainer, train
+    cams = np.load(os.path.join(golden_dir, "cameras_00004926.npz"))
+    edges = np.load(os.path.join(golden_dir, "edges_00004926.npz"))
+    views = list(edges["views"])
+    H, W = int(cams["height"]), int(cams["width"])
+    gt = torch.zeros(len(views), H, W)
+    for i, k in enumerate(views):
+        gt[i].view(-1)[torch.from_numpy(edges[f"idx_{k}"]).long()] = torch.from_numpy(edges[f"val_{k}"]).float() / 255.0
+    g = torch.Generator().manual_seed(0)
+    n = 2500  # init_min_num_gaussians (configs/ABC_DexiNed.json:27)
+    means = 1.1 * torch.rand(n, 3, generator=g) - 0.55 + 0.5
+    tr = EdgeTrainer(means, torch.full((n, 3), math.log(0.004)), synth.random_quats(n, g),
+                     torch.logit(torch.full((n, 1), 0.08)), torch.from_numpy(cams["viewmats"][views]),
+                     torch.from_numpy(cams["Ks"][views]), gt, W, H)
+    model_cfg = {"if_duplicate_high_pos_grad": True, "dup_threshold_type": "absolute", "dup_threshold_value": 0.5,
+                 "dup_factor": 3, "dup_high_pos_grads_at_epoch": [4, 8], "init_dup_rand_noise_scale": 0.05,
+                 "if_cull_low_opacity": True, "cull_opacity_type": "absolute", "cull_opacity_value": 0.05,
+                 "cull_opacity_at_epoch": [10], "if_cull_gaussians_not_projecting": True,
+                 "cull_gaussians_not_projecting_at_epoch": [12], "cull_gaussians_not_projecting_threshold": 0.1}
+    optim = json.load(open(os.path.join(golden_dir, "abc_optim_config.json")))
+    for k in ("scales", "opacities", "quats"):
+        optim[k]["start_at_epoch"] = 2  # compress the calendar: 16 epochs instead of 400
+    training_cfg = {"num_epochs": 16, "optim": optim, "loss": {
+        "orientation_losses": {"start_dir_loss_at_epoch": 9, "start_ratio_loss_at_epoch": 6, "dir_loss_num_nn": 5,
+                               "dir_loss_scale_factor": 0.01, "ratio_loss_scale_factor": 0.01},
+        "projection_losses": {"lambda_annealing": "constant", "lambda_start": 1, "lambda_end": 1,
+                              "loss_before_alternating": "whole", "less_freq_loss": "bg_edge_ratio",
+                              "more_freq_loss": "whole", "start_alternating_at_epoch": 3,
+                              "bg_edge_pixel_ratio_annealing": "constant", "bg_edge_pixel_ratio_start": 1,
+                              "bg_edge_pixel_ratio_end": 1, "sampling_whole_num_epochs_ratio": 5}}}
+    counts = []
+    order = lambda epoch: [v for _ in range(12) for v in torch.randperm(4, generator=g).tolist()]  # noqa: E731
+    hist = train(tr, model_cfg, training_cfg, order, on_epoch=lambda e, l, nn: counts.append(nn))
+    assert len(hist) == 16 and all(math.isfinite(x) for x in hist) and not tr.overflowed()
+    assert hist[3] < hist[0]  # 'whole' epochs: comparable losses, and training reduces them
+    assert counts[3] == 2500 and counts[4] > counts[3] and counts[8] >= counts[7]  # duplication events
+    assert counts[10] <= counts[9] and counts[12] <= counts[11]                   # cull events
+    assert tr.group_steps[0] > tr.group_steps[3] > 0                              # regulariser steps happened
+    assert torch.isfinite(tr.means).all() and torch.isfinite(tr.logit_opacities).all()
+    sd = tr.state_dict()
+    assert sd["gauss_params.opacities"].shape == (tr.N, 1)
+
+
 # ------------------------------------------------------------------ densify / cull vs the reference's own outputs
 def test_densify_cull_golden(env, golden_dir):
     import os
