@@ -463,6 +463,33 @@ def test_data_parallel_leg_on_gpu_single_rank(env):
     assert abs(a.pop_loss() - b.pop_loss()) < 1e-6
 
 
+def test_fused_step_vs_c_oracle_at_config1_size(env):
+    """BASELINE config 1 (30 k Gaussians, 512x512) end to end against the plain-C oracle: two training
+    iterations (different views, different strategies), loss / M / parameter updates / absgrads."""
+    _lib, synth, O = env
+    from edgegaussians_amd import EdgeTrainer, LRSchedule, rasterization
+    from oracle import c_oracle as CO
+    n, W, H = 30_000, 512, 512
+    sc = synth.make_scene(n, 3, W, H, seed=0, anisotropy=5.0, spread_opacity=True)
+    sched = LRSchedule(scales_start=0, quats_start=0, opacities_start=0)
+    ct = CO.CpuTrainer(sc.means.numpy(), sc.log_scales.numpy(), sc.quats.numpy(), sc.logit_opacities.numpy(), sched.at(0))
+    tr = EdgeTrainer(sc.means, sc.log_scales, sc.quats, sc.logit_opacities, sc.viewmats, sc.Ks, sc.gt, W, H, schedule=sched)
+    tr.ensure_capacity()
+    for s, (v, strat) in enumerate([(0, "whole"), (2, "bg_edge_ratio")]):
+        w = synth.weight_map(strat, sc.gt[v], generator=torch.Generator().manual_seed(s))
+        lc, M = ct.train_step(sc.viewmats[v].numpy(), sc.Ks[v].numpy(), W, H, sc.gt[v].numpy(), w.numpy())
+        tr.train_step(v, w.cuda())
+        lg = tr.pop_loss()
+        assert abs(lg - lc) <= 2e-4 * abs(lc), (s, lg, lc)
+        assert tr.last_m() <= M  # tight tile boxes only drop (Gaussian, tile) pairs
+    assert not tr.overflowed()
+    for name, mine, theirs in (("means", tr.means, ct.means), ("scales", tr.log_scales, ct.log_scales),
+                               ("quats", tr.quats, ct.quats), ("opacities", tr.logit_opacities, ct.logit)):
+        init = {"means": sc.means, "scales": sc.log_scales, "quats": sc.quats, "opacities": sc.logit_opacities.view(-1)}[name]
+        assert_close(mine.cpu() - init, torch.from_numpy(theirs) - init, rtol=2e-3, max_bad=2e-2, name=f"delta {name}")
+    assert_close(tr.absgrads, ct.absgrads, max_bad=5e-3, name="absgrads")
+
+
 # ------------------------------------------------------------------ edge cases and full-size properties
 def test_empty_and_degenerate_scenes(env):
     """M = 0 (everything culled), N = 1, and an image smaller than one tile: no faults, exact zeros."""
