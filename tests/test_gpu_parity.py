@@ -569,6 +569,31 @@ def test_full_size_properties_config2(env):
     assert torch.equal(r2, r.detach()) and torch.equal(info2["flatten_ids"], flat)
 
 
+@pytest.mark.parametrize("W,H", [(2100, 2100), (1900, 1600)])
+def test_large_tile_grids_take_the_fallback_binning_paths(env, W, H):
+    """T > 16384 tiles: the LDS-privatised counters no longer fit and projection / count / emit fall back
+    to direct atomics; 8192 < T <= 16384: projection keeps LDS counters, emit falls back.  Fused step vs the
+    plain-C oracle."""
+    _lib, synth, O = env
+    from edgegaussians_amd import EdgeTrainer, LRSchedule
+    from oracle import c_oracle as CO
+    T = math.ceil(W / 16) * math.ceil(H / 16)
+    assert T > 8192
+    sc = synth.make_scene(6000, 1, W, H, seed=2, spread_opacity=True, scale=0.006)
+    sched = LRSchedule(scales_start=0, quats_start=0, opacities_start=0)
+    ct = CO.CpuTrainer(sc.means.numpy(), sc.log_scales.numpy(), sc.quats.numpy(), sc.logit_opacities.numpy(), sched.at(0))
+    tr = EdgeTrainer(sc.means, sc.log_scales, sc.quats, sc.logit_opacities, sc.viewmats, sc.Ks, sc.gt, W, H, schedule=sched)
+    tr.ensure_capacity()
+    w = synth.weight_map("weighted", sc.gt[0])
+    lc, M = ct.train_step(sc.viewmats[0].numpy(), sc.Ks[0].numpy(), W, H, sc.gt[0].numpy(), w.numpy())
+    tr.train_step(0, w.cuda())
+    lg = tr.pop_loss()
+    assert abs(lg - lc) <= 2e-4 * abs(lc) and 0 < tr.last_m() <= M and not tr.overflowed()
+    assert int(tr.tile_counts.abs().sum()) == 0  # emit returned every counter to zero
+    assert_close(tr.absgrads, ct.absgrads, max_bad=5e-3, name="absgrads")
+    assert_close(tr.means.cpu() - sc.means, torch.from_numpy(ct.means) - sc.means, rtol=2e-3, max_bad=2e-2, name="delta means")
+
+
 # ------------------------------------------------------------------ 8(f): kNN + orientation regularisers
 @pytest.mark.parametrize("k,clustered", [(6, False), (6, True), (16, False)])
 def test_knn_matches_sklearn(env, k, clustered):
