@@ -744,9 +744,9 @@ footprint_bwd_kernel(const float4 *__restrict__ splat, int N, int width, int hei
                      const float2 *__restrict__ gtstop, float *__restrict__ g2d, int *__restrict__ big_list,
                      int parity) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  const int g = t >> 3, c = t & 7;
+  const int g = t / kLanesPerGauss, c = t % kLanesPerGauss;
   if (t == 0) big_list[parity ^ 1] = 0;  // the NEXT call's counter (this call's is zero on entry)
-  if (g >= N) return;  // whole 8-lane groups leave together
+  if (g >= N) return;  // whole lane groups leave together
   const float4 s0 = splat[2 * g], s1 = splat[2 * g + 1];
   const Footprint fp = footprint_of(s0, s1, width, height);
   const int fw = fp.j1 - fp.j0 + 1, fh = fp.i1 - fp.i0 + 1;
@@ -759,20 +759,27 @@ footprint_bwd_kernel(const float4 *__restrict__ splat, int N, int width, int hei
       return;
     }
     if (!ROWSPAN) {
-      // small footprints: plain AABB walk, software-pipelined (the record of the NEXT pixel is in
-      // flight while this one is evaluated)
+      // small footprints: plain AABB walk, two rows per iteration so that two independent gathers are
+      // in flight per lane, and the pair of the NEXT iteration is prefetched while this one is evaluated
       int i = fp.i0, j = fp.j0 + c;
       bool more = j <= fp.j1;
-      float2 nxt = make_float2(0.f, 0.f);
-      if (more) nxt = gtstop[i * width + j];
+      float2 na = make_float2(0.f, 0.f), nb = na;
+      if (more) {
+        na = gtstop[i * width + j];
+        if (i + 1 <= fp.i1) nb = gtstop[(i + 1) * width + j];
+      }
       while (more) {
-        const float2 rec = nxt;
+        const float2 ra = na, rb = nb;
         const int ci = i, cj = j;
         j += kLanesPerGauss;
-        if (j > fp.j1) { j = fp.j0 + c; ++i; }
+        if (j > fp.j1) { j = fp.j0 + c; i += 2; }
         more = i <= fp.i1;
-        if (more) nxt = gtstop[i * width + j];
-        footprint_pixel(s0, s1, fp.thr, g, ci, cj, rec, splat, a);
+        if (more) {
+          na = gtstop[i * width + j];
+          nb = (i + 1 <= fp.i1) ? gtstop[(i + 1) * width + j] : make_float2(0.f, 0.f);
+        }
+        footprint_pixel(s0, s1, fp.thr, g, ci, cj, ra, splat, a);
+        if (ci + 1 <= fp.i1) footprint_pixel(s0, s1, fp.thr, g, ci + 1, cj, rb, splat, a);
       }
     } else {
       // Row-span walk: on pixel row i the ellipse sigma <= thr is the interval
@@ -811,15 +818,18 @@ footprint_bwd_kernel(const float4 *__restrict__ splat, int N, int width, int hei
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     float v = a.v[k];
-    v += __shfl_xor(v, 1, 64);
-    v += __shfl_xor(v, 2, 64);
-    v += __shfl_xor(v, 4, 64);
+#pragma unroll
+    for (int d = 1; d < kLanesPerGauss; d <<= 1) v += __shfl_xor(v, d, 64);
     a.v[k] = v;
   }
-  float out = a.v[0];
+  // lane c stores components c, c + L, ... (one coalesced 32-byte record per Gaussian)
 #pragma unroll
-  for (int k = 1; k < 8; ++k) out = (c == k) ? a.v[k] : out;
-  g2d[(size_t)g * 8 + c] = out;
+  for (int base = 0; base < 8; base += kLanesPerGauss) {
+    float out = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) out = (base + c == k) ? a.v[k] : out;
+    if (base + c < 8) g2d[(size_t)g * 8 + base + c] = out;
+  }
 }
 
 // one wavefront per big-footprint Gaussian: lanes stride over the footprint, full butterfly
