@@ -44,8 +44,7 @@ def algorithmic_bytes(n, m, hw):
     design (DESIGN.md 'algorithmic bytes'); the 8 B/isect of gsplat's offset-encode pass has no
     counterpart here (offsets come from the per-tile scan)."""
     return {
-        "project_fwd": 108 * n,            # G1 80 + per-Gaussian binning 28
-        "tile_offsets": 0,
+        "project_bin": 108 * n,            # G1 80 + per-Gaussian binning 28 (+ the fused scan, ~8 T bytes)
         "tile_emit": 12 * m,
         "tile_sort": 24 * m,
         "composite_fwd": 28 * m + 20 * hw,

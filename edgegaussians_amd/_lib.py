@@ -42,6 +42,7 @@ class StepArgs(C.Structure):
         ("width", _i32), ("height", _i32), ("loss_scale", _f),
         ("splat", _vp), ("g2d", _vp),
         ("tile_counts", _vp), ("offsets", _vp), ("item_offsets", _vp), ("total", _vp),
+        ("tile_mask", _vp), ("ticket", _vp),
         ("workspace", _vp), ("max_items", _i64),
         ("keys", _vp), ("flatten_ids", _vp), ("capacity", _i64),
         ("render", _vp), ("alphas", _vp), ("vpix", _vp), ("loss", _vp), ("gtstop", _vp), ("big_list", _vp),
@@ -56,7 +57,8 @@ _SIGS = {
     "eg_project_fwd": [_vp] * 6 + [_i32, _i32, _i32, _f, _f, _f, _f, _u32] + [_vp] * 9 + [_vp],
     "eg_tile_count": [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp],
     "eg_tile_offsets": [_vp, _i32, _i64, _vp, _vp, _vp, _vp],
-    "eg_tile_emit": [_vp, _vp, _vp, _vp, _u32, _i32, _i32, _i32, _vp, _vp, _i64, _vp, _vp],
+    "eg_tile_emit": [_vp, _vp, _vp, _vp, _u32, _i32, _i32, _i32, _vp, _vp, _i64, _vp, _vp, _vp],
+    "eg_project_bin": [_vp] * 6 + [_i32, _i32, _i32, _u32, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp],
     "eg_sort_pairs": [_vp, _vp, _i32, _i64, _vp, _vp, _vp],
     "eg_composite_fwd": [_vp, _vp, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp,
                          _vp, _vp, _i64, _vp, _vp, _vp],

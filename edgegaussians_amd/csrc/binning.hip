@@ -142,7 +142,7 @@ __global__ void __launch_bounds__(kBinThreads)
 tile_emit_kernel(const float2 *__restrict__ means2d, const int *__restrict__ radii,
                  const float *__restrict__ depths, const float4 *__restrict__ splat, unsigned flags, int N,
                  int width, int height, const int *__restrict__ offsets, int *__restrict__ cursor,
-                 long long capacity, unsigned long long *__restrict__ keys) {
+                 long long capacity, unsigned long long *__restrict__ keys, const unsigned *__restrict__ tile_mask) {
   extern __shared__ __attribute__((aligned(16))) int s_mem[];
   const int tw = (width + kTile - 1) / kTile, th = (height + kTile - 1) / kTile, T = tw * th;
   int *s_hist = s_mem, *s_base = s_mem + T;
@@ -170,7 +170,13 @@ tile_emit_kernel(const float2 *__restrict__ means2d, const int *__restrict__ rad
   }
   const unsigned long long key = ((unsigned long long)(unsigned)__float_as_int(depth) << 32) | (unsigned)g;
   const bool exact = splat && (flags & EG_FLAG_TIGHT_TILES);  // must mirror the counting pass exactly
-#define EG_TILE_OK(tx, ty) (!exact || splat_hits_tile(x, y, s0.z, s0.w, s1.x, s1.y, tx, ty))
+  // the counting pass left the exact hits of small boxes as a bit mask (all ones = "re-test")
+  const unsigned mask = (exact && tile_mask && g < N) ? tile_mask[g] : 0xffffffffu;
+  const bool use_mask = exact && mask != 0xffffffffu;
+  const int bw = x1 - x0;
+#define EG_TILE_OK(tx, ty)                                                           \
+  (!exact || (use_mask ? ((mask >> (((ty)-y0) * bw + ((tx)-x0))) & 1u) != 0u         \
+                       : splat_hits_tile(x, y, s0.z, s0.w, s1.x, s1.y, tx, ty)))
   if (!LDS) {
     for (int ty = y0; ty < y1; ++ty)
       for (int tx = x0; tx < x1; ++tx) {
@@ -249,30 +255,6 @@ __device__ __forceinline__ void bitonic_lds(unsigned long long *s, int P, int k_
 // Keys are unique 64-bit values, so the rank (number of smaller keys in the bucket) is the final
 // position: the result equals the stable (tile, depth) sort bit for bit.  A bucket that is too full
 // (many equal depths) falls back to the bitonic network for that tile.
-template <int THREADS>
-__device__ __forceinline__ int block_excl_scan(int c, int *wave_tmp, int &block_total) {
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  constexpr int NW = THREADS / 64;
-  int s = c;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const int o = __shfl_up(s, d, 64);
-    if (lane >= d) s += o;
-  }
-  if (lane == 63) wave_tmp[wv] = s;
-  __syncthreads();
-  int pre = 0, tot = 0;
-#pragma unroll
-  for (int w = 0; w < NW; ++w) {
-    const int v = wave_tmp[w];
-    pre += (w < wv) ? v : 0;
-    tot += v;
-  }
-  block_total = tot;
-  __syncthreads();
-  return pre + (s - c);
-}
-
 template <int THREADS>
 __device__ __forceinline__ unsigned block_reduce_u32(unsigned v, bool take_max, unsigned *wave_tmp) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -477,7 +459,7 @@ extern "C" int eg_tile_offsets(const int32_t *tile_counts, int32_t T, int64_t ca
 
 extern "C" int eg_tile_emit(const float *means2d, const int32_t *radii, const float *depths, const float *splat,
                             uint32_t flags, int32_t N, int32_t width, int32_t height, const int32_t *offsets, int32_t *tile_cursor,
-                            int64_t capacity, uint64_t *keys, eg_stream_t stream) {
+                            int64_t capacity, uint64_t *keys, const uint32_t *tile_mask, eg_stream_t stream) {
   EG_REQUIRE(N >= 0 && width > 0 && height > 0 && capacity >= 0, "bad sizes");
   if (N == 0) return EG_OK;
   EG_REQUIRE(offsets && tile_cursor && (keys || capacity == 0), "null pointer");
@@ -486,11 +468,11 @@ extern "C" int eg_tile_emit(const float *means2d, const int32_t *radii, const fl
   if (2 * T <= kMaxLdsTiles)
     tile_emit_kernel<true><<<cdiv(N, kBinThreads), kBinThreads, sizeof(int) * 2 * T, as_stream(stream)>>>(
         (const float2 *)means2d, radii, depths, (const float4 *)splat, flags, N, width, height, offsets,
-        tile_cursor, (long long)capacity, (unsigned long long *)keys);
+        tile_cursor, (long long)capacity, (unsigned long long *)keys, tile_mask);
   else
     tile_emit_kernel<false><<<cdiv(N, kBinThreads), kBinThreads, 0, as_stream(stream)>>>(
         (const float2 *)means2d, radii, depths, (const float4 *)splat, flags, N, width, height, offsets,
-        tile_cursor, (long long)capacity, (unsigned long long *)keys);
+        tile_cursor, (long long)capacity, (unsigned long long *)keys, tile_mask);
   return check_launch("tile_emit");
 }
 

@@ -43,6 +43,31 @@ __device__ __forceinline__ void tile_box(float x, float y, int radius, int tw, i
   y1 = min(max((int)ceilf(ty + tr), 0), th);
 }
 
+// exclusive scan of one int per thread over a THREADS-wide workgroup (wave64 shuffles + one LDS hop)
+template <int THREADS>
+__device__ __forceinline__ int block_excl_scan(int c, int *wave_tmp, int &block_total) {
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  constexpr int NW = THREADS / 64;
+  int s = c;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int o = __shfl_up(s, d, 64);
+    if (lane >= d) s += o;
+  }
+  if (lane == 63) wave_tmp[wv] = s;
+  __syncthreads();
+  int pre = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) {
+    const int v = wave_tmp[w];
+    pre += (w < wv) ? v : 0;
+    tot += v;
+  }
+  block_total = tot;
+  __syncthreads();
+  return pre + (s - c);
+}
+
 // Opacity-aware tight tile box (fused training path only; the gsplat-compatible API keeps the
 // 3-sigma square box so that info["tiles_per_gauss"/"flatten_ids"] stay bit-identical).
 // A pixel can only pass alpha = o * exp(-sigma) >= 1/255 inside the ellipse sigma <= ln(255 o);

@@ -141,7 +141,10 @@ project_fwd_kernel(const float *__restrict__ means, const float *__restrict__ qu
                    float near_plane, float far_plane, float eps2d, float radius_clip, uint32_t flags,
                    float4 *__restrict__ splat, int *__restrict__ radii, float *__restrict__ means2d,
                    float *__restrict__ depths, float *__restrict__ conics, float *__restrict__ comps,
-                   int *__restrict__ tiles_per_gauss, int *__restrict__ tile_counts, float4 *__restrict__ g2d) {
+                   int *__restrict__ tiles_per_gauss, int *__restrict__ tile_counts, float4 *__restrict__ g2d,
+                   unsigned *__restrict__ tile_mask, int *__restrict__ scan_offsets,
+                   int *__restrict__ scan_item_offsets, int *__restrict__ scan_total, long long scan_capacity,
+                   int *__restrict__ scan_ticket) {
   extern __shared__ __attribute__((aligned(16))) int s_hist[];
   const int tw = (width + kTile - 1) / kTile, th = (height + kTile - 1) / kTile, T = tw * th;
   if (LDS_COUNT) {
@@ -182,13 +185,22 @@ project_fwd_kernel(const float *__restrict__ means, const float *__restrict__ qu
       else tile_box(s0.x, s0.y, radius, tw, th, x0, y0, x1, y1);
       const bool exact = flags & EG_FLAG_TIGHT_TILES;  // drop tiles the ellipse itself does not reach
       n = exact ? 0 : (y1 - y0) * (x1 - x0);
+      // the exact hits of boxes up to 32 tiles are remembered as a bit mask so that the emit pass does
+      // not evaluate the ellipse test a second time (bit = row-major index inside the box)
+      unsigned mask = 0u;
+      const bool small_box = (y1 - y0) * (x1 - x0) <= 32;
+      int bit = 0;
       if (tile_counts || exact)
         for (int ty = y0; ty < y1; ++ty)
-          for (int tx = x0; tx < x1; ++tx) {
+          for (int tx = x0; tx < x1; ++tx, ++bit) {
             if (exact && !splat_hits_tile(s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, tx, ty)) continue;
             if (exact) ++n;
+            if (small_box) mask |= 1u << bit;
             if (tile_counts) atomicAdd(LDS_COUNT ? &s_hist[ty * tw + tx] : &tile_counts[ty * tw + tx], 1);
           }
+      if (tile_mask) tile_mask[g] = small_box ? mask : 0xffffffffu;  // all ones on a big box: "re-test"
+    } else if (live && tile_mask) {
+      tile_mask[g] = 0u;
     }
     if (live && tiles_per_gauss) tiles_per_gauss[g] = n;
   }
@@ -197,6 +209,49 @@ project_fwd_kernel(const float *__restrict__ means, const float *__restrict__ qu
     for (int t = threadIdx.x; t < T; t += 256) {
       const int c = s_hist[t];
       if (c) atomicAdd(&tile_counts[t], c);
+    }
+  }
+  // Fused scan (saves the tile_offsets launch of the training step): the LAST workgroup to finish --
+  // found with a device-scope ticket -- scans the per-tile counters.  They are only ever written by
+  // device-scope atomics (performed at the coherence point, not in an XCD-private L2 line) and are read
+  // here with device-scope atomic loads, so no cache write-back / invalidate fence is needed: each wave
+  // only has to drain its own outstanding atomics (vmcnt) before the workgroup takes its ticket.
+  if (scan_ticket) {
+    __shared__ int s_last;
+    __shared__ int s_tmp[4];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = (atomicAdd(scan_ticket, 1) == (int)gridDim.x - 1);
+    __syncthreads();
+    if (s_last) {
+      const int per = (T + 255) / 256, t0 = threadIdx.x * per, t1 = min(T, t0 + per);
+      int sum = 0, isum = 0, cmax = 0;
+      for (int t = t0; t < t1; ++t) {
+        const int c = __hip_atomic_load(&tile_counts[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sum += c; isum += (c + 127) >> 7; cmax = max(cmax, c);
+      }
+      int tot, itot;
+      int e = block_excl_scan<256>(sum, s_tmp, tot);
+      int ie = block_excl_scan<256>(isum, s_tmp, itot);
+      for (int t = t0; t < t1; ++t) {
+        const int c = __hip_atomic_load(&tile_counts[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        scan_offsets[t] = (int)min((long long)e, scan_capacity);
+        scan_item_offsets[t] = ie;
+        e += c; ie += (c + 127) >> 7;
+      }
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) cmax = max(cmax, __shfl_xor(cmax, d, 64));
+      if ((threadIdx.x & 63) == 0) s_tmp[threadIdx.x >> 6] = cmax;
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        scan_offsets[T] = (int)min((long long)tot, scan_capacity);
+        scan_item_offsets[T] = itot;
+        scan_total[0] = tot;
+        scan_total[1] = ((long long)tot > scan_capacity) ? 1 : 0;
+        scan_total[2] = itot;
+        scan_total[3] = max(max(s_tmp[0], s_tmp[1]), max(s_tmp[2], s_tmp[3]));
+        *scan_ticket = 0;  // ready for the next launch
+      }
     }
   }
 }
@@ -431,6 +486,27 @@ static AdamK make_adamk(const eg_adam_hyper &h) {
 
 using namespace eg;
 
+static int launch_project_fwd(const float *means, const float *quats, const float *scales, const float *opacities,
+                              const float *viewmat, const float *K, int32_t N, int32_t width, int32_t height,
+                              float near_plane, float far_plane, float eps2d, float radius_clip, uint32_t flags,
+                              float *splat, int32_t *radii, float *means2d, float *depths, float *conics,
+                              float *compensations, int32_t *tiles_per_gauss, int32_t *tile_counts, float *g2d,
+                              uint32_t *tile_mask, int32_t *offsets, int32_t *item_offsets, int32_t *total,
+                              int64_t capacity, int32_t *ticket, eg_stream_t stream) {
+  const int T = cdiv(width, kTile) * cdiv(height, kTile);
+  if (tile_counts && T <= 16384)
+    project_fwd_kernel<true><<<cdiv(N, 256), 256, sizeof(int) * T, as_stream(stream)>>>(
+        means, quats, scales, opacities, viewmat, K, N, width, height, near_plane, far_plane, eps2d, radius_clip,
+        flags, (float4 *)splat, radii, means2d, depths, conics, compensations, tiles_per_gauss, tile_counts,
+        (float4 *)g2d, tile_mask, offsets, item_offsets, total, (long long)capacity, ticket);
+  else
+    project_fwd_kernel<false><<<cdiv(N, 256), 256, 0, as_stream(stream)>>>(
+        means, quats, scales, opacities, viewmat, K, N, width, height, near_plane, far_plane, eps2d, radius_clip,
+        flags, (float4 *)splat, radii, means2d, depths, conics, compensations, tiles_per_gauss, tile_counts,
+        (float4 *)g2d, tile_mask, offsets, item_offsets, total, (long long)capacity, ticket);
+  return check_launch("project_fwd");
+}
+
 extern "C" int eg_project_fwd(const float *means, const float *quats, const float *scales, const float *opacities,
                               const float *viewmat, const float *K, int32_t N, int32_t width, int32_t height,
                               float near_plane, float far_plane, float eps2d, float radius_clip, uint32_t flags,
@@ -440,18 +516,23 @@ extern "C" int eg_project_fwd(const float *means, const float *quats, const floa
   EG_REQUIRE(N >= 0 && width > 0 && height > 0, "bad sizes");
   if (N == 0) return EG_OK;
   EG_REQUIRE(means && quats && scales && opacities && viewmat && K && splat, "null pointer");
-  const int T = cdiv(width, kTile) * cdiv(height, kTile);
-  if (tile_counts && T <= 16384)
-    project_fwd_kernel<true><<<cdiv(N, 256), 256, sizeof(int) * T, as_stream(stream)>>>(
-        means, quats, scales, opacities, viewmat, K, N, width, height, near_plane, far_plane, eps2d, radius_clip,
-        flags, (float4 *)splat, radii, means2d, depths, conics, compensations, tiles_per_gauss, tile_counts,
-        (float4 *)g2d);
-  else
-    project_fwd_kernel<false><<<cdiv(N, 256), 256, 0, as_stream(stream)>>>(
-        means, quats, scales, opacities, viewmat, K, N, width, height, near_plane, far_plane, eps2d, radius_clip,
-        flags, (float4 *)splat, radii, means2d, depths, conics, compensations, tiles_per_gauss, tile_counts,
-        (float4 *)g2d);
-  return check_launch("project_fwd");
+  return launch_project_fwd(means, quats, scales, opacities, viewmat, K, N, width, height, near_plane, far_plane,
+                            eps2d, radius_clip, flags, splat, radii, means2d, depths, conics, compensations,
+                            tiles_per_gauss, tile_counts, g2d, nullptr, nullptr, nullptr, nullptr, 0, nullptr, stream);
+}
+
+extern "C" int eg_project_bin(const float *means, const float *quats, const float *log_scales,
+                              const float *logit_opacities, const float *viewmat, const float *K, int32_t N,
+                              int32_t width, int32_t height, uint32_t flags, float *splat, int32_t *tile_counts,
+                              uint32_t *tile_mask, int64_t capacity, int32_t *offsets, int32_t *item_offsets,
+                              int32_t *total, int32_t *ticket, eg_stream_t stream) {
+  EG_REQUIRE(N > 0 && width > 0 && height > 0, "bad sizes");
+  EG_REQUIRE(means && quats && log_scales && logit_opacities && viewmat && K && splat && tile_counts && tile_mask &&
+                 offsets && item_offsets && total && ticket,
+             "null pointer");
+  return launch_project_fwd(means, quats, log_scales, logit_opacities, viewmat, K, N, width, height, 0.01f, 1e10f,
+                            0.3f, 0.0f, flags, splat, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, tile_counts,
+                            nullptr, tile_mask, offsets, item_offsets, total, capacity, ticket, stream);
 }
 
 extern "C" int eg_project_bwd(const float *means, const float *quats, const float *scales, const float *opacities,

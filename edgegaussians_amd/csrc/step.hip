@@ -8,7 +8,8 @@
 //   update_absgrads()          -> fused in the projection VJP
 //   4x Adam.step(), zero_grad  -> fused in the projection VJP (single-GPU) or left to eg_adam_multi after
 //                                 the RCCL all-reduce (multi-GPU)
-// 10 launches per step instead of ~60 (torch glue + gsplat + CUB passes + 4 unfused Adams).
+// 10 launches per step (project+count+scan, emit, sort x2, slice, combine, re-walk, footprint x2,
+// project-bwd+Adam) instead of ~60 (torch glue + gsplat + CUB passes + 4 unfused Adams).
 #include <cstdarg>
 #include <cstdio>
 
@@ -55,8 +56,8 @@ extern "C" int eg_device_count(void) {
 // (Driving the stages from Python to time them measures the Python call overhead instead: a
 // 20-argument ctypes call costs ~100 us, the kernels 5-50 us.)
 namespace eg {
-constexpr int kStages = 7;
-static const char *kStageNames[kStages] = {"project_fwd", "tile_offsets", "tile_emit", "tile_sort",
+constexpr int kStages = 6;
+static const char *kStageNames[kStages] = {"project_bin", "tile_emit", "tile_sort",
                                            "composite_fwd", "composite_bwd_footprint", "project_bwd_adam"};
 static hipEvent_t *g_ev = nullptr;  // [(kStages + 1) * g_ev_steps]
 static int g_ev_steps = 0, g_ev_next = 0;
@@ -117,33 +118,30 @@ extern "C" int eg_train_step(const eg_step_args *a, eg_stream_t stream) {
 #define EG_MARK(k) do { if (ev) (void)hipEventRecord(ev[k], st); } while (0)
   int rc;
   EG_MARK(0);
-  // tile_counts is zero on entry (caller zero-initialises it once): the projection counts it up,
-  // the emit pass counts it back down to zero.
-  rc = eg_project_fwd(a->means, a->quats, a->log_scales, a->logit_opacities, a->viewmat, a->K, a->N, a->width,
-                      a->height, 0.01f, 1e10f, 0.3f, 0.0f, flags, a->splat, nullptr, nullptr, nullptr, nullptr,
-                      nullptr, nullptr, a->tile_counts, nullptr, stream);
+  // tile_counts is zero on entry (caller zero-initialises it once): the projection counts it up and its
+  // last workgroup scans it; the emit pass counts it back down to zero.
+  rc = eg_project_bin(a->means, a->quats, a->log_scales, a->logit_opacities, a->viewmat, a->K, a->N, a->width,
+                      a->height, flags, a->splat, a->tile_counts, a->tile_mask, a->capacity, a->offsets,
+                      a->item_offsets, a->total, a->ticket, stream);
   if (rc) return rc;
   EG_MARK(1);
-  rc = eg_tile_offsets(a->tile_counts, T, a->capacity, a->offsets, a->item_offsets, a->total, stream);
+  rc = eg_tile_emit(nullptr, nullptr, nullptr, a->splat, flags, a->N, a->width, a->height, a->offsets,
+                    a->tile_counts, a->capacity, a->keys, a->tile_mask, stream);
   if (rc) return rc;
   EG_MARK(2);
-  rc = eg_tile_emit(nullptr, nullptr, nullptr, a->splat, flags, a->N, a->width, a->height, a->offsets,
-                    a->tile_counts, a->capacity, a->keys, stream);
-  if (rc) return rc;
-  EG_MARK(3);
   rc = eg_sort_pairs(a->keys, a->offsets, T, a->capacity, a->flatten_ids, nullptr, stream);
   if (rc) return rc;
-  EG_MARK(4);
+  EG_MARK(3);
   rc = eg_composite_fwd(a->splat, nullptr, 1, a->offsets, a->flatten_ids, a->width, a->height, a->render,
                         a->alphas, a->last_ids, a->gt, a->wmap, a->loss_scale, a->vpix, a->loss, a->item_offsets,
                         a->total, a->max_items, a->workspace, a->gtstop, stream);
   if (rc) return rc;
-  EG_MARK(5);
+  EG_MARK(4);
   // backward: footprint compositing VJP, then projection VJP + absgrad (+ Adam)
   rc = eg_composite_bwd_footprint(a->splat, a->N, a->width, a->height, a->gtstop, a->g2d, a->big_list, a->parity,
                                   a->row_span, stream);
   if (rc) return rc;
-  EG_MARK(6);
+  EG_MARK(5);
   if (a->adam_host)
     rc = eg_project_bwd_adam(a->means, a->quats, a->log_scales, a->logit_opacities, a->viewmat, a->K, a->N,
                              a->width, a->height, 0.3f, flags, a->splat, a->g2d, a->adam_m, a->adam_v, a->absgrads,
@@ -152,7 +150,7 @@ extern "C" int eg_train_step(const eg_step_args *a, eg_stream_t stream) {
     rc = eg_project_bwd(a->means, a->quats, a->log_scales, a->logit_opacities, a->viewmat, a->K, a->N, a->width,
                         a->height, 0.3f, flags | EG_FLAG_ABSGRAD_WRITE, a->splat, a->g2d, nullptr, nullptr, a->v_means, a->v_quats,
                         a->v_scales, a->v_opacities, a->absgrads, stream);
-  EG_MARK(7);
+  EG_MARK(6);
 #undef EG_MARK
   if (ev) ++g_ev_next;
   return rc;

@@ -182,7 +182,7 @@ def isect_tiles_and_sort(means2d: Tensor, radii: Tensor, depths: Tensor, counts:
     flat = torch.empty(max(M, 1), dtype=torch.int32, device=dev)
     ids = torch.empty(max(M, 1), dtype=torch.int64, device=dev) if want_isect_ids else None
     call("eg_tile_emit", ptr(means2d), ptr(radii), ptr(depths), None, 0, N, width, height, ptr(offsets),
-         ptr(counts), M, ptr(keys), stream())
+         ptr(counts), M, ptr(keys), None, stream())
     call("eg_sort_pairs", ptr(keys), ptr(offsets), T, M, ptr(flat), ptr(ids) if ids is not None else None,
          stream())
     return offsets, flat[:M], (ids[:M] if ids is not None else None), M, item_offsets, total, n_items

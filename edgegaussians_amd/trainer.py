@@ -117,6 +117,7 @@ class EdgeTrainer:
         N, d = self.N, self.dev
         self.splat = torch.empty(N, 8, device=d)
         self.g2d = torch.empty(N, 8, device=d)  # written (not accumulated) by the footprint backward
+        self.tile_mask = torch.zeros(N, dtype=torch.int32, device=d)  # exact tile hits per Gaussian (bit mask)
         self.big_list = torch.zeros(2 + N, dtype=torch.int32, device=d)  # big-footprint work list
         self._parity = 0
         self.grads = torch.zeros(N, 12, device=d)  # [means3|quats4|scales3|opac1|absgrad-inc1] for all-reduce
@@ -128,6 +129,7 @@ class EdgeTrainer:
         self.offsets = torch.zeros(self.T + 1, dtype=torch.int32, device=d)
         self.item_offsets = torch.zeros(self.T + 1, dtype=torch.int32, device=d)
         self.total = torch.zeros(4, dtype=torch.int32, device=d)  # M, overflow, items, largest tile
+        self.ticket = torch.zeros(1, dtype=torch.int32, device=d)  # last-workgroup ticket of the fused scan
         self.render = torch.zeros(H, W, device=d)
         self.alphas = torch.zeros(H, W, device=d)
         self.vpix = torch.zeros(H, W, device=d)
@@ -225,6 +227,7 @@ class EdgeTrainer:
             a.row_span = self.row_span
             a.tile_counts, a.offsets, a.total = ptr(self.tile_counts), ptr(self.offsets), ptr(self.total)
             a.item_offsets, a.workspace, a.max_items = ptr(self.item_offsets), ptr(self.workspace), self.max_items
+            a.tile_mask, a.ticket = ptr(self.tile_mask), ptr(self.ticket)
             a.keys, a.flatten_ids, a.capacity = ptr(self.keys), ptr(self.flatten_ids), self.capacity
             a.render, a.alphas, a.vpix = ptr(self.render), ptr(self.alphas), ptr(self.vpix)
             a.loss, a.last_ids = ptr(self.loss_acc), ptr(self.last_ids)
@@ -297,7 +300,7 @@ class EdgeTrainer:
              ptr(self.item_offsets), ptr(self.total), st)
         mark("tile_offsets")
         call("eg_tile_emit", None, None, None, ptr(self.splat), fl, N, W, H, ptr(self.offsets), ptr(self.tile_counts),
-             self.capacity, ptr(self.keys), st)
+             self.capacity, ptr(self.keys), None, st)
         mark("tile_emit")
         call("eg_sort_pairs", ptr(self.keys), ptr(self.offsets), self.T, self.capacity, ptr(self.flatten_ids),
              None, st)

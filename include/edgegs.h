@@ -68,6 +68,18 @@ int eg_project_fwd(const float *means, const float *quats, const float *scales, 
                    int32_t *tiles_per_gauss /*[N]|NULL*/, int32_t *tile_counts /*[T]|NULL*/,
                    float *g2d /*[N,8]|NULL*/, eg_stream_t stream);
 
+/* ---- G1 + G2 + G3 for the fused training step: projection of raw parameters (log-scales, logits,
+ * antialiased), per-tile counting with the opacity-aware exact tile test, AND the scan -- the last
+ * workgroup to finish (device-scope ticket) produces offsets / item_offsets / total, which saves the
+ * eg_tile_offsets launch.  tile_mask[N] receives each Gaussian's exact tile hits (bit mask over its
+ * box, 0xffffffff = box larger than 32 tiles) for eg_tile_emit.  ticket: int32[1], zero-initialised
+ * once by the caller (the kernel returns it to zero). */
+int eg_project_bin(const float *means, const float *quats, const float *log_scales, const float *logit_opacities,
+                   const float *viewmat, const float *K, int32_t N, int32_t width, int32_t height, uint32_t flags,
+                   float *splat /*[N,8]*/, int32_t *tile_counts /*[T], zero on entry*/, uint32_t *tile_mask /*[N]*/,
+                   int64_t capacity, int32_t *offsets /*[T+1]*/, int32_t *item_offsets /*[T+1]*/,
+                   int32_t *total /*[4]*/, int32_t *ticket /*[1]*/, eg_stream_t stream);
+
 /* ---- G2 (per-Gaussian part) on caller-supplied screen data: tiles_per_gauss + tile_counts from
  * (means2d, radii).  Used when projection ran elsewhere (parity tests feed oracle floats). */
 int eg_tile_count(const float *means2d, const int32_t *radii, int32_t N, int32_t width, int32_t height,
@@ -88,7 +100,8 @@ int eg_tile_emit(const float *means2d_or_null, const int32_t *radii_or_null, con
                  const float *splat_or_null, uint32_t flags /*EG_FLAG_TIGHT_TILES needs splat*/,
                  int32_t N, int32_t width, int32_t height,
                  const int32_t *offsets /*[T+1]*/, int32_t *tile_counts /*[T]: counts on entry, zero on exit*/,
-                 int64_t capacity, uint64_t *keys /*[capacity]*/, eg_stream_t stream);
+                 int64_t capacity, uint64_t *keys /*[capacity]*/,
+                 const uint32_t *tile_mask /*[N]|NULL: exact tile hits left by eg_project_bin*/, eg_stream_t stream);
 
 /* ---- G5: segmented sort -- every tile segment ascending by (depth bits, gaussian id), which equals
  * gsplat's stable radix sort on (tile, depth) of index-ordered emissions.  Writes the sorted
@@ -258,6 +271,8 @@ typedef struct {
   /* workspace */
   float *splat, *g2d;
   int32_t *tile_counts, *offsets, *item_offsets, *total; /* [T], [T+1], [T+1], [4] */
+  uint32_t *tile_mask;                                   /* [N] */
+  int32_t *ticket;                                       /* [1], zero-initialised once */
   void *workspace;   /* eg_composite_workspace_bytes(max_items, T) bytes */
   int64_t max_items; /* >= ceil(capacity/128) + T */
   uint64_t *keys;
