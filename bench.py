@@ -47,8 +47,11 @@ def algorithmic_bytes(n, m, hw):
         "project_bin": 108 * n,            # G1 80 + per-Gaussian binning 28 (+ the fused scan, ~8 T bytes)
         "tile_emit": 12 * m,
         "tile_sort": 24 * m,
-        "composite_fwd": 28 * m + 20 * hw,
-        "composite_bwd_footprint": 28 * m + 20 * hw + 64 * n,  # G8 gather + per-pixel + outputs
+        "composite_slice_fwd": 28 * m,     # G7 gather
+        "composite_combine_fwd": 20 * hw,  # G7 per-pixel reads/writes (+ fused loss)
+        "composite_rewalk_fwd": 0,
+        "footprint_bwd": 28 * m + 20 * hw + 64 * n,  # G8 gather + per-pixel + outputs
+        "footprint_big": 0,
         "project_bwd_adam": 454 * n,       # G9 130 + absgrad 16 + Adam 308
         "step_total": 626 * n + 100 * m + 40 * hw,
     }

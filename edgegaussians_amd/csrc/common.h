@@ -18,6 +18,13 @@ constexpr float kFovClamp = 1.3f;
 void set_error(const char *fmt, ...);
 int check_launch(const char *what);
 
+// kernel-granular timing marks of the training step (step.hip): no-ops unless a timing window is open
+enum TimingMark {
+  kMarkStart = 0, kMarkProjectBin, kMarkEmit, kMarkSort, kMarkSlice, kMarkCombine, kMarkRewalk, kMarkFootprint,
+  kMarkFootprintBig, kMarkProjectBwd, kNumMarks
+};
+void timing_mark(int mark, hipStream_t stream);
+
 inline hipStream_t as_stream(eg_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 

@@ -1025,15 +1025,18 @@ extern "C" int eg_composite_fwd(const float *splat, const float *colors, int32_t
     StopInfo *stopinfo = (StopInfo *)(item_flags + max_items);
     composite_slice_fwd_kernel<<<(unsigned)max_items, 256, 0, s>>>((const float4 *)splat, offsets, item_offsets,
                                                                   total, flatten_ids, tw, th, sliceP, sliceL);
+    timing_mark(kMarkSlice, s);
 #define EG_LAUNCH_CB(CH)                                                                                          \
   do {                                                                                                            \
     composite_combine_fwd_kernel<CH><<<tw * th, 256, 0, s>>>(item_offsets, flatten_ids, width, height, tw, th,    \
                                                             sliceP, sliceL, item_flags, stopinfo, render, alphas,\
                                                             last_ids, gt, wmap, loss_scale, vpix, loss_out,       \
                                                             (float2 *)gtstop);                                    \
+    timing_mark(kMarkCombine, s);                                                                                 \
     composite_rewalk_fwd_kernel<CH><<<(unsigned)max_items, 256, 0, s>>>(                                          \
         (const float4 *)splat, offsets, item_offsets, total, flatten_ids, width, height, tw, th, item_flags,      \
         stopinfo, render, alphas, last_ids, gt, wmap, loss_scale, vpix, loss_out, (float2 *)gtstop);              \
+    timing_mark(kMarkRewalk, s);                                                                                  \
   } while (0)
     if (channels == 1) EG_LAUNCH_CB(1); else EG_LAUNCH_CB(3);
 #undef EG_LAUNCH_CB
@@ -1080,8 +1083,10 @@ extern "C" int eg_composite_bwd_footprint(const float *splat, int32_t N, int32_t
   else
     footprint_bwd_kernel<false><<<cdiv((int64_t)N * kLanesPerGauss, 256), 256, 0, st>>>(
         (const float4 *)splat, N, width, height, (const float2 *)gtstop, g2d, big_list, parity);
+  timing_mark(kMarkFootprint, st);
   footprint_big_kernel<<<64, 256, 0, st>>>((const float4 *)splat, width, height, (const float2 *)gtstop, g2d,
                                           big_list, parity);
+  timing_mark(kMarkFootprintBig, st);
   return check_launch("composite_bwd_footprint");
 }
 

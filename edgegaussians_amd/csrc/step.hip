@@ -56,11 +56,17 @@ extern "C" int eg_device_count(void) {
 // (Driving the stages from Python to time them measures the Python call overhead instead: a
 // 20-argument ctypes call costs ~100 us, the kernels 5-50 us.)
 namespace eg {
-constexpr int kStages = 6;
-static const char *kStageNames[kStages] = {"project_bin", "tile_emit", "tile_sort",
-                                           "composite_fwd", "composite_bwd_footprint", "project_bwd_adam"};
+constexpr int kStages = kNumMarks - 1;  // one stage ends at every mark after kMarkStart
+static const char *kStageNames[kStages] = {"project_bin", "tile_emit", "tile_sort", "composite_slice_fwd",
+                                           "composite_combine_fwd", "composite_rewalk_fwd", "footprint_bwd",
+                                           "footprint_big", "project_bwd_adam"};
 static hipEvent_t *g_ev = nullptr;  // [(kStages + 1) * g_ev_steps]
 static int g_ev_steps = 0, g_ev_next = 0;
+static hipEvent_t *g_ev_cur = nullptr;  // events of the step being enqueued (nullptr outside a window)
+
+void timing_mark(int mark, hipStream_t stream) {
+  if (g_ev_cur) (void)hipEventRecord(g_ev_cur[mark], stream);
+}
 }  // namespace eg
 
 extern "C" int eg_timing_begin(int32_t n_steps) {
@@ -113,35 +119,35 @@ extern "C" int eg_train_step(const eg_step_args *a, eg_stream_t stream) {
   EG_REQUIRE(a->N > 0 && a->width > 0 && a->height > 0 && a->capacity > 0, "bad sizes");
   const int tw = cdiv(a->width, kTile), th = cdiv(a->height, kTile), T = tw * th;
   const uint32_t flags = EG_FLAG_LOG_SCALES | EG_FLAG_LOGIT_OPACITIES | EG_FLAG_ANTIALIASED | EG_FLAG_TIGHT_TILES;
-  hipEvent_t *ev = (g_ev && g_ev_next < g_ev_steps) ? &g_ev[(kStages + 1) * g_ev_next] : nullptr;
+  g_ev_cur = (g_ev && g_ev_next < g_ev_steps) ? &g_ev[(kStages + 1) * g_ev_next] : nullptr;
   hipStream_t st = as_stream(stream);
-#define EG_MARK(k) do { if (ev) (void)hipEventRecord(ev[k], st); } while (0)
+#define EG_MARK(k) timing_mark(k, st)
   int rc;
-  EG_MARK(0);
+  EG_MARK(kMarkStart);
   // tile_counts is zero on entry (caller zero-initialises it once): the projection counts it up and its
   // last workgroup scans it; the emit pass counts it back down to zero.
   rc = eg_project_bin(a->means, a->quats, a->log_scales, a->logit_opacities, a->viewmat, a->K, a->N, a->width,
                       a->height, flags, a->splat, a->tile_counts, a->tile_mask, a->capacity, a->offsets,
                       a->item_offsets, a->total, a->ticket, stream);
   if (rc) return rc;
-  EG_MARK(1);
+  EG_MARK(kMarkProjectBin);
   rc = eg_tile_emit(nullptr, nullptr, nullptr, a->splat, flags, a->N, a->width, a->height, a->offsets,
                     a->tile_counts, a->capacity, a->keys, a->tile_mask, stream);
   if (rc) return rc;
-  EG_MARK(2);
+  EG_MARK(kMarkEmit);
   rc = eg_sort_pairs(a->keys, a->offsets, T, a->capacity, a->flatten_ids, nullptr, stream);
   if (rc) return rc;
-  EG_MARK(3);
+  EG_MARK(kMarkSort);
   rc = eg_composite_fwd(a->splat, nullptr, 1, a->offsets, a->flatten_ids, a->width, a->height, a->render,
                         a->alphas, a->last_ids, a->gt, a->wmap, a->loss_scale, a->vpix, a->loss, a->item_offsets,
                         a->total, a->max_items, a->workspace, a->gtstop, stream);
   if (rc) return rc;
-  EG_MARK(4);
+  // (slice / combine / re-walk marks are recorded inside eg_composite_fwd)
   // backward: footprint compositing VJP, then projection VJP + absgrad (+ Adam)
   rc = eg_composite_bwd_footprint(a->splat, a->N, a->width, a->height, a->gtstop, a->g2d, a->big_list, a->parity,
                                   a->row_span, stream);
   if (rc) return rc;
-  EG_MARK(5);
+  // (footprint / footprint_big marks are recorded inside eg_composite_bwd_footprint)
   if (a->adam_host)
     rc = eg_project_bwd_adam(a->means, a->quats, a->log_scales, a->logit_opacities, a->viewmat, a->K, a->N,
                              a->width, a->height, 0.3f, flags, a->splat, a->g2d, a->adam_m, a->adam_v, a->absgrads,
@@ -150,8 +156,9 @@ extern "C" int eg_train_step(const eg_step_args *a, eg_stream_t stream) {
     rc = eg_project_bwd(a->means, a->quats, a->log_scales, a->logit_opacities, a->viewmat, a->K, a->N, a->width,
                         a->height, 0.3f, flags | EG_FLAG_ABSGRAD_WRITE, a->splat, a->g2d, nullptr, nullptr, a->v_means, a->v_quats,
                         a->v_scales, a->v_opacities, a->absgrads, stream);
-  EG_MARK(6);
+  EG_MARK(kMarkProjectBwd);
 #undef EG_MARK
-  if (ev) ++g_ev_next;
+  if (g_ev_cur) ++g_ev_next;
+  g_ev_cur = nullptr;
   return rc;
 }
