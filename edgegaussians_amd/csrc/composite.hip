@@ -666,203 +666,262 @@ composite_bwd_item_kernel(const float4 *__restrict__ splat, const int *__restric
 // With colours == 1 and no background dL/dalpha_i = v_p T_final,p / (1 - alpha_i) for every Gaussian
 // that contributed to pixel p, independent of the depth order.  So a Gaussian's whole 2D gradient is
 // a sum over ITS OWN footprint: the pixels of gsplat's tile box that lie inside the ellipse
-// sigma <= ln(255 o) (outside it alpha < 1/255 and the forward skipped the pair).  8 lanes share one
-// Gaussian (8 Gaussians per wavefront): each lane takes every 8th column of the footprint, so a
-// wave reads 64-byte row segments of the packed {v * T_final, stop id} image written by the forward;
-// a 3-step butterfly over the 8 lanes leaves the 8 partial derivatives in all of them and lane c
-// stores component c -- one coalesced 32-byte store per Gaussian into g2d, which needs no zeroing.
-// The transmittance stop (pixels whose front-to-back walk ended on T <= 1e-4) is the only
-// order-dependent part: for those pixels the forward records the id of the last contributing
-// Gaussian and a candidate contributes iff its (depth bits, id) <= that Gaussian's.
-// Footprints above kBigFootprint pixels are deferred to a wavefront-per-Gaussian kernel.
+// sigma <= ln(255 o) (outside it alpha < 1/255 and the forward skipped the pair), read from the
+// packed {v * T_final, stop id} image the forward wrote.  The transmittance stop (pixels whose
+// front-to-back walk ended on T <= 1e-4) is the only order-dependent part: for those pixels the
+// forward records the id of the last contributing Gaussian and a candidate contributes iff its
+// (depth bits, id) <= that Gaussian's.
+//
+// The walk.  On pixel row i the ellipse is the interval  x_g + (b/a) dy -/+ sqrt(2 a thr - det dy^2)/a,
+// dy = y_g - (i + 0.5): its centre moves linearly with the row and its half width never exceeds
+// hw = sqrt(2 thr / a).  So the footprint is covered by a SHEARED box of constant width
+// pw = floor(2 hw) + 1 columns starting at ceil(x_g + (b/a) dy - hw - 0.5) -- pi/4 of it lies inside
+// the ellipse whatever the orientation, where the axis-aligned box of a thin diagonal edge Gaussian
+// is mostly empty.  (If the sheared box is not narrower than the axis-aligned one the latter is used.)
+// The rows x pw cells are numbered row-major and dealt to lanes with a stride, which needs one
+// divmod per lane and stream; after that a position advances by a constant (rows, columns) step with
+// a carry.
+//
+// Lanes.  A wavefront owns 8 consecutive Gaussians and hands its 64 lanes out in proportion to their
+// cell counts (every non-empty footprint gets at least one lane), so that all lanes of the wave run
+// (nearly) the same number of visits whatever the size mix -- with a fixed 8 lanes per Gaussian the
+// wave waits for its largest footprint (measured 1.7x on random scenes) and rows whose width is not
+// a multiple of 8 leave lanes idle.  Each lane accumulates first/second moments of w = dL/dsigma
+// (the gradient is linear in them); the partial g2d records go through LDS and lane (k, component)
+// adds the partials of Gaussian k in lane order: deterministic, no atomics, one coalesced 256-byte
+// store per wave, g2d needs no zeroing.  Footprints above kBigFootprint cells are deferred to a
+// wavefront-per-Gaussian kernel through a device work list.
 constexpr int kBigFootprint = 8192;
-constexpr int kLanesPerGauss = 8;
 
-struct Footprint {
-  int i0, i1, j0, j1;  // inclusive pixel bounds; empty if i1 < i0 or j1 < j0
-  float thr;
+struct Walk {
+  int i0, fh;     // rows i0 .. i0 + fh - 1
+  int pw;         // cells per row
+  int jlo, jhi;   // inclusive column clip: gsplat's tile box, the image, the ellipse's extent
+  int cells;      // fh * pw, 0 for an invisible Gaussian
+  float thr;      // sigma threshold ln(255 o) (+ margin)
+  float xoff, shear;  // first column of row i: ceil(xoff + shear * (y_g - (i + 0.5)))
 };
 
-__device__ __forceinline__ Footprint footprint_of(const float4 s0, const float4 s1, int width, int height) {
-  Footprint f;
-  f.i0 = f.j0 = 0;
-  f.i1 = f.j1 = -1;
+__device__ __forceinline__ Walk walk_of(const float4 s0, const float4 s1, int width, int height) {
+  Walk w;
+  w.i0 = w.fh = w.pw = w.jlo = w.cells = 0;
+  w.jhi = -1;
+  w.thr = w.xoff = w.shear = 0.f;
   const int radius = __float_as_int(s1.w);
-  f.thr = __logf(255.f * s1.y) + kThrMargin;
+  const float thr = __logf(255.f * s1.y) + kThrMargin;
   const float det = s0.z * s1.x - s0.w * s0.w;
-  if (radius <= 0 || !(f.thr > 0.f) || !(det > 0.f)) return f;
+  if (radius <= 0 || !(thr > 0.f) || !(det > 0.f) || !(s0.z > 0.f)) return w;
   const int tw = (width + kTile - 1) / kTile, th = (height + kTile - 1) / kTile;
   int x0, y0, x1, y1;
   tile_box(s0.x, s0.y, radius, tw, th, x0, y0, x1, y1);  // pixels outside gsplat's box never see it
-  const float ex = sqrtf(2.f * f.thr * s1.x / det) * 1.001f + 0.01f;
-  const float ey = sqrtf(2.f * f.thr * s0.z / det) * 1.001f + 0.01f;
-  f.j0 = max(x0 * kTile, (int)ceilf(s0.x - ex - 0.5f));
-  f.j1 = min(min(x1 * kTile, width) - 1, (int)floorf(s0.x + ex - 0.5f));
-  f.i0 = max(y0 * kTile, (int)ceilf(s0.y - ey - 0.5f));
-  f.i1 = min(min(y1 * kTile, height) - 1, (int)floorf(s0.y + ey - 0.5f));
-  return f;
+  // hardware sqrt / rcp (1 ulp): the 0.1 % + 0.01 px inflation swallows their error
+  const float k = 2.f * thr * __builtin_amdgcn_rcpf(det);
+  const float ex = __builtin_amdgcn_sqrtf(k * s1.x) * 1.001f + 0.01f;
+  const float ey = __builtin_amdgcn_sqrtf(k * s0.z) * 1.001f + 0.01f;
+  const int j0 = max(x0 * kTile, (int)ceilf(s0.x - ex - 0.5f));
+  const int j1 = min(min(x1 * kTile, width) - 1, (int)floorf(s0.x + ex - 0.5f));
+  const int i0 = max(y0 * kTile, (int)ceilf(s0.y - ey - 0.5f));
+  const int i1 = min(min(y1 * kTile, height) - 1, (int)floorf(s0.y + ey - 0.5f));
+  const int fw = j1 - j0 + 1, fh = i1 - i0 + 1;
+  if (fw <= 0 || fh <= 0) return w;
+  const float inv_a = __builtin_amdgcn_rcpf(s0.z);
+  const float hw = __builtin_amdgcn_sqrtf(2.f * thr * inv_a) * 1.001f + 0.01f;
+  const int pw = (int)(2.f * hw) + 1;
+  w.i0 = i0; w.fh = fh; w.jlo = j0; w.jhi = j1; w.thr = thr;
+  if (pw < fw) {
+    w.pw = pw; w.shear = s0.w * inv_a; w.xoff = s0.x - hw - 0.5f;
+  } else {
+    w.pw = fw; w.shear = 0.f; w.xoff = (float)j0;
+  }
+  w.cells = w.pw * fh;
+  return w;
 }
 
-struct Acc8 {
-  float v[8];  // vx, vy, |vx|, |vy|, va, vb, vc, vo  (the g2d record)
+struct Moments {
+  float w_x, w_y, w_xx, w_xy, w_yy, abs_x, abs_y, v_o;
 };
 
-__device__ __forceinline__ void footprint_pixel(const float4 s0, const float4 s1, float thr, int g, int i, int j,
-                                                const float2 rec, const float4 *__restrict__ splat, Acc8 &a) {
+__device__ __forceinline__ void footprint_visit(const float4 s0, const float4 s1, float thr, int g, int i, int j,
+                                                const float2 rec, const float4 *__restrict__ splat, Moments &m) {
+  // One branch on the ellipse test (whole waves fall outside on large footprints), none after it:
+  // the lanes of a wave sit in up to eight footprints, accepted and rejected pixels are mixed, and
+  // further branching only adds exec-mask bookkeeping.  A rejected pixel contributes w = 0.
   const float gT = rec.x;
-  if (gT == 0.f) return;
   const float dx = s0.x - ((float)j + 0.5f), dy = s0.y - ((float)i + 0.5f);
   const float sigma = 0.5f * (s0.z * dx * dx + s1.x * dy * dy) + s0.w * dx * dy;
-  if (sigma < 0.f || sigma > thr) return;
+  if (!(gT != 0.f && sigma >= 0.f && sigma <= thr)) return;
   const float vis = __expf(-sigma);
   const float araw = s1.y * vis;
-  const float alpha = fminf(kAlphaMax, araw);
-  if (alpha < kAlphaMin) return;
+  // forward: skip if min(0.999, araw) < 1/255; gsplat's backward: no gradient through a clamped alpha
+  bool ok = araw >= kAlphaMin && araw <= kAlphaMax;
   const int stop_id = __float_as_int(rec.y);
-  if (stop_id >= 0 && stop_id != g) {
+  if (ok && stop_id >= 0 && stop_id != g) {
     // the walk of this pixel stopped: only Gaussians at or before the last contributor count
     const unsigned dl = (unsigned)__float_as_int(splat[2 * stop_id + 1].z), dg = (unsigned)__float_as_int(s1.z);
-    if (dg > dl || (dg == dl && g > stop_id)) return;
+    ok = !(dg > dl || (dg == dl && g > stop_id));
   }
-  const float v_alpha = gT * __builtin_amdgcn_rcpf(1.f - alpha);
-  if (araw <= kAlphaMax) {
-    const float v_sigma = -araw * v_alpha;
-    const float gx = v_sigma * (s0.z * dx + s0.w * dy);
-    const float gy = v_sigma * (s0.w * dx + s1.x * dy);
-    a.v[0] += gx; a.v[1] += gy;
-    a.v[2] += fabsf(gx); a.v[3] += fabsf(gy);
-    a.v[4] += 0.5f * v_sigma * dx * dx;
-    a.v[5] += v_sigma * dx * dy;
-    a.v[6] += 0.5f * v_sigma * dy * dy;
-    a.v[7] += vis * v_alpha;
+  const float v_alpha = ok ? gT * __builtin_amdgcn_rcpf(1.f - araw) : 0.f;
+  m.v_o += vis * v_alpha;
+  const float w = -araw * v_alpha;
+  const float wx = w * dx, wy = w * dy;
+  m.w_x += wx; m.w_y += wy;
+  m.w_xx += wx * dx; m.w_xy += wx * dy; m.w_yy += wy * dy;
+  m.abs_x += fabsf(s0.z * wx + s0.w * wy);
+  m.abs_y += fabsf(s0.w * wx + s1.x * wy);
+}
+
+// Lane r of n walks cells r, r + n, r + 2n, ... of Gaussian g's sheared box as two interleaved streams
+// (r, r + 2n, ... and r + n, r + 3n, ...: two independent gathers in flight per lane); the records of
+// the NEXT pair are prefetched while this one is evaluated.
+__device__ __forceinline__ void footprint_walk(const float4 s0, const float4 s1, int g, int r, int n, int i0,
+                                               int pw, int cells, int jlo, int jhi, float thr, float xoff,
+                                               float shear, int width, const float2 *__restrict__ gtstop,
+                                               const float4 *__restrict__ splat, Moments &m) {
+  const float inv_pw = __builtin_amdgcn_rcpf((float)pw);
+  // cell -> (row, column) offsets; the quotient estimate is exact for cells < 2^21, the fix-up is free
+  auto divmod = [&](int q, int &qi, int &qj) {
+    qi = (int)(((float)q + 0.5f) * inv_pw);
+    qj = q - __mul24(qi, pw);
+    if (qj < 0) { qj += pw; --qi; }
+    if (qj >= pw) { qj -= pw; ++qi; }
+  };
+  auto fetch = [&](int i, int c, int &j) -> float2 {
+    j = (int)ceilf(xoff + shear * (s0.y - ((float)i + 0.5f))) + c;
+    return (j >= jlo && j <= jhi) ? gtstop[__mul24(i, width) + j] : make_float2(0.f, 0.f);
+  };
+  int di, dc;
+  divmod(2 * n, di, dc);
+  int ia, ca, ib, cb;
+  divmod(r, ia, ca);
+  divmod(r + n, ib, cb);
+  ia += i0; ib += i0;
+  int left_a = cells - r, left_b = cells - r - n;  // > 0 while the stream still has a visit
+  int ja = 0, jb = 0;
+  float2 na = make_float2(0.f, 0.f), nb = na;
+  if (left_a > 0) na = fetch(ia, ca, ja);
+  if (left_b > 0) nb = fetch(ib, cb, jb);
+  while (left_a > 0) {
+    const float2 ra = na, rb = nb;
+    const int cia = ia, cja = ja, cib = ib, cjb = jb;
+    left_a -= 2 * n;
+    left_b -= 2 * n;
+    ia += di; ca += dc;
+    if (ca >= pw) { ca -= pw; ++ia; }
+    ib += di; cb += dc;
+    if (cb >= pw) { cb -= pw; ++ib; }
+    na = nb = make_float2(0.f, 0.f);
+    if (left_a > 0) na = fetch(ia, ca, ja);
+    if (left_b > 0) nb = fetch(ib, cb, jb);
+    footprint_visit(s0, s1, thr, g, cia, cja, ra, splat, m);
+    footprint_visit(s0, s1, thr, g, cib, cjb, rb, splat, m);  // an exhausted stream holds a zero record
   }
 }
 
-template <bool ROWSPAN>
 __global__ void __launch_bounds__(256)
 footprint_bwd_kernel(const float4 *__restrict__ splat, int N, int width, int height,
                      const float2 *__restrict__ gtstop, float *__restrict__ g2d, int *__restrict__ big_list,
                      int parity) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  const int g = t / kLanesPerGauss, c = t % kLanesPerGauss;
-  if (t == 0) big_list[parity ^ 1] = 0;  // the NEXT call's counter (this call's is zero on entry)
-  if (g >= N) return;  // whole lane groups leave together
-  const float4 s0 = splat[2 * g], s1 = splat[2 * g + 1];
-  const Footprint fp = footprint_of(s0, s1, width, height);
-  const int fw = fp.j1 - fp.j0 + 1, fh = fp.i1 - fp.i0 + 1;
-  Acc8 a;
-#pragma unroll
-  for (int k = 0; k < 8; ++k) a.v[k] = 0.f;
-  if (fw > 0 && fh > 0) {
-    if (fw * fh > kBigFootprint) {
-      if (c == 0) big_list[2 + atomicAdd(&big_list[parity], 1)] = g;  // a whole wavefront takes it
-      return;
-    }
-    if (!ROWSPAN) {
-      // small footprints: plain AABB walk, two rows per iteration so that two independent gathers are
-      // in flight per lane, and the pair of the NEXT iteration is prefetched while this one is evaluated
-      int i = fp.i0, j = fp.j0 + c;
-      bool more = j <= fp.j1;
-      float2 na = make_float2(0.f, 0.f), nb = na;
-      if (more) {
-        na = gtstop[i * width + j];
-        if (i + 1 <= fp.i1) nb = gtstop[(i + 1) * width + j];
-      }
-      while (more) {
-        const float2 ra = na, rb = nb;
-        const int ci = i, cj = j;
-        j += kLanesPerGauss;
-        if (j > fp.j1) { j = fp.j0 + c; i += 2; }
-        more = i <= fp.i1;
-        if (more) {
-          na = gtstop[i * width + j];
-          nb = (i + 1 <= fp.i1) ? gtstop[(i + 1) * width + j] : make_float2(0.f, 0.f);
-        }
-        footprint_pixel(s0, s1, fp.thr, g, ci, cj, ra, splat, a);
-        if (ci + 1 <= fp.i1) footprint_pixel(s0, s1, fp.thr, g, ci + 1, cj, rb, splat, a);
-      }
-    } else {
-      // Row-span walk: on pixel row i the ellipse sigma <= thr is the interval
-      //   px in x + (b dy -/+ sqrt(2 a thr - det dy^2)) / a,   dy = y - (i + 0.5)
-      // (thin diagonal edge Gaussians fill a small fraction of their AABB).  Two rows are processed per
-      // iteration so that two independent gathers are in flight per lane.
-      const float ca = s0.z, cb = s0.w, cc = s1.x;
-      const float det = ca * cc - cb * cb, inv_a = 1.f / ca, two_a_thr = 2.f * ca * fp.thr;
-      for (int i = fp.i0; i <= fp.i1; i += 2) {
-        int jl[2], jr[2];
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-          const float dy = s0.y - ((float)(i + r) + 0.5f);
-          const float disc = two_a_thr - det * dy * dy;
-          jl[r] = 1; jr[r] = 0;
-          if (i + r <= fp.i1 && disc >= 0.f) {
-            const float sq = sqrtf(disc) * 1.001f + 0.01f * ca;  // same inflation as the AABB
-            const float lo = s0.x + (cb * dy - sq) * inv_a, hi = s0.x + (cb * dy + sq) * inv_a;
-            jl[r] = max(fp.j0, (int)ceilf(lo - 0.5f));
-            jr[r] = min(fp.j1, (int)floorf(hi - 0.5f));
-          }
-        }
-        for (int k = c;; k += kLanesPerGauss) {
-          const int ja = jl[0] + k, jb = jl[1] + k;
-          const bool va = ja <= jr[0], vb = jb <= jr[1];
-          if (!va && !vb) break;
-          float2 ra = make_float2(0.f, 0.f), rb = ra;
-          if (va) ra = gtstop[i * width + ja];
-          if (vb) rb = gtstop[(i + 1) * width + jb];
-          if (va) footprint_pixel(s0, s1, fp.thr, g, i, ja, ra, splat, a);
-          if (vb) footprint_pixel(s0, s1, fp.thr, g, i + 1, jb, rb, splat, a);
-        }
+  __shared__ float red[4][64 * 8];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int wave = blockIdx.x * 4 + wv;
+  if (blockIdx.x == 0 && threadIdx.x == 0) big_list[parity ^ 1] = 0;  // the NEXT call's counter
+  const int gbase = wave * 8;
+  if (gbase >= N) return;  // whole waves leave; there is no workgroup barrier below
+
+  // home phase: the 8 lanes of group k all size the footprint of Gaussian gbase + k
+  Walk h = walk_of(make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f), width, height);
+  bool h_big = false;
+  {
+    const int hg = gbase + (lane >> 3);
+    if (hg < N) {
+      h = walk_of(splat[2 * hg], splat[2 * hg + 1], width, height);
+      if (h.cells > kBigFootprint) {
+        if ((lane & 7) == 0) big_list[2 + atomicAdd(&big_list[parity], 1)] = hg;  // a whole wavefront takes it
+        h.cells = 0;
+        h_big = true;
       }
     }
   }
+  // Lanes per Gaussian, computed group-parallel: one lane for every live footprint, the other
+  // 64 - live in proportion to the cell counts (rounded down), the slack (<= live) one each to the
+  // first live groups.
+  int packed = h.cells + (h.cells > 0 ? 1 << 20 : 0);  // cells sum to < 2^17: the live count rides on top
+  packed += __shfl_xor(packed, 8, 64);
+  packed += __shfl_xor(packed, 16, 64);
+  packed += __shfl_xor(packed, 32, 64);
+  const int total = packed & 0xfffff, live = packed >> 20;
+  int h_n = 0, h_first = 0;
+  Moments m = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+  if (total > 0) {
+    const float share = (float)(64 - live) * (1.f - 1e-5f) * __builtin_amdgcn_rcpf((float)total);
+    h_n = h.cells > 0 ? 1 + (int)((float)h.cells * share) : 0;
+    int incl = h_n + (h.cells > 0 ? 1 << 16 : 0);  // inclusive scan over the groups of (lanes, live flag)
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    float v = a.v[k];
+    for (int d = 8; d < 64; d <<= 1) {
+      const int up = __shfl_up(incl, d, 64);
+      if (lane >= d) incl += up;
+    }
+    const int slack = 64 - (__builtin_amdgcn_readlane(incl, 63) & 0xffff);
+    const int rank = (incl >> 16) - (h.cells > 0 ? 1 : 0);  // live groups before this one
+    h_first = (incl & 0xffff) - h_n + min(rank, slack);
+    if (h.cells > 0 && rank < slack) ++h_n;
+    // lane -> Gaussian: the group whose lane range holds this lane (a lane past the last range idles)
+    int k = 0;
 #pragma unroll
-    for (int d = 1; d < kLanesPerGauss; d <<= 1) v += __shfl_xor(v, d, 64);
-    a.v[k] = v;
+    for (int q = 1; q < 8; ++q) k += lane >= __builtin_amdgcn_readlane(h_first, 8 * q);
+    const int src = 8 * k;
+    const int n = max(__shfl(h_n, src, 64), 1);
+    const int r = lane - __shfl(h_first, src, 64);
+    const int g = min(gbase + k, N - 1);
+    const int cells = r < n ? __shfl(h.cells, src, 64) : 0;
+    s0 = splat[2 * g];
+    s1 = splat[2 * g + 1];
+    footprint_walk(s0, s1, g, r, n, __shfl(h.i0, src, 64), max(__shfl(h.pw, src, 64), 1), cells,
+                   __shfl(h.jlo, src, 64), __shfl(h.jhi, src, 64), __shfl(h.thr, src, 64),
+                   __shfl(h.xoff, src, 64), __shfl(h.shear, src, 64), width, gtstop, splat, m);
   }
-  // lane c stores components c, c + L, ... (one coalesced 32-byte record per Gaussian)
-#pragma unroll
-  for (int base = 0; base < 8; base += kLanesPerGauss) {
-    float out = 0.f;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) out = (base + c == k) ? a.v[k] : out;
-    if (base + c < 8) g2d[(size_t)g * 8 + base + c] = out;
-  }
+  // partial g2d record of this lane: vx vy |vx| |vy| va vb vc vo
+  float *mine = &red[wv][lane * 8];
+  *(float4 *)mine = make_float4(s0.z * m.w_x + s0.w * m.w_y, s0.w * m.w_x + s1.x * m.w_y, m.abs_x, m.abs_y);
+  *(float4 *)(mine + 4) = make_float4(0.5f * m.w_xx, m.w_xy, 0.5f * m.w_yy, m.v_o);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  // lane (k, component) adds the partial records of Gaussian k's lanes in lane order
+  const int comp = lane & 7;
+  float sum = 0.f;
+  for (int t = 0; t < h_n; ++t) sum += red[wv][(h_first + t) * 8 + comp];
+  if (gbase + (lane >> 3) < N && !h_big) g2d[(size_t)gbase * 8 + lane] = sum;  // big ones are written later
 }
 
-// one wavefront per big-footprint Gaussian: lanes stride over the footprint, full butterfly
+// one wavefront per big-footprint Gaussian: the 64 lanes stride over its cells, full butterfly
 __global__ void __launch_bounds__(256)
 footprint_big_kernel(const float4 *__restrict__ splat, int width, int height, const float2 *__restrict__ gtstop,
                      float *__restrict__ g2d, const int *__restrict__ big_list, int parity) {
   const int lane = threadIdx.x & 63;
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
-  const int n_big = big_list[parity];
-  for (int b = wave; b < n_big; b += n_waves) {
-    const int g = big_list[2 + b];
+  const int count = big_list[parity];
+  for (int e = wave; e < count; e += n_waves) {
+    const int g = big_list[2 + e];
     const float4 s0 = splat[2 * g], s1 = splat[2 * g + 1];
-    const Footprint fp = footprint_of(s0, s1, width, height);
-    const int fw = fp.j1 - fp.j0 + 1, fh = fp.i1 - fp.i0 + 1;
-    Acc8 a;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) a.v[k] = 0.f;
-    const int area = fw * fh;
-    for (int q = lane; q < area; q += 64) {
-      const int i = fp.i0 + q / fw, j = fp.j0 + q % fw;
-      footprint_pixel(s0, s1, fp.thr, g, i, j, gtstop[(size_t)i * width + j], splat, a);
-    }
+    const Walk w = walk_of(s0, s1, width, height);
+    Moments m = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    footprint_walk(s0, s1, g, lane, 64, w.i0, max(w.pw, 1), w.cells, w.jlo, w.jhi, w.thr, w.xoff, w.shear, width,
+                   gtstop, splat, m);
+    float part[8] = {s0.z * m.w_x + s0.w * m.w_y, s0.w * m.w_x + s1.x * m.w_y, m.abs_x, m.abs_y,
+                     0.5f * m.w_xx, m.w_xy, 0.5f * m.w_yy, m.v_o};
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      float v = a.v[k];
+      float v = part[k];
 #pragma unroll
       for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-      a.v[k] = v;
+      part[k] = v;
     }
     if (lane < 8) {
-      float out = a.v[0];
+      float out = part[0];
 #pragma unroll
-      for (int k = 1; k < 8; ++k) out = (lane == k) ? a.v[k] : out;
+      for (int k = 1; k < 8; ++k) out = (lane == k) ? part[k] : out;
       g2d[(size_t)g * 8 + lane] = out;
     }
   }
@@ -1077,12 +1136,9 @@ extern "C" int eg_composite_bwd_footprint(const float *splat, int32_t N, int32_t
   if (N == 0) return EG_OK;
   EG_REQUIRE(splat && gtstop && g2d && big_list, "null pointer");
   hipStream_t st = as_stream(stream);
-  if (row_span)
-    footprint_bwd_kernel<true><<<cdiv((int64_t)N * kLanesPerGauss, 256), 256, 0, st>>>(
-        (const float4 *)splat, N, width, height, (const float2 *)gtstop, g2d, big_list, parity);
-  else
-    footprint_bwd_kernel<false><<<cdiv((int64_t)N * kLanesPerGauss, 256), 256, 0, st>>>(
-        (const float4 *)splat, N, width, height, (const float2 *)gtstop, g2d, big_list, parity);
+  (void)row_span;  // kept for ABI stability: the walk adapts per Gaussian now
+  footprint_bwd_kernel<<<cdiv((int64_t)N, 32), 256, 0, st>>>((const float4 *)splat, N, width, height,
+                                                            (const float2 *)gtstop, g2d, big_list, parity);
   timing_mark(kMarkFootprint, st);
   footprint_big_kernel<<<64, 256, 0, st>>>((const float4 *)splat, width, height, (const float2 *)gtstop, g2d,
                                           big_list, parity);

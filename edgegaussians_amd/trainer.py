@@ -22,6 +22,8 @@ Differences from the reference that are deliberate (documented in DESIGN.md):
 """
 from __future__ import annotations
 
+import os
+
 import ctypes as C
 import math
 from dataclasses import dataclass, field
@@ -206,9 +208,6 @@ class EdgeTrainer:
         if need > self.capacity:
             self._alloc_isect(need)
         self.m_max_seen = m_max
-        # tuning hint for the footprint backward: large footprints (many tiles per Gaussian) favour the
-        # per-row ellipse-span walk, small ones the plain AABB walk (identical results either way)
-        self.row_span = 1 if m_max > 4 * self.N else 0
         self._args_cache = {}
         return m_max
 

@@ -173,14 +173,16 @@ typedef struct {
                              means / scales / quats, so the counts drift apart) */
 } eg_adam_hyper;
 
-/* ---- G8, footprint form (unit colours, fused path): 8 lanes per Gaussian walk the Gaussian's own
- * footprint in the gtstop image written by eg_composite_fwd (the unit-colour backward is
- * order-independent), and WRITE its g2d record -- no tile lists, no atomics, no zeroing of g2d.
- * big_list: int32[2 + N] scratch, zero-initialised ONCE by the caller (footprints above 8192 px are
- * queued there and handled by a wavefront each).  `parity` (0/1) must alternate between consecutive
- * calls on the same big_list: call k uses counter big_list[parity] and clears the other one for
- * call k+1, which saves a memset node per step.  row_span != 0 selects the per-row ellipse-span
- * walk (pays off when footprints are large, i.e. M/N above ~4); 0 the AABB walk.  Same results. */
+/* ---- G8, footprint form (unit colours, fused path): every Gaussian's gradient is summed over its
+ * own footprint in the gtstop image written by eg_composite_fwd (the unit-colour backward is
+ * order-independent); a wavefront owns 8 Gaussians and deals its 64 lanes out in proportion to
+ * their footprint sizes; the footprint is walked as a sheared box that follows the ellipse.  The g2d
+ * record is WRITTEN -- no tile lists, no atomics, no zeroing of g2d, deterministic.
+ * big_list: int32[2 + N] scratch, zero-initialised ONCE by the caller (footprints above 8192 cells
+ * are queued there and handled by a wavefront each).  `parity` (0/1) must alternate between
+ * consecutive calls on the same big_list: call k uses counter big_list[parity] and clears the other
+ * one for call k+1, which saves a memset node per step.  row_span is ignored (it selected between
+ * two walks in an earlier revision; the walk adapts per Gaussian now) and kept for ABI stability. */
 int eg_composite_bwd_footprint(const float *splat, int32_t N, int32_t width, int32_t height,
                                const float *gtstop /*[H,W,2]*/, float *g2d /*[N,8] written*/,
                                int32_t *big_list, int32_t parity, int32_t row_span, eg_stream_t stream);
@@ -282,7 +284,7 @@ typedef struct {
   float *gtstop;                        /* [H,W,2] */
   int32_t *big_list;                    /* [2 + N], zero-initialised once */
   int32_t parity;                       /* 0/1, alternates every step (see eg_composite_bwd_footprint) */
-  int32_t row_span;                     /* tuning hint of eg_composite_bwd_footprint */
+  int32_t row_span;                     /* ignored (see eg_composite_bwd_footprint) */
   int32_t *last_ids;
   /* gradient outputs (used when adam == NULL, e.g. before an RCCL all-reduce) */
   float *v_means, *v_quats, *v_scales, *v_opacities;
