@@ -266,6 +266,8 @@ def main():
         dist.destroy_process_group()
     if rank == 0:  # last thing on stdout: the one JSON line
         sys.stdout.flush()
+        import ctypes
+        ctypes.CDLL(None).fflush(None)  # RCCL's version banner sits in the C stdio buffer until exit
         print(json.dumps(out), flush=True)
 
 

@@ -86,6 +86,30 @@ project_hits_kernel(const float *__restrict__ means, int N, const float *__restr
   hits[g] += h;
 }
 
+// filter_by_projection twin: x = K (R X + t) in that association order, np.round (half to even),
+// sum of the float edge strengths over the views the point lands in
+__global__ void __launch_bounds__(256)
+project_visibility_kernel(const float *__restrict__ means, int N, const float *__restrict__ cams, int V,
+                          const float *__restrict__ edge_maps, int width, int height, float *__restrict__ visib) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= N) return;
+  const float x = means[3 * g], y = means[3 * g + 1], z = means[3 * g + 2];
+  float acc = 0.f;
+  for (int v = 0; v < V; ++v) {
+    const float *K = cams + 21 * v, *R = K + 9, *t = K + 18;
+    const float cx = R[0] * x + R[1] * y + R[2] * z + t[0];
+    const float cy = R[3] * x + R[4] * y + R[5] * z + t[1];
+    const float cz = R[6] * x + R[7] * y + R[8] * z + t[2];
+    const float a = K[0] * cx + K[1] * cy + K[2] * cz;
+    const float b = K[3] * cx + K[4] * cy + K[5] * cz;
+    const float c = K[6] * cx + K[7] * cy + K[8] * cz;
+    const float u = rintf(a / c), w = rintf(b / c);
+    if (u >= 0.f && u < (float)width && w >= 0.f && w < (float)height)
+      acc += edge_maps[((size_t)v * height + (int)w) * width + (int)u];
+  }
+  visib[g] += acc;
+}
+
 }  // namespace eg
 
 using namespace eg;
@@ -126,4 +150,15 @@ extern "C" int eg_project_hits(const float *means, int32_t N, const float *P, in
   EG_REQUIRE(means && P && edge_masks && hits, "null pointer");
   project_hits_kernel<<<cdiv(N, 256), 256, 0, as_stream(stream)>>>(means, N, P, V, edge_masks, width, height, hits);
   return check_launch("project_hits");
+}
+
+extern "C" int eg_project_visibility(const float *means, int32_t N, const float *cams, int32_t V,
+                                     const float *edge_maps, int32_t width, int32_t height, float *visib,
+                                     eg_stream_t stream) {
+  EG_REQUIRE(N >= 0 && V >= 0 && width > 0 && height > 0, "bad sizes");
+  if (N == 0 || V == 0) return EG_OK;
+  EG_REQUIRE(means && cams && edge_maps && visib, "null pointer");
+  project_visibility_kernel<<<cdiv(N, 256), 256, 0, as_stream(stream)>>>(means, N, cams, V, edge_maps, width,
+                                                                        height, visib);
+  return check_launch("project_visibility");
 }

@@ -452,3 +452,23 @@ def adam_reference(params, grads, m, v, step, lr, b1=0.9, b2=0.999, eps=1e-8):
     bc2 = 1 - b2 ** step
     denom = v.sqrt() / math.sqrt(bc2) + eps
     return params - (lr / bc1) * m / denom, m, v
+
+
+def filter_by_projection(means, edge_images, cameras, visib_thresh=0.1):
+    """Restatement of edge_extraction/filtering.py:80-123 (numpy): x = K (R X + t), divide by the last
+    row, np.round, bounds check, sum of the edge strengths at the hit pixels, mean over ALL views,
+    strict > threshold.  Returns (inlier mask [N], mean visibility [N])."""
+    import numpy as np
+    means = np.asarray(means)
+    n, v = means.shape[0], len(edge_images)
+    vis = np.zeros((n, v))
+    for i in range(v):
+        K, R, t = cameras[i]["K"], cameras[i]["R"], cameras[i]["t"]
+        h, w = cameras[i]["h"], cameras[i]["w"]
+        x = (K @ (R @ means.reshape(-1, 3).T + t)).T
+        uv = np.round((x / x[:, -1:])[:, :2]).astype(np.int32)
+        ok = (uv[:, 0] >= 0) & (uv[:, 0] < w) & (uv[:, 1] >= 0) & (uv[:, 1] < h)
+        emap = np.asarray(edge_images[i])
+        vis[ok, i] += emap[uv[ok, 1], uv[ok, 0]]
+    mean_vis = vis.mean(axis=1)
+    return mean_vis > visib_thresh, mean_vis

@@ -61,6 +61,7 @@ def _recording_rasterization(**kw):
 
 _stub("ipdb")
 _stub("open3d")
+_stub("cv2")
 _stub("plyfile", PlyData=object, PlyElement=object)
 _stub("dacite", from_dict=_from_dict)
 _stub("gsplat", rasterization=_recording_rasterization)
@@ -266,8 +267,30 @@ def boundary_trace(views):
     json.dump(TRACE, open(os.path.join(OUT, "boundary_trace.json"), "w"), indent=1, sort_keys=True)
 
 
+def filter_projection(views, keep):
+    """edge_extraction/filtering.py:80-123 run as-is on seeded points and the four fixture views."""
+    from edgegaussians.edge_extraction import filtering
+    rng = np.random.default_rng(3)
+    means = (1.1 * rng.random((3000, 3)) - 0.05).astype(np.float32)
+    cams, imgs = [], []
+    for k in keep:
+        cam = views[k]["camera"]
+        vm = cam.viewmat.cpu().numpy()
+        cams.append({"K": cam.get_K().cpu().numpy()[0], "R": vm[:3, :3], "t": vm[:3, 3:], "h": cam.height,
+                     "w": cam.width})
+        imgs.append(views[k]["image"] / 255.0)
+    out = {}
+    for thr in (0.1, 0.3):
+        out[f"inliers_{thr}"] = filtering.filter_by_projection(means, imgs, cams, visib_thresh=thr)
+    np.savez_compressed(os.path.join(OUT, "filter_projection.npz"), means=means, views=np.array(keep), **out)
+
+
 if __name__ == "__main__":
     views, keep = cameras_and_edges()
+    if "--only-filter" in sys.argv:
+        filter_projection(views, keep)
+        raise SystemExit(0)
+    filter_projection(views, keep)
     quats()
     lr_table()
     m, cams = losses_and_masks(views, keep)

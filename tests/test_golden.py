@@ -111,3 +111,14 @@ def test_boundary_trace_is_what_rasterization_accepts(golden_dir):
     assert set(tr["kwargs"]) <= set(params)
     assert tr["kwargs"]["tile_size"] == 16 and tr["kwargs"]["packed"] is False and tr["kwargs"]["absgrad"] is True
     assert tr["forward_returns"]["rgb"][-1] == 3 and tr["forward_returns"]["accumulation"][-1] == 1
+
+
+def test_filter_by_projection_restatement_matches_reference(golden_dir):
+    """oracle.filter_by_projection vs the reference's own output (edge_extraction/filtering.py:80-123
+    run in the build container, fixture filter_projection.npz): identical inlier sets."""
+    from tests.util import filter_fixture
+    d, images, cameras = filter_fixture(golden_dir)
+    for thr in (0.1, 0.3):
+        mask, _ = O.filter_by_projection(d["means"], images, cameras, thr)
+        assert np.array_equal(mask, d[f"inliers_{thr}"])
+        assert 0 < mask.sum() < mask.size

@@ -807,3 +807,18 @@ def test_densify_cull_golden(env, golden_dir):
     tr.absgrads = torch.arange(tr.N, device="cuda").float()
     tr.cull_not_projecting((gt >= 0.5).to(torch.uint8).cuda(), 0.1)
     assert np.array_equal(to_np(tr.absgrads).astype(np.int64), d["np_kept_index"])
+
+
+def test_filter_by_projection_matches_reference(env, golden_dir):
+    """Device twin of the edge-extraction filter (filtering.py:80-123) vs the reference's own inlier
+    masks (fixture) and vs the oracle's per-Gaussian visibility: index work, so exact."""
+    from tests.util import filter_fixture
+    _lib, synth, O = env
+    from edgegaussians_amd import filtering
+    d, images, cameras = filter_fixture(golden_dir)
+    for thr in (0.1, 0.3):
+        got = filtering.filter_by_projection(d["means"], [torch.from_numpy(i) for i in images], cameras, thr)
+        assert got.dtype == bool and got.shape == (d["means"].shape[0],)
+        assert np.array_equal(got, d[f"inliers_{thr}"])
+    assert filtering.filter_by_projection(d["means"][:0], images, cameras).shape == (0,)
+    assert np.array_equal(filtering.filter_by_opacity(np.array([[0.2], [0.01]]), 0.05), np.array([True, False]))

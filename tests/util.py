@@ -27,3 +27,22 @@ def assert_close(a, b, rtol=1e-4, max_bad=0.0, name=""):
     between two correct implementations (different exp / rounding order)."""
     fb = frac_bad(a, b, rtol)
     assert fb <= max_bad, f"{name}: {fb:.2e} of elements off by > {rtol} (allowed {max_bad}); norm-rel {rel_err(a, b):.3e}"
+
+
+def filter_fixture(golden_dir):
+    """Inputs of the reference's filter_by_projection run (tests/golden/make_golden.py:filter_projection):
+    means, float edge images (DexiNed / 255) and the camera dicts of filtering.py:42-56."""
+    import os
+    import numpy as np
+    d = np.load(os.path.join(golden_dir, "filter_projection.npz"))
+    cams = np.load(os.path.join(golden_dir, "cameras_00004926.npz"))
+    edges = np.load(os.path.join(golden_dir, "edges_00004926.npz"))
+    H, W = int(cams["height"]), int(cams["width"])
+    images, cameras = [], []
+    for k in d["views"]:
+        im = np.zeros(H * W, np.float32)
+        im[edges[f"idx_{k}"]] = edges[f"val_{k}"].astype(np.float32) / np.float32(255.0)
+        images.append(im.reshape(H, W))
+        vm = cams["viewmats"][k]
+        cameras.append({"K": cams["Ks"][k], "R": vm[:3, :3], "t": vm[:3, 3:], "h": H, "w": W})
+    return d, images, cameras
