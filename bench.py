@@ -158,11 +158,15 @@ def main():
     args = ap.parse_args()
 
     from edgegaussians_amd import dist as egdist
-    rank, local, world = egdist.init_from_env("nccl")
+    # EG_DIST_BACKEND=gloo lets the N-rank flow be exercised on a box with fewer GPUs than ranks (RCCL
+    # refuses two ranks on one device); the driver's runs use the default, RCCL.
+    backend = os.environ.get("EG_DIST_BACKEND", "nccl")
+    rank, local, world = egdist.init_from_env(backend)
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     device = f"cuda:{local}"
     import torch.distributed as dist
@@ -212,7 +216,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        t = torch.tensor([dt], device=device if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     loss_sum = tr.pop_loss()
@@ -238,14 +242,18 @@ def main():
         "host_enqueue_ms_per_step": 1e3 * t_enq / args.steps,
     }
 
-    if rank == 0 and world == 1 and not args.profile_only and dp is None:
+    if not args.profile_only:
         # ---- per-stage launch durations: HIP events recorded natively between the stages of
-        # eg_train_step on the launch stream, over a second window of the same steps (one sync)
+        # eg_train_step on the launch stream, over a second window of the same steps (one sync).
+        # With N ranks every rank runs the window (the all-reduce is collective), rank 0 records.
         k = min(args.steps, 200)
-        tr.timing_begin(k)
+        if rank == 0:
+            tr.timing_begin(k)
         run(k, args.warmup + args.steps)
-        stage_us = tr.timing_end()
+        stage_us = tr.timing_end() if rank == 0 else None
+        barrier()
         tr.pop_loss()
+    if rank == 0 and not args.profile_only:
         ab = algorithmic_bytes(n, m_last, w * h)
         dom = max(stage_us, key=stage_us.get)
         achieved = ab[dom] / (stage_us[dom] * 1e-6) / 1e9
@@ -260,7 +268,7 @@ def main():
         out["step_roofline"] = {"algorithmic_bytes_per_step": ab["step_total"],
                                 "achieved_GBps": ab["step_total"] / (dt / args.steps) / 1e9,
                                 "frac": ab["step_total"] / (dt / args.steps) / 1e9 / HBM_PEAK_GBS}
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(sc, args.cpu_budget, args.cpu_oracle)
     if world > 1 or args.force_dp:
         dist.destroy_process_group()

@@ -90,11 +90,11 @@ project_hits_kernel(const float *__restrict__ means, int N, const float *__restr
 // sum of the float edge strengths over the views the point lands in
 __global__ void __launch_bounds__(256)
 project_visibility_kernel(const float *__restrict__ means, int N, const float *__restrict__ cams, int V,
-                          const float *__restrict__ edge_maps, int width, int height, float *__restrict__ visib) {
+                          const float *__restrict__ edge_maps, int width, int height, double *__restrict__ visib) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= N) return;
   const float x = means[3 * g], y = means[3 * g + 1], z = means[3 * g + 2];
-  float acc = 0.f;
+  double acc = 0.0;  // the reference accumulates the float32 edge strengths in a float64 matrix
   for (int v = 0; v < V; ++v) {
     const float *K = cams + 21 * v, *R = K + 9, *t = K + 18;
     const float cx = R[0] * x + R[1] * y + R[2] * z + t[0];
@@ -105,7 +105,7 @@ project_visibility_kernel(const float *__restrict__ means, int N, const float *_
     const float c = K[6] * cx + K[7] * cy + K[8] * cz;
     const float u = rintf(a / c), w = rintf(b / c);
     if (u >= 0.f && u < (float)width && w >= 0.f && w < (float)height)
-      acc += edge_maps[((size_t)v * height + (int)w) * width + (int)u];
+      acc += (double)edge_maps[((size_t)v * height + (int)w) * width + (int)u];
   }
   visib[g] += acc;
 }
@@ -153,7 +153,7 @@ extern "C" int eg_project_hits(const float *means, int32_t N, const float *P, in
 }
 
 extern "C" int eg_project_visibility(const float *means, int32_t N, const float *cams, int32_t V,
-                                     const float *edge_maps, int32_t width, int32_t height, float *visib,
+                                     const float *edge_maps, int32_t width, int32_t height, double *visib,
                                      eg_stream_t stream) {
   EG_REQUIRE(N >= 0 && V >= 0 && width > 0 && height > 0, "bad sizes");
   if (N == 0 || V == 0) return EG_OK;

@@ -61,5 +61,11 @@ class DataParallelStep:
     def step(self, view: int, wmap: torch.Tensor) -> None:
         grads = self.worker.grad_step(view, wmap)
         if self.world > 1:
-            dist.all_reduce(grads, op=dist.ReduceOp.SUM, group=self.group)
+            if grads.is_cuda and dist.get_backend(self.group) == "gloo":
+                # test mode only (several ranks sharing one GPU, RCCL refuses that): stage through the host
+                host = grads.cpu()
+                dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+                grads.copy_(host)
+            else:
+                dist.all_reduce(grads, op=dist.ReduceOp.SUM, group=self.group)
         self.worker.apply_adam()

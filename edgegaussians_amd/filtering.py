@@ -38,10 +38,10 @@ def filter_by_projection(gaussian_means, edge_images, cameras: Sequence[Dict], v
     maps = torch.stack([torch.as_tensor(e).to(device=device, dtype=torch.float32) for e in edge_images]).contiguous()
     if tuple(maps.shape) != (V, h, w):
         raise ValueError(f"edge_images must be {V} maps of {h}x{w}, got {tuple(maps.shape)}")
-    visib = torch.zeros(means.shape[0], dtype=torch.float32, device=device)
+    visib = torch.zeros(means.shape[0], dtype=torch.float64, device=device)  # numpy's accumulator type there
     call("eg_project_visibility", ptr(means), means.shape[0], ptr(pack_cameras(cameras, device)), V, ptr(maps), w, h,
          ptr(visib), stream())
-    return ((visib / float(V)) > visib_thresh).cpu().numpy().reshape(-1)
+    return (visib.cpu().numpy() / float(V) > visib_thresh).reshape(-1)
 
 
 def filter_by_opacity(opacities, min_opacity: float) -> np.ndarray:

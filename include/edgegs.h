@@ -240,10 +240,11 @@ int eg_project_hits(const float *means, int32_t N, const float *P /*[V,3,4] = K 
 /* ---- 8(f) rank 3 twin: filter_by_projection (edge_extraction/filtering.py:80-123): the post-hoc filter
  * of the edge-extraction stage.  visib[g] += edge_maps[v][round(v_g), round(u_g)] (the float edge
  * strength, not a mask) for every view v in which x = K (R X + t) lands inside the image; the caller
- * divides by V and thresholds.  cams: [V, 21] floats = K (9, row-major) | R (9) | t (3). */
+ * divides by V and thresholds (in float64, like numpy does there).  cams: [V, 21] floats = K (9, row-major) | R (9) | t (3). */
 int eg_project_visibility(const float *means, int32_t N, const float *cams /*[V,21]*/, int32_t V,
                           const float *edge_maps /*[V,H,W]*/, int32_t width, int32_t height,
-                          float *visib /*[N] zeroed by caller*/, eg_stream_t stream);
+                          double *visib /*[N] f64 (the reference's accumulator type), zeroed by caller*/,
+                          eg_stream_t stream);
 
 /* ---- nearest neighbours + orientation regularisers (train_gaussians.py:108-131).
  * eg_knn: exact K <= 16 nearest neighbours (self excluded, ascending distance, ties by index) of N 3D
