@@ -90,8 +90,9 @@ __device__ __forceinline__ void tile_box_tight(float x, float y, int radius, flo
   const float thr = __logf(255.f * o) + kThrMargin;
   const float det = a * c - b * b;
   if (!(thr > 0.f) || !(det > 0.f)) { x1 = x0; y1 = y0; return; }
-  const float ex = sqrtf(2.f * thr * c / det) * 1.001f + 0.01f;
-  const float ey = sqrtf(2.f * thr * a / det) * 1.001f + 0.01f;
+  const float k2 = 2.f * thr * __builtin_amdgcn_rcpf(det);  // hardware rcp / sqrt: the inflation covers 1 ulp
+  const float ex = __builtin_amdgcn_sqrtf(k2 * c) * 1.001f + 0.01f;
+  const float ey = __builtin_amdgcn_sqrtf(k2 * a) * 1.001f + 0.01f;
   // tile t holds pixel centres 16 t + 0.5 .. 16 t + 15.5
   const float ts = (float)kTile;
   x0 = max(x0, (int)ceilf((x - ex - 15.5f) / ts));
@@ -117,14 +118,18 @@ __device__ __forceinline__ bool ellipse_hits_rect(float x, float y, float a, flo
   const float u0 = rx0 - x, u1 = rx1 - x, v0 = ry0 - y, v1 = ry1 - y;
   if (u0 <= 0.f && u1 >= 0.f && v0 <= 0.f && v1 >= 0.f) return true;
   float best = 3.0e38f;
+  // hardware reciprocals (1 ulp): the minimiser only moves by a relative 1e-7, a second-order change
+  // of the minimum that the slack below swallows; four IEEE divisions per call were a third of the
+  // staging cost of the slice kernel
+  const float nba = -b * __builtin_amdgcn_rcpf(a), nbc = -b * __builtin_amdgcn_rcpf(c);
   // edges v = v0 and v = v1: minimise over u in [u0,u1]: u* = -b v / a
   {
-    const float us0 = fminf(fmaxf(-b * v0 / a, u0), u1), us1 = fminf(fmaxf(-b * v1 / a, u0), u1);
+    const float us0 = fminf(fmaxf(nba * v0, u0), u1), us1 = fminf(fmaxf(nba * v1, u0), u1);
     best = fminf(best, fminf(sigma_at(a, b, c, us0, v0), sigma_at(a, b, c, us1, v1)));
   }
   // edges u = u0 and u = u1: v* = -b u / c
   {
-    const float vs0 = fminf(fmaxf(-b * u0 / c, v0), v1), vs1 = fminf(fmaxf(-b * u1 / c, v0), v1);
+    const float vs0 = fminf(fmaxf(nbc * u0, v0), v1), vs1 = fminf(fmaxf(nbc * u1, v0), v1);
     best = fminf(best, fminf(sigma_at(a, b, c, u0, vs0), sigma_at(a, b, c, u1, vs1)));
   }
   return best <= thr * 1.001f + 1e-3f;

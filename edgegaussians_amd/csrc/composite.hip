@@ -257,6 +257,24 @@ __device__ __forceinline__ int item_tile(const int *__restrict__ item_offsets, i
   return lo;
 }
 
+// The same lookup done by the whole 256-thread workgroup in two parallel probes (256 samples at a
+// fixed stride, then the entries of the selected stride) instead of log2(T) dependent loads by
+// everyone: the serial search was 10-13 global-memory latencies at the head of every workgroup.
+// Contains two workgroup barriers; `s_tmp` is 5 ints of LDS.
+__device__ __forceinline__ int item_tile_coop(const int *__restrict__ item_offsets, int T, int b, int *s_tmp) {
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int S = (T + 256) / 256;  // ceil((T + 1) / 256) entries per sample
+  const bool le = item_offsets[min(tid * S, T)] <= b;  // monotone: true for a prefix of the threads
+  const unsigned long long bal = __ballot(le);
+  if (lane == 0) s_tmp[wv] = __popcll(bal);
+  __syncthreads();
+  const int base = (s_tmp[0] + s_tmp[1] + s_tmp[2] + s_tmp[3] - 1) * S;  // item_offsets[0] = 0 <= b
+  if (tid < S && base + tid < T && item_offsets[base + tid] <= b && b < item_offsets[base + tid + 1])
+    s_tmp[4] = base + tid;  // the one tile whose (non-empty) item range holds b
+  __syncthreads();
+  return s_tmp[4];
+}
+
 // pixel of thread `tid` in the slice-parallel kernels: wave w owns the 8x8 quadrant (w & 1, w >> 1)
 // of the tile, lane l the pixel (l & 7, l >> 3) inside it (a compact 8x8 block culls far better
 // against thin ellipses than a 4x16 strip)
@@ -275,13 +293,18 @@ composite_slice_fwd_kernel(const float4 *__restrict__ splat, const int *__restri
                            const int *__restrict__ item_offsets, const int *__restrict__ total,
                            const int *__restrict__ flat, int tw, int th, float *__restrict__ sliceP,
                            int *__restrict__ sliceL) {
-  __shared__ float4 sA[4][kSlice + 4];  // x, y, a, b
-  __shared__ float4 sB[4][kSlice + 4];  // c, o, sigma threshold, slice-local index (int bits)
+  // compacted per-quadrant lists, stored as PAIRS of Gaussians so that the walk can evaluate two
+  // Gaussians per lane with packed fp32 (v_pk_*: the walk is VALU-issue-bound)
+  __shared__ float4 sX[4][kSlice / 2 + 2];  // x0 x1 y0 y1
+  __shared__ float4 sC[4][kSlice / 2 + 2];  // a0/2 a1/2 b0 b1
+  __shared__ float4 sD[4][kSlice / 2 + 2];  // c0/2 c1/2 o0 o1
+  __shared__ float4 sE[4][kSlice / 2 + 2];  // sigma thresholds thr0 thr1, slice-local indices idx0 idx1 (int bits)
   static_assert(kSlice <= kTilePix, "one staging thread per Gaussian of the slice");
   __shared__ int sCnt[4][4];            // [quadrant][source wave]
+  __shared__ int sTile[5];
   const int b = blockIdx.x;
   if (b >= total[2]) return;
-  const int tile = item_tile(item_offsets, tw * th, b);
+  const int tile = item_tile_coop(item_offsets, tw * th, b, sTile);
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int ty = tile / tw, tx = tile - ty * tw;
   int di, dj;
@@ -301,8 +324,9 @@ composite_slice_fwd_kernel(const float4 *__restrict__ splat, const int *__restri
     rB = make_float4(s1.x, s1.y, thr, __int_as_float(tid));
     const float det = s0.z * s1.x - s0.w * s0.w;
     if (thr > 0.f && det > 0.f) {
-      const float ex = sqrtf(2.f * thr * s1.x / det) * 1.001f + 0.01f;
-      const float ey = sqrtf(2.f * thr * s0.z / det) * 1.001f + 0.01f;
+      const float k2 = 2.f * thr * __builtin_amdgcn_rcpf(det);  // hardware rcp / sqrt: the inflation covers 1 ulp
+      const float ex = __builtin_amdgcn_sqrtf(k2 * s1.x) * 1.001f + 0.01f;
+      const float ey = __builtin_amdgcn_sqrtf(k2 * s0.z) * 1.001f + 0.01f;
       const float X0 = (float)(tx * kTile), Y0 = (float)(ty * kTile);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -334,38 +358,61 @@ composite_slice_fwd_kernel(const float4 *__restrict__ splat, const int *__restri
     }
     if (hitq[q]) {
       const int pos = base + __popcll(bal[q] & ((1ull << lane) - 1ull));
-      sA[q][pos] = s0;
-      sB[q][pos] = rB;
+      const int pr = pos >> 1, sl = pos & 1;
+      float *X = (float *)&sX[q][pr], *Cc = (float *)&sC[q][pr], *D = (float *)&sD[q][pr], *E = (float *)&sE[q][pr];
+      X[sl] = s0.x; X[2 + sl] = s0.y;
+      Cc[sl] = 0.5f * s0.z; Cc[2 + sl] = s0.w;
+      D[sl] = 0.5f * rB.x; D[2 + sl] = rB.y;
+      E[sl] = rB.z; E[2 + sl] = rB.w;
     }
     if (q == wv) n_mine = tot;
     // sentinels (threshold < 0 => rejected) so the 4-way unrolled walk may read past the end
     if (tid >= 64 * q && tid < 64 * q + 3) {
       const int e = tot + (tid - 64 * q);
-      sB[q][e] = make_float4(0.f, 0.f, -1.f, 0.f);
-      sA[q][e] = make_float4(0.f, 0.f, 0.f, 0.f);
+      const int pr = e >> 1, sl = e & 1;
+      ((float *)&sX[q][pr])[sl] = 0.f; ((float *)&sX[q][pr])[2 + sl] = 0.f;
+      ((float *)&sC[q][pr])[sl] = 0.f; ((float *)&sC[q][pr])[2 + sl] = 0.f;
+      ((float *)&sD[q][pr])[sl] = 0.f; ((float *)&sD[q][pr])[2 + sl] = 0.f;
+      ((float *)&sE[q][pr])[sl] = -1.f; ((float *)&sE[q][pr])[2 + sl] = 0.f;
     }
   }
   __syncthreads();
 
-  const float4 *lA = sA[wv], *lB = sB[wv];
+  typedef float v2f __attribute__((ext_vector_type(2)));
+  const float4 *lX = sX[wv], *lC = sC[wv], *lD = sD[wv], *lE = sE[wv];
+  const v2f px2 = {px, px}, py2 = {py, py};
   float P = 1.f;
   int L = -1;
-  // 4-way unrolled walk: the eight LDS reads of a group are issued before the first use, so one
-  // lgkmcnt wait covers four Gaussians (the loop is latency-bound, not issue-bound)
+  // Walk, two pairs (four Gaussians) per iteration: all LDS reads of a group are issued before the
+  // first use.  No branches: every listed Gaussian reaches some pixel of the quadrant (exact test
+  // above), so a wave-level skip never fires and exec-mask bookkeeping is pure overhead; a rejected
+  // pair multiplies by 1.
   for (int t = 0; t < n_mine; t += 4) {
-    float4 A[4], B[4];
+    float4 X[2], Cq[2], D[2], E[2];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) { A[u] = lA[t + u]; B[u] = lB[t + u]; }
+    for (int u = 0; u < 2; ++u) {
+      X[u] = lX[(t >> 1) + u]; Cq[u] = lC[(t >> 1) + u]; D[u] = lD[(t >> 1) + u]; E[u] = lE[(t >> 1) + u];
+    }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const float dx = A[u].x - px, dy = A[u].y - py;
-      const float sigma = 0.5f * (A[u].z * dx * dx + B[u].x * dy * dy) + A[u].w * dx * dy;
-      if (sigma >= 0.f && sigma <= B[u].z) {
-        const float alpha = fminf(kAlphaMax, B[u].y * __expf(-sigma));
-        if (alpha >= kAlphaMin) { P *= (1.f - alpha); L = start + __float_as_int(B[u].w); }
-      }
+    for (int u = 0; u < 2; ++u) {
+      const v2f x = {X[u].x, X[u].y}, y = {X[u].z, X[u].w}, ha = {Cq[u].x, Cq[u].y}, bb = {Cq[u].z, Cq[u].w};
+      const v2f hc = {D[u].x, D[u].y}, o = {D[u].z, D[u].w};
+      const v2f dx = x - px2, dy = y - py2;
+      const v2f sigma = dx * (ha * dx + bb * dy) + hc * dy * dy;
+      const v2f arg = sigma * -1.44269504088896341f;
+      const v2f e = {__builtin_amdgcn_exp2f(arg.x), __builtin_amdgcn_exp2f(arg.y)};
+      const v2f araw = o * e;
+      const float a0 = fminf(kAlphaMax, araw.x), a1 = fminf(kAlphaMax, araw.y);
+      // '&': no short-circuit branches
+      const bool k0 = (sigma.x >= 0.f) & (sigma.x <= E[u].x) & (a0 >= kAlphaMin);
+      const bool k1 = (sigma.y >= 0.f) & (sigma.y <= E[u].y) & (a1 >= kAlphaMin);
+      P *= k0 ? 1.f - a0 : 1.f;  // depth order kept: (P * m0) * m1
+      P *= k1 ? 1.f - a1 : 1.f;
+      L = k0 ? t + 2 * u : L;    // list position (wave-uniform value); translated once after the walk
+      L = k1 ? t + 2 * u + 1 : L;
     }
   }
+  if (L >= 0) L = start + __float_as_int(((const float *)&lE[L >> 1])[2 + (L & 1)]);
   sliceP[(size_t)b * kTilePix + tid] = P;
   sliceL[(size_t)b * kTilePix + tid] = L;
 }
@@ -472,7 +519,7 @@ composite_combine_fwd_kernel(const int *__restrict__ item_offsets, const int *__
   si.last = last;
   if (__syncthreads_or(si.slice >= 0)) {  // only tiles that hand pixels over need the per-pixel records
     stopinfo[(size_t)tile * kTilePix + tid] = si;
-    if (si.slice >= 0) item_flags[i0 + si.slice] = 1;  // benign race: every writer stores 1
+    if (si.slice >= 0) item_flags[i0 + si.slice] = tile + 1;  // flag = owning tile + 1 (benign race: same value)
   }
 
   float l = 0.f;
@@ -505,9 +552,10 @@ composite_rewalk_fwd_kernel(const float4 *__restrict__ splat, const int *__restr
   quad_pixel(tid, di, dj);
   const int n_items = total[2];
   for (int b = blockIdx.x; b < n_items; b += gridDim.x) {
-  if (item_flags[b] == 0) continue;
+  const int flag = item_flags[b];
+  if (flag == 0) continue;
   __syncthreads();
-  const int tile = item_tile(item_offsets, tw * th, b);
+  const int tile = flag - 1;  // the combine kernel left the owning tile in the flag
   const int ty = tile / tw, tx = tile - ty * tw;
   const int i = ty * kTile + di, j = tx * kTile + dj;
   const float px = (float)j + 0.5f, py = (float)i + 0.5f;
