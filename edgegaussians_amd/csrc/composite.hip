@@ -284,6 +284,88 @@ __device__ __forceinline__ void quad_pixel(int tid, int &di, int &dj) {
   dj = ((w & 1) << 3) + (l & 7);
 }
 
+// Per-quadrant compacted lists of one slice in LDS, stored as PAIRS of Gaussians so that the walks
+// can evaluate two Gaussians per lane with packed fp32 (v_pk_*: the walks are VALU-issue-bound).
+struct QuadLists {
+  float4 X[4][kSlice / 2 + 2];  // x0 x1 y0 y1
+  float4 C[4][kSlice / 2 + 2];  // a0/2 a1/2 b0 b1
+  float4 D[4][kSlice / 2 + 2];  // c0/2 c1/2 o0 o1
+  float4 E[4][kSlice / 2 + 2];  // sigma thresholds thr0 thr1, slice-local indices idx0 idx1 (int bits)
+  int cnt[4][4];                // [quadrant][source wave]
+};
+
+// Thread tid < kSlice brings Gaussian (s0 = x y a b, rB = c o thr idx) and the quadrants it reaches;
+// on return wave w's list (quadrant w) is complete, in slice order, padded with three rejecting
+// sentinels so that a 4-way unrolled walk may read past the end.  Two workgroup barriers.  Returns
+// the length of the calling wave's list.
+__device__ __forceinline__ int build_quad_lists(QuadLists &ql, const bool (&hitq)[4], const float4 s0,
+                                                const float4 rB, int tid) {
+  const int lane = tid & 63, wv = tid >> 6;
+  unsigned long long bal[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    bal[q] = __ballot(hitq[q]);
+    if (lane == 0) ql.cnt[q][wv] = __popcll(bal[q]);
+  }
+  __syncthreads();
+  int n_mine = 0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const int c = ql.cnt[q][w];
+      base += (w < wv) ? c : 0;
+      tot += c;
+    }
+    if (hitq[q]) {
+      const int pos = base + __popcll(bal[q] & ((1ull << lane) - 1ull));
+      const int pr = pos >> 1, sl = pos & 1;
+      float *X = (float *)&ql.X[q][pr], *Cc = (float *)&ql.C[q][pr], *D = (float *)&ql.D[q][pr],
+            *E = (float *)&ql.E[q][pr];
+      X[sl] = s0.x; X[2 + sl] = s0.y;
+      Cc[sl] = 0.5f * s0.z; Cc[2 + sl] = s0.w;  // the walks want the half conics
+      D[sl] = 0.5f * rB.x; D[2 + sl] = rB.y;
+      E[sl] = rB.z; E[2 + sl] = rB.w;
+    }
+    if (q == wv) n_mine = tot;
+    if (tid >= 64 * q && tid < 64 * q + 3) {  // sentinels: threshold < 0 => rejected
+      const int e = tot + (tid - 64 * q);
+      const int pr = e >> 1, sl = e & 1;
+      ((float *)&ql.X[q][pr])[sl] = 0.f; ((float *)&ql.X[q][pr])[2 + sl] = 0.f;
+      ((float *)&ql.C[q][pr])[sl] = 0.f; ((float *)&ql.C[q][pr])[2 + sl] = 0.f;
+      ((float *)&ql.D[q][pr])[sl] = 0.f; ((float *)&ql.D[q][pr])[2 + sl] = 0.f;
+      ((float *)&ql.E[q][pr])[sl] = -1.f; ((float *)&ql.E[q][pr])[2 + sl] = 0.f;
+    }
+  }
+  __syncthreads();
+  return n_mine;
+}
+
+// alpha of a pair of listed Gaussians at pixel (px, py) with packed fp32, and whether each one counts
+typedef float v2f __attribute__((ext_vector_type(2)));
+struct PairEval {
+  float a0, a1;
+  bool k0, k1;
+};
+__device__ __forceinline__ PairEval eval_pair(const float4 X, const float4 Cq, const float4 D, const float4 E,
+                                              const v2f px2, const v2f py2) {
+  const v2f x = {X.x, X.y}, y = {X.z, X.w}, ha = {Cq.x, Cq.y}, bb = {Cq.z, Cq.w};
+  const v2f hc = {D.x, D.y}, o = {D.z, D.w};
+  const v2f dx = x - px2, dy = y - py2;
+  const v2f sigma = dx * (ha * dx + bb * dy) + hc * dy * dy;
+  const v2f arg = sigma * -1.44269504088896341f;
+  const v2f e = {__builtin_amdgcn_exp2f(arg.x), __builtin_amdgcn_exp2f(arg.y)};
+  const v2f araw = o * e;
+  PairEval r;
+  r.a0 = fminf(kAlphaMax, araw.x);
+  r.a1 = fminf(kAlphaMax, araw.y);
+  // '&': no short-circuit branches
+  r.k0 = (sigma.x >= 0.f) & (sigma.x <= E.x) & (r.a0 >= kAlphaMin);
+  r.k1 = (sigma.y >= 0.f) & (sigma.y <= E.y) & (r.a1 >= kAlphaMin);
+  return r;
+}
+
 // forward phase A: per (tile, slice) transmittance products.
 // Staging: thread t fetches Gaussian t of the slice, computes its conservative alpha >= 1/255 extent
 // (ex, ey) and appends the packed record to the list of every quadrant it can touch (ballot +
@@ -292,20 +374,14 @@ __global__ void __launch_bounds__(256)
 composite_slice_fwd_kernel(const float4 *__restrict__ splat, const int *__restrict__ offsets,
                            const int *__restrict__ item_offsets, const int *__restrict__ total,
                            const int *__restrict__ flat, int tw, int th, float *__restrict__ sliceP,
-                           int *__restrict__ sliceL) {
-  // compacted per-quadrant lists, stored as PAIRS of Gaussians so that the walk can evaluate two
-  // Gaussians per lane with packed fp32 (v_pk_*: the walk is VALU-issue-bound)
-  __shared__ float4 sX[4][kSlice / 2 + 2];  // x0 x1 y0 y1
-  __shared__ float4 sC[4][kSlice / 2 + 2];  // a0/2 a1/2 b0 b1
-  __shared__ float4 sD[4][kSlice / 2 + 2];  // c0/2 c1/2 o0 o1
-  __shared__ float4 sE[4][kSlice / 2 + 2];  // sigma thresholds thr0 thr1, slice-local indices idx0 idx1 (int bits)
+                           int *__restrict__ sliceL, unsigned char *__restrict__ sliceQ) {
+  __shared__ QuadLists ql;
   static_assert(kSlice <= kTilePix, "one staging thread per Gaussian of the slice");
-  __shared__ int sCnt[4][4];            // [quadrant][source wave]
   __shared__ int sTile[5];
   const int b = blockIdx.x;
   if (b >= total[2]) return;
   const int tile = item_tile_coop(item_offsets, tw * th, b, sTile);
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int tid = threadIdx.x, wv = tid >> 6;
   const int ty = tile / tw, tx = tile - ty * tw;
   int di, dj;
   quad_pixel(tid, di, dj);
@@ -339,47 +415,12 @@ composite_slice_fwd_kernel(const float4 *__restrict__ splat, const int *__restri
       }
     }
   }
-  unsigned long long bal[4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    bal[q] = __ballot(hitq[q]);
-    if (lane == 0) sCnt[q][wv] = __popcll(bal[q]);
-  }
-  __syncthreads();
-  int n_mine = 0;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    int base = 0, tot = 0;
-#pragma unroll
-    for (int w = 0; w < 4; ++w) {
-      const int c = sCnt[q][w];
-      base += (w < wv) ? c : 0;
-      tot += c;
-    }
-    if (hitq[q]) {
-      const int pos = base + __popcll(bal[q] & ((1ull << lane) - 1ull));
-      const int pr = pos >> 1, sl = pos & 1;
-      float *X = (float *)&sX[q][pr], *Cc = (float *)&sC[q][pr], *D = (float *)&sD[q][pr], *E = (float *)&sE[q][pr];
-      X[sl] = s0.x; X[2 + sl] = s0.y;
-      Cc[sl] = 0.5f * s0.z; Cc[2 + sl] = s0.w;
-      D[sl] = 0.5f * rB.x; D[2 + sl] = rB.y;
-      E[sl] = rB.z; E[2 + sl] = rB.w;
-    }
-    if (q == wv) n_mine = tot;
-    // sentinels (threshold < 0 => rejected) so the 4-way unrolled walk may read past the end
-    if (tid >= 64 * q && tid < 64 * q + 3) {
-      const int e = tot + (tid - 64 * q);
-      const int pr = e >> 1, sl = e & 1;
-      ((float *)&sX[q][pr])[sl] = 0.f; ((float *)&sX[q][pr])[2 + sl] = 0.f;
-      ((float *)&sC[q][pr])[sl] = 0.f; ((float *)&sC[q][pr])[2 + sl] = 0.f;
-      ((float *)&sD[q][pr])[sl] = 0.f; ((float *)&sD[q][pr])[2 + sl] = 0.f;
-      ((float *)&sE[q][pr])[sl] = -1.f; ((float *)&sE[q][pr])[2 + sl] = 0.f;
-    }
-  }
-  __syncthreads();
+  if (tid < kSlice)  // which quadrants each Gaussian of the slice reaches: reused by the exact-stop re-walk
+    sliceQ[(size_t)b * kSlice + tid] = (unsigned char)((int)hitq[0] | ((int)hitq[1] << 1) | ((int)hitq[2] << 2) |
+                                                       ((int)hitq[3] << 3));
+  const int n_mine = build_quad_lists(ql, hitq, s0, rB, tid);
 
-  typedef float v2f __attribute__((ext_vector_type(2)));
-  const float4 *lX = sX[wv], *lC = sC[wv], *lD = sD[wv], *lE = sE[wv];
+  const float4 *lX = ql.X[wv], *lC = ql.C[wv], *lD = ql.D[wv], *lE = ql.E[wv];
   const v2f px2 = {px, px}, py2 = {py, py};
   float P = 1.f;
   int L = -1;
@@ -395,21 +436,11 @@ composite_slice_fwd_kernel(const float4 *__restrict__ splat, const int *__restri
     }
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      const v2f x = {X[u].x, X[u].y}, y = {X[u].z, X[u].w}, ha = {Cq[u].x, Cq[u].y}, bb = {Cq[u].z, Cq[u].w};
-      const v2f hc = {D[u].x, D[u].y}, o = {D[u].z, D[u].w};
-      const v2f dx = x - px2, dy = y - py2;
-      const v2f sigma = dx * (ha * dx + bb * dy) + hc * dy * dy;
-      const v2f arg = sigma * -1.44269504088896341f;
-      const v2f e = {__builtin_amdgcn_exp2f(arg.x), __builtin_amdgcn_exp2f(arg.y)};
-      const v2f araw = o * e;
-      const float a0 = fminf(kAlphaMax, araw.x), a1 = fminf(kAlphaMax, araw.y);
-      // '&': no short-circuit branches
-      const bool k0 = (sigma.x >= 0.f) & (sigma.x <= E[u].x) & (a0 >= kAlphaMin);
-      const bool k1 = (sigma.y >= 0.f) & (sigma.y <= E[u].y) & (a1 >= kAlphaMin);
-      P *= k0 ? 1.f - a0 : 1.f;  // depth order kept: (P * m0) * m1
-      P *= k1 ? 1.f - a1 : 1.f;
-      L = k0 ? t + 2 * u : L;    // list position (wave-uniform value); translated once after the walk
-      L = k1 ? t + 2 * u + 1 : L;
+      const PairEval ev = eval_pair(X[u], Cq[u], D[u], E[u], px2, py2);
+      P *= ev.k0 ? 1.f - ev.a0 : 1.f;  // depth order kept: (P * m0) * m1
+      P *= ev.k1 ? 1.f - ev.a1 : 1.f;
+      L = ev.k0 ? t + 2 * u : L;       // list position (wave-uniform value); translated once after the walk
+      L = ev.k1 ? t + 2 * u + 1 : L;
     }
   }
   if (L >= 0) L = start + __float_as_int(((const float *)&lE[L >> 1])[2 + (L & 1)]);
@@ -539,15 +570,15 @@ composite_rewalk_fwd_kernel(const float4 *__restrict__ splat, const int *__restr
                             const int *__restrict__ item_offsets, const int *__restrict__ total,
                             const int *__restrict__ flat, int width, int height, int tw, int th,
                             const int *__restrict__ item_flags, const StopInfo *__restrict__ stopinfo,
+                            const unsigned char *__restrict__ sliceQ,
                             float *__restrict__ render, float *__restrict__ alphas, int *__restrict__ last_ids,
                             const float *__restrict__ gt, const float *__restrict__ wmap, float loss_scale,
                             float *__restrict__ vpix, float *__restrict__ loss_out, float2 *__restrict__ gtstop) {
-  __shared__ float4 sA[kSlice];
-  __shared__ float4 sB[kSlice];
+  __shared__ QuadLists ql;
   __shared__ float sRed[4];
   // a fixed small grid strides over the items: in scenes without stops this whole launch is a scan of
   // the flag array
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, wv = tid >> 6;
   int di, dj;
   quad_pixel(tid, di, dj);
   const int n_items = total[2];
@@ -559,7 +590,9 @@ composite_rewalk_fwd_kernel(const float4 *__restrict__ splat, const int *__restr
   const int ty = tile / tw, tx = tile - ty * tw;
   const int i = ty * kTile + di, j = tx * kTile + dj;
   const float px = (float)j + 0.5f, py = (float)i + 0.5f;
-  const int s0 = b - item_offsets[tile], ns = item_offsets[tile + 1] - item_offsets[tile];
+  const v2f px2 = {px, px}, py2 = {py, py};
+  const int ib = item_offsets[tile];
+  const int s0 = b - ib, ns = item_offsets[tile + 1] - ib;
   const StopInfo si = stopinfo[(size_t)tile * kTilePix + tid];
   const bool mine = si.slice == s0;
   float T = si.T;
@@ -567,29 +600,54 @@ composite_rewalk_fwd_kernel(const float4 *__restrict__ splat, const int *__restr
   bool found = false;
   for (int s = s0; s < ns; ++s) {
     if (!__syncthreads_or(mine && !found)) break;
+    // stage the slice exactly like the slice kernel did; the quadrant test is not repeated, the slice
+    // kernel left its verdicts in sliceQ
     const int start = offsets[tile] + s * kSlice, end = min(offsets[tile + 1], start + kSlice);
+    float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), rB = g0;
+    bool hitq[4] = {false, false, false, false};
     if (start + tid < end) {
       const int g = flat[start + tid];
-      const float4 r0 = splat[2 * g], r1 = splat[2 * g + 1];
-      sA[tid] = r0;
-      sB[tid] = make_float4(r1.x, r1.y, __logf(255.f * r1.y) + kThrMargin, 0.f);
+      g0 = splat[2 * g];
+      const float4 g1 = splat[2 * g + 1];
+      rB = make_float4(g1.x, g1.y, __logf(255.f * g1.y) + kThrMargin, __int_as_float(tid));
+      const int m = sliceQ[(size_t)(ib + s) * kSlice + tid];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) hitq[q] = (m >> q) & 1;
     }
-    __syncthreads();
-    if (mine && !found) {
-      const int n = end - start;
-      for (int t = 0; t < n; ++t) {
-        const float4 A = sA[t], B = sB[t];
-        const float dx = A.x - px, dy = A.y - py;
-        const float sigma = 0.5f * (A.z * dx * dx + B.x * dy * dy) + A.w * dx * dy;
-        if (sigma < 0.f || sigma > B.z) continue;
-        const float alpha = fminf(kAlphaMax, B.y * __expf(-sigma));
-        if (alpha < kAlphaMin) continue;
-        const float next_T = T * (1.f - alpha);
-        if (next_T <= kTStop) { found = true; break; }
-        T = next_T;
-        last = start + t;
+    const int n_mine = build_quad_lists(ql, hitq, g0, rB, tid);
+    const float4 *lX = ql.X[wv], *lC = ql.C[wv], *lD = ql.D[wv], *lE = ql.E[wv];
+    // sequential walk with the stop rule, branch-free inside: `live` lanes are still looking for
+    // their stop; a wave leaves as soon as none of its lanes is
+    bool live = mine && !found;
+    int lastpos = -1;
+    for (int t = 0; t < n_mine && __ballot(live) != 0ull; t += 4) {
+      float4 X[2], Cq[2], D[2], E[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        X[u] = lX[(t >> 1) + u]; Cq[u] = lC[(t >> 1) + u]; D[u] = lD[(t >> 1) + u]; E[u] = lE[(t >> 1) + u];
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const PairEval ev = eval_pair(X[u], Cq[u], D[u], E[u], px2, py2);
+        {
+          const float nT = T * (1.f - ev.a0);
+          const bool hit = live & ev.k0, stop = hit & (nT <= kTStop), upd = hit & !stop;
+          T = upd ? nT : T;
+          lastpos = upd ? t + 2 * u : lastpos;
+          found = found | stop;
+          live = live & !stop;
+        }
+        {
+          const float nT = T * (1.f - ev.a1);
+          const bool hit = live & ev.k1, stop = hit & (nT <= kTStop), upd = hit & !stop;
+          T = upd ? nT : T;
+          lastpos = upd ? t + 2 * u + 1 : lastpos;
+          found = found | stop;
+          live = live & !stop;
+        }
       }
     }
+    if (lastpos >= 0) last = start + __float_as_int(((const float *)&lE[lastpos >> 1])[2 + (lastpos & 1)]);
   }
   float l = 0.f;
   if (mine)
@@ -1107,7 +1165,7 @@ using namespace eg;
 extern "C" int64_t eg_composite_workspace_bytes(int64_t max_items, int64_t n_tiles) {
   if (max_items < 0 || n_tiles < 0) return 0;
   return max_items * kTilePix * (int64_t)(sizeof(float) + sizeof(int32_t)) + max_items * (int64_t)sizeof(int32_t) +
-         n_tiles * kTilePix * (int64_t)sizeof(StopInfo);
+         n_tiles * kTilePix * (int64_t)sizeof(StopInfo) + max_items * (int64_t)kSlice;
 }
 
 extern "C" int eg_composite_fwd(const float *splat, const float *colors, int32_t channels, const int32_t *offsets,
@@ -1130,8 +1188,9 @@ extern "C" int eg_composite_fwd(const float *splat, const float *colors, int32_t
     int *sliceL = (int *)(sliceP + (size_t)max_items * kTilePix);
     int *item_flags = sliceL + (size_t)max_items * kTilePix;
     StopInfo *stopinfo = (StopInfo *)(item_flags + max_items);
+    unsigned char *sliceQ = (unsigned char *)(stopinfo + (size_t)tw * th * kTilePix);
     composite_slice_fwd_kernel<<<(unsigned)max_items, 256, 0, s>>>((const float4 *)splat, offsets, item_offsets,
-                                                                  total, flatten_ids, tw, th, sliceP, sliceL);
+                                                                  total, flatten_ids, tw, th, sliceP, sliceL, sliceQ);
     timing_mark(kMarkSlice, s);
 #define EG_LAUNCH_CB(CH)                                                                                          \
   do {                                                                                                            \
@@ -1142,7 +1201,7 @@ extern "C" int eg_composite_fwd(const float *splat, const float *colors, int32_t
     timing_mark(kMarkCombine, s);                                                                                 \
     composite_rewalk_fwd_kernel<CH><<<(unsigned)max_items, 256, 0, s>>>(                                          \
         (const float4 *)splat, offsets, item_offsets, total, flatten_ids, width, height, tw, th, item_flags,      \
-        stopinfo, render, alphas, last_ids, gt, wmap, loss_scale, vpix, loss_out, (float2 *)gtstop);              \
+        stopinfo, sliceQ, render, alphas, last_ids, gt, wmap, loss_scale, vpix, loss_out, (float2 *)gtstop);      \
     timing_mark(kMarkRewalk, s);                                                                                  \
   } while (0)
     if (channels == 1) EG_LAUNCH_CB(1); else EG_LAUNCH_CB(3);
