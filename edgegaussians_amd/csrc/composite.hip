@@ -450,12 +450,25 @@ composite_slice_fwd_kernel(const float4 *__restrict__ splat, const int *__restri
 
 // per-pixel epilogue shared by the combine and re-walk kernels: outputs, fused clamp + weighted L1
 // (edge_gs.py:279,288-324) and the packed record the footprint backward reads.  Returns the loss term.
+// Per-pixel record the fused forward leaves for the footprint backward (12 bytes, one dwordx3 load):
+// v * T_final, and -- only for pixels whose front-to-back walk ended on the transmittance rule -- the
+// id and the depth bits of the last contributing Gaussian, so that a candidate decides "at or before
+// the stop" from the record alone (a per-visit gather of the stop Gaussian's depth cost 12 us/step
+// on a trained-like scene).
+struct StopRec {
+  float gT;
+  int stop_id;          // -1: the walk did not stop
+  unsigned stop_depth;  // depth float bits of Gaussian stop_id
+};
+static_assert(sizeof(StopRec) == 12, "gtstop is [H,W,3] 32-bit words");
+
 template <int CH>
 __device__ __forceinline__ float finalize_pixel(int p, float T, int last, bool stopped, const int *__restrict__ flat,
                                                 float *__restrict__ render, float *__restrict__ alphas,
                                                 int *__restrict__ last_ids, const float *__restrict__ gt,
                                                 const float *__restrict__ wmap, float loss_scale,
-                                                float *__restrict__ vpix, float2 *__restrict__ gtstop) {
+                                                float *__restrict__ vpix, StopRec *__restrict__ gtstop,
+                                                const float4 *__restrict__ splat) {
   const float pix = 1.f - T;  // unit colours, no background: sum_i alpha_i T_i == 1 - T_final
   alphas[p] = pix;
   last_ids[p] = last;
@@ -473,8 +486,11 @@ __device__ __forceinline__ float finalize_pixel(int p, float T, int last, bool s
     if (gtstop) {
       // v * T_final, and -- only for pixels whose walk stopped on the transmittance rule -- the id of
       // the last contributing Gaussian
-      const int stop_id = stopped ? flat[last] : -1;
-      gtstop[p] = make_float2((T < 1.f) ? v * T : 0.f, __int_as_float(stop_id));
+      StopRec r;
+      r.gT = (T < 1.f) ? v * T : 0.f;
+      r.stop_id = stopped ? flat[last] : -1;
+      r.stop_depth = stopped ? (unsigned)__float_as_int(splat[2 * r.stop_id + 1].z) : 0u;
+      gtstop[p] = r;
     }
   }
   return l;
@@ -511,7 +527,7 @@ composite_combine_fwd_kernel(const int *__restrict__ item_offsets, const int *__
                              float *__restrict__ alphas, int *__restrict__ last_ids,
                              const float *__restrict__ gt, const float *__restrict__ wmap, float loss_scale,
                              float *__restrict__ vpix, float *__restrict__ loss_out,
-                             float2 *__restrict__ gtstop) {
+                             StopRec *__restrict__ gtstop) {
   __shared__ float sRed[4];
   const int tile = blockIdx.x, tid = threadIdx.x;
   const int ty = tile / tw, tx = tile - ty * tw;
@@ -556,7 +572,7 @@ composite_combine_fwd_kernel(const int *__restrict__ item_offsets, const int *__
   float l = 0.f;
   if (inside && stop_slice < 0)
     l = finalize_pixel<CH>(i * width + j, T, last, false, flat, render, alphas, last_ids, gt, wmap, loss_scale, vpix,
-                           gtstop);
+                           gtstop, nullptr);  // pixels finalised here did not stop
   if (wmap && loss_out) block_loss_add(l, sRed, loss_out);
 }
 
@@ -573,7 +589,7 @@ composite_rewalk_fwd_kernel(const float4 *__restrict__ splat, const int *__restr
                             const unsigned char *__restrict__ sliceQ,
                             float *__restrict__ render, float *__restrict__ alphas, int *__restrict__ last_ids,
                             const float *__restrict__ gt, const float *__restrict__ wmap, float loss_scale,
-                            float *__restrict__ vpix, float *__restrict__ loss_out, float2 *__restrict__ gtstop) {
+                            float *__restrict__ vpix, float *__restrict__ loss_out, StopRec *__restrict__ gtstop) {
   __shared__ QuadLists ql;
   __shared__ float sRed[4];
   // a fixed small grid strides over the items: in scenes without stops this whole launch is a scan of
@@ -652,7 +668,7 @@ composite_rewalk_fwd_kernel(const float4 *__restrict__ splat, const int *__restr
   float l = 0.f;
   if (mine)
     l = finalize_pixel<CH>(i * width + j, T, last, found, flat, render, alphas, last_ids, gt, wmap, loss_scale, vpix,
-                           gtstop);
+                           gtstop, splat);
   if (wmap && loss_out) block_loss_add(l, sRed, loss_out);
   }  // item loop
 }
@@ -848,24 +864,22 @@ struct Moments {
 };
 
 __device__ __forceinline__ void footprint_visit(const float4 s0, const float4 s1, float thr, int g, int i, int j,
-                                                const float2 rec, const float4 *__restrict__ splat, Moments &m) {
+                                                const StopRec rec, Moments &m) {
   // One branch on the ellipse test (whole waves fall outside on large footprints), none after it:
   // the lanes of a wave sit in up to eight footprints, accepted and rejected pixels are mixed, and
   // further branching only adds exec-mask bookkeeping.  A rejected pixel contributes w = 0.
-  const float gT = rec.x;
+  const float gT = rec.gT;
   const float dx = s0.x - ((float)j + 0.5f), dy = s0.y - ((float)i + 0.5f);
   const float sigma = 0.5f * (s0.z * dx * dx + s1.x * dy * dy) + s0.w * dx * dy;
   if (!(gT != 0.f && sigma >= 0.f && sigma <= thr)) return;
   const float vis = __expf(-sigma);
   const float araw = s1.y * vis;
   // forward: skip if min(0.999, araw) < 1/255; gsplat's backward: no gradient through a clamped alpha
-  bool ok = araw >= kAlphaMin && araw <= kAlphaMax;
-  const int stop_id = __float_as_int(rec.y);
-  if (ok && stop_id >= 0 && stop_id != g) {
-    // the walk of this pixel stopped: only Gaussians at or before the last contributor count
-    const unsigned dl = (unsigned)__float_as_int(splat[2 * stop_id + 1].z), dg = (unsigned)__float_as_int(s1.z);
-    ok = !(dg > dl || (dg == dl && g > stop_id));
-  }
+  // where the walk of this pixel stopped only Gaussians at or before the last contributor count:
+  // (depth bits, id) <= (its depth bits, its id)
+  const unsigned dg = (unsigned)__float_as_int(s1.z);
+  const bool after_stop = (rec.stop_id >= 0) & ((dg > rec.stop_depth) | ((dg == rec.stop_depth) & (g > rec.stop_id)));
+  const bool ok = (araw >= kAlphaMin) & (araw <= kAlphaMax) & !after_stop;
   const float v_alpha = ok ? gT * __builtin_amdgcn_rcpf(1.f - araw) : 0.f;
   m.v_o += vis * v_alpha;
   const float w = -araw * v_alpha;
@@ -881,7 +895,7 @@ __device__ __forceinline__ void footprint_visit(const float4 s0, const float4 s1
 // the NEXT pair are prefetched while this one is evaluated.
 __device__ __forceinline__ void footprint_walk(const float4 s0, const float4 s1, int g, int r, int n, int i0,
                                                int pw, int cells, int jlo, int jhi, float thr, float xoff,
-                                               float shear, int width, const float2 *__restrict__ gtstop,
+                                               float shear, int width, const StopRec *__restrict__ gtstop,
                                                const float4 *__restrict__ splat, Moments &m) {
   const float inv_pw = __builtin_amdgcn_rcpf((float)pw);
   // cell -> (row, column) offsets; the quotient estimate is exact for cells < 2^21, the fix-up is free
@@ -891,9 +905,10 @@ __device__ __forceinline__ void footprint_walk(const float4 s0, const float4 s1,
     if (qj < 0) { qj += pw; --qi; }
     if (qj >= pw) { qj -= pw; ++qi; }
   };
-  auto fetch = [&](int i, int c, int &j) -> float2 {
+  const StopRec none = {0.f, -1, 0u};  // gT == 0: the visit is skipped
+  auto fetch = [&](int i, int c, int &j) -> StopRec {
     j = (int)ceilf(xoff + shear * (s0.y - ((float)i + 0.5f))) + c;
-    return (j >= jlo && j <= jhi) ? gtstop[__mul24(i, width) + j] : make_float2(0.f, 0.f);
+    return (j >= jlo && j <= jhi) ? gtstop[__mul24(i, width) + j] : none;
   };
   int di, dc;
   divmod(2 * n, di, dc);
@@ -903,11 +918,11 @@ __device__ __forceinline__ void footprint_walk(const float4 s0, const float4 s1,
   ia += i0; ib += i0;
   int left_a = cells - r, left_b = cells - r - n;  // > 0 while the stream still has a visit
   int ja = 0, jb = 0;
-  float2 na = make_float2(0.f, 0.f), nb = na;
+  StopRec na = none, nb = none;
   if (left_a > 0) na = fetch(ia, ca, ja);
   if (left_b > 0) nb = fetch(ib, cb, jb);
   while (left_a > 0) {
-    const float2 ra = na, rb = nb;
+    const StopRec ra = na, rb = nb;
     const int cia = ia, cja = ja, cib = ib, cjb = jb;
     left_a -= 2 * n;
     left_b -= 2 * n;
@@ -915,17 +930,17 @@ __device__ __forceinline__ void footprint_walk(const float4 s0, const float4 s1,
     if (ca >= pw) { ca -= pw; ++ia; }
     ib += di; cb += dc;
     if (cb >= pw) { cb -= pw; ++ib; }
-    na = nb = make_float2(0.f, 0.f);
+    na = nb = none;
     if (left_a > 0) na = fetch(ia, ca, ja);
     if (left_b > 0) nb = fetch(ib, cb, jb);
-    footprint_visit(s0, s1, thr, g, cia, cja, ra, splat, m);
-    footprint_visit(s0, s1, thr, g, cib, cjb, rb, splat, m);  // an exhausted stream holds a zero record
+    footprint_visit(s0, s1, thr, g, cia, cja, ra, m);
+    footprint_visit(s0, s1, thr, g, cib, cjb, rb, m);  // an exhausted stream holds a zero record
   }
 }
 
 __global__ void __launch_bounds__(256)
 footprint_bwd_kernel(const float4 *__restrict__ splat, int N, int width, int height,
-                     const float2 *__restrict__ gtstop, float *__restrict__ g2d, int *__restrict__ big_list,
+                     const StopRec *__restrict__ gtstop, float *__restrict__ g2d, int *__restrict__ big_list,
                      int parity) {
   __shared__ float red[4][64 * 8];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -1003,7 +1018,7 @@ footprint_bwd_kernel(const float4 *__restrict__ splat, int N, int width, int hei
 
 // one wavefront per big-footprint Gaussian: the 64 lanes stride over its cells, full butterfly
 __global__ void __launch_bounds__(256)
-footprint_big_kernel(const float4 *__restrict__ splat, int width, int height, const float2 *__restrict__ gtstop,
+footprint_big_kernel(const float4 *__restrict__ splat, int width, int height, const StopRec *__restrict__ gtstop,
                      float *__restrict__ g2d, const int *__restrict__ big_list, int parity) {
   const int lane = threadIdx.x & 63;
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
@@ -1197,11 +1212,11 @@ extern "C" int eg_composite_fwd(const float *splat, const float *colors, int32_t
     composite_combine_fwd_kernel<CH><<<tw * th, 256, 0, s>>>(item_offsets, flatten_ids, width, height, tw, th,    \
                                                             sliceP, sliceL, item_flags, stopinfo, render, alphas,\
                                                             last_ids, gt, wmap, loss_scale, vpix, loss_out,       \
-                                                            (float2 *)gtstop);                                    \
+                                                            (StopRec *)gtstop);                                    \
     timing_mark(kMarkCombine, s);                                                                                 \
     composite_rewalk_fwd_kernel<CH><<<(unsigned)max_items, 256, 0, s>>>(                                          \
         (const float4 *)splat, offsets, item_offsets, total, flatten_ids, width, height, tw, th, item_flags,      \
-        stopinfo, sliceQ, render, alphas, last_ids, gt, wmap, loss_scale, vpix, loss_out, (float2 *)gtstop);      \
+        stopinfo, sliceQ, render, alphas, last_ids, gt, wmap, loss_scale, vpix, loss_out, (StopRec *)gtstop);      \
     timing_mark(kMarkRewalk, s);                                                                                  \
   } while (0)
     if (channels == 1) EG_LAUNCH_CB(1); else EG_LAUNCH_CB(3);
@@ -1245,9 +1260,9 @@ extern "C" int eg_composite_bwd_footprint(const float *splat, int32_t N, int32_t
   hipStream_t st = as_stream(stream);
   (void)row_span;  // kept for ABI stability: the walk adapts per Gaussian now
   footprint_bwd_kernel<<<cdiv((int64_t)N, 32), 256, 0, st>>>((const float4 *)splat, N, width, height,
-                                                            (const float2 *)gtstop, g2d, big_list, parity);
+                                                            (const StopRec *)gtstop, g2d, big_list, parity);
   timing_mark(kMarkFootprint, st);
-  footprint_big_kernel<<<64, 256, 0, st>>>((const float4 *)splat, width, height, (const float2 *)gtstop, g2d,
+  footprint_big_kernel<<<64, 256, 0, st>>>((const float4 *)splat, width, height, (const StopRec *)gtstop, g2d,
                                           big_list, parity);
   timing_mark(kMarkFootprintBig, st);
   return check_launch("composite_bwd_footprint");

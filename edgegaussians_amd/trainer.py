@@ -135,7 +135,7 @@ class EdgeTrainer:
         self.render = torch.zeros(H, W, device=d)
         self.alphas = torch.zeros(H, W, device=d)
         self.vpix = torch.zeros(H, W, device=d)
-        self.gtstop = torch.zeros(H, W, 2, device=d)  # {vpix * T_final, stop id} for the fused backward
+        self.gtstop = torch.zeros(H, W, 3, device=d)  # {vpix * T_final, stop id, stop depth bits} for the fused backward
         self.last_ids = torch.zeros(H, W, dtype=torch.int32, device=d)
         self.loss_acc = torch.zeros(1, device=d)
 

@@ -127,8 +127,9 @@ int eg_composite_fwd(const float *splat, const float *colors /*[N,channels]|NULL
                      float *vpix /*[H,W]|NULL*/, float *loss_out /*[1]|NULL*/,
                      const int32_t *item_offsets /*[T+1]|NULL*/, const int32_t *total /*[4]|NULL*/,
                      int64_t max_items, void *workspace,
-                     float *gtstop /*[H,W,2]|NULL: {vpix * T_final, id of the last contributor if the
-                                     pixel's walk stopped on T <= 1e-4 else -1} for eg_backward_fused*/,
+                     float *gtstop /*[H,W,3] 32-bit words|NULL: {vpix * T_final (f32), id of the last contributor
+                                     if the pixel's walk stopped on T <= 1e-4 else -1 (i32), that Gaussian's
+                                     depth bits (u32)} for eg_backward_fused*/,
                      eg_stream_t stream);
 
 /* ---- G8: compositing backward for unit colours (replaces gsplat rasterize_to_pixels bwd for the
@@ -184,7 +185,7 @@ typedef struct {
  * one for call k+1, which saves a memset node per step.  row_span is ignored (it selected between
  * two walks in an earlier revision; the walk adapts per Gaussian now) and kept for ABI stability. */
 int eg_composite_bwd_footprint(const float *splat, int32_t N, int32_t width, int32_t height,
-                               const float *gtstop /*[H,W,2]*/, float *g2d /*[N,8] written*/,
+                               const float *gtstop /*[H,W,3]*/, float *g2d /*[N,8] written*/,
                                int32_t *big_list, int32_t parity, int32_t row_span, eg_stream_t stream);
 
 /* ---- whole backward of the fused path: eg_composite_bwd_footprint, then eg_project_bwd_adam
@@ -290,7 +291,7 @@ typedef struct {
   int32_t *flatten_ids;
   int64_t capacity;
   float *render, *alphas, *vpix, *loss; /* [H,W], [H,W], [H,W], [1] accumulated */
-  float *gtstop;                        /* [H,W,2] */
+  float *gtstop;                        /* [H,W,3] */
   int32_t *big_list;                    /* [2 + N], zero-initialised once */
   int32_t parity;                       /* 0/1, alternates every step (see eg_composite_bwd_footprint) */
   int32_t row_span;                     /* ignored (see eg_composite_bwd_footprint) */
