@@ -470,10 +470,13 @@ __device__ __forceinline__ float finalize_pixel(int p, float T, int last, bool s
                                                 float *__restrict__ vpix, StopRec *__restrict__ gtstop,
                                                 const float4 *__restrict__ splat) {
   const float pix = 1.f - T;  // unit colours, no background: sum_i alpha_i T_i == 1 - T_final
-  alphas[p] = pix;
-  last_ids[p] = last;
+  // the images are optional in the fused training step, whose backward reads only the gtstop record
+  if (alphas) alphas[p] = pix;
+  if (last_ids) last_ids[p] = last;
+  if (render) {
 #pragma unroll
-  for (int k = 0; k < CH; ++k) render[(size_t)p * CH + k] = pix;
+    for (int k = 0; k < CH; ++k) render[(size_t)p * CH + k] = pix;
+  }
   float l = 0.f;
   if (wmap) {
     const float w = wmap[p];
@@ -1191,7 +1194,8 @@ extern "C" int eg_composite_fwd(const float *splat, const float *colors, int32_t
                                 eg_stream_t stream) {
   EG_REQUIRE(width > 0 && height > 0, "bad sizes");
   EG_REQUIRE(channels == 1 || channels == 3, "channels must be 1 or 3");
-  EG_REQUIRE(splat && offsets && render && alphas && last_ids, "null pointer");
+  EG_REQUIRE(splat && offsets, "null pointer");
+  EG_REQUIRE((render && alphas && last_ids) || gtstop, "render / alphas / last_ids are optional only with gtstop");
   EG_REQUIRE(!wmap || gt, "wmap needs gt");
   EG_REQUIRE(!gtstop || (wmap && !colors && item_offsets && total && workspace && max_items > 0),
              "gtstop needs the fused loss and the slice-parallel unit-colour mode");

@@ -74,8 +74,11 @@ class EdgeTrainer:
     def __init__(self, means: Tensor, log_scales: Tensor, quats: Tensor, logit_opacities: Tensor,
                  viewmats: Tensor, Ks: Tensor, gt: Tensor, width: int, height: int,
                  device: str = "cuda", schedule: Optional[LRSchedule] = None,
-                 betas=(0.9, 0.999), eps: float = 1e-8):
+                 betas=(0.9, 0.999), eps: float = 1e-8, keep_images: bool = False):
         _lib.load()
+        # keep_images: also materialise render / alphas / last_ids / vpix every step (the training step
+        # itself needs none of them: its backward reads only the packed gtstop record)
+        self.keep_images = bool(keep_images)
         self.dev = torch.device(device)
         f = dict(device=self.dev, dtype=torch.float32)
         self.means = means.detach().to(**f).contiguous().clone()
@@ -132,11 +135,10 @@ class EdgeTrainer:
         self.item_offsets = torch.zeros(self.T + 1, dtype=torch.int32, device=d)
         self.total = torch.zeros(4, dtype=torch.int32, device=d)  # M, overflow, items, largest tile
         self.ticket = torch.zeros(1, dtype=torch.int32, device=d)  # last-workgroup ticket of the fused scan
-        self.render = torch.zeros(H, W, device=d)
-        self.alphas = torch.zeros(H, W, device=d)
-        self.vpix = torch.zeros(H, W, device=d)
+        img = (lambda **k: torch.zeros(H, W, device=d, **k)) if self.keep_images else (lambda **k: None)
+        self.render, self.alphas, self.vpix = img(), img(), img()
         self.gtstop = torch.zeros(H, W, 3, device=d)  # {vpix * T_final, stop id, stop depth bits} for the fused backward
-        self.last_ids = torch.zeros(H, W, dtype=torch.int32, device=d)
+        self.last_ids = img(dtype=torch.int32)
         self.loss_acc = torch.zeros(1, device=d)
 
     def _alloc_isect(self, capacity: int):

@@ -118,12 +118,14 @@ int eg_sort_pairs(uint64_t *keys /*[capacity] in/out*/, const int32_t *offsets /
  * Slice-parallel mode (unit colours only): pass item_offsets + total from eg_tile_offsets, an upper
  * bound max_items >= total[2] (e.g. ceil(capacity/128) + T) and a workspace of
  * eg_composite_workspace_bytes(max_items, T) bytes; one workgroup runs per (tile, 128-Gaussian slice).
- * With item_offsets == NULL (or per-Gaussian colours) one workgroup walks each tile. */
+ * With item_offsets == NULL (or per-Gaussian colours) one workgroup walks each tile.
+ * When gtstop != NULL (the fused training step, whose backward reads nothing else) render, alphas,
+ * last_ids and vpix may each be NULL and are then not materialised. */
 int64_t eg_composite_workspace_bytes(int64_t max_items, int64_t n_tiles);
 int eg_composite_fwd(const float *splat, const float *colors /*[N,channels]|NULL*/, int32_t channels,
                      const int32_t *offsets, const int32_t *flatten_ids, int32_t width, int32_t height,
-                     float *render /*[H,W,channels]*/, float *alphas /*[H,W]*/, int32_t *last_ids /*[H,W]*/,
-                     const float *gt /*[H,W]|NULL*/, const float *wmap /*[H,W]|NULL*/, float loss_scale,
+                     float *render /*[H,W,channels]|NULL*/, float *alphas /*[H,W]|NULL*/,
+                     int32_t *last_ids /*[H,W]|NULL*/, const float *gt /*[H,W]|NULL*/, const float *wmap /*[H,W]|NULL*/, float loss_scale,
                      float *vpix /*[H,W]|NULL*/, float *loss_out /*[1]|NULL*/,
                      const int32_t *item_offsets /*[T+1]|NULL*/, const int32_t *total /*[4]|NULL*/,
                      int64_t max_items, void *workspace,

@@ -368,6 +368,15 @@ def test_grad_step_equals_autograd_path(env):
     assert_close(go, lo.grad.view(-1), rtol=1e-4, max_bad=1e-3, name="opacities")
     inc = tr.grads.view(-1)[11 * N:]
     assert_close(inc, info["means2d"].absgrad[0].norm(dim=-1), rtol=1e-4, max_bad=1e-3, name="absgrad inc")
+    # the step does not materialise the images unless asked to; when asked they are the operator's
+    assert tr.render is None and tr.alphas is None and tr.last_ids is None and tr.vpix is None
+    tk = EdgeTrainer(sc.means, sc.log_scales, sc.quats, sc.logit_opacities, sc.viewmats, sc.Ks, sc.gt,
+                     sc.width, sc.height, keep_images=True)
+    tk.ensure_capacity()
+    tk.grad_step(1, w)
+    assert_close(tk.render, render[0, ..., 0].detach(), rtol=1e-5, name="kept render")
+    assert_close(tk.alphas, alpha[0, ..., 0].detach(), rtol=1e-5, name="kept alpha")
+    assert torch.equal(tk.grad_views()[0], gm), "same gradients with and without images"
 
 
 def _grad_step_vs_oracle(env, sc, view, strategy="whole"):
