@@ -70,8 +70,11 @@ def build_trainer(cfg, seed, device, spread_opacity=False):
     sched = LRSchedule(means_lr=2e-3 * LR_SCALE, scales_lr=1e-4 * LR_SCALE, quats_lr=1e-3 * LR_SCALE,
                        opacities_lr=0.03 * LR_SCALE, means_milestones=[], scales_start=0, quats_start=0,
                        opacities_start=0)
+    # spatial_order: the trainer keeps its rows in Morton order (a relabelling; checkpoints and PLY
+    # exports come back in the reference's row order) -- the synthetic scene, like the reference's
+    # initialisation, hands them over in random order
     tr = EdgeTrainer(sc.means, sc.log_scales, sc.quats, sc.logit_opacities, sc.viewmats, sc.Ks, sc.gt,
-                     w, h, device=device, schedule=sched)
+                     w, h, device=device, schedule=sched, spatial_order=not os.environ.get("EG_NO_SPATIAL_ORDER"))
     g = torch.Generator().manual_seed(seed + 1)
     whole = synth.weight_map("whole", sc.gt[0]).to(device).contiguous()
     ratio = [synth.weight_map("bg_edge_ratio", sc.gt[i], 1.0, g).to(device).contiguous() for i in range(v)]
@@ -237,6 +240,7 @@ def main():
                                f"{n_views} views @{w}x{h}, loss whole/bg_edge_ratio 4:1",
                    "n_gaussians": n, "views": n_views, "width": w, "height": h, "lr_scale": LR_SCALE,
                    "tile_intersections_M": m_last, "views_per_step": world,
+                   "gaussian_row_order": "morton" if tr.spatial_order else "as given",
                    "parallelism": f"dp{world} (views sharded, RCCL all-reduce of [N,12] grads)" if world > 1 else "single GPU"},
         "mean_loss": loss_sum / (args.warmup + args.steps),
         "host_enqueue_ms_per_step": 1e3 * t_enq / args.steps,

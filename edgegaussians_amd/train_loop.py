@@ -105,6 +105,8 @@ def train(tr: EdgeTrainer, model_cfg: Dict, training_cfg: Dict, view_order: Call
         # "if reset_opacity" (with a space) never matches the dataclass field (configs/*.json:37): always False
         if changed:
             tr.reset_absgrads()          # train_gaussians.py:218-219
+            if tr.spatial_order:
+                tr.spatial_sort()        # new rows were appended / rows were dropped: restore the layout
             tr.ensure_capacity()         # N changed: re-size the isect buffers (one count-only sweep)
         if on_epoch:
             on_epoch(epoch, avg, tr.N)

@@ -74,7 +74,8 @@ class EdgeTrainer:
     def __init__(self, means: Tensor, log_scales: Tensor, quats: Tensor, logit_opacities: Tensor,
                  viewmats: Tensor, Ks: Tensor, gt: Tensor, width: int, height: int,
                  device: str = "cuda", schedule: Optional[LRSchedule] = None,
-                 betas=(0.9, 0.999), eps: float = 1e-8, keep_images: bool = False):
+                 betas=(0.9, 0.999), eps: float = 1e-8, keep_images: bool = False,
+                 spatial_order: bool = False):
         _lib.load()
         # keep_images: also materialise render / alphas / last_ids / vpix every step (the training step
         # itself needs none of them: its backward reads only the packed gtstop record)
@@ -104,6 +105,15 @@ class EdgeTrainer:
         self._hyper = AdamHyper()
         self._alloc_state()
         self._alloc_pixels()
+        # spatial_order: keep the Gaussian rows in 3-D Morton order (re-sorted after every densify / cull
+        # event).  Neighbouring rows then project to neighbouring pixels in every view, so a binning
+        # workgroup touches a handful of tile counters instead of hundreds and the gathers of the
+        # compositing kernels stay local.  ref_index remembers where each row sits in the reference's
+        # own arrays; state_dict() / export_as_ply() hand the rows back in that order.
+        self.spatial_order = bool(spatial_order)
+        self.ref_index: Optional[Tensor] = None
+        if self.spatial_order:
+            self.spatial_sort()
 
     # ------------------------------------------------------------------ allocation
     @property
@@ -436,6 +446,49 @@ class EdgeTrainer:
         call("eg_mask_scan", ptr(mask_u8), self.N, ptr(pos), ptr(cnt), stream())
         return pos, int(cnt.item())
 
+    # ------------------------------------------------------------------ row order (data layout)
+    def _morton_perm(self) -> Tensor:
+        m = self.means
+        lo, hi = m.min(0).values, m.max(0).values
+        q = ((m - lo) / (hi - lo + 1e-12) * 1023.0).long().clamp_(0, 1023)
+
+        def spread(v):  # 10 bits -> every third bit
+            v = (v | (v << 16)) & 0x030000FF
+            v = (v | (v << 8)) & 0x0300F00F
+            v = (v | (v << 4)) & 0x030C30C3
+            return (v | (v << 2)) & 0x09249249
+        code = spread(q[:, 0]) | (spread(q[:, 1]) << 1) | (spread(q[:, 2]) << 2)
+        return torch.argsort(code, stable=True)
+
+    def spatial_sort(self) -> None:
+        """Permute every per-Gaussian array (parameters, Adam moments, absgrads) into Morton order of
+        the current means.  A pure relabelling: the step treats Gaussians independently."""
+        N = self.N
+        if N == 0:
+            return
+        perm = self._morton_perm()
+        m_old, v_old = self._moment_views(self.adam_m), self._moment_views(self.adam_v)
+        names = list(self._params().keys())
+        self.adam_m = torch.cat([m_old[k][perm].reshape(-1) for k in names]).contiguous()
+        self.adam_v = torch.cat([v_old[k][perm].reshape(-1) for k in names]).contiguous()
+        self.means = self.means[perm].contiguous()
+        self.log_scales = self.log_scales[perm].contiguous()
+        self.quats = self.quats[perm].contiguous()
+        self.logit_opacities = self.logit_opacities[perm].contiguous()
+        self.absgrads = self.absgrads[perm].contiguous()
+        ref = self.ref_index if self.ref_index is not None else torch.arange(N, device=self.dev)
+        self.ref_index = ref[perm].contiguous()
+        self.nn_indices = None
+        self._alloc_per_gaussian()
+
+    def _in_reference_order(self, t: Tensor) -> Tensor:
+        """Rows of a per-Gaussian tensor put back where the reference's arrays hold them."""
+        if self.ref_index is None:
+            return t
+        out = torch.empty_like(t)
+        out[self.ref_index] = t
+        return out
+
     def cull(self, cull_mask: Tensor, reset_opacity_value: float = 0.08) -> int:
         """cull_gaussians (edge_gs.py:412-429) + remove_from_all_optim (:384-409): rows of the 4
         params, 8 moment tensors and absgrads where ~cull_mask, then the reference's opacity clamp
@@ -462,6 +515,11 @@ class EdgeTrainer:
         self.means, self.log_scales, self.quats = new_p["means"], new_p["scales"], new_p["quats"]
         self.logit_opacities = new_p["opacities"].view(-1).clamp_(max=reset_opacity_value)
         self.adam_m, self.adam_v, self.absgrads = new_m, new_v, ag.view(-1)
+        if self.ref_index is not None:  # the reference compacts its own arrays: ranks among the survivors
+            kept = self.ref_index[keep.bool()]
+            ranks = torch.empty_like(kept)
+            ranks[torch.argsort(kept)] = torch.arange(kept.numel(), device=self.dev)
+            self.ref_index = ranks
         self._alloc_per_gaussian()
         return N - n_keep
 
@@ -479,6 +537,15 @@ class EdgeTrainer:
         N, n_new = self.N, self.N + copies * n_sel
         if noise is None:
             noise = torch.randn(copies * n_sel, 3, device=self.dev)
+        new_ref = None
+        if self.ref_index is not None and n_sel:
+            # the reference appends copy k of its j-th selected row at N + k n_sel + j: our j-th selected
+            # row is its rank-th one; a caller-supplied `noise` is in the reference's order
+            sel_ref = self.ref_index[sel.bool()]
+            rank = torch.empty_like(sel_ref)
+            rank[torch.argsort(sel_ref)] = torch.arange(n_sel, device=self.dev)
+            new_ref = torch.cat([N + k * n_sel + rank for k in range(copies)])
+            noise = noise.to(self.dev)[new_ref - N]
         noise = (noise.to(self.dev) * noise_scale).contiguous()
         m_old, v_old = self._moment_views(self.adam_m), self._moment_views(self.adam_v)
         new_m = torch.zeros(11 * n_new, device=self.dev)
@@ -499,6 +566,8 @@ class EdgeTrainer:
         self.means, self.log_scales, self.quats = new_p["means"], new_p["scales"], new_p["quats"]
         self.logit_opacities = new_p["opacities"].view(-1)
         self.adam_m, self.adam_v = new_m, new_v
+        if new_ref is not None:
+            self.ref_index = torch.cat([self.ref_index, new_ref])
         self.reset_absgrads()
         self._alloc_per_gaussian()
         return n_sel
@@ -540,9 +609,14 @@ class EdgeTrainer:
         self.logit_opacities = state["gauss_params.opacities"].detach().to(**f).reshape(-1).contiguous().clone()
         self._alloc_state()
         self.capacity = 0
+        self.ref_index = None
+        if self.spatial_order:
+            self.spatial_sort()
 
     def state_dict(self) -> Dict[str, Tensor]:
-        """Same keys / shapes as the reference's checkpoint (edge_gs.py:625-633)."""
-        return {"gauss_params.means": self.means.clone(), "gauss_params.scales": self.log_scales.clone(),
-                "gauss_params.quats": self.quats.clone(),
-                "gauss_params.opacities": self.logit_opacities.view(-1, 1).clone()}
+        """Same keys / shapes -- and, whatever the internal row order, the same row order -- as the
+        reference's checkpoint (edge_gs.py:625-633)."""
+        r = self._in_reference_order
+        return {"gauss_params.means": r(self.means).clone(), "gauss_params.scales": r(self.log_scales).clone(),
+                "gauss_params.quats": r(self.quats).clone(),
+                "gauss_params.opacities": r(self.logit_opacities).view(-1, 1).clone()}

@@ -831,3 +831,59 @@ def test_filter_by_projection_matches_reference(env, golden_dir):
         assert np.array_equal(got, d[f"inliers_{thr}"])
     assert filtering.filter_by_projection(d["means"][:0], images, cameras).shape == (0,)
     assert np.array_equal(filtering.filter_by_opacity(np.array([[0.2], [0.01]]), 0.05), np.array([True, False]))
+
+
+def test_spatial_row_order_is_a_pure_relabelling(env):
+    """EdgeTrainer(spatial_order=True) keeps its rows in Morton order internally; gradients, densify /
+    cull events and checkpoints must be those of the as-given order once mapped back (ref_index)."""
+    _lib, synth, O = env
+    from edgegaussians_amd import EdgeTrainer
+    sc = _scene(synth, n=3000, w=160, h=112, views=2)
+    mk = lambda so: EdgeTrainer(sc.means, sc.log_scales, sc.quats, sc.logit_opacities, sc.viewmats, sc.Ks,  # noqa: E731
+                                sc.gt, sc.width, sc.height, spatial_order=so)
+    ta, tb = mk(False), mk(True)
+    assert tb.ref_index is not None and not torch.equal(tb.ref_index, torch.arange(3000, device="cuda"))
+    for k, v in ta.state_dict().items():
+        assert torch.equal(v, tb.state_dict()[k]), k
+    w = synth.weight_map("weighted", sc.gt[1]).cuda()
+    ta.ensure_capacity(); tb.ensure_capacity()
+    ta.grad_step(1, w); tb.grad_step(1, w)
+    la, lb = ta.pop_loss(), tb.pop_loss()
+    assert abs(la - lb) <= 1e-5 * abs(la)
+    for ga, gb, name in zip(ta.grad_views(), tb.grad_views(), ("means", "quats", "scales", "opacities")):
+        assert_close(tb._in_reference_order(gb), ga, rtol=1e-4, max_bad=1e-3, name=f"grad {name}")
+    # three optimizer steps, then the densify / cull events with the same (reference-order) noise
+    for t in (ta, tb):
+        for s in range(3):
+            t.train_step(s % 2, w)
+    assert_close(tb._in_reference_order(tb.absgrads), ta.absgrads, rtol=1e-4, max_bad=2e-3, name="absgrads")
+    tb.absgrads = ta.absgrads[tb.ref_index].clone()          # identical selection on both sides
+    for name in ("means", "log_scales", "quats", "logit_opacities"):
+        setattr(tb, name, getattr(ta, name)[tb.ref_index].clone())
+    ma, mb = ta._moment_views(ta.adam_m), tb._moment_views(tb.adam_m)
+    for k in ma:
+        mb[k].copy_(ma[k][tb.ref_index])
+    g = ta.absgrads / ta.absgrads_normalize_factor
+    n_sel = int(((g - g.min()) / (g.max() - g.min()) > 0.5).sum())
+    assert n_sel > 0
+    noise = torch.randn(2 * n_sel, 3, generator=torch.Generator().manual_seed(3))
+    assert ta.duplicate_high_pos_gradients(0.5, 3, 0.05, noise.clone()) == n_sel
+    assert tb.duplicate_high_pos_gradients(0.5, 3, 0.05, noise.clone()) == n_sel
+    for k, v in ta.state_dict().items():
+        assert torch.equal(v, tb.state_dict()[k]), f"after duplicate: {k}"
+    low = torch.zeros(ta.N, dtype=torch.bool)
+    low[::7] = True
+    ta.logit_opacities[low.cuda()] = -6.0
+    tb.logit_opacities[low.cuda()[tb.ref_index]] = -6.0
+    assert ta.cull_opacity(0.05) == tb.cull_opacity(0.05) == int(low.sum())
+    for k, v in ta.state_dict().items():
+        assert torch.equal(v, tb.state_dict()[k]), f"after cull: {k}"
+    ma, mb = ta._moment_views(ta.adam_m), tb._moment_views(tb.adam_m)
+    for k in ma:
+        assert torch.equal(tb._in_reference_order(mb[k].contiguous()), ma[k].contiguous()), f"moments {k}"
+    tb.spatial_sort()                                          # what train() does after an event
+    for k, v in ta.state_dict().items():
+        assert torch.equal(v, tb.state_dict()[k]), f"after re-sort: {k}"
+    ta.ensure_capacity(); tb.ensure_capacity()
+    ta.train_step(0, w); tb.train_step(0, w)
+    assert abs(ta.pop_loss() - tb.pop_loss()) <= 1e-5 * abs(la)
