@@ -51,7 +51,6 @@ def algorithmic_bytes(n, m, hw):
         "composite_combine_fwd": 20 * hw,  # G7 per-pixel reads/writes (+ fused loss)
         "composite_rewalk_fwd": 0,
         "footprint_bwd": 28 * m + 20 * hw + 64 * n,  # G8 gather + per-pixel + outputs
-        "footprint_big": 0,
         "project_bwd_adam": 454 * n,       # G9 130 + absgrad 16 + Adam 308
         "step_total": 626 * n + 100 * m + 40 * hw,
     }

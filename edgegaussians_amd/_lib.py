@@ -45,8 +45,8 @@ class StepArgs(C.Structure):
         ("tile_mask", _vp), ("ticket", _vp),
         ("workspace", _vp), ("max_items", _i64),
         ("keys", _vp), ("flatten_ids", _vp), ("capacity", _i64),
-        ("render", _vp), ("alphas", _vp), ("vpix", _vp), ("loss", _vp), ("gtstop", _vp), ("big_list", _vp),
-        ("parity", _i32), ("row_span", _i32), ("last_ids", _vp),
+        ("render", _vp), ("alphas", _vp), ("vpix", _vp), ("loss", _vp), ("gtstop", _vp),
+        ("last_ids", _vp),
         ("v_means", _vp), ("v_quats", _vp), ("v_scales", _vp), ("v_opacities", _vp),
         ("adam_host", C.POINTER(AdamHyper)),
     ]
@@ -66,9 +66,8 @@ _SIGS = {
     "eg_composite_bwd_colors": [_vp, _vp, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "eg_project_bwd": [_vp] * 6 + [_i32, _i32, _i32, _f, _u32] + [_vp] * 9 + [_vp],
     "eg_absgrad_accum": [_vp, _i32, _vp, _vp],
-    "eg_composite_bwd_footprint": [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _vp],
-    "eg_backward_fused": [_vp] * 6 + [_i32, _i32, _i32, _f, _u32] + [_vp] * 10 + [C.POINTER(AdamHyper), _vp, _i32,
-                                                                                 _i32, _vp],
+    "eg_composite_bwd_footprint": [_vp, _i32, _i32, _i32, _vp, _vp, _vp],
+    "eg_backward_fused": [_vp] * 6 + [_i32, _i32, _i32, _f, _u32] + [_vp] * 10 + [C.POINTER(AdamHyper), _vp],
     "eg_adam_multi": [_vp] * 10 + [_i32, AdamHyper, _vp, _vp, _vp],
     "eg_project_bwd_adam": [_vp] * 6 + [_i32, _i32, _i32, _f, _u32] + [_vp] * 5 + [AdamHyper, _vp],
     "eg_mask_scan": [_vp, _i32, _vp, _vp, _vp],

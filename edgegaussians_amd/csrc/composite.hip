@@ -814,9 +814,7 @@ composite_bwd_item_kernel(const float4 *__restrict__ splat, const int *__restric
 // a multiple of 8 leave lanes idle.  Each lane accumulates first/second moments of w = dL/dsigma
 // (the gradient is linear in them); the partial g2d records go through LDS and lane (k, component)
 // adds the partials of Gaussian k in lane order: deterministic, no atomics, one coalesced 256-byte
-// store per wave, g2d needs no zeroing.  Footprints above kBigFootprint cells are deferred to a
-// wavefront-per-Gaussian kernel through a device work list.
-constexpr int kBigFootprint = 8192;
+// store per wave, g2d needs no zeroing.
 
 struct Walk {
   int i0, fh;     // rows i0 .. i0 + fh - 1
@@ -943,37 +941,29 @@ __device__ __forceinline__ void footprint_walk(const float4 s0, const float4 s1,
 
 __global__ void __launch_bounds__(256)
 footprint_bwd_kernel(const float4 *__restrict__ splat, int N, int width, int height,
-                     const StopRec *__restrict__ gtstop, float *__restrict__ g2d, int *__restrict__ big_list,
-                     int parity) {
+                     const StopRec *__restrict__ gtstop, float *__restrict__ g2d) {
   __shared__ float red[4][64 * 8];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int wave = blockIdx.x * 4 + wv;
-  if (blockIdx.x == 0 && threadIdx.x == 0) big_list[parity ^ 1] = 0;  // the NEXT call's counter
   const int gbase = wave * 8;
   if (gbase >= N) return;  // whole waves leave; there is no workgroup barrier below
 
   // home phase: the 8 lanes of group k all size the footprint of Gaussian gbase + k
   Walk h = walk_of(make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f), width, height);
-  bool h_big = false;
   {
     const int hg = gbase + (lane >> 3);
-    if (hg < N) {
-      h = walk_of(splat[2 * hg], splat[2 * hg + 1], width, height);
-      if (h.cells > kBigFootprint) {
-        if ((lane & 7) == 0) big_list[2 + atomicAdd(&big_list[parity], 1)] = hg;  // a whole wavefront takes it
-        h.cells = 0;
-        h_big = true;
-      }
-    }
+    if (hg < N) h = walk_of(splat[2 * hg], splat[2 * hg + 1], width, height);
   }
   // Lanes per Gaussian, computed group-parallel: one lane for every live footprint, the other
   // 64 - live in proportion to the cell counts (rounded down), the slack (<= live) one each to the
-  // first live groups.
-  int packed = h.cells + (h.cells > 0 ? 1 << 20 : 0);  // cells sum to < 2^17: the live count rides on top
-  packed += __shfl_xor(packed, 8, 64);
-  packed += __shfl_xor(packed, 16, 64);
-  packed += __shfl_xor(packed, 32, 64);
-  const int total = packed & 0xfffff, live = packed >> 20;
+  // first live groups.  A footprint of any size is handled here: a screen-filling Gaussian simply
+  // takes (nearly) all lanes of its wave.
+  int total = h.cells, live = h.cells > 0 ? 1 : 0;
+#pragma unroll
+  for (int d = 8; d < 64; d <<= 1) {
+    total += __shfl_xor(total, d, 64);
+    live += __shfl_xor(live, d, 64);
+  }
   int h_n = 0, h_first = 0;
   Moments m = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
@@ -1016,39 +1006,7 @@ footprint_bwd_kernel(const float4 *__restrict__ splat, int N, int width, int hei
   const int comp = lane & 7;
   float sum = 0.f;
   for (int t = 0; t < h_n; ++t) sum += red[wv][(h_first + t) * 8 + comp];
-  if (gbase + (lane >> 3) < N && !h_big) g2d[(size_t)gbase * 8 + lane] = sum;  // big ones are written later
-}
-
-// one wavefront per big-footprint Gaussian: the 64 lanes stride over its cells, full butterfly
-__global__ void __launch_bounds__(256)
-footprint_big_kernel(const float4 *__restrict__ splat, int width, int height, const StopRec *__restrict__ gtstop,
-                     float *__restrict__ g2d, const int *__restrict__ big_list, int parity) {
-  const int lane = threadIdx.x & 63;
-  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
-  const int count = big_list[parity];
-  for (int e = wave; e < count; e += n_waves) {
-    const int g = big_list[2 + e];
-    const float4 s0 = splat[2 * g], s1 = splat[2 * g + 1];
-    const Walk w = walk_of(s0, s1, width, height);
-    Moments m = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    footprint_walk(s0, s1, g, lane, 64, w.i0, max(w.pw, 1), w.cells, w.jlo, w.jhi, w.thr, w.xoff, w.shear, width,
-                   gtstop, splat, m);
-    float part[8] = {s0.z * m.w_x + s0.w * m.w_y, s0.w * m.w_x + s1.x * m.w_y, m.abs_x, m.abs_y,
-                     0.5f * m.w_xx, m.w_xy, 0.5f * m.w_yy, m.v_o};
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      float v = part[k];
-#pragma unroll
-      for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-      part[k] = v;
-    }
-    if (lane < 8) {
-      float out = part[0];
-#pragma unroll
-      for (int k = 1; k < 8; ++k) out = (lane == k) ? part[k] : out;
-      g2d[(size_t)g * 8 + lane] = out;
-    }
-  }
+  if (gbase + (lane >> 3) < N) g2d[(size_t)gbase * 8 + lane] = sum;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1256,19 +1214,14 @@ extern "C" int eg_composite_bwd(const float *splat, const int32_t *offsets, cons
 }
 
 extern "C" int eg_composite_bwd_footprint(const float *splat, int32_t N, int32_t width, int32_t height,
-                                          const float *gtstop, float *g2d, int32_t *big_list, int32_t parity,
-                                          int32_t row_span, eg_stream_t stream) {
-  EG_REQUIRE(N >= 0 && width > 0 && height > 0 && (parity == 0 || parity == 1), "bad sizes / parity");
+                                          const float *gtstop, float *g2d, eg_stream_t stream) {
+  EG_REQUIRE(N >= 0 && width > 0 && height > 0, "bad sizes");
   if (N == 0) return EG_OK;
-  EG_REQUIRE(splat && gtstop && g2d && big_list, "null pointer");
+  EG_REQUIRE(splat && gtstop && g2d, "null pointer");
   hipStream_t st = as_stream(stream);
-  (void)row_span;  // kept for ABI stability: the walk adapts per Gaussian now
   footprint_bwd_kernel<<<cdiv((int64_t)N, 32), 256, 0, st>>>((const float4 *)splat, N, width, height,
-                                                            (const StopRec *)gtstop, g2d, big_list, parity);
+                                                            (const StopRec *)gtstop, g2d);
   timing_mark(kMarkFootprint, st);
-  footprint_big_kernel<<<64, 256, 0, st>>>((const float4 *)splat, width, height, (const StopRec *)gtstop, g2d,
-                                          big_list, parity);
-  timing_mark(kMarkFootprintBig, st);
   return check_launch("composite_bwd_footprint");
 }
 

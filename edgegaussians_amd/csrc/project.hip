@@ -572,12 +572,11 @@ extern "C" int eg_backward_fused(float *means, float *quats, float *scales, floa
                                  float eps2d, uint32_t flags, const float *splat, const float *gtstop, float *g2d,
                                  float *v_means, float *v_quats, float *v_scales, float *v_opacities,
                                  float *absgrads, float *m, float *v, const eg_adam_hyper *hyper_host,
-                                 int32_t *big_list, int32_t parity, int32_t row_span, eg_stream_t stream) {
+                                 eg_stream_t stream) {
   EG_REQUIRE(N >= 0 && width > 0 && height > 0, "bad sizes");
   if (N == 0) return EG_OK;
-  EG_REQUIRE(means && quats && scales && opacities && viewmat && K && splat && gtstop && g2d && big_list,
-             "null pointer");
-  int rc = eg_composite_bwd_footprint(splat, N, width, height, gtstop, g2d, big_list, parity, row_span, stream);
+  EG_REQUIRE(means && quats && scales && opacities && viewmat && K && splat && gtstop && g2d, "null pointer");
+  int rc = eg_composite_bwd_footprint(splat, N, width, height, gtstop, g2d, stream);
   if (rc) return rc;
   if (hyper_host)
     return eg_project_bwd_adam(means, quats, scales, opacities, viewmat, K, N, width, height, eps2d, flags, splat,

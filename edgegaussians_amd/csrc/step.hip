@@ -59,7 +59,7 @@ namespace eg {
 constexpr int kStages = kNumMarks - 1;  // one stage ends at every mark after kMarkStart
 static const char *kStageNames[kStages] = {"project_bin", "tile_emit", "tile_sort", "composite_slice_fwd",
                                            "composite_combine_fwd", "composite_rewalk_fwd", "footprint_bwd",
-                                           "footprint_big", "project_bwd_adam"};
+                                           "project_bwd_adam"};
 static hipEvent_t *g_ev = nullptr;  // [(kStages + 1) * g_ev_steps]
 static int g_ev_steps = 0, g_ev_next = 0;
 static hipEvent_t *g_ev_cur = nullptr;  // events of the step being enqueued (nullptr outside a window)
@@ -144,10 +144,9 @@ extern "C" int eg_train_step(const eg_step_args *a, eg_stream_t stream) {
   if (rc) return rc;
   // (slice / combine / re-walk marks are recorded inside eg_composite_fwd)
   // backward: footprint compositing VJP, then projection VJP + absgrad (+ Adam)
-  rc = eg_composite_bwd_footprint(a->splat, a->N, a->width, a->height, a->gtstop, a->g2d, a->big_list, a->parity,
-                                  a->row_span, stream);
+  rc = eg_composite_bwd_footprint(a->splat, a->N, a->width, a->height, a->gtstop, a->g2d, stream);
   if (rc) return rc;
-  // (footprint / footprint_big marks are recorded inside eg_composite_bwd_footprint)
+  // (the footprint mark is recorded inside eg_composite_bwd_footprint)
   if (a->adam_host)
     rc = eg_project_bwd_adam(a->means, a->quats, a->log_scales, a->logit_opacities, a->viewmat, a->K, a->N,
                              a->width, a->height, 0.3f, flags, a->splat, a->g2d, a->adam_m, a->adam_v, a->absgrads,

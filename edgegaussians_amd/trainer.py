@@ -101,7 +101,6 @@ class EdgeTrainer:
         self.epoch = 0
         self.loss_scale = 1.0  # lambda_projection (train_gaussians.py:98; constant 1 in every config)
         self.capacity = 0
-        self.row_span = 0
         self._hyper = AdamHyper()
         self._alloc_state()
         self._alloc_pixels()
@@ -133,8 +132,6 @@ class EdgeTrainer:
         self.splat = torch.empty(N, 8, device=d)
         self.g2d = torch.empty(N, 8, device=d)  # written (not accumulated) by the footprint backward
         self.tile_mask = torch.zeros(N, dtype=torch.int32, device=d)  # exact tile hits per Gaussian (bit mask)
-        self.big_list = torch.zeros(2 + N, dtype=torch.int32, device=d)  # big-footprint work list
-        self._parity = 0
         self.grads = torch.zeros(N, 12, device=d)  # [means3|quats4|scales3|opac1|absgrad-inc1] for all-reduce
         self._args_cache: Dict = {}
 
@@ -234,8 +231,7 @@ class EdgeTrainer:
             a.N = self.N
             a.width, a.height = self.width, self.height
             a.splat, a.g2d = ptr(self.splat), ptr(self.g2d)
-            a.gtstop, a.big_list = ptr(self.gtstop), ptr(self.big_list)
-            a.row_span = self.row_span
+            a.gtstop = ptr(self.gtstop)
             a.tile_counts, a.offsets, a.total = ptr(self.tile_counts), ptr(self.offsets), ptr(self.total)
             a.item_offsets, a.workspace, a.max_items = ptr(self.item_offsets), ptr(self.workspace), self.max_items
             a.tile_mask, a.ticket = ptr(self.tile_mask), ptr(self.ticket)
@@ -254,8 +250,6 @@ class EdgeTrainer:
         a.gt = self.gt.data_ptr() + 4 * self.height * self.width * view
         a.wmap = wmap.data_ptr()
         a.loss_scale = self.loss_scale
-        a.parity = self._parity
-        self._parity ^= 1
         if fused_adam:
             a.absgrads = ptr(self.absgrads)
             a.adam_host = self._args_cache["hyper_ptr"]
@@ -323,9 +317,7 @@ class EdgeTrainer:
         mark("composite_fwd")
         call("eg_backward_fused", ptr(self.means), ptr(self.quats), ptr(self.log_scales),
              ptr(self.logit_opacities), vm, K, N, W, H, 0.3, fl, ptr(self.splat), ptr(self.gtstop), ptr(self.g2d),
-             None, None, None, None, ptr(self.absgrads), ptr(self.adam_m), ptr(self.adam_v), C.byref(self._hyper),
-             ptr(self.big_list), self._parity, self.row_span, st)
-        self._parity ^= 1
+             None, None, None, None, ptr(self.absgrads), ptr(self.adam_m), ptr(self.adam_v), C.byref(self._hyper), st)
         mark("backward_fused")
         self.absgrads_normalize_factor += 1
         self.step += 1

@@ -181,14 +181,11 @@ typedef struct {
  * order-independent); a wavefront owns 8 Gaussians and deals its 64 lanes out in proportion to
  * their footprint sizes; the footprint is walked as a sheared box that follows the ellipse.  The g2d
  * record is WRITTEN -- no tile lists, no atomics, no zeroing of g2d, deterministic.
- * big_list: int32[2 + N] scratch, zero-initialised ONCE by the caller (footprints above 8192 cells
- * are queued there and handled by a wavefront each).  `parity` (0/1) must alternate between
- * consecutive calls on the same big_list: call k uses counter big_list[parity] and clears the other
- * one for call k+1, which saves a memset node per step.  row_span is ignored (it selected between
- * two walks in an earlier revision; the walk adapts per Gaussian now) and kept for ABI stability. */
+ * Footprints of any size are handled in the one launch (a screen-filling Gaussian takes the lanes of
+ * its wavefront). */
 int eg_composite_bwd_footprint(const float *splat, int32_t N, int32_t width, int32_t height,
                                const float *gtstop /*[H,W,3]*/, float *g2d /*[N,8] written*/,
-                               int32_t *big_list, int32_t parity, int32_t row_span, eg_stream_t stream);
+                               eg_stream_t stream);
 
 /* ---- whole backward of the fused path: eg_composite_bwd_footprint, then eg_project_bwd_adam
  * (hyper_host != NULL: absgrads accumulated, Adam applied) or eg_project_bwd (hyper_host == NULL:
@@ -198,8 +195,7 @@ int eg_backward_fused(float *means, float *quats, float *scales, float *opacitie
                       float eps2d, uint32_t flags, const float *splat, const float *gtstop, float *g2d,
                       float *v_means, float *v_quats, float *v_scales, float *v_opacities,
                       float *absgrads /*[N]|NULL*/, float *m, float *v,
-                      const eg_adam_hyper *hyper_host /*NULL = write gradients*/, int32_t *big_list,
-                      int32_t parity, int32_t row_span, eg_stream_t stream);
+                      const eg_adam_hyper *hyper_host /*NULL = write gradients*/, eg_stream_t stream);
 
 /* ---- a6: absgrad accumulate on its own (edge_gs.py:607-613): absgrads += ||means2d.absgrad||_2 */
 int eg_absgrad_accum(const float *means2d_absgrad /*[N,2]*/, int32_t N, float *absgrads, eg_stream_t stream);
@@ -294,9 +290,6 @@ typedef struct {
   int64_t capacity;
   float *render, *alphas, *vpix, *loss; /* [H,W], [H,W], [H,W], [1] accumulated */
   float *gtstop;                        /* [H,W,3] */
-  int32_t *big_list;                    /* [2 + N], zero-initialised once */
-  int32_t parity;                       /* 0/1, alternates every step (see eg_composite_bwd_footprint) */
-  int32_t row_span;                     /* ignored (see eg_composite_bwd_footprint) */
   int32_t *last_ids;
   /* gradient outputs (used when adam == NULL, e.g. before an RCCL all-reduce) */
   float *v_means, *v_quats, *v_scales, *v_opacities;

@@ -1,3 +1,4 @@
-cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
-timeout 600 python -m pytest tests -m gpu -x -q -k "spatial or training_loop or densify or io" 2>&1 | grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl" | tail -25 > gpurun_out/exp_pytest.log
-timeout 300 python bench.py --config config2 --no-cpu-baseline 2>gpurun_out/exp_err.log | tail -1 > gpurun_out/exp_config2.json
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+timeout 600 rocprofv3 --kernel-trace -d /tmp/prof_c2 -o r01 -- python $R/bench.py --steps 200 --warmup 20 --profile-only > /dev/null 2>$R/gpurun_out/prof.err
+cd $R; python tools/timeline_gaps.py /tmp/prof_c2/r01_results.db > gpurun_out/gaps.txt; cat gpurun_out/gaps.txt

@@ -16,7 +16,7 @@ STAGE_OF = {
     "project_fwd_kernel": "project_bin", "tile_offsets_kernel": "tile_offsets", "tile_emit_kernel": "tile_emit",
     "tile_sort_kernel": "tile_sort", "composite_slice_fwd_kernel": "composite_slice_fwd",
     "composite_combine_fwd_kernel": "composite_combine_fwd", "composite_rewalk_fwd_kernel": "composite_rewalk_fwd",
-    "footprint_bwd_kernel": "footprint_bwd", "footprint_big_kernel": "footprint_big",
+    "footprint_bwd_kernel": "footprint_bwd",
     "project_bwd_kernel": "project_bwd_adam",
 }
 
