@@ -238,7 +238,8 @@ def main():
                                f"{'U(0.05,0.9)' if args.spread_opacity else '0.08'}), "
                                f"{n_views} views @{w}x{h}, loss whole/bg_edge_ratio 4:1",
                    "n_gaussians": n, "views": n_views, "width": w, "height": h, "lr_scale": LR_SCALE,
-                   "tile_intersections_M": m_last, "views_per_step": world,
+                   "tile_intersections_M": m_last, "largest_tile_population": int(tr.total[3].item()),
+                   "views_per_step": world,
                    "gaussian_row_order": "morton" if tr.spatial_order else "as given",
                    "parallelism": f"dp{world} (views sharded, RCCL all-reduce of [N,12] grads)" if world > 1 else "single GPU"},
         "mean_loss": loss_sum / (args.warmup + args.steps),

@@ -479,7 +479,7 @@ extern "C" int eg_tile_emit(const float *means2d, const int32_t *radii, const fl
 static bool g_sort_attr_set = false;
 
 extern "C" int eg_sort_pairs(uint64_t *keys, const int32_t *offsets, int32_t T, int64_t capacity,
-                             int32_t *flatten_ids, int64_t *isect_ids, eg_stream_t stream) {
+                             int32_t *flatten_ids, int64_t *isect_ids, int32_t max_tile_hint, eg_stream_t stream) {
   EG_REQUIRE(T > 0 && offsets, "bad arguments");
   if (capacity == 0) return EG_OK;
   EG_REQUIRE(keys && flatten_ids, "null pointer");
@@ -491,9 +491,16 @@ extern "C" int eg_sort_pairs(uint64_t *keys, const int32_t *offsets, int32_t T, 
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLargeLds);
     g_sort_attr_set = true;
   }
+  // max_tile_hint: the largest tile population the caller has seen (0 = unknown).  If even 1.5x that
+  // fits the small variant, the launch of the large one (256 workgroups of 1024 threads and 136 KiB of
+  // LDS that would all find nothing to do: ~3 us) is skipped and the small variant owns EVERY tile -- a
+  // tile that outgrew the hint is then still sorted correctly, by the slower paths of the small variant.
+  const bool small_only = max_tile_hint > 0 && (int64_t)max_tile_hint * 3 / 2 <= kSmall;
   tile_sort_kernel<256, kSmall, false><<<T, 256, kSmallLds, as_stream(stream)>>>(
-      (unsigned long long *)keys, offsets, T, (long long)capacity, kSmall, flatten_ids, (long long *)isect_ids);
-  tile_sort_kernel<1024, kLarge, true><<<min(T, 256), 1024, kLargeLds, as_stream(stream)>>>(
-      (unsigned long long *)keys, offsets, T, (long long)capacity, kSmall, flatten_ids, (long long *)isect_ids);
+      (unsigned long long *)keys, offsets, T, (long long)capacity, small_only ? 0x7fffffff : kSmall, flatten_ids,
+      (long long *)isect_ids);
+  if (!small_only)
+    tile_sort_kernel<1024, kLarge, true><<<min(T, 256), 1024, kLargeLds, as_stream(stream)>>>(
+        (unsigned long long *)keys, offsets, T, (long long)capacity, kSmall, flatten_ids, (long long *)isect_ids);
   return check_launch("tile_sort");
 }

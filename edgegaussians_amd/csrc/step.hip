@@ -135,7 +135,7 @@ extern "C" int eg_train_step(const eg_step_args *a, eg_stream_t stream) {
                     a->tile_counts, a->capacity, a->keys, a->tile_mask, stream);
   if (rc) return rc;
   EG_MARK(kMarkEmit);
-  rc = eg_sort_pairs(a->keys, a->offsets, T, a->capacity, a->flatten_ids, nullptr, stream);
+  rc = eg_sort_pairs(a->keys, a->offsets, T, a->capacity, a->flatten_ids, nullptr, a->max_tile_hint, stream);
   if (rc) return rc;
   EG_MARK(kMarkSort);
   rc = eg_composite_fwd(a->splat, nullptr, 1, a->offsets, a->flatten_ids, a->width, a->height, a->render,

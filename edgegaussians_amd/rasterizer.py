@@ -164,7 +164,7 @@ class _Compositing(torch.autograd.Function):
 
 
 def isect_tiles_and_sort(means2d: Tensor, radii: Tensor, depths: Tensor, counts: Tensor, width: int,
-                         height: int, want_isect_ids: bool = True
+                         height: int, want_isect_ids: bool = True, max_tile_hint: Optional[int] = None
                          ) -> Tuple[Tensor, Tensor, Optional[Tensor], int, Tensor, Tensor, int]:
     """Per camera: offsets[T+1] (scan of `counts`), keys -> sorted flatten_ids (+ int64 isect ids).
 
@@ -177,14 +177,14 @@ def isect_tiles_and_sort(means2d: Tensor, radii: Tensor, depths: Tensor, counts:
     item_offsets = torch.empty(T + 1, dtype=torch.int32, device=dev)
     total = torch.empty(4, dtype=torch.int32, device=dev)
     call("eg_tile_offsets", ptr(counts), T, 1 << 40, ptr(offsets), ptr(item_offsets), ptr(total), stream())
-    M, _ovf, n_items, _nmax = (int(v) for v in total.tolist())
+    M, _ovf, n_items, nmax = (int(v) for v in total.tolist())
     keys = torch.empty(max(M, 1), dtype=torch.int64, device=dev)
     flat = torch.empty(max(M, 1), dtype=torch.int32, device=dev)
     ids = torch.empty(max(M, 1), dtype=torch.int64, device=dev) if want_isect_ids else None
     call("eg_tile_emit", ptr(means2d), ptr(radii), ptr(depths), None, 0, N, width, height, ptr(offsets),
          ptr(counts), M, ptr(keys), None, stream())
     call("eg_sort_pairs", ptr(keys), ptr(offsets), T, M, ptr(flat), ptr(ids) if ids is not None else None,
-         stream())
+         nmax if max_tile_hint is None else max_tile_hint, stream())  # the host knows the exact maximum here
     return offsets, flat[:M], (ids[:M] if ids is not None else None), M, item_offsets, total, n_items
 
 

@@ -204,15 +204,20 @@ class EdgeTrainer:
              None, None, None, None, None, None, ptr(self.tile_counts), None, stream())
         call("eg_tile_offsets", ptr(self.tile_counts), self.T, 1 << 40, ptr(self.offsets), ptr(self.item_offsets),
              ptr(self.total), stream())
-        m = int(self.total[0].item())
+        tot = self.total.tolist()  # one host sync: M, overflow flag, items, largest tile population
+        self._last_tile_max = int(tot[3])
         self.tile_counts.zero_()
-        return m
+        return int(tot[0])
 
     def ensure_capacity(self, slack: float = 1.3, views: Optional[List[int]] = None) -> int:
         """Sizes the isect buffers from a count-only sweep (called at start and after every
         densify / cull event, i.e. whenever N changes -- 22 times in a 400-epoch ABC run)."""
         views = list(range(self.V)) if views is None else views
-        m_max = max(self.count_intersections(v) for v in views)
+        m_max, tile_max = 0, 0
+        for v in views:
+            m_max = max(m_max, self.count_intersections(v))
+            tile_max = max(tile_max, self._last_tile_max)
+        self.max_tile_seen = tile_max  # launch-shape hint of the tile sort (never affects results)
         need = int(m_max * slack) + 4096
         if need > self.capacity:
             self._alloc_isect(need)
@@ -232,6 +237,7 @@ class EdgeTrainer:
             a.width, a.height = self.width, self.height
             a.splat, a.g2d = ptr(self.splat), ptr(self.g2d)
             a.gtstop = ptr(self.gtstop)
+            a.max_tile_hint = getattr(self, "max_tile_seen", 0)
             a.tile_counts, a.offsets, a.total = ptr(self.tile_counts), ptr(self.offsets), ptr(self.total)
             a.item_offsets, a.workspace, a.max_items = ptr(self.item_offsets), ptr(self.workspace), self.max_items
             a.tile_mask, a.ticket = ptr(self.tile_mask), ptr(self.ticket)
@@ -308,7 +314,7 @@ class EdgeTrainer:
              self.capacity, ptr(self.keys), None, st)
         mark("tile_emit")
         call("eg_sort_pairs", ptr(self.keys), ptr(self.offsets), self.T, self.capacity, ptr(self.flatten_ids),
-             None, st)
+             None, getattr(self, "max_tile_seen", 0), st)
         mark("tile_sort")
         call("eg_composite_fwd", ptr(self.splat), None, 1, ptr(self.offsets), ptr(self.flatten_ids), W, H,
              ptr(self.render), ptr(self.alphas), ptr(self.last_ids), ptr(self.gt[view]), ptr(wmap),
@@ -414,6 +420,11 @@ class EdgeTrainer:
         train_gaussians.py:99) -- ONE device sync for many steps instead of two per step."""
         v = float(self.loss_acc.item())
         self.loss_acc.zero_()
+        # the stream is drained anyway: refresh the tile-sort launch hint from the last step's scan
+        tile_max = int(self.total[3].item())
+        if tile_max > getattr(self, "max_tile_seen", 0):
+            self.max_tile_seen = tile_max
+            self._args_cache = {}
         return v
 
     def overflowed(self) -> bool:

@@ -108,6 +108,8 @@ int eg_tile_emit(const float *means2d_or_null, const int32_t *radii_or_null, con
  * Gaussian ids (gsplat flatten_ids) and optionally the int64 isect ids (tile<<32 | depth_bits). */
 int eg_sort_pairs(uint64_t *keys /*[capacity] in/out*/, const int32_t *offsets /*[T+1]*/, int32_t T,
                   int64_t capacity, int32_t *flatten_ids /*[capacity]*/, int64_t *isect_ids /*[capacity]|NULL*/,
+                  int32_t max_tile_hint /*largest tile population seen so far, 0 = unknown: launch-shape hint
+                  only (skips the idle launch of the large-tile variant), never affects the result*/,
                   eg_stream_t stream);
 
 /* ---- G7: alpha compositing forward (replaces gsplat rasterize_to_pixels fwd).
@@ -288,6 +290,7 @@ typedef struct {
   uint64_t *keys;
   int32_t *flatten_ids;
   int64_t capacity;
+  int32_t max_tile_hint;                /* see eg_sort_pairs; 0 = unknown */
   float *render, *alphas, *vpix, *loss; /* [H,W], [H,W], [H,W], [1] accumulated */
   float *gtstop;                        /* [H,W,3] */
   int32_t *last_ids;

@@ -76,7 +76,7 @@ def test_projection_forward(env):
 
 
 # ------------------------------------------------------------------ G2-G6 (bit exact on oracle floats)
-def _bin_on_device(means2d, radii, depths, W, H):
+def _bin_on_device(means2d, radii, depths, W, H, max_tile_hint=None):
     from edgegaussians_amd._lib import call, ptr, stream
     from edgegaussians_amd.rasterizer import isect_tiles_and_sort
     N = means2d.shape[0]
@@ -86,13 +86,14 @@ def _bin_on_device(means2d, radii, depths, W, H):
     counts = torch.zeros(tw * th, dtype=torch.int32, device="cuda")
     call("eg_tile_count", ptr(m), ptr(r), N, W, H, ptr(tpg), ptr(counts), stream())
     counts_copy = counts.clone()
-    offsets, flat, ids, M = isect_tiles_and_sort(m, r, d, counts, W, H)[:4]
+    offsets, flat, ids, M = isect_tiles_and_sort(m, r, d, counts, W, H, max_tile_hint=max_tile_hint)[:4]
     torch.cuda.synchronize()
     assert int(counts.abs().sum()) == 0, "emit must return the tile counters to zero"
     return to_np(tpg), to_np(ids), to_np(flat), to_np(offsets), M, to_np(counts_copy)
 
 
-@pytest.mark.parametrize("case", ["scene", "ties", "huge_tile", "giant_tile", "empty"])
+@pytest.mark.parametrize("case", ["scene", "ties", "huge_tile", "giant_tile", "empty", "mid_tile_stale_hint",
+                                  "huge_tile_stale_hint"])
 def test_binning_bit_exact(env, case):
     _lib, synth, O = env
     W, H = 200, 136
@@ -106,10 +107,12 @@ def test_binning_bit_exact(env, case):
         m2d = torch.rand(n, 2, generator=g) * torch.tensor([W, H])
         radii = torch.randint(1, 30, (n,), generator=g, dtype=torch.int32)
         dep = torch.randint(1, 5, (n,), generator=g).float()
-    elif case in ("huge_tile", "giant_tile"):
+    elif case in ("huge_tile", "giant_tile", "mid_tile_stale_hint", "huge_tile_stale_hint"):
         # huge: 8192 < n <= 16384 in one tile -> in-LDS bitonic network; giant: > 16384 -> hybrid
         # global/LDS network.  (scene: bucket+rank; ties: bucket overflow -> bitonic fallback)
-        n = 11000 if case == "huge_tile" else 21000
+        # *_stale_hint: the caller's tile-population hint (1) is far too small, so the large-tile launch is
+        # skipped and the small variant must sort 2048 < n <= 4096 (in-LDS network) and n > 4096 (hybrid) itself
+        n = {"huge_tile": 11000, "giant_tile": 21000, "mid_tile_stale_hint": 3400, "huge_tile_stale_hint": 11000}[case]
         m2d = torch.rand(n, 2, generator=g) * 10 + torch.tensor([40.0, 40.0])
         radii = torch.randint(1, 4, (n,), generator=g, dtype=torch.int32)
         dep = torch.rand(n, generator=g) * 5 + 0.5
@@ -121,8 +124,10 @@ def test_binning_bit_exact(env, case):
         dep = torch.zeros(n)
     tpg_o, ids_o, flat_o = O.isect_tiles(to_np(m2d), to_np(radii), to_np(dep), 16, tw, th)
     offs_o = O.isect_offset_encode(ids_o, tw, th).reshape(-1)
-    tpg, ids, flat, offsets, M, counts = _bin_on_device(m2d, radii, dep, W, H)
+    tpg, ids, flat, offsets, M, counts = _bin_on_device(m2d, radii, dep, W, H, 1 if case.endswith("stale_hint") else None)
     assert M == len(ids_o)
+    if case == "mid_tile_stale_hint":
+        assert 2048 < counts.max() <= 4096
     if case == "huge_tile":
         assert 8192 < counts.max() <= 16384
     if case == "giant_tile":

@@ -20,7 +20,7 @@ def bind(name, *args):
     return f
 fwd = bind("eg_composite_fwd", ptr(tr.splat), None, 1, ptr(tr.offsets), ptr(tr.flatten_ids), W, H, ptr(tr.render), ptr(tr.alphas), ptr(tr.last_ids), ptr(tr.gt[view]), ptr(whole), 1.0, ptr(tr.vpix), ptr(tr.loss_acc), ptr(tr.item_offsets), ptr(tr.total), tr.max_items, ptr(tr.workspace), ptr(tr.gtstop), st)
 fp = bind("eg_composite_bwd_footprint", ptr(tr.splat), N, W, H, ptr(tr.gtstop), ptr(tr.g2d), st)
-srt = bind("eg_sort_pairs", ptr(tr.keys), ptr(tr.offsets), tr.T, tr.capacity, ptr(tr.flatten_ids), None, st)
+srt = bind("eg_sort_pairs", ptr(tr.keys), ptr(tr.offsets), tr.T, tr.capacity, ptr(tr.flatten_ids), None, 0, st)
 def host_time(f, reps):
     f(); torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(reps): f()
