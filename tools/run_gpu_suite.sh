@@ -8,7 +8,7 @@ mkdir -p $O
 cd $R
 timeout 1200 python -m pytest tests -m gpu -x -q 2>&1 | grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl" | tail -6 > $O/pytest_gpu.log
 timeout 600 python bench.py 2>/dev/null | tail -1 > $O/bench_c2.json
-for c in config1 config3; do
+for c in config1 config3 config4; do
   timeout 600 python bench.py --config $c --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_${c}.json
 done
 timeout 600 python bench.py --config config2 --spread-opacity --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_c2_spread.json
