@@ -872,15 +872,16 @@ __device__ __forceinline__ void footprint_visit(const float4 s0, const float4 s1
   const float gT = rec.gT;
   const float dx = s0.x - ((float)j + 0.5f), dy = s0.y - ((float)i + 0.5f);
   const float sigma = 0.5f * (s0.z * dx * dx + s1.x * dy * dy) + s0.w * dx * dy;
-  if (!(gT != 0.f && sigma >= 0.f && sigma <= thr)) return;
+  // where the walk of this pixel stopped only Gaussians at or before the last contributor count:
+  // (depth bits, id) <= (its depth bits, its id).  Tested before the exp: in dense scenes most visits
+  // of a saturated pixel are behind its stop.
+  const unsigned dg = (unsigned)__float_as_int(s1.z);
+  const bool after_stop = (rec.stop_id >= 0) & ((dg > rec.stop_depth) | ((dg == rec.stop_depth) & (g > rec.stop_id)));
+  if (!(gT != 0.f && sigma >= 0.f && sigma <= thr) || after_stop) return;
   const float vis = __expf(-sigma);
   const float araw = s1.y * vis;
   // forward: skip if min(0.999, araw) < 1/255; gsplat's backward: no gradient through a clamped alpha
-  // where the walk of this pixel stopped only Gaussians at or before the last contributor count:
-  // (depth bits, id) <= (its depth bits, its id)
-  const unsigned dg = (unsigned)__float_as_int(s1.z);
-  const bool after_stop = (rec.stop_id >= 0) & ((dg > rec.stop_depth) | ((dg == rec.stop_depth) & (g > rec.stop_id)));
-  const bool ok = (araw >= kAlphaMin) & (araw <= kAlphaMax) & !after_stop;
+  const bool ok = (araw >= kAlphaMin) & (araw <= kAlphaMax);
   const float v_alpha = ok ? gT * __builtin_amdgcn_rcpf(1.f - araw) : 0.f;
   m.v_o += vis * v_alpha;
   const float w = -araw * v_alpha;
