@@ -285,12 +285,61 @@ def filter_projection(views, keep):
     np.savez_compressed(os.path.join(OUT, "filter_projection.npz"), means=means, views=np.array(keep), **out)
 
 
+def train_fixture(views):
+    """A small end-to-end training problem cut from the reference's own data: 16 of the 50 DexiNed
+    edge maps of scan 00004926 at half resolution (2x2 block mean, sparse), their cameras, and 4000 of
+    the ground-truth edge points the reference's eval.py scores against (groundtruth/sampled_pts)."""
+    sel = list(range(0, 48, 3))
+    H, W = views[0]["camera"].height, views[0]["camera"].width
+    out = {"views": np.array(sel), "height": H // 2, "width": W // 2}
+    Ks, vms = [], []
+    for k in sel:
+        cam = views[k]["camera"]
+        K = cam.get_K().cpu().numpy()[0].astype(np.float64).copy()
+        K[0, 0] *= 0.5; K[1, 1] *= 0.5                      # pixel centres at integer + 0.5 in both grids
+        K[0, 2] = (K[0, 2] + 0.5) * 0.5 - 0.5; K[1, 2] = (K[1, 2] + 0.5) * 0.5 - 0.5
+        Ks.append(K.astype(np.float32)); vms.append(cam.viewmat.cpu().numpy().astype(np.float32))
+        im = views[k]["image"].numpy().astype(np.float32).reshape(H // 2, 2, W // 2, 2).mean(axis=(1, 3))
+        im = np.round(im).astype(np.uint8)
+        nz = np.flatnonzero(im)
+        out[f"idx_{k}"] = nz.astype(np.int32)
+        out[f"val_{k}"] = im.reshape(-1)[nz]
+    out["Ks"], out["viewmats"] = np.stack(Ks), np.stack(vms)
+    # binary little-endian PLY written by Open3D: double x y z + uchar r g b per vertex
+    raw = open(os.path.join(REF, "data/ABC-NEF_Edge/groundtruth/sampled_pts/00004926_0.005.ply"), "rb").read()
+    head_end = raw.index(b"end_header\n") + len(b"end_header\n")
+    n = int([ln for ln in raw[:head_end].decode().splitlines() if ln.startswith("element vertex")][0].split()[-1])
+    rec = np.frombuffer(raw, dtype=np.dtype([("p", "<f8", 3), ("c", "u1", 3)]), count=n, offset=head_end)
+    pick = np.random.default_rng(0).choice(n, 4000, replace=False)
+    out["gt_points"] = rec["p"][np.sort(pick)].astype(np.float32)
+    np.savez_compressed(os.path.join(OUT, "abc_00004926_train.npz"), **out)
+
+
+def train_config():
+    """The schedule the training loop consumes (numbers only), as parsed from configs/ABC_DexiNed.json."""
+    used_model = ["if_duplicate_high_pos_grad", "dup_threshold_type", "dup_threshold_value", "dup_factor",
+                  "dup_high_pos_grads_at_epoch", "if_cull_low_opacity", "cull_opacity_type", "cull_opacity_value",
+                  "cull_opacity_at_epoch", "if_cull_gaussians_not_projecting", "cull_gaussians_not_projecting_at_epoch",
+                  "cull_gaussians_not_projecting_threshold", "init_min_num_gaussians", "random_init_box_center",
+                  "random_init_box_size", "init_dup_rand_noise_scale", "init_scales_val", "init_opacity_val"]
+    tr = CFG["training"]
+    out = {"model": {k: CFG["model"][k] for k in used_model},
+           "training": {"num_epochs": tr["num_epochs"], "optim": tr["optim"], "loss": tr["loss"]}}
+    json.dump(out, open(os.path.join(OUT, "abc_train_config.json"), "w"), indent=1, sort_keys=True)
+
+
 if __name__ == "__main__":
     views, keep = cameras_and_edges()
+    if "--only-train" in sys.argv:
+        train_fixture(views)
+        train_config()
+        raise SystemExit(0)
     if "--only-filter" in sys.argv:
         filter_projection(views, keep)
         raise SystemExit(0)
     filter_projection(views, keep)
+    train_fixture(views)
+    train_config()
     quats()
     lr_table()
     m, cams = losses_and_masks(views, keep)

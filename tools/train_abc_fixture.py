@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""End-to-end training on the ABC-NEF 00004926 fixture (16 real DexiNed views at 400x400, cameras and
+ground-truth edge points cut from the reference's data by tests/golden/make_golden.py): the reference's
+ABC schedule (optionally with the calendar compressed to `--epochs`), then the precision / recall of the surviving
+Gaussian means against the ground-truth edge points at `--tau` (the reference's eval.py scores edges
+fitted to these means the same way).
+
+    python tools/train_abc_fixture.py            # the full 400-epoch calendar: 6400 steps, ~1.5 s
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def load_fixture(golden_dir):
+    d = np.load(os.path.join(golden_dir, "abc_00004926_train.npz"))
+    H, W = int(d["height"]), int(d["width"])
+    views = list(d["views"])
+    gt = torch.zeros(len(views), H * W)
+    for i, k in enumerate(views):
+        gt[i][torch.from_numpy(d[f"idx_{k}"]).long()] = torch.from_numpy(d[f"val_{k}"]).float() / 255.0
+    return gt.view(len(views), H, W), torch.from_numpy(d["viewmats"]), torch.from_numpy(d["Ks"]), W, H, d["gt_points"]
+
+
+def run(epochs=400, seed=0, n_init=2500, verbose=False):
+    from edgegaussians_amd import EdgeTrainer, synth, train
+    golden = os.path.join(ROOT, "tests", "golden")
+    gt, vms, Ks, W, H, gt_points = load_fixture(golden)
+    g = torch.Generator().manual_seed(seed)
+    means = 1.1 * torch.rand(n_init, 3, generator=g) - 0.55 + 0.5         # random_init_box_center 0.5, size 1.1
+    tr = EdgeTrainer(means, torch.full((n_init, 3), math.log(0.004)), synth.random_quats(n_init, g),
+                     torch.logit(torch.full((n_init, 1), 0.08)), vms, Ks, gt, W, H, spatial_order=True)
+    cfg = json.load(open(os.path.join(golden, "abc_train_config.json")))   # configs/ABC_DexiNed.json, parsed
+    model_cfg, training_cfg = cfg["model"], cfg["training"]
+    if epochs != training_cfg["num_epochs"]:                                # compress the 400-epoch calendar
+        f = epochs / float(training_cfg["num_epochs"])
+        sc = lambda e: max(1, int(round(e * f)))                            # noqa: E731
+        for k in ("scales", "opacities", "quats"):
+            training_cfg["optim"][k]["start_at_epoch"] = sc(training_cfg["optim"][k]["start_at_epoch"])
+        for k in ("dup_high_pos_grads_at_epoch", "cull_opacity_at_epoch", "cull_gaussians_not_projecting_at_epoch"):
+            model_cfg[k] = sorted({sc(e) for e in model_cfg[k]})
+        ol, pl = training_cfg["loss"]["orientation_losses"], training_cfg["loss"]["projection_losses"]
+        ol["start_dir_loss_at_epoch"], ol["start_ratio_loss_at_epoch"] = sc(ol["start_dir_loss_at_epoch"]), sc(ol["start_ratio_loss_at_epoch"])
+        pl["start_alternating_at_epoch"] = sc(pl["start_alternating_at_epoch"])
+        training_cfg["num_epochs"] = epochs
+    V = gt.shape[0]
+    order = lambda epoch: torch.randperm(V, generator=g).tolist()          # noqa: E731
+    log = []
+    t0 = time.perf_counter()
+    hist = train(tr, model_cfg, training_cfg, order,
+                 on_epoch=(lambda e, l, n: log.append((e, l, n))) if verbose else None)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    sd = tr.state_dict()
+    keep = torch.sigmoid(sd["gauss_params.opacities"].view(-1)) > 0.5
+    pts = sd["gauss_params.means"][keep]
+    gtp = torch.from_numpy(gt_points).to(pts.device)
+    d = torch.cdist(pts, gtp)
+    return {"epochs": epochs, "steps": tr.step, "seconds": dt, "n_final": tr.N, "n_opaque": int(keep.sum()),
+            "loss_first": hist[0], "loss_last": hist[-1], "d_pred_to_gt": d.min(1).values, "d_gt_to_pred": d.min(0).values,
+            "log": log}
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--epochs", type=int, default=400)
+    ap.add_argument("--seed", type=int, default=0)
+    a = ap.parse_args()
+    r = run(a.epochs, a.seed, verbose=True)
+    for tau in (0.01, 0.02, 0.04):
+        print(f"tau {tau}: precision {float((r['d_pred_to_gt'] < tau).float().mean()):.3f}  "
+              f"recall {float((r['d_gt_to_pred'] < tau).float().mean()):.3f}")
+    print({k: v for k, v in r.items() if k not in ("d_pred_to_gt", "d_gt_to_pred", "log")})
+    print("epoch loss N:", [(e, round(l, 5), n) for e, l, n in r["log"][::max(1, a.epochs // 12)]])
