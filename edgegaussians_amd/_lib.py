@@ -132,5 +132,11 @@ def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return t.data_ptr()
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream() -> int:
+    """The current torch stream's raw handle (what every entry point takes as its last argument)."""
+    if _raw_stream is not None:  # ~1 us instead of ~9 us for the Stream-object round trip: it is paid per step
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
