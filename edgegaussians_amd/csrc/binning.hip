@@ -285,7 +285,7 @@ tile_sort_kernel(unsigned long long *__restrict__ keys, const int *__restrict__ 
   unsigned long long *kin = s, *kout = s + CAP;
   int *hist = (int *)(s + 2 * CAP);  // [THREADS] counts -> exclusive starts
   int *cursor = hist + THREADS;      // [THREADS]
-  __shared__ unsigned wave_tmp[16];
+  __shared__ unsigned wave_tmp[32], wave_tmp2[32];  // two hops per tile, never the same array twice in a row
 
   const int tid = threadIdx.x;
   // the large variant runs a small grid (<= 256 workgroups of 136 KiB LDS) striding over the tiles
@@ -312,8 +312,18 @@ tile_sort_kernel(unsigned long long *__restrict__ keys, const int *__restrict__ 
     }
     hist[tid] = 0;
     cursor[tid] = 0;
-    dmin = block_reduce_u32<THREADS>(dmin, false, wave_tmp);
-    dmax = block_reduce_u32<THREADS>(dmax, true, wave_tmp);
+    // depth range of the tile: both reductions share one LDS hop and one barrier
+    constexpr int NW = THREADS / 64;
+    const int lane = tid & 63, wv = tid >> 6;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+      dmin = min(dmin, (unsigned)__shfl_xor((int)dmin, d, 64));
+      dmax = max(dmax, (unsigned)__shfl_xor((int)dmax, d, 64));
+    }
+    if (lane == 0) { wave_tmp[wv] = dmin; wave_tmp[16 + wv] = dmax; }
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < NW; ++w) { dmin = min(dmin, wave_tmp[w]); dmax = max(dmax, wave_tmp[16 + w]); }
     const float scale = (float)THREADS / ((float)(dmax - dmin) + 1.f);
     for (int i = tid; i < n; i += THREADS) {
       const unsigned d = (unsigned)(kin[i] >> 32);
@@ -321,12 +331,28 @@ tile_sort_kernel(unsigned long long *__restrict__ keys, const int *__restrict__ 
       atomicAdd(&hist[bk], 1);
     }
     __syncthreads();
+    // exclusive scan of the bucket counts and their maximum, again one hop and one barrier
     const int cnt = hist[tid];
-    const unsigned fill = block_reduce_u32<THREADS>((unsigned)cnt, true, wave_tmp);
+    int incl = cnt, wmax = cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int o = __shfl_up(incl, d, 64);
+      if (lane >= d) incl += o;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) wmax = max(wmax, __shfl_xor(wmax, d, 64));
+    if (lane == 63) wave_tmp2[wv] = (unsigned)incl;
+    if (lane == 0) wave_tmp2[16 + wv] = (unsigned)wmax;
+    __syncthreads();
+    int pre = 0;
+    unsigned fill = 0u;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      pre += (w < wv) ? (int)wave_tmp2[w] : 0;
+      fill = max(fill, wave_tmp2[16 + w]);
+    }
     if (fill <= (unsigned)kMaxBucketFill) {
-      int tot;
-      const int excl = block_excl_scan<THREADS>(cnt, (int *)wave_tmp, tot);
-      hist[tid] = excl;
+      hist[tid] = pre + (incl - cnt);
       __syncthreads();
       for (int i = tid; i < n; i += THREADS) {
         const unsigned long long k = kin[i];

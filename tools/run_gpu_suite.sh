@@ -18,6 +18,7 @@ timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/pmc_fetch -o f -- 
 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/pmc_write -o w -- python $R/bench.py --steps 40 --warmup 5 --profile-only > /dev/null 2>$O/pmc_w.err
 cd $R
 python tools/rocpd_summary.py /tmp/prof_c2/r01_results.db $O/kstats.txt > /dev/null
+python tools/timeline_gaps.py /tmp/prof_c2/r01_results.db > $O/gaps.txt
 python tools/pmc_summary.py /tmp/pmc_fetch/f_results.db /tmp/pmc_write/w_results.db $O/pmc_config2.json > /dev/null
 # second bench pass so that roofline.traffic is filled from the PMC file of THIS build
 cp $O/pmc_config2.json $R/profiles/r01_pmc_config2.json
