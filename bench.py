@@ -238,9 +238,10 @@ def main():
                                f"{'U(0.05,0.9)' if args.spread_opacity else '0.08'}), "
                                f"{n_views} views @{w}x{h}, loss whole/bg_edge_ratio 4:1",
                    "n_gaussians": n, "views": n_views, "width": w, "height": h, "lr_scale": LR_SCALE,
-                   "tile_intersections_M": m_last, "largest_tile_population": int(tr.total[3].item()),
+                   "tile_intersections_M": m_last, "largest_tile_population": int(tr.max_tile_seen),
                    "views_per_step": world,
                    "gaussian_row_order": "morton" if tr.spatial_order else "as given",
+                   "binning": "segmented" if tr.segmented else "scan",
                    "parallelism": f"dp{world} (views sharded, RCCL all-reduce of [N,12] grads)" if world > 1 else "single GPU"},
         "mean_loss": loss_sum / (args.warmup + args.steps),
         "host_enqueue_ms_per_step": 1e3 * t_enq / args.steps,
@@ -259,6 +260,9 @@ def main():
         tr.pop_loss()
     if rank == 0 and not args.profile_only:
         ab = algorithmic_bytes(n, m_last, w * h)
+        if tr.segmented:  # projection and key emission are one kernel; the emit stage is an empty pair of events
+            ab["project_bin"] += ab.pop("tile_emit")
+            stage_us.pop("tile_emit", None)
         dom = max(stage_us, key=stage_us.get)
         achieved = ab[dom] / (stage_us[dom] * 1e-6) / 1e9
         traffic = None

@@ -45,6 +45,7 @@ class StepArgs(C.Structure):
         ("tile_mask", _vp), ("ticket", _vp),
         ("workspace", _vp), ("max_items", _i64),
         ("keys", _vp), ("flatten_ids", _vp), ("capacity", _i64), ("max_tile_hint", _i32),
+        ("seg_cap", _i32), ("tile_end", _vp), ("item_end", _vp), ("item_tile", _vp),
         ("render", _vp), ("alphas", _vp), ("vpix", _vp), ("loss", _vp), ("gtstop", _vp),
         ("last_ids", _vp),
         ("v_means", _vp), ("v_quats", _vp), ("v_scales", _vp), ("v_opacities", _vp),
@@ -60,6 +61,9 @@ _SIGS = {
     "eg_tile_emit": [_vp, _vp, _vp, _vp, _u32, _i32, _i32, _i32, _vp, _vp, _i64, _vp, _vp, _vp],
     "eg_project_bin": [_vp] * 6 + [_i32, _i32, _i32, _u32, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp],
     "eg_sort_pairs": [_vp, _vp, _i32, _i64, _vp, _vp, _i32, _vp],
+    "eg_project_emit": [_vp] * 6 + [_i32, _i32, _i32, _u32, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _vp],
+    "eg_sort_segments": [_vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp],
+    "eg_composite_fwd_segments": [_vp] * 7 + [_i32, _i32, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _i64, _vp, _vp, _vp],
     "eg_composite_fwd": [_vp, _vp, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp,
                          _vp, _vp, _i64, _vp, _vp, _vp],
     "eg_composite_bwd": [_vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp],

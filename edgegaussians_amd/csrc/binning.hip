@@ -275,12 +275,27 @@ __device__ __forceinline__ unsigned block_reduce_u32(unsigned v, bool take_max, 
 
 constexpr int kMaxBucketFill = 96;  // beyond this a bucket's rank pass degenerates: use the network
 
+// Segmented layout (eg_project_emit): tile t owns keys[t * seg_cap ...), its population sits in
+// cursor[t] and the first of its items (128-Gaussian slices) in item_first[t].  The small variant
+// (always launched, one workgroup per tile) writes the per-tile tables exactly once -- key range, item
+// range, item -> tile map -- and returns the cursor to zero; the large variant, launched after it,
+// reads the ranges.  cursor == nullptr: classic layout, ranges come from `offsets`.
+struct SegTable {
+  int *cursor;
+  int seg_cap;
+  int *tile_start, *tile_end;  // [T]
+  const int *item_first;       // [T] (from the scan in eg_project_emit)
+  int *item_end;               // [T]
+  int *item_tile;              // [max_items]
+  int max_items;
+};
+
 // THREADS = number of buckets; CAP = keys per buffer (two buffers).  n_lo < n handled here.
 template <int THREADS, int CAP, bool LARGE>
 __global__ void __launch_bounds__(THREADS)
 tile_sort_kernel(unsigned long long *__restrict__ keys, const int *__restrict__ offsets, int T,
                  long long capacity, int small_cap, int *__restrict__ flatten_ids,
-                 long long *__restrict__ isect_ids) {
+                 long long *__restrict__ isect_ids, const SegTable seg) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long s[];
   unsigned long long *kin = s, *kout = s + CAP;
   int *hist = (int *)(s + 2 * CAP);  // [THREADS] counts -> exclusive starts
@@ -291,9 +306,30 @@ tile_sort_kernel(unsigned long long *__restrict__ keys, const int *__restrict__ 
   // the large variant runs a small grid (<= 256 workgroups of 136 KiB LDS) striding over the tiles
   for (int tile = blockIdx.x; tile < T; tile += gridDim.x) {
   __syncthreads();
-  const long long start = offsets[tile];
-  long long end = offsets[tile + 1];
-  if (end > capacity) end = capacity;
+  long long start, end;
+  if (seg.cursor) {
+    if (!LARGE) {
+      const int kept = min(seg.cursor[tile], seg.seg_cap);  // every thread reads it; reset after the barrier
+      const int first = seg.item_first[tile], items = min((kept + 127) >> 7, max(0, seg.max_items - first));
+      __syncthreads();
+      if (tid == 0) {
+        seg.cursor[tile] = 0;  // ready for the next step
+        seg.tile_start[tile] = tile * seg.seg_cap;
+        seg.tile_end[tile] = tile * seg.seg_cap + kept;
+        seg.item_end[tile] = first + items;
+      }
+      for (int i = tid; i < items; i += THREADS) seg.item_tile[first + i] = tile;
+      start = (long long)tile * seg.seg_cap;
+      end = start + kept;
+    } else {  // launched after the small variant: the ranges are in place
+      start = seg.tile_start[tile];
+      end = seg.tile_end[tile];
+    }
+  } else {
+    start = offsets[tile];
+    end = offsets[tile + 1];
+    if (end > capacity) end = capacity;
+  }
   const int n = (int)(end - start);
   if (n <= 0) continue;
   if (LARGE ? (n <= small_cap) : (n > small_cap)) continue;  // the other variant owns this tile
@@ -504,11 +540,9 @@ extern "C" int eg_tile_emit(const float *means2d, const int32_t *radii, const fl
 
 static bool g_sort_attr_set = false;
 
-extern "C" int eg_sort_pairs(uint64_t *keys, const int32_t *offsets, int32_t T, int64_t capacity,
-                             int32_t *flatten_ids, int64_t *isect_ids, int32_t max_tile_hint, eg_stream_t stream) {
-  EG_REQUIRE(T > 0 && offsets, "bad arguments");
-  if (capacity == 0) return EG_OK;
-  EG_REQUIRE(keys && flatten_ids, "null pointer");
+static int launch_tile_sort(uint64_t *keys, const int32_t *offsets, int32_t T, int64_t capacity,
+                            int32_t *flatten_ids, int64_t *isect_ids, int32_t max_tile_hint, const SegTable seg,
+                            eg_stream_t stream) {
   // small: 256 threads / buckets, 2 x 2048 keys; large: 1024 threads / buckets, 2 x 8192 keys
   constexpr int kSmall = 2048, kLarge = 8192;
   constexpr size_t kSmallLds = 2 * kSmall * 8 + 2 * 256 * 4, kLargeLds = 2 * kLarge * 8 + 2 * 1024 * 4;
@@ -524,9 +558,33 @@ extern "C" int eg_sort_pairs(uint64_t *keys, const int32_t *offsets, int32_t T, 
   const bool small_only = max_tile_hint > 0 && (int64_t)max_tile_hint * 3 / 2 <= kSmall;
   tile_sort_kernel<256, kSmall, false><<<T, 256, kSmallLds, as_stream(stream)>>>(
       (unsigned long long *)keys, offsets, T, (long long)capacity, small_only ? 0x7fffffff : kSmall, flatten_ids,
-      (long long *)isect_ids);
+      (long long *)isect_ids, seg);
   if (!small_only)
     tile_sort_kernel<1024, kLarge, true><<<min(T, 256), 1024, kLargeLds, as_stream(stream)>>>(
-        (unsigned long long *)keys, offsets, T, (long long)capacity, kSmall, flatten_ids, (long long *)isect_ids);
+        (unsigned long long *)keys, offsets, T, (long long)capacity, kSmall, flatten_ids, (long long *)isect_ids,
+        seg);
   return check_launch("tile_sort");
+}
+
+extern "C" int eg_sort_pairs(uint64_t *keys, const int32_t *offsets, int32_t T, int64_t capacity,
+                             int32_t *flatten_ids, int64_t *isect_ids, int32_t max_tile_hint, eg_stream_t stream) {
+  EG_REQUIRE(T > 0 && offsets, "bad arguments");
+  if (capacity == 0) return EG_OK;
+  EG_REQUIRE(keys && flatten_ids, "null pointer");
+  return launch_tile_sort(keys, offsets, T, capacity, flatten_ids, isect_ids, max_tile_hint, SegTable{}, stream);
+}
+
+extern "C" int eg_sort_segments(uint64_t *keys, int32_t *tile_cursor, int32_t T, int32_t seg_cap,
+                                int32_t *flatten_ids, int32_t *tile_start, int32_t *tile_end,
+                                const int32_t *item_first, int32_t *item_end, int32_t *item_tile,
+                                int32_t max_items, int32_t max_tile_hint, eg_stream_t stream) {
+  EG_REQUIRE(T > 0 && seg_cap > 0 && max_items > 0, "bad sizes");
+  EG_REQUIRE(keys && tile_cursor && flatten_ids && tile_start && tile_end && item_first && item_end && item_tile,
+             "null pointer");
+  SegTable seg;
+  seg.cursor = tile_cursor; seg.seg_cap = seg_cap;
+  seg.tile_start = tile_start; seg.tile_end = tile_end;
+  seg.item_first = item_first; seg.item_end = item_end;
+  seg.item_tile = item_tile; seg.max_items = max_items;
+  return launch_tile_sort(keys, nullptr, T, (int64_t)T * seg_cap, flatten_ids, nullptr, max_tile_hint, seg, stream);
 }

@@ -275,6 +275,14 @@ __device__ __forceinline__ int item_tile_coop(const int *__restrict__ item_offse
   return s_tmp[4];
 }
 
+// Where a tile's sorted ids and its items (128-Gaussian slices) live.  Classic layout: start = offsets,
+// end = offsets + 1, item_first = item_offsets, item_end = item_offsets + 1, item_tile = nullptr (the
+// owner of an item is found by search).  Segmented layout (eg_sort_segments): four explicit arrays and
+// the item -> tile map.
+struct TileTable {
+  const int *start, *end, *item_first, *item_end, *item_tile;
+};
+
 // pixel of thread `tid` in the slice-parallel kernels: wave w owns the 8x8 quadrant (w & 1, w >> 1)
 // of the tile, lane l the pixel (l & 7, l >> 3) inside it (a compact 8x8 block culls far better
 // against thin ellipses than a 4x16 strip)
@@ -371,8 +379,7 @@ __device__ __forceinline__ PairEval eval_pair(const float4 X, const float4 Cq, c
 // (ex, ey) and appends the packed record to the list of every quadrant it can touch (ballot +
 // popcount compaction, 4 lists x 256 records in LDS).  Each wave then walks only ITS list.
 __global__ void __launch_bounds__(256)
-composite_slice_fwd_kernel(const float4 *__restrict__ splat, const int *__restrict__ offsets,
-                           const int *__restrict__ item_offsets, const int *__restrict__ total,
+composite_slice_fwd_kernel(const float4 *__restrict__ splat, const TileTable tt, const int *__restrict__ total,
                            const int *__restrict__ flat, int tw, int th, float *__restrict__ sliceP,
                            int *__restrict__ sliceL, unsigned char *__restrict__ sliceQ) {
   __shared__ QuadLists ql;
@@ -380,14 +387,14 @@ composite_slice_fwd_kernel(const float4 *__restrict__ splat, const int *__restri
   __shared__ int sTile[5];
   const int b = blockIdx.x;
   if (b >= total[2]) return;
-  const int tile = item_tile_coop(item_offsets, tw * th, b, sTile);
+  const int tile = tt.item_tile ? tt.item_tile[b] : item_tile_coop(tt.item_first, tw * th, b, sTile);
   const int tid = threadIdx.x, wv = tid >> 6;
   const int ty = tile / tw, tx = tile - ty * tw;
   int di, dj;
   quad_pixel(tid, di, dj);
   const float px = (float)(tx * kTile + dj) + 0.5f, py = (float)(ty * kTile + di) + 0.5f;
-  const int start = offsets[tile] + (b - item_offsets[tile]) * kSlice;
-  const int end = min(offsets[tile + 1], start + kSlice);
+  const int start = tt.start[tile] + (b - tt.item_first[tile]) * kSlice;
+  const int end = min(tt.end[tile], start + kSlice);
   const int idx = start + tid;
 
   float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), rB = s0;
@@ -523,7 +530,7 @@ struct StopInfo {
 // kernel (item flag + StopInfo); every other pixel is finalised here.
 template <int CH>
 __global__ void __launch_bounds__(256)
-composite_combine_fwd_kernel(const int *__restrict__ item_offsets, const int *__restrict__ flat, int width,
+composite_combine_fwd_kernel(const TileTable tt, const int *__restrict__ flat, int width,
                              int height, int tw, int th, const float *__restrict__ sliceP,
                              const int *__restrict__ sliceL, int *__restrict__ item_flags,
                              StopInfo *__restrict__ stopinfo, float *__restrict__ render,
@@ -538,7 +545,7 @@ composite_combine_fwd_kernel(const int *__restrict__ item_offsets, const int *__
   quad_pixel(tid, di, dj);  // same thread -> pixel map as the slice kernel
   const int i = ty * kTile + di, j = tx * kTile + dj;
   const bool inside = (i < height) && (j < width);
-  const int i0 = item_offsets[tile], ns = item_offsets[tile + 1] - i0;
+  const int i0 = tt.item_first[tile], ns = tt.item_end[tile] - i0;
   for (int s = tid; s < ns; s += 256) item_flags[i0 + s] = 0;
   __syncthreads();
 
@@ -585,8 +592,7 @@ composite_combine_fwd_kernel(const int *__restrict__ item_offsets, const int *__
 // same lanes carry on through the following slices.
 template <int CH>
 __global__ void __launch_bounds__(256)
-composite_rewalk_fwd_kernel(const float4 *__restrict__ splat, const int *__restrict__ offsets,
-                            const int *__restrict__ item_offsets, const int *__restrict__ total,
+composite_rewalk_fwd_kernel(const float4 *__restrict__ splat, const TileTable tt, const int *__restrict__ total,
                             const int *__restrict__ flat, int width, int height, int tw, int th,
                             const int *__restrict__ item_flags, const StopInfo *__restrict__ stopinfo,
                             const unsigned char *__restrict__ sliceQ,
@@ -610,8 +616,8 @@ composite_rewalk_fwd_kernel(const float4 *__restrict__ splat, const int *__restr
   const int i = ty * kTile + di, j = tx * kTile + dj;
   const float px = (float)j + 0.5f, py = (float)i + 0.5f;
   const v2f px2 = {px, px}, py2 = {py, py};
-  const int ib = item_offsets[tile];
-  const int s0 = b - ib, ns = item_offsets[tile + 1] - ib;
+  const int ib = tt.item_first[tile];
+  const int s0 = b - ib, ns = tt.item_end[tile] - ib;
   const StopInfo si = stopinfo[(size_t)tile * kTilePix + tid];
   const bool mine = si.slice == s0;
   float T = si.T;
@@ -621,7 +627,7 @@ composite_rewalk_fwd_kernel(const float4 *__restrict__ splat, const int *__restr
     if (!__syncthreads_or(mine && !found)) break;
     // stage the slice exactly like the slice kernel did; the quadrant test is not repeated, the slice
     // kernel left its verdicts in sliceQ
-    const int start = offsets[tile] + s * kSlice, end = min(offsets[tile + 1], start + kSlice);
+    const int start = tt.start[tile] + s * kSlice, end = min(tt.end[tile], start + kSlice);
     float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), rB = g0;
     bool hitq[4] = {false, false, false, false};
     if (start + tid < end) {
@@ -1145,6 +1151,37 @@ extern "C" int64_t eg_composite_workspace_bytes(int64_t max_items, int64_t n_til
          n_tiles * kTilePix * (int64_t)sizeof(StopInfo) + max_items * (int64_t)kSlice;
 }
 
+// unit colours: slice-parallel forward (slice products -> combine -> exact-stop re-walk)
+static int launch_sliced_fwd(const float4 *splat, const TileTable tt, int channels, const int32_t *flatten_ids,
+                             int width, int height, float *render, float *alphas, int32_t *last_ids, const float *gt,
+                             const float *wmap, float loss_scale, float *vpix, float *loss_out, const int32_t *total,
+                             int64_t max_items, void *workspace, float *gtstop, hipStream_t s) {
+  const int tw = cdiv(width, kTile), th = cdiv(height, kTile);
+  float *sliceP = (float *)workspace;
+  int *sliceL = (int *)(sliceP + (size_t)max_items * kTilePix);
+  int *item_flags = sliceL + (size_t)max_items * kTilePix;
+  StopInfo *stopinfo = (StopInfo *)(item_flags + max_items);
+  unsigned char *sliceQ = (unsigned char *)(stopinfo + (size_t)tw * th * kTilePix);
+  composite_slice_fwd_kernel<<<(unsigned)max_items, 256, 0, s>>>(splat, tt, total, flatten_ids, tw, th, sliceP, sliceL,
+                                                                sliceQ);
+  timing_mark(kMarkSlice, s);
+#define EG_LAUNCH_CB(CH)                                                                                          \
+  do {                                                                                                            \
+    composite_combine_fwd_kernel<CH><<<tw * th, 256, 0, s>>>(tt, flatten_ids, width, height, tw, th, sliceP,      \
+                                                            sliceL, item_flags, stopinfo, render, alphas,        \
+                                                            last_ids, gt, wmap, loss_scale, vpix, loss_out,       \
+                                                            (StopRec *)gtstop);                                   \
+    timing_mark(kMarkCombine, s);                                                                                 \
+    composite_rewalk_fwd_kernel<CH><<<(unsigned)max_items, 256, 0, s>>>(                                          \
+        splat, tt, total, flatten_ids, width, height, tw, th, item_flags, stopinfo, sliceQ, render, alphas,       \
+        last_ids, gt, wmap, loss_scale, vpix, loss_out, (StopRec *)gtstop);                                       \
+    timing_mark(kMarkRewalk, s);                                                                                  \
+  } while (0)
+  if (channels == 1) EG_LAUNCH_CB(1); else EG_LAUNCH_CB(3);
+#undef EG_LAUNCH_CB
+  return check_launch("composite_fwd(sliced)");
+}
+
 extern "C" int eg_composite_fwd(const float *splat, const float *colors, int32_t channels, const int32_t *offsets,
                                 const int32_t *flatten_ids, int32_t width, int32_t height, float *render,
                                 float *alphas, int32_t *last_ids, const float *gt, const float *wmap,
@@ -1161,30 +1198,9 @@ extern "C" int eg_composite_fwd(const float *splat, const float *colors, int32_t
   const int tw = cdiv(width, kTile), th = cdiv(height, kTile);
   hipStream_t s = as_stream(stream);
   if (!colors && item_offsets && total && workspace && max_items > 0) {
-    // unit colours: slice-parallel forward (slice products -> combine -> exact-stop re-walk)
-    float *sliceP = (float *)workspace;
-    int *sliceL = (int *)(sliceP + (size_t)max_items * kTilePix);
-    int *item_flags = sliceL + (size_t)max_items * kTilePix;
-    StopInfo *stopinfo = (StopInfo *)(item_flags + max_items);
-    unsigned char *sliceQ = (unsigned char *)(stopinfo + (size_t)tw * th * kTilePix);
-    composite_slice_fwd_kernel<<<(unsigned)max_items, 256, 0, s>>>((const float4 *)splat, offsets, item_offsets,
-                                                                  total, flatten_ids, tw, th, sliceP, sliceL, sliceQ);
-    timing_mark(kMarkSlice, s);
-#define EG_LAUNCH_CB(CH)                                                                                          \
-  do {                                                                                                            \
-    composite_combine_fwd_kernel<CH><<<tw * th, 256, 0, s>>>(item_offsets, flatten_ids, width, height, tw, th,    \
-                                                            sliceP, sliceL, item_flags, stopinfo, render, alphas,\
-                                                            last_ids, gt, wmap, loss_scale, vpix, loss_out,       \
-                                                            (StopRec *)gtstop);                                    \
-    timing_mark(kMarkCombine, s);                                                                                 \
-    composite_rewalk_fwd_kernel<CH><<<(unsigned)max_items, 256, 0, s>>>(                                          \
-        (const float4 *)splat, offsets, item_offsets, total, flatten_ids, width, height, tw, th, item_flags,      \
-        stopinfo, sliceQ, render, alphas, last_ids, gt, wmap, loss_scale, vpix, loss_out, (StopRec *)gtstop);      \
-    timing_mark(kMarkRewalk, s);                                                                                  \
-  } while (0)
-    if (channels == 1) EG_LAUNCH_CB(1); else EG_LAUNCH_CB(3);
-#undef EG_LAUNCH_CB
-    return check_launch("composite_fwd(sliced)");
+    const TileTable tt = {offsets, offsets + 1, item_offsets, item_offsets + 1, nullptr};
+    return launch_sliced_fwd((const float4 *)splat, tt, channels, flatten_ids, width, height, render, alphas, last_ids,
+                             gt, wmap, loss_scale, vpix, loss_out, total, max_items, workspace, gtstop, s);
   }
 #define EG_LAUNCH_FWD(CH, UNIT)                                                                              \
   composite_fwd_kernel<CH, UNIT><<<tw * th, 256, 0, s>>>((const float4 *)splat, colors, offsets, flatten_ids, \
@@ -1194,6 +1210,25 @@ extern "C" int eg_composite_fwd(const float *splat, const float *colors, int32_t
   else               { if (colors) EG_LAUNCH_FWD(3, false); else EG_LAUNCH_FWD(3, true); }
 #undef EG_LAUNCH_FWD
   return check_launch("composite_fwd");
+}
+
+extern "C" int eg_composite_fwd_segments(const float *splat, const int32_t *tile_start, const int32_t *tile_end,
+                                         const int32_t *item_first, const int32_t *item_end,
+                                         const int32_t *item_tile, const int32_t *flatten_ids, int32_t width,
+                                         int32_t height, float *render, float *alphas, int32_t *last_ids,
+                                         const float *gt, const float *wmap, float loss_scale, float *vpix,
+                                         float *loss_out, const int32_t *total, int64_t max_items, void *workspace,
+                                         float *gtstop, eg_stream_t stream) {
+  EG_REQUIRE(width > 0 && height > 0 && max_items > 0, "bad sizes");
+  EG_REQUIRE(splat && tile_start && tile_end && item_first && item_end && item_tile && flatten_ids && total &&
+                 workspace,
+             "null pointer");
+  EG_REQUIRE((render && alphas && last_ids) || gtstop, "render / alphas / last_ids are optional only with gtstop");
+  EG_REQUIRE(!wmap || gt, "wmap needs gt");
+  EG_REQUIRE(!gtstop || wmap, "gtstop needs the fused loss");
+  const TileTable tt = {tile_start, tile_end, item_first, item_end, item_tile};
+  return launch_sliced_fwd((const float4 *)splat, tt, 1, flatten_ids, width, height, render, alphas, last_ids, gt, wmap,
+                           loss_scale, vpix, loss_out, total, max_items, workspace, gtstop, as_stream(stream));
 }
 
 extern "C" int eg_composite_bwd(const float *splat, const int32_t *offsets, const int32_t *flatten_ids,

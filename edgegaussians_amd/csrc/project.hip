@@ -486,6 +486,154 @@ static AdamK make_adamk(const eg_adam_hyper &h) {
 
 using namespace eg;
 
+// ---------------------------------------------------------------------------------------------
+// Projection + binning in ONE pass for the training step ("segmented" layout): every tile owns a
+// fixed segment of seg_cap slots in the key array, so a Gaussian's keys can be placed without knowing
+// the other tiles' totals -- no count pass, no scan, no second (emit) kernel.  Per workgroup: count
+// the hits of its 256 Gaussians in an LDS histogram, reserve a run of slots per touched tile with ONE
+// returning global atomic on that tile's cursor, hand the slots out from LDS.  With the rows in
+// spatial order a workgroup touches a handful of tiles.  The cursor ends up holding the tile's
+// population (the sort kernel reads it and returns it to zero); a tile that outgrows its segment
+// raises total[1] and drops the excess (the caller re-sizes, like for the global capacity).
+// What the last workgroup of eg_project_emit leaves behind: the scan over the tiles.  (The per-tile
+// tables -- key range, item range, item -> tile map, cursor reset -- are written by the sort kernel,
+// one workgroup per tile, in parallel.)
+struct SegOut {
+  int *item_first;  // [T]: first item (128-Gaussian slice) of every tile, an exclusive scan
+  int max_items;
+  int *total;       // [4]: M, overflow flag, items, largest tile population
+  int *ticket;      // [1]: zero on entry, zero on exit
+};
+
+template <bool LDS_HIST>
+__global__ void __launch_bounds__(256)
+project_emit_kernel(const float *__restrict__ means, const float *__restrict__ quats,
+                    const float *__restrict__ scales, const float *__restrict__ opacities,
+                    const float *__restrict__ viewmat, const float *__restrict__ K, int N, int width, int height,
+                    uint32_t flags, float4 *__restrict__ splat, int *__restrict__ cursor, int seg_cap,
+                    unsigned long long *__restrict__ keys, const SegOut out) {
+  extern __shared__ __attribute__((aligned(16))) int s_mem[];
+  const int tw = (width + kTile - 1) / kTile, th = (height + kTile - 1) / kTile, T = tw * th;
+  int *s_hist = s_mem, *s_base = s_mem + T;
+  if (LDS_HIST) {
+    for (int t = threadIdx.x; t < T; t += 256) s_hist[t] = 0;
+    __syncthreads();
+  }
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = g < N;
+  const Cam cam = load_cam(viewmat, K);
+  Fwd f;
+  int radius = 0;
+  if (live && forward_geom(cam, means, quats, scales, opacities, g, width, height, 0.01f, 1e10f, 0.3f, flags, f))
+    radius = radius_of(f, width, height, 0.f);
+  const bool aa = flags & EG_FLAG_ANTIALIASED;
+  float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+  if (radius > 0) {
+    s0 = make_float4(f.u, f.v, f.a, f.b);
+    s1 = make_float4(f.c, aa ? f.o * f.comp : f.o, f.z, __int_as_float(radius));
+  }
+  if (live) {
+    splat[2 * g] = s0;
+    splat[2 * g + 1] = s1;
+  }
+  // exact tile hits (gsplat's box, the ellipse's extent, the ellipse-vs-tile test), remembered as a bit
+  // mask for boxes of up to 32 tiles so that the second walk below does not repeat the test
+  int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
+  if (radius > 0) tile_box_tight(s0.x, s0.y, radius, s0.z, s0.w, s1.x, s1.y, tw, th, x0, y0, x1, y1);
+  const int bw = x1 - x0;
+  const bool small_box = (y1 - y0) * bw <= 32;
+  unsigned mask = 0u;
+  {
+    int bit = 0;
+    for (int ty = y0; ty < y1; ++ty)
+      for (int tx = x0; tx < x1; ++tx, ++bit) {
+        if (!splat_hits_tile(s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, tx, ty)) continue;
+        if (small_box) mask |= 1u << bit;
+        if (LDS_HIST) atomicAdd(&s_hist[ty * tw + tx], 1);
+      }
+  }
+  const unsigned long long key = ((unsigned long long)(unsigned)__float_as_int(s1.z) << 32) | (unsigned)g;
+#define EG_HIT(tx, ty) \
+  (small_box ? ((mask >> (((ty)-y0) * bw + ((tx)-x0))) & 1u) != 0u : splat_hits_tile(s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, tx, ty))
+  if (!LDS_HIST) {  // very large tile grids: one global atomic per hit
+    for (int ty = y0; ty < y1; ++ty)
+      for (int tx = x0; tx < x1; ++tx) {
+        if (!EG_HIT(tx, ty)) continue;
+        const int t = ty * tw + tx;
+        const int slot = atomicAdd(&cursor[t], 1);
+        if (slot < seg_cap) keys[(size_t)t * seg_cap + slot] = key;
+      }
+  } else {
+    __syncthreads();
+    for (int t = threadIdx.x; t < T; t += 256) {
+      const int c = s_hist[t];
+      if (c) {
+        s_base[t] = atomicAdd(&cursor[t], c);  // slots [base, base + c) of tile t's segment
+        s_hist[t] = 0;
+      }
+    }
+    __syncthreads();
+    for (int ty = y0; ty < y1; ++ty)
+      for (int tx = x0; tx < x1; ++tx) {
+        if (!EG_HIT(tx, ty)) continue;
+        const int t = ty * tw + tx;
+        const int slot = s_base[t] + atomicAdd(&s_hist[t], 1);
+        if (slot < seg_cap) keys[(size_t)t * seg_cap + slot] = key;
+      }
+  }
+#undef EG_HIT
+  // The LAST workgroup to finish -- found with a device-scope ticket -- scans the tile populations.  The cursors are only ever touched by device-scope atomics (performed at the
+  // coherence point, not in an XCD-private L2 line) and are read here with device-scope atomic loads,
+  // so no cache write-back / invalidate fence is needed: every wave only drains its own outstanding
+  // atomics (vmcnt) before the workgroup takes its ticket.
+  __shared__ int s_last;
+  __shared__ int s_tmp[4];
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) s_last = (atomicAdd(out.ticket, 1) == (int)gridDim.x - 1);
+  __syncthreads();
+  if (!s_last) return;
+  // stage the T populations in LDS with coalesced, independent loads; every thread then owns a
+  // contiguous run of tiles (the scan needs runs, the memory system wants strides)
+  const int per = (T + 255) / 256, t0 = threadIdx.x * per, t1 = min(T, t0 + per);
+  if (LDS_HIST) {
+    for (int t = threadIdx.x; t < T; t += 256)
+      s_hist[t] = __hip_atomic_load(&cursor[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+  }
+  int isum = 0, msum = 0, cmax = 0;
+  for (int t = t0; t < t1; ++t) {
+    const int pop = LDS_HIST ? s_hist[t] : __hip_atomic_load(&cursor[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int kept = min(pop, seg_cap);
+    isum += (kept + 127) >> 7; msum += kept; cmax = max(cmax, pop);
+  }
+  int itot, mtot;
+  int ie = block_excl_scan<256>(isum, s_tmp, itot);
+  (void)block_excl_scan<256>(msum, s_tmp, mtot);
+  for (int t = t0; t < t1; ++t) {
+    const int pop = LDS_HIST ? s_hist[t] : __hip_atomic_load(&cursor[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (LDS_HIST) s_base[t] = ie; else out.item_first[t] = min(ie, out.max_items);
+    ie += (min(pop, seg_cap) + 127) >> 7;
+  }
+  if (LDS_HIST) {
+    __syncthreads();
+    for (int t = threadIdx.x; t < T; t += 256) out.item_first[t] = min(s_base[t], out.max_items);
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) cmax = max(cmax, __shfl_xor(cmax, d, 64));
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) s_tmp[threadIdx.x >> 6] = cmax;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int m = max(max(s_tmp[0], s_tmp[1]), max(s_tmp[2], s_tmp[3]));
+    out.total[0] = mtot;
+    out.total[1] = (m > seg_cap || itot > out.max_items) ? 1 : 0;
+    out.total[2] = min(itot, out.max_items);
+    out.total[3] = m;
+    *out.ticket = 0;  // ready for the next launch
+  }
+}
+
 static int launch_project_fwd(const float *means, const float *quats, const float *scales, const float *opacities,
                               const float *viewmat, const float *K, int32_t N, int32_t width, int32_t height,
                               float near_plane, float far_plane, float eps2d, float radius_clip, uint32_t flags,
@@ -533,6 +681,32 @@ extern "C" int eg_project_bin(const float *means, const float *quats, const floa
   return launch_project_fwd(means, quats, log_scales, logit_opacities, viewmat, K, N, width, height, 0.01f, 1e10f,
                             0.3f, 0.0f, flags, splat, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, tile_counts,
                             nullptr, tile_mask, offsets, item_offsets, total, capacity, ticket, stream);
+}
+
+extern "C" int eg_project_emit(const float *means, const float *quats, const float *log_scales,
+                               const float *logit_opacities, const float *viewmat, const float *K, int32_t N,
+                               int32_t width, int32_t height, uint32_t flags, float *splat, int32_t *tile_cursor,
+                               int32_t seg_cap, uint64_t *keys, int32_t *item_first, int32_t max_items,
+                               int32_t *total, int32_t *ticket, eg_stream_t stream) {
+  EG_REQUIRE(N > 0 && width > 0 && height > 0 && seg_cap > 0 && max_items > 0, "bad sizes");
+  EG_REQUIRE(means && quats && log_scales && logit_opacities && viewmat && K && splat && tile_cursor && keys &&
+                 item_first && total && ticket,
+             "null pointer");
+  EG_REQUIRE((flags & EG_FLAG_TIGHT_TILES) != 0, "the segmented path bins with the exact tile test");
+  const int T = cdiv(width, kTile) * cdiv(height, kTile);
+  EG_REQUIRE((int64_t)T * seg_cap < (1ll << 31), "T * seg_cap must fit 31 bits");
+  SegOut out;
+  out.item_first = item_first; out.max_items = max_items;
+  out.total = total; out.ticket = ticket;
+  if (2 * T <= 16384)
+    project_emit_kernel<true><<<cdiv(N, 256), 256, sizeof(int) * 2 * T, as_stream(stream)>>>(
+        means, quats, log_scales, logit_opacities, viewmat, K, N, width, height, flags, (float4 *)splat, tile_cursor,
+        seg_cap, (unsigned long long *)keys, out);
+  else
+    project_emit_kernel<false><<<cdiv(N, 256), 256, 0, as_stream(stream)>>>(
+        means, quats, log_scales, logit_opacities, viewmat, K, N, width, height, flags, (float4 *)splat, tile_cursor,
+        seg_cap, (unsigned long long *)keys, out);
+  return check_launch("project_emit");
 }
 
 extern "C" int eg_project_bwd(const float *means, const float *quats, const float *scales, const float *opacities,

@@ -117,6 +117,7 @@ extern "C" int eg_timing_end(float *stage_us /*[kStages] host*/, int32_t *n_step
 extern "C" int eg_train_step(const eg_step_args *a, eg_stream_t stream) {
   EG_REQUIRE(a != nullptr, "null args");
   EG_REQUIRE(a->N > 0 && a->width > 0 && a->height > 0 && a->capacity > 0, "bad sizes");
+  EG_REQUIRE(a->seg_cap <= 0 || (a->tile_end && a->item_end && a->item_tile), "segmented binning needs its tables");
   const int tw = cdiv(a->width, kTile), th = cdiv(a->height, kTile), T = tw * th;
   const uint32_t flags = EG_FLAG_LOG_SCALES | EG_FLAG_LOGIT_OPACITIES | EG_FLAG_ANTIALIASED | EG_FLAG_TIGHT_TILES;
   g_ev_cur = (g_ev && g_ev_next < g_ev_steps) ? &g_ev[(kStages + 1) * g_ev_next] : nullptr;
@@ -124,6 +125,26 @@ extern "C" int eg_train_step(const eg_step_args *a, eg_stream_t stream) {
 #define EG_MARK(k) timing_mark(k, st)
   int rc;
   EG_MARK(kMarkStart);
+  if (a->seg_cap > 0) {
+    // segmented binning: projection + binning (+ the item scan by its last workgroup) in one pass, then the
+    // per-tile sort, which also writes the tile / item tables; there is no emit kernel, its stage stays empty
+    rc = eg_project_emit(a->means, a->quats, a->log_scales, a->logit_opacities, a->viewmat, a->K, a->N, a->width,
+                         a->height, flags, a->splat, a->tile_counts, a->seg_cap, a->keys, a->item_offsets,
+                         (int32_t)a->max_items, a->total, a->ticket, stream);
+    if (rc) return rc;
+    EG_MARK(kMarkProjectBin);
+    EG_MARK(kMarkEmit);
+    rc = eg_sort_segments(a->keys, a->tile_counts, T, a->seg_cap, a->flatten_ids, a->offsets, a->tile_end,
+                          a->item_offsets, a->item_end, a->item_tile, (int32_t)a->max_items, a->max_tile_hint,
+                          stream);
+    if (rc) return rc;
+    EG_MARK(kMarkSort);
+    rc = eg_composite_fwd_segments(a->splat, a->offsets, a->tile_end, a->item_offsets, a->item_end, a->item_tile,
+                                   a->flatten_ids, a->width, a->height, a->render, a->alphas, a->last_ids, a->gt,
+                                   a->wmap, a->loss_scale, a->vpix, a->loss, a->total, a->max_items, a->workspace,
+                                   a->gtstop, stream);
+    if (rc) return rc;
+  } else {
   // tile_counts is zero on entry (caller zero-initialises it once): the projection counts it up and its
   // last workgroup scans it; the emit pass counts it back down to zero.
   rc = eg_project_bin(a->means, a->quats, a->log_scales, a->logit_opacities, a->viewmat, a->K, a->N, a->width,
@@ -142,6 +163,7 @@ extern "C" int eg_train_step(const eg_step_args *a, eg_stream_t stream) {
                         a->alphas, a->last_ids, a->gt, a->wmap, a->loss_scale, a->vpix, a->loss, a->item_offsets,
                         a->total, a->max_items, a->workspace, a->gtstop, stream);
   if (rc) return rc;
+  }
   // (slice / combine / re-walk marks are recorded inside eg_composite_fwd)
   // backward: footprint compositing VJP, then projection VJP + absgrad (+ Adam)
   rc = eg_composite_bwd_footprint(a->splat, a->N, a->width, a->height, a->gtstop, a->g2d, stream);

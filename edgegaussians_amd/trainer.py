@@ -75,11 +75,16 @@ class EdgeTrainer:
                  viewmats: Tensor, Ks: Tensor, gt: Tensor, width: int, height: int,
                  device: str = "cuda", schedule: Optional[LRSchedule] = None,
                  betas=(0.9, 0.999), eps: float = 1e-8, keep_images: bool = False,
-                 spatial_order: bool = False):
+                 spatial_order: bool = False, segmented: Optional[bool] = None):
         _lib.load()
         # keep_images: also materialise render / alphas / last_ids / vpix every step (the training step
         # itself needs none of them: its backward reads only the packed gtstop record)
         self.keep_images = bool(keep_images)
+        # segmented (default; EG_SEGMENTED=0 or segmented=False selects the count / scan / emit sequence of
+        # the operator path): the training step bins with fixed per-tile key segments -- projection +
+        # binning in one kernel, no emit pass; same results, the isect buffers become [T * seg_cap]
+        self.segmented = bool(int(os.environ.get("EG_SEGMENTED", "1"))) if segmented is None else bool(segmented)
+        self.seg_cap = 0
         self.dev = torch.device(device)
         f = dict(device=self.dev, dtype=torch.float32)
         self.means = means.detach().to(**f).contiguous().clone()
@@ -148,11 +153,19 @@ class EdgeTrainer:
         self.last_ids = img(dtype=torch.int32)
         self.loss_acc = torch.zeros(1, device=d)
 
-    def _alloc_isect(self, capacity: int):
+    def _alloc_isect(self, capacity: int, seg_cap: int = 0):
+        """capacity: upper bound on the tile intersections of one view (sizes the item workspace);
+        seg_cap > 0: segmented binning, the key / id arrays hold T fixed segments of seg_cap slots."""
         self.capacity = int(capacity)
-        self.keys = torch.empty(self.capacity, dtype=torch.int64, device=self.dev)
-        self.flatten_ids = torch.empty(self.capacity, dtype=torch.int32, device=self.dev)
+        self.seg_cap = int(seg_cap)
+        n_keys = max(self.T * self.seg_cap, self.capacity)  # (the staged path always uses the classic layout)
+        self.keys = torch.empty(n_keys, dtype=torch.int64, device=self.dev)
+        self.flatten_ids = torch.empty(n_keys, dtype=torch.int32, device=self.dev)
         self.max_items = (self.capacity + 127) // 128 + self.T
+        if self.seg_cap:
+            self.tile_end = torch.zeros(self.T, dtype=torch.int32, device=self.dev)
+            self.item_end = torch.zeros(self.T, dtype=torch.int32, device=self.dev)
+            self.item_tile = torch.zeros(self.max_items, dtype=torch.int32, device=self.dev)
         self.workspace = torch.empty(_lib.load().eg_composite_workspace_bytes(self.max_items, self.T), dtype=torch.uint8,
                                      device=self.dev)
         self._args_cache = {}
@@ -219,8 +232,9 @@ class EdgeTrainer:
             tile_max = max(tile_max, self._last_tile_max)
         self.max_tile_seen = tile_max  # launch-shape hint of the tile sort (never affects results)
         need = int(m_max * slack) + 4096
-        if need > self.capacity:
-            self._alloc_isect(need)
+        seg = (int(tile_max * 1.5) // 128 + 2) * 128 if self.segmented else 0
+        if need > self.capacity or seg > self.seg_cap:
+            self._alloc_isect(max(need, self.capacity), max(seg, self.seg_cap))
         self.m_max_seen = m_max
         self._args_cache = {}
         return m_max
@@ -238,6 +252,9 @@ class EdgeTrainer:
             a.splat, a.g2d = ptr(self.splat), ptr(self.g2d)
             a.gtstop = ptr(self.gtstop)
             a.max_tile_hint = getattr(self, "max_tile_seen", 0)
+            a.seg_cap = self.seg_cap
+            if self.seg_cap:
+                a.tile_end, a.item_end, a.item_tile = ptr(self.tile_end), ptr(self.item_end), ptr(self.item_tile)
             a.tile_counts, a.offsets, a.total = ptr(self.tile_counts), ptr(self.offsets), ptr(self.total)
             a.item_offsets, a.workspace, a.max_items = ptr(self.item_offsets), ptr(self.workspace), self.max_items
             a.tile_mask, a.ticket = ptr(self.tile_mask), ptr(self.ticket)
@@ -425,6 +442,8 @@ class EdgeTrainer:
         if tile_max > getattr(self, "max_tile_seen", 0):
             self.max_tile_seen = tile_max
             self._args_cache = {}
+        if self.seg_cap and tile_max * 1.15 > self.seg_cap:  # a tile is about to outgrow its segment
+            self._alloc_isect(self.capacity, (int(tile_max * 1.5) // 128 + 2) * 128)
         return v
 
     def overflowed(self) -> bool:

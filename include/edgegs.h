@@ -112,6 +112,35 @@ int eg_sort_pairs(uint64_t *keys /*[capacity] in/out*/, const int32_t *offsets /
                   only (skips the idle launch of the large-tile variant), never affects the result*/,
                   eg_stream_t stream);
 
+/* ---- segmented binning (training step): projection + binning in ONE pass.  Tile t owns the fixed
+ * segment keys[t * seg_cap ... (t + 1) * seg_cap), so a Gaussian's keys are placed (one returning atomic
+ * per workgroup and touched tile on tile_cursor[t]) without a count pass, a global scan of offsets or a
+ * second (emit) kernel.  The last workgroup to finish (device-scope ticket) scans the populations:
+ * item_first [T] (first 128-Gaussian slice of every tile) and total[4] = {M, overflow flag, items, largest
+ * tile population}.  eg_sort_segments sorts every segment in place (same order as eg_sort_pairs) and
+ * its one-workgroup-per-tile kernel writes the per-tile tables: tile_start/tile_end [T] (the keys),
+ * item_end [T], item_tile [max_items] (owner of every item), and returns the cursors to zero.  A tile
+ * above seg_cap (or more items than max_items) drops the excess and raises total[1].
+ * eg_composite_fwd_segments = the slice-parallel eg_composite_fwd on those tables. */
+int eg_project_emit(const float *means, const float *quats, const float *log_scales, const float *logit_opacities,
+                    const float *viewmat, const float *K, int32_t N, int32_t width, int32_t height,
+                    uint32_t flags /*must include EG_FLAG_TIGHT_TILES*/, float *splat /*[N,8]*/,
+                    int32_t *tile_cursor /*[T] zero on entry*/, int32_t seg_cap, uint64_t *keys /*[T*seg_cap]*/,
+                    int32_t *item_first /*[T]*/, int32_t max_items, int32_t *total /*[4]*/,
+                    int32_t *ticket /*[1] zero-initialised once*/, eg_stream_t stream);
+int eg_sort_segments(uint64_t *keys, int32_t *tile_cursor /*[T] in: populations, out: zero*/, int32_t T,
+                     int32_t seg_cap, int32_t *flatten_ids /*[T*seg_cap]*/, int32_t *tile_start /*[T]*/,
+                     int32_t *tile_end /*[T]*/, const int32_t *item_first /*[T]*/, int32_t *item_end /*[T]*/,
+                     int32_t *item_tile /*[max_items]*/, int32_t max_items, int32_t max_tile_hint,
+                     eg_stream_t stream);
+int eg_composite_fwd_segments(const float *splat, const int32_t *tile_start, const int32_t *tile_end,
+                              const int32_t *item_first, const int32_t *item_end, const int32_t *item_tile,
+                              const int32_t *flatten_ids, int32_t width, int32_t height,
+                              float *render /*[H,W]|NULL*/, float *alphas /*[H,W]|NULL*/,
+                              int32_t *last_ids /*[H,W]|NULL*/, const float *gt, const float *wmap, float loss_scale,
+                              float *vpix /*[H,W]|NULL*/, float *loss_out /*[1]*/, const int32_t *total,
+                              int64_t max_items, void *workspace, float *gtstop /*[H,W,3]*/, eg_stream_t stream);
+
 /* ---- G7: alpha compositing forward (replaces gsplat rasterize_to_pixels fwd).
  * channels = 1 or 3.  colors == NULL means "all ones" (the reference's colours, edge_gs.py:247).
  * Fused weighted-L1 (edge_gs.py:279,288-324 in weight-map form): when wmap != NULL,
@@ -291,6 +320,9 @@ typedef struct {
   int32_t *flatten_ids;
   int64_t capacity;
   int32_t max_tile_hint;                /* see eg_sort_pairs; 0 = unknown */
+  int32_t seg_cap;                      /* > 0: segmented binning (eg_project_emit ...): keys / flatten_ids are
+                                           [T * seg_cap], offsets / item_offsets serve as tile_start / item_first */
+  int32_t *tile_end, *item_end, *item_tile; /* [T], [T], [max_items]; used when seg_cap > 0 */
   float *render, *alphas, *vpix, *loss; /* [H,W], [H,W], [H,W], [1] accumulated */
   float *gtstop;                        /* [H,W,3] */
   int32_t *last_ids;

@@ -345,13 +345,15 @@ def test_fused_train_step_matches_reference_protocol(env):
     assert tr.absgrads_normalize_factor == 1 + len(views)
 
 
-def test_grad_step_equals_autograd_path(env):
-    """eg_train_step without Adam (the data-parallel leg) == rasterization() + torch autograd."""
+@pytest.mark.parametrize("segmented", [False, True])
+def test_grad_step_equals_autograd_path(env, segmented):
+    """eg_train_step without Adam (the data-parallel leg) == rasterization() + torch autograd, for both
+    binning layouts of the step (count / scan / emit, and the one-pass segmented layout)."""
     _lib, synth, O = env
     from edgegaussians_amd import EdgeTrainer, rasterization
     sc = _scene(synth, n=2500, w=160, h=112, views=2)
     tr = EdgeTrainer(sc.means, sc.log_scales, sc.quats, sc.logit_opacities, sc.viewmats, sc.Ks, sc.gt,
-                     sc.width, sc.height)
+                     sc.width, sc.height, segmented=segmented)
     tr.ensure_capacity()
     w = synth.weight_map("weighted", sc.gt[1]).cuda()
     tr.grad_step(1, w)
@@ -376,7 +378,7 @@ def test_grad_step_equals_autograd_path(env):
     # the step does not materialise the images unless asked to; when asked they are the operator's
     assert tr.render is None and tr.alphas is None and tr.last_ids is None and tr.vpix is None
     tk = EdgeTrainer(sc.means, sc.log_scales, sc.quats, sc.logit_opacities, sc.viewmats, sc.Ks, sc.gt,
-                     sc.width, sc.height, keep_images=True)
+                     sc.width, sc.height, keep_images=True, segmented=segmented)
     tk.ensure_capacity()
     tk.grad_step(1, w)
     assert_close(tk.render, render[0, ..., 0].detach(), rtol=1e-5, name="kept render")
@@ -909,3 +911,32 @@ def test_end_to_end_training_recovers_ground_truth_edges(env):
     assert r["steps"] == 6400 and r["n_opaque"] > 1000
     assert r["loss_last"] > 0 and math.isfinite(r["loss_last"])
     assert precision > 0.8 and recall > 0.9, (precision, recall, r["n_final"], r["n_opaque"])
+
+
+def test_binning_layouts_agree_and_segment_overflow_is_flagged(env):
+    """The two binning layouts of the fused step give the same step (same kernels downstream, same sorted
+    order per tile); a tile that outgrows its fixed segment drops the excess and raises the flag."""
+    _lib, synth, O = env
+    from edgegaussians_amd import EdgeTrainer
+    sc = _scene(synth, n=6000, w=200, h=136, views=2)
+    mk = lambda seg: EdgeTrainer(sc.means, sc.log_scales, sc.quats, sc.logit_opacities, sc.viewmats, sc.Ks,  # noqa: E731
+                                 sc.gt, sc.width, sc.height, segmented=seg)
+    ta, tb = mk(False), mk(True)
+    w = synth.weight_map("weighted", sc.gt[0]).cuda()
+    ta.ensure_capacity(); tb.ensure_capacity()
+    assert tb.seg_cap > 0 and ta.seg_cap == 0
+    for s in range(3):
+        ta.train_step(s % 2, w); tb.train_step(s % 2, w)
+    assert ta.last_m() == tb.last_m() and not ta.overflowed() and not tb.overflowed()
+    assert int(ta.total[2]) == int(tb.total[2]) and int(ta.total[3]) == int(tb.total[3])
+    la, lb = ta.pop_loss(), tb.pop_loss()
+    assert abs(la - lb) <= 1e-6 * abs(la)
+    for k, v in ta.state_dict().items():
+        assert_close(tb.state_dict()[k], v, rtol=1e-5, max_bad=1e-3, name=k)
+    assert int(tb.tile_counts.abs().sum()) == 0, "the segment cursors must be back at zero"
+    # overflow: segments far too small for the busiest tiles
+    tb._alloc_isect(tb.capacity, 128)
+    assert tb.max_tile_seen > 128
+    tb.train_step(0, w)
+    assert tb.overflowed() and math.isfinite(tb.pop_loss())
+    assert int(tb.tile_counts.abs().sum()) == 0

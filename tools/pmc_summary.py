@@ -13,7 +13,7 @@ import sqlite3
 import sys
 
 STAGE_OF = {
-    "project_fwd_kernel": "project_bin", "tile_offsets_kernel": "tile_offsets", "tile_emit_kernel": "tile_emit",
+    "project_fwd_kernel": "project_bin", "project_emit_kernel": "project_bin", "tile_offsets_kernel": "tile_offsets", "tile_emit_kernel": "tile_emit",
     "tile_sort_kernel": "tile_sort", "composite_slice_fwd_kernel": "composite_slice_fwd",
     "composite_combine_fwd_kernel": "composite_combine_fwd", "composite_rewalk_fwd_kernel": "composite_rewalk_fwd",
     "footprint_bwd_kernel": "footprint_bwd",
