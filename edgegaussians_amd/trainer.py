@@ -233,6 +233,9 @@ class EdgeTrainer:
         self.max_tile_seen = tile_max  # launch-shape hint of the tile sort (never affects results)
         need = int(m_max * slack) + 4096
         seg = (int(tile_max * 1.5) // 128 + 2) * 128 if self.segmented else 0
+        if self.T * seg > (1 << 28):  # a few monster tiles would make T fixed segments absurdly large (> 3 GB):
+            seg = 0                   # fall back to the count / scan / emit layout for this scene
+            self.seg_cap = 0
         if need > self.capacity or seg > self.seg_cap:
             self._alloc_isect(max(need, self.capacity), max(seg, self.seg_cap))
         self.m_max_seen = m_max
@@ -443,7 +446,8 @@ class EdgeTrainer:
             self.max_tile_seen = tile_max
             self._args_cache = {}
         if self.seg_cap and tile_max * 1.15 > self.seg_cap:  # a tile is about to outgrow its segment
-            self._alloc_isect(self.capacity, (int(tile_max * 1.5) // 128 + 2) * 128)
+            seg = (int(tile_max * 1.5) // 128 + 2) * 128
+            self._alloc_isect(self.capacity, seg if self.T * seg <= (1 << 28) else 0)
         return v
 
     def overflowed(self) -> bool:
