@@ -940,3 +940,25 @@ def test_binning_layouts_agree_and_segment_overflow_is_flagged(env):
     tb.train_step(0, w)
     assert tb.overflowed() and math.isfinite(tb.pop_loss())
     assert int(tb.tile_counts.abs().sum()) == 0
+
+
+def test_segmented_layout_with_a_giant_tile(env):
+    """20000 Gaussians piled onto one spot: a single tile holds them all (> 16384 keys: the hybrid
+    global/LDS sort network) inside its fixed segment; the step must equal the scan layout's."""
+    _lib, synth, O = env
+    from edgegaussians_amd import EdgeTrainer
+    sc = _scene(synth, n=20000, w=128, h=96, views=1)
+    g = torch.Generator().manual_seed(5)
+    means = torch.tensor([0.5, 0.5, 0.5]) + 0.004 * torch.randn(20000, 3, generator=g)
+    mk = lambda seg: EdgeTrainer(means, sc.log_scales, sc.quats, sc.logit_opacities, sc.viewmats, sc.Ks,  # noqa: E731
+                                 sc.gt, sc.width, sc.height, segmented=seg)
+    ta, tb = mk(False), mk(True)
+    ta.ensure_capacity(); tb.ensure_capacity()
+    assert tb.seg_cap > 16384 and tb.max_tile_seen > 16384
+    w = synth.weight_map("whole", sc.gt[0]).cuda()
+    ta.train_step(0, w); tb.train_step(0, w)
+    assert not ta.overflowed() and not tb.overflowed() and ta.last_m() == tb.last_m()
+    la, lb = ta.pop_loss(), tb.pop_loss()
+    assert math.isfinite(la) and abs(la - lb) <= 1e-5 * abs(la)
+    for k, v in ta.state_dict().items():
+        assert_close(tb.state_dict()[k], v, rtol=1e-5, max_bad=2e-3, name=k)
