@@ -472,10 +472,9 @@ static_assert(sizeof(StopRec) == 12, "gtstop is [H,W,3] 32-bit words");
 template <int CH>
 __device__ __forceinline__ float finalize_pixel(int p, float T, int last, bool stopped, const int *__restrict__ flat,
                                                 float *__restrict__ render, float *__restrict__ alphas,
-                                                int *__restrict__ last_ids, const float *__restrict__ gt,
-                                                const float *__restrict__ wmap, float loss_scale,
-                                                float *__restrict__ vpix, StopRec *__restrict__ gtstop,
-                                                const float4 *__restrict__ splat) {
+                                                int *__restrict__ last_ids, bool has_loss, float gt_p, float w,
+                                                float loss_scale, float *__restrict__ vpix,
+                                                StopRec *__restrict__ gtstop, const float4 *__restrict__ splat) {
   const float pix = 1.f - T;  // unit colours, no background: sum_i alpha_i T_i == 1 - T_final
   // the images are optional in the fused training step, whose backward reads only the gtstop record
   if (alphas) alphas[p] = pix;
@@ -485,10 +484,9 @@ __device__ __forceinline__ float finalize_pixel(int p, float T, int last, bool s
     for (int k = 0; k < CH; ++k) render[(size_t)p * CH + k] = pix;
   }
   float l = 0.f;
-  if (wmap) {
-    const float w = wmap[p];
+  if (has_loss) {  // gt_p, w: this pixel's target and weight, loaded by the caller ahead of its own work
     const float c0 = fminf(fmaxf(pix, 0.f), 1.f);
-    const float d = c0 - gt[p];
+    const float d = c0 - gt_p;
     l = w * fabsf(d);
     const float sgn = (d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f);
     const float v = loss_scale * w * sgn;  // pix is in [0,1): the clamp always passes the gradient
@@ -546,6 +544,10 @@ composite_combine_fwd_kernel(const TileTable tt, const int *__restrict__ flat, i
   const int i = ty * kTile + di, j = tx * kTile + dj;
   const bool inside = (i < height) && (j < width);
   const int i0 = tt.item_first[tile], ns = tt.item_end[tile] - i0;
+  // the pixel's target and loss weight do not depend on the slices: fetch them under the slice loads
+  const bool has_loss = wmap != nullptr;
+  const float w_p = (has_loss && inside) ? wmap[i * width + j] : 0.f;
+  const float gt_p = (has_loss && inside) ? gt[i * width + j] : 0.f;
   for (int s = tid; s < ns; s += 256) item_flags[i0 + s] = 0;
   __syncthreads();
 
@@ -581,8 +583,8 @@ composite_combine_fwd_kernel(const TileTable tt, const int *__restrict__ flat, i
 
   float l = 0.f;
   if (inside && stop_slice < 0)
-    l = finalize_pixel<CH>(i * width + j, T, last, false, flat, render, alphas, last_ids, gt, wmap, loss_scale, vpix,
-                           gtstop, nullptr);  // pixels finalised here did not stop
+    l = finalize_pixel<CH>(i * width + j, T, last, false, flat, render, alphas, last_ids, has_loss, gt_p, w_p,
+                           loss_scale, vpix, gtstop, nullptr);  // pixels finalised here did not stop
   if (wmap && loss_out) block_loss_add(l, sRed, loss_out);
 }
 
@@ -676,8 +678,9 @@ composite_rewalk_fwd_kernel(const float4 *__restrict__ splat, const TileTable tt
   }
   float l = 0.f;
   if (mine)
-    l = finalize_pixel<CH>(i * width + j, T, last, found, flat, render, alphas, last_ids, gt, wmap, loss_scale, vpix,
-                           gtstop, splat);
+    l = finalize_pixel<CH>(i * width + j, T, last, found, flat, render, alphas, last_ids, wmap != nullptr,
+                           wmap ? gt[i * width + j] : 0.f, wmap ? wmap[i * width + j] : 0.f, loss_scale, vpix, gtstop,
+                           splat);
   if (wmap && loss_out) block_loss_add(l, sRed, loss_out);
   }  // item loop
 }
