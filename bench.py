@@ -141,8 +141,10 @@ def cpu_baseline(sc, budget_s=15.0, which="c"):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    # defaults: a 0.1 s timed window (a 200-step window lasts 20 ms, which a single scheduling hiccup on a
+    # shared box can double)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--config", default="config2", choices=sorted(CONFIGS))
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
