@@ -490,7 +490,7 @@ using namespace eg;
 // Projection + binning in ONE pass for the training step ("segmented" layout): every tile owns a
 // fixed segment of seg_cap slots in the key array, so a Gaussian's keys can be placed without knowing
 // the other tiles' totals -- no count pass, no scan, no second (emit) kernel.  Per workgroup: count
-// the hits of its 256 Gaussians in an LDS histogram, reserve a run of slots per touched tile with ONE
+// the hits of its Gaussians in an LDS histogram, reserve a run of slots per touched tile with ONE
 // returning global atomic on that tile's cursor, hand the slots out from LDS.  With the rows in
 // spatial order a workgroup touches a handful of tiles.  The cursor ends up holding the tile's
 // population (the sort kernel reads it and returns it to zero); a tile that outgrows its segment
