@@ -21,11 +21,14 @@ def frac_bad(a, b, rtol=1e-4, atol=None):
     return float((np.abs(a - b) > atol + rtol * np.abs(b)).mean())
 
 
-def assert_close(a, b, rtol=1e-4, max_bad=0.0, name=""):
+def assert_close(a, b, rtol=1e-4, max_bad=0.0, name="", atol_floor=0.0):
     """north_star tolerance: 1e-4 relative.  `max_bad` admits the few elements whose value hinges
     on a float-borderline branch (alpha >= 1/255, transmittance stop, radius ceil) that flips
     between two correct implementations (different exp / rounding order)."""
-    fb = frac_bad(a, b, rtol)
+    # atol_floor: absolute floor for tensors that are zero up to round-off (e.g. the quaternion gradient of
+    # an isotropic Gaussian), given by the caller in the units of the problem
+    bn = to_np(b).astype(np.float64)
+    fb = frac_bad(a, b, rtol, max(rtol * max(np.abs(bn).max() if bn.size else 0.0, 1e-30), atol_floor))
     assert fb <= max_bad, f"{name}: {fb:.2e} of elements off by > {rtol} (allowed {max_bad}); norm-rel {rel_err(a, b):.3e}"
 
 
