@@ -80,7 +80,7 @@ _SIGS = {
     "eg_project_hits": [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _vp, _vp],
     "eg_project_visibility": [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _vp, _vp],
     "eg_knn": [_vp, _i32, _i32, C.POINTER(_f), _f, C.POINTER(_i32), _vp, _vp, _vp, _vp, _vp, _vp, _vp],
-    "eg_direction_loss": [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp],
+    "eg_direction_loss": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp],
     "eg_ratio_loss": [_vp, _i32, _vp, _vp, _vp],
     "eg_train_step": [C.POINTER(StepArgs), _vp],
 }

@@ -128,7 +128,7 @@ tile_offsets_kernel(const int *__restrict__ counts, int T, long long capacity, i
     if (item_offsets) item_offsets[T] = icarry;
     if (total) {
       total[0] = carry;
-      total[1] = ((long long)carry > capacity) ? 1 : 0;
+      if ((long long)carry > capacity) total[1] = 1;  // sticky: only the host clears it
       total[2] = icarry;
       total[3] = cmax;
     }

@@ -111,13 +111,16 @@ knn_query_kernel(const float *__restrict__ pts, int N, int K, Grid g, const int 
 }
 
 // ---------------------------------------------------------------------------------------------
-// direction loss (edge_gs.py:346-373, 'enforce_full'): 1 - mean_i mean_k | m_i . unit(mu_i - mu_nn(i,k)) |
+// direction loss (edge_gs.py:346-373): 1 - mean_i mean_k | m_i . unit(mu_i - mu_nn(i,k)) |
 // with m_i = column argmax_k(scale) of R(q_i).  One thread per Gaussian: value (sum of alignments, the
 // caller forms 1 - sum / (N k)) and UNSCALED gradients d(sum)/d{mu, q} (the caller multiplies by
 // -lambda / (N k); lambda is data-dependent in the reference, train_gaussians.py:113).
+// top_k in (0, K): the 'enforce_half' method (edge_gs.py:366-369) -- only the top_k best-aligned of the K
+// listed neighbours count (sort descending, mean of the first k); otherwise every neighbour counts.
+constexpr int kMaxDirNN = 32;
 __global__ void __launch_bounds__(256)
 direction_loss_kernel(const float *__restrict__ means, const float *__restrict__ quats,
-                      const float *__restrict__ log_scales, const int *__restrict__ nn, int N, int K,
+                      const float *__restrict__ log_scales, const int *__restrict__ nn, int N, int K, int top_k,
                       float *__restrict__ g_means, float *__restrict__ g_quats, float *__restrict__ sum_out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   float acc = 0.f;
@@ -134,9 +137,33 @@ direction_loss_kernel(const float *__restrict__ means, const float *__restrict__
     const float mx = R[c], my = R[3 + c], mz = R[6 + c];
     const float px = means[3 * i], py = means[3 * i + 1], pz = means[3 * i + 2];
     float vmx = 0.f, vmy = 0.f, vmz = 0.f, vpx = 0.f, vpy = 0.f, vpz = 0.f;
+    // enforce_half: mark the top_k largest alignments (first pass), ties resolved towards the lower slot
+    unsigned chosen = 0xffffffffu;
+    if (top_k > 0 && top_k < K) {
+      float al[kMaxDirNN];
+      for (int k = 0; k < K; ++k) {
+        const int j = nn[(size_t)i * K + k];
+        float a = -1.f;
+        if (j >= 0) {
+          const float dx = px - means[3 * j], dy = py - means[3 * j + 1], dz = pz - means[3 * j + 2];
+          const float n2 = dx * dx + dy * dy + dz * dz;
+          // a coincident neighbour gives 0/0 = NaN in the reference; it is skipped here like below
+          if (n2 > 0.f) a = fabsf((mx * dx + my * dy + mz * dz) * rsqrtf(n2));
+        }
+        al[k] = a;
+      }
+      chosen = 0u;
+      for (int t = 0; t < top_k; ++t) {
+        int best = -1;
+        float bv = -2.f;
+        for (int k = 0; k < K; ++k)
+          if (!((chosen >> k) & 1u) && al[k] > bv) { bv = al[k]; best = k; }
+        if (best >= 0) chosen |= 1u << best;
+      }
+    }
     for (int k = 0; k < K; ++k) {
       const int j = nn[(size_t)i * K + k];
-      if (j < 0) continue;
+      if (j < 0 || !((chosen >> k) & 1u)) continue;
       const float dx = px - means[3 * j], dy = py - means[3 * j + 1], dz = pz - means[3 * j + 2];
       const float n2 = dx * dx + dy * dy + dz * dz;
       if (!(n2 > 0.f)) continue;
@@ -211,7 +238,7 @@ extern "C" int eg_knn(const float *points, int32_t N, int32_t K, const float *or
                       int32_t *cell_counts /*[C], zero on entry and on exit*/, int32_t *cell_start /*[C+1]*/,
                       int32_t *sorted /*[N]*/, int32_t *out_idx /*[N,K]*/, float *out_d2 /*[N,K]|NULL*/,
                       eg_stream_t stream) {
-  EG_REQUIRE(N >= 0 && K >= 1 && K <= 16 && cell > 0.f && origin_host && dims_host, "bad arguments");
+  EG_REQUIRE(N >= 0 && K >= 1 && K <= 32 && cell > 0.f && origin_host && dims_host, "bad arguments");
   if (N == 0) return EG_OK;
   EG_REQUIRE(points && cell_of && cell_counts && cell_start && sorted && out_idx, "null pointer");
   Grid g;
@@ -227,20 +254,22 @@ extern "C" int eg_knn(const float *points, int32_t N, int32_t K, const float *or
   knn_scatter_kernel<<<cdiv(N, 256), 256, 0, st>>>(cell_of, N, cell_start, cell_counts, sorted);
   if (K <= 8)
     knn_query_kernel<8><<<cdiv(N, 128), 128, 0, st>>>(points, N, K, g, cell_start, sorted, out_idx, out_d2);
-  else
+  else if (K <= 16)
     knn_query_kernel<16><<<cdiv(N, 128), 128, 0, st>>>(points, N, K, g, cell_start, sorted, out_idx, out_d2);
+  else  // 'enforce_half' with dir_loss_num_nn = 10 asks for 2 k + 1 = 21 neighbours (edge_gs.py:339-340)
+    knn_query_kernel<32><<<cdiv(N, 128), 128, 0, st>>>(points, N, K, g, cell_start, sorted, out_idx, out_d2);
   return check_launch("knn");
 }
 
 extern "C" int eg_direction_loss(const float *means, const float *quats, const float *log_scales,
-                                 const int32_t *nn_idx /*[N,K]*/, int32_t N, int32_t K,
+                                 const int32_t *nn_idx /*[N,K]*/, int32_t N, int32_t K, int32_t top_k,
                                  float *g_means /*[N,3] accumulated*/, float *g_quats /*[N,4] written*/,
                                  float *sum_out /*[1] accumulated*/, eg_stream_t stream) {
-  EG_REQUIRE(N >= 0 && K >= 1, "bad sizes");
+  EG_REQUIRE(N >= 0 && K >= 1 && K <= kMaxDirNN, "bad sizes (K <= 32)");
   if (N == 0) return EG_OK;
   EG_REQUIRE(means && quats && log_scales && nn_idx && g_means && g_quats && sum_out, "null pointer");
-  direction_loss_kernel<<<cdiv(N, 256), 256, 0, as_stream(stream)>>>(means, quats, log_scales, nn_idx, N, K, g_means,
-                                                                   g_quats, sum_out);
+  direction_loss_kernel<<<cdiv(N, 256), 256, 0, as_stream(stream)>>>(means, quats, log_scales, nn_idx, N, K, top_k,
+                                                                   g_means, g_quats, sum_out);
   return check_launch("direction_loss");
 }
 

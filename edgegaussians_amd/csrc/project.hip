@@ -247,7 +247,7 @@ project_fwd_kernel(const float *__restrict__ means, const float *__restrict__ qu
         scan_offsets[T] = (int)min((long long)tot, scan_capacity);
         scan_item_offsets[T] = itot;
         scan_total[0] = tot;
-        scan_total[1] = ((long long)tot > scan_capacity) ? 1 : 0;
+        if ((long long)tot > scan_capacity) scan_total[1] = 1;  // sticky: only the host clears it
         scan_total[2] = itot;
         scan_total[3] = max(max(s_tmp[0], s_tmp[1]), max(s_tmp[2], s_tmp[3]));
         *scan_ticket = 0;  // ready for the next launch
@@ -629,7 +629,7 @@ project_emit_kernel(const float *__restrict__ means, const float *__restrict__ q
     int m = 0;
     for (int w = 0; w < kPE / 64; ++w) m = max(m, s_tmp[w]);
     out.total[0] = mtot;
-    out.total[1] = (m > seg_cap || itot > out.max_items) ? 1 : 0;
+    if (m > seg_cap || itot > out.max_items) out.total[1] = 1;  // sticky: only the host clears it
     out.total[2] = min(itot, out.max_items);
     out.total[3] = m;
     *out.ticket = 0;  // ready for the next launch

@@ -175,7 +175,7 @@ def isect_tiles_and_sort(means2d: Tensor, radii: Tensor, depths: Tensor, counts:
     T = counts.shape[0]
     offsets = torch.empty(T + 1, dtype=torch.int32, device=dev)
     item_offsets = torch.empty(T + 1, dtype=torch.int32, device=dev)
-    total = torch.empty(4, dtype=torch.int32, device=dev)
+    total = torch.zeros(4, dtype=torch.int32, device=dev)  # total[1] (overflow) is sticky: start from zero
     call("eg_tile_offsets", ptr(counts), T, 1 << 40, ptr(offsets), ptr(item_offsets), ptr(total), stream())
     M, _ovf, n_items, nmax = (int(v) for v in total.tolist())
     keys = torch.empty(max(M, 1), dtype=torch.int64, device=dev)

@@ -21,7 +21,7 @@ def knn(points: Tensor, k: int, want_dist: bool = False) -> Tuple[Tensor, Tensor
     """Indices [N,k] (int32, ascending distance, self excluded) and, optionally, distances [N,k].
     One host sync (the bounding box), where the reference had a full D2H copy + CPU tree build."""
     assert points.is_cuda and points.dtype == torch.float32 and points.dim() == 2 and points.shape[1] == 3
-    assert 1 <= k <= 16
+    assert 1 <= k <= 32
     pts = points.detach().contiguous()
     N = pts.shape[0]
     dev = pts.device
@@ -46,23 +46,25 @@ def knn(points: Tensor, k: int, want_dist: bool = False) -> Tuple[Tensor, Tensor
     return idx, (d2.sqrt() if d2 is not None else None)
 
 
-def reference_nn_indices(points: Tensor, dir_loss_num_nn: int) -> Tensor:
-    """`update_nearest_neighbors` for every enforce method but 'enforce_half' (edge_gs.py:326-344):
-    k_nearest_sklearn(points, k+1) already drops the point itself, and `indices[:, 1:]` then drops the
-    NEAREST neighbour as well -- the reference aligns with neighbours 2 .. k+1.  Kept as is."""
-    idx, _ = knn(points, dir_loss_num_nn + 1)
+def reference_nn_indices(points: Tensor, dir_loss_num_nn: int, enforce_method: str = "enforce_full") -> Tensor:
+    """`update_nearest_neighbors` (edge_gs.py:326-344): k_nearest_sklearn(points, k+1) -- 2k+1 for
+    'enforce_half' -- already drops the point itself, and `indices[:, 1:]` then drops the NEAREST
+    neighbour as well: the reference aligns with neighbours 2 .. k+1 (2 .. 2k+1).  Kept as is."""
+    n = 2 * dir_loss_num_nn + 1 if enforce_method == "enforce_half" else dir_loss_num_nn + 1
+    idx, _ = knn(points, n)
     return idx[:, 1:].contiguous()
 
 
-def direction_loss(means: Tensor, quats: Tensor, log_scales: Tensor, nn_idx: Tensor):
-    """Returns (loss [device scalar], dloss/dmeans [N,3], dloss/dquats [N,4]) of edge_gs.py:346-373."""
+def direction_loss(means: Tensor, quats: Tensor, log_scales: Tensor, nn_idx: Tensor, top_k: int = 0):
+    """Returns (loss [device scalar], dloss/dmeans [N,3], dloss/dquats [N,4]) of edge_gs.py:346-373.
+    top_k = dir_loss_num_nn with a [N,2k] neighbour table is the 'enforce_half' method (:366-369)."""
     N, K = nn_idx.shape
     g_means = torch.zeros(N, 3, device=means.device)
     g_quats = torch.empty(N, 4, device=means.device)
     s = torch.zeros(1, device=means.device)
     call("eg_direction_loss", ptr(means.contiguous()), ptr(quats.contiguous()), ptr(log_scales.contiguous()),
-         ptr(nn_idx.contiguous()), N, K, ptr(g_means), ptr(g_quats), ptr(s), stream())
-    w = -1.0 / (N * K)
+         ptr(nn_idx.contiguous()), N, K, int(top_k), ptr(g_means), ptr(g_quats), ptr(s), stream())
+    w = -1.0 / (N * (top_k if 0 < top_k < K else K))
     return 1.0 + w * s[0], g_means * w, g_quats * w
 
 

@@ -59,7 +59,8 @@ def train_epoch(tr: EdgeTrainer, views: Iterable[int], epoch: int, num_epochs: i
             loss_sum += tr.pop_loss()  # the device accumulator holds the UNSCALED losses (train_gaussians.py:99)
             if apply_dir:
                 tr.regulariser_step("direction", loss_sum, orientation_cfg["dir_loss_scale_factor"],
-                                    orientation_cfg["dir_loss_num_nn"])
+                                    orientation_cfg["dir_loss_num_nn"],
+                                    orientation_cfg.get("dir_loss_enforce_method", "enforce_full"))
             if apply_ratio:
                 tr.regulariser_step("ratio", loss_sum, orientation_cfg["ratio_loss_scale_factor"])
     loss_sum += tr.pop_loss()
@@ -85,10 +86,15 @@ def train(tr: EdgeTrainer, model_cfg: Dict, training_cfg: Dict, view_order: Call
         history.append(avg)
         changed = False
         if get("if_duplicate_high_pos_grad", True) and epoch in get("dup_high_pos_grads_at_epoch", []):
-            if get("dup_threshold_type", "percentile") == "absolute":  # the only branch the reference executes
-                tr.duplicate_high_pos_gradients(get("dup_threshold_value", 0.95), get("dup_factor", 2),
-                                                get("init_dup_rand_noise_scale", 0.05))
-                changed = True
+            kind = get("dup_threshold_type", "percentile")
+            if kind not in ("absolute", "percentile_top"):
+                # the reference has exactly these two branches (edge_gs.py:559-573); any other value -- the
+                # dataclass default "percentile" included -- dies there with an unbound `dup_mask`
+                raise NotImplementedError(f"dup_threshold_type={kind!r}: the reference defines only 'absolute' "
+                                          "and 'percentile_top' (edge_gs.py:559-573)")
+            tr.duplicate_high_pos_gradients(get("dup_threshold_value", 0.95), get("dup_factor", 2),
+                                            get("init_dup_rand_noise_scale", 0.05), threshold_type=kind)
+            changed = True
         if get("if_cull_gaussians_not_projecting", True) and epoch in get("cull_gaussians_not_projecting_at_epoch", []):
             if edge_masks_u8 is None:
                 edge_masks_u8 = (tr.gt >= thr).to(torch.uint8)

@@ -38,6 +38,11 @@ from ._lib import AdamHyper, StepArgs, call, ptr, stream
 TILE = 16
 
 
+class IsectOverflow(RuntimeError):
+    """A view produced more tile intersections than the isect buffers hold and the affected steps could
+    not be replayed (journal off, or the data-parallel leg).  Results since the last check are invalid."""
+
+
 @dataclass
 class LRSchedule:
     """Per-epoch learning rates of ``train_utils.get_optimizers_schedulers`` (train_utils.py:48-65):
@@ -75,8 +80,22 @@ class EdgeTrainer:
                  viewmats: Tensor, Ks: Tensor, gt: Tensor, width: int, height: int,
                  device: str = "cuda", schedule: Optional[LRSchedule] = None,
                  betas=(0.9, 0.999), eps: float = 1e-8, keep_images: bool = False,
-                 spatial_order: bool = False, segmented: Optional[bool] = None):
+                 spatial_order: bool = False, segmented: Optional[bool] = None, replay_on_overflow: bool = True,
+                 seed: int = 0):
         _lib.load()
+        # replay_on_overflow: the steps enqueued since the last read-back (pop_loss) are journalled and the
+        # state before them is kept, so that an intersection overflow -- noticed at the read-back through
+        # the STICKY device flag total[1] -- is repaired by growing the buffers and re-running exactly those
+        # steps instead of silently training on dropped intersections.  Costs one state copy (136 B per
+        # Gaussian) per run of steps between read-backs.
+        self.replay_on_overflow = bool(replay_on_overflow)
+        self._journal: List = []
+        self._snap: Optional[Dict] = None
+        self.overflow_events = 0
+        # noise of duplicate() comes from a dedicated generator seeded with (seed, event number): identical
+        # on every data-parallel rank whatever else the ranks drew (edge_gs.py:462-467 uses the global RNG)
+        self.seed = int(seed)
+        self._dup_events = 0
         # keep_images: also materialise render / alphas / last_ids / vpix every step (the training step
         # itself needs none of them: its backward reads only the packed gtstop record)
         self.keep_images = bool(keep_images)
@@ -203,7 +222,8 @@ class EdgeTrainer:
             perm = torch.randperm(hw - n_e, device=self.dev)[:n_sel] % hw
             sel = torch.zeros(hw, device=self.dev)
             sel[perm] = 1.0
-            w = edge.reshape(-1).float() / max(n_e, 1) + sel / max(float(sel.sum().item()), 1.0)
+            # randperm values are distinct and < hw, so exactly n_sel pixels are selected: no read-back
+            w = edge.reshape(-1).float() / max(n_e, 1) + sel / max(float(n_sel), 1.0)
             return w.reshape(H, W).contiguous()
         raise ValueError(f"Unknown projection loss strategy: {strategy}")
 
@@ -302,11 +322,70 @@ class EdgeTrainer:
         `wmap` [H,W]: the per-pixel loss weights of the strategy chosen for this step."""
         if self.capacity == 0:
             self.ensure_capacity()
+        if self.replay_on_overflow:
+            if not self._journal:
+                self._snapshot()
+            self._journal.append((view, wmap, self.epoch, self.loss_scale))
+        self._step_raw(view, wmap)
+
+    def _step_raw(self, view: int, wmap: Tensor) -> None:
         self._advance_all()
         self._set_hyper()
         call("eg_train_step", C.byref(self._args(view, wmap, True)), stream())
         self.absgrads_normalize_factor += 1  # edge_gs.py:613
         self.step += 1
+
+    # ------------------------------------------------------------------ overflow: journal, snapshot, replay
+    _SNAP_TENSORS = ("means", "log_scales", "quats", "logit_opacities", "adam_m", "adam_v", "absgrads")
+
+    def _snapshot(self) -> None:
+        self._snap = {k: getattr(self, k).clone() for k in self._SNAP_TENSORS}
+        self._snap["scalars"] = (self.adam_step, list(self.group_steps), self.step, self.absgrads_normalize_factor,
+                                 self.epoch, self.loss_scale)
+
+    def _restore(self) -> None:
+        for k in self._SNAP_TENSORS:
+            getattr(self, k).copy_(self._snap[k])  # in place: the cached argument block keeps its pointers
+        (self.adam_step, gs, self.step, self.absgrads_normalize_factor, self.epoch, self.loss_scale) = self._snap["scalars"]
+        self.group_steps = list(gs)
+
+    def _grow_isect(self, factor: float = 2.0) -> None:
+        seg = int(self.seg_cap * factor) // 128 * 128 if self.seg_cap else 0
+        if self.T * seg > (1 << 28):
+            seg = 0  # absurd fixed segments: the count / scan / emit layout takes over
+        self._alloc_isect(int(self.capacity * factor), seg)
+
+    def _recover_from_overflow(self) -> None:
+        """Called with the stream drained and total[1] raised: some step since the last read-back dropped
+        intersections.  Grow, put the state back, run the journalled steps again; repeat until clean."""
+        if not (self.replay_on_overflow and self._journal and self._snap is not None):
+            self.total.zero_()
+            self._grow_isect(2.0)  # leave usable buffers behind for a caller that catches and restarts
+            raise IsectOverflow("tile-intersection buffers overflowed and the steps since the last read-back "
+                                "cannot be replayed (journal off or data-parallel leg): results are invalid; "
+                                "buffers were grown, restart from the last checkpoint")
+        journal = list(self._journal)
+        epoch_now, ls_now = self.epoch, self.loss_scale
+        for _ in range(8):
+            self.overflow_events += 1
+            self._grow_isect(2.0)
+            self.total.zero_()
+            self.loss_acc.zero_()
+            self._restore()
+            for view, wmap, epoch, ls in journal:
+                self.epoch, self.loss_scale = epoch, ls
+                self._step_raw(view, wmap)
+            if int(self.total[1].item()) == 0:
+                self.epoch, self.loss_scale = epoch_now, ls_now
+                return
+        raise IsectOverflow("tile-intersection buffers still overflow after 8 doublings")
+
+    def flush(self) -> None:
+        """Drain the stream, verify that no step since the last read-back overflowed (repairing it if one
+        did) and forget the journal.  Every operation that changes the state outside train_step calls it."""
+        if int(self.total[1].item()) != 0:
+            self._recover_from_overflow()
+        self._journal.clear()
 
     def train_step_staged(self, view: int, wmap: Tensor, mark=None) -> None:
         """The same step as ``train_step`` but sequenced from Python, one C-ABI call per stage, with
@@ -392,15 +471,15 @@ class EdgeTrainer:
         self.absgrads_normalize_factor += 1
 
     # ------------------------------------------------------------------ orientation regularisers (8f)
-    def update_nearest_neighbors(self, dir_loss_num_nn: int = 5) -> Tensor:
+    def update_nearest_neighbors(self, dir_loss_num_nn: int = 5, enforce_method: str = "enforce_full") -> Tensor:
         """`update_nearest_neighbors` (edge_gs.py:326-344) on device; keeps the reference's quirk of
         skipping the nearest neighbour (see regularizers.reference_nn_indices)."""
         from . import regularizers as R
-        self.nn_indices = R.reference_nn_indices(self.means, dir_loss_num_nn)
+        self.nn_indices = R.reference_nn_indices(self.means, dir_loss_num_nn, enforce_method)
         return self.nn_indices
 
     def regulariser_step(self, kind: str, avg_loss_sum: float, scale_factor: float,
-                         dir_loss_num_nn: int = 5) -> float:
+                         dir_loss_num_nn: int = 5, enforce_method: str = "enforce_full") -> float:
         """One regulariser iteration of train_gaussians.py:108-131 ('direction' or 'ratio'):
         loss -> lambda = avg_loss_sum * scale_factor / loss.item() -> backward -> Adam step of the
         means / scales / quats optimizers only (their step counts advance, the opacity optimizer's does
@@ -408,12 +487,15 @@ class EdgeTrainer:
         parameter is outside the loss still step on a zero gradient; that is reproduced.  Returns the
         loss value (one host sync, where the reference has `.item()`)."""
         from . import regularizers as R
+        if self._journal:
+            self.flush()
         N = self.N
         gm, gq, gs, go = self.grad_views()
         self.grads.zero_()
         if kind == "direction":
-            self.update_nearest_neighbors(dir_loss_num_nn)
-            loss, dm, dq = R.direction_loss(self.means, self.quats, self.log_scales, self.nn_indices)
+            self.update_nearest_neighbors(dir_loss_num_nn, enforce_method)
+            loss, dm, dq = R.direction_loss(self.means, self.quats, self.log_scales, self.nn_indices,
+                                            dir_loss_num_nn if enforce_method == "enforce_half" else 0)
             val = float(loss)
             lam = avg_loss_sum * scale_factor / val
             gm.copy_(dm * lam)
@@ -439,19 +521,36 @@ class EdgeTrainer:
         """Sum of the projection losses since the last call (the reference's avg_loss numerator,
         train_gaussians.py:99) -- ONE device sync for many steps instead of two per step."""
         v = float(self.loss_acc.item())
+        m_last, ovf, _items, tile_max = (int(x) for x in self.total.tolist())
+        if ovf:  # sticky flag: SOME step since the last read-back dropped intersections
+            self._recover_from_overflow()  # raises IsectOverflow when the steps cannot be replayed
+            v = float(self.loss_acc.item())
+            m_last, _, _items, tile_max = (int(x) for x in self.total.tolist())
+        self._journal.clear()
         self.loss_acc.zero_()
         # the stream is drained anyway: refresh the tile-sort launch hint from the last step's scan
-        tile_max = int(self.total[3].item())
         if tile_max > getattr(self, "max_tile_seen", 0):
             self.max_tile_seen = tile_max
             self._args_cache = {}
-        if self.seg_cap and tile_max * 1.15 > self.seg_cap:  # a tile is about to outgrow its segment
+        # ... and grow ahead of the drift (opacities climbing, Gaussians converging on the edges)
+        seg = self.seg_cap
+        if seg and tile_max * 1.15 > seg:  # a tile is about to outgrow its segment
             seg = (int(tile_max * 1.5) // 128 + 2) * 128
-            self._alloc_isect(self.capacity, seg if self.T * seg <= (1 << 28) else 0)
+            if self.T * seg > (1 << 28):
+                seg = 0
+        cap = self.capacity
+        if m_last * 1.15 > cap:
+            cap = int(m_last * 1.5) + 4096
+        if seg != self.seg_cap or cap != self.capacity:
+            self._alloc_isect(cap, seg)
         return v
 
     def overflowed(self) -> bool:
+        """True if ANY step since the flag was last cleared dropped intersections (the device flag is sticky)."""
         return bool(self.total[1].item() != 0)
+
+    def clear_overflow(self) -> None:
+        self.total[1:2].zero_()
 
     def last_m(self) -> int:
         return int(self.total[0].item())
@@ -492,6 +591,8 @@ class EdgeTrainer:
         N = self.N
         if N == 0:
             return
+        if self._journal:
+            self.flush()
         perm = self._morton_perm()
         m_old, v_old = self._moment_views(self.adam_m), self._moment_views(self.adam_v)
         names = list(self._params().keys())
@@ -519,6 +620,8 @@ class EdgeTrainer:
         """cull_gaussians (edge_gs.py:412-429) + remove_from_all_optim (:384-409): rows of the 4
         params, 8 moment tensors and absgrads where ~cull_mask, then the reference's opacity clamp
         (a probability-space constant applied in LOGIT space -- kept, it is what the reference does)."""
+        if self._journal:
+            self.flush()
         keep = (~cull_mask.to(self.dev).bool()).to(torch.uint8).contiguous()
         pos, n_keep = self._scan(keep)
         N = self.N
@@ -557,12 +660,16 @@ class EdgeTrainer:
                   noise: Optional[Tensor] = None) -> int:
         """dup_gaussians (edge_gs.py:460-474) + dup_in_all_optim (:431-457): append dup_factor-1
         copies of the masked rows; means get N(0, noise_scale^2) noise, moments of new rows are 0."""
+        if self._journal:
+            self.flush()
         sel = dup_mask.to(self.dev).bool().to(torch.uint8).contiguous()
         pos, n_sel = self._scan(sel)
         copies = dup_factor - 1
         N, n_new = self.N, self.N + copies * n_sel
         if noise is None:
-            noise = torch.randn(copies * n_sel, 3, device=self.dev)
+            gen = torch.Generator(device=self.dev).manual_seed(self.seed * 1_000_003 + self._dup_events)
+            noise = torch.randn(copies * n_sel, 3, device=self.dev, generator=gen)
+        self._dup_events += 1
         new_ref = None
         if self.ref_index is not None and n_sel:
             # the reference appends copy k of its j-th selected row at N + k n_sel + j: our j-th selected
@@ -599,11 +706,24 @@ class EdgeTrainer:
         return n_sel
 
     def duplicate_high_pos_gradients(self, threshold: float = 0.5, dup_factor: int = 3,
-                                     noise_scale: float = 0.05, noise: Optional[Tensor] = None) -> int:
-        """'absolute' branch of edge_gs.py:544-576: min-max normalised mean absgrad > threshold."""
+                                     noise_scale: float = 0.05, noise: Optional[Tensor] = None,
+                                     threshold_type: str = "absolute") -> int:
+        """edge_gs.py:544-576.  'absolute': min-max normalised mean absgrad > threshold (every shipped
+        config).  'percentile_top' (:559-568): the threshold is the int(1/value)-quantile boundary of the
+        RAW mean absgrads ('lower' interpolation) -- and is then compared with the NORMALISED values, as the
+        reference does."""
         g = self.absgrads / self.absgrads_normalize_factor
         gn = (g - g.min()) / (g.max() - g.min())
-        return self.duplicate(gn > threshold, dup_factor, noise_scale, noise)
+        if threshold_type == "absolute":
+            mask = gn > threshold
+        elif threshold_type == "percentile_top":
+            nq = int(1 / threshold)
+            thr = torch.quantile(g, (nq - 1) / nq, interpolation="lower") if nq > 1 else torch.zeros((), device=g.device)
+            mask = gn > thr
+        else:
+            raise NotImplementedError(f"dup_threshold_type={threshold_type!r} (edge_gs.py:559-573 defines "
+                                      "'absolute' and 'percentile_top')")
+        return self.duplicate(mask, dup_factor, noise_scale, noise)
 
     def reset_absgrads(self):
         self.absgrads = torch.zeros(self.means.shape[0], device=self.dev)
@@ -626,14 +746,18 @@ class EdgeTrainer:
         egio.export_as_ply(self.state_dict(), ply_path)
 
     def load_state_dict(self, state: Dict[str, Tensor]) -> None:
-        """Weights only, like the reference's `--ckpt_path` (edge_gs.py:625-633): Adam moments and
-        absgrads restart from zero."""
+        """Weights only, like the reference's `--ckpt_path` (edge_gs.py:625-633, train_gaussians.py builds
+        fresh optimizers after loading): Adam moments, absgrads AND every step counter (Adam bias
+        correction, model.step alternation phase, absgrad normaliser) restart."""
+        if self._journal:
+            self.flush()
         f = dict(device=self.dev, dtype=torch.float32)
         self.means = state["gauss_params.means"].detach().to(**f).contiguous().clone()
         self.log_scales = state["gauss_params.scales"].detach().to(**f).contiguous().clone()
         self.quats = state["gauss_params.quats"].detach().to(**f).contiguous().clone()
         self.logit_opacities = state["gauss_params.opacities"].detach().to(**f).reshape(-1).contiguous().clone()
         self._alloc_state()
+        self.adam_step, self.group_steps, self.step = 0, [0, 0, 0, 0], 0
         self.capacity = 0
         self.ref_index = None
         if self.spatial_order:

@@ -89,7 +89,10 @@ int eg_tile_count(const float *means2d, const int32_t *radii, int32_t N, int32_t
  * gsplat's isect_offset_encode result.  tile_counts is left intact: eg_tile_emit
  * counts it back down to zero.  item_offsets[T+1] (may be NULL) is the exclusive scan of
  * ceil(count/128): the (tile, 128-Gaussian slice) work items of the compositing kernels.
- * total[4] = { M, overflow flag (M > capacity), number of items, largest tile population }. */
+ * total[4] = { M, overflow flag (M > capacity), number of items, largest tile population }.
+ * The overflow flag is STICKY: every producer (this scan, eg_project_bin, eg_project_emit) only ever
+ * raises total[1]; the caller zero-initialises it and clears it after reading, so one read after K
+ * steps tells whether ANY of them dropped intersections. */
 int eg_tile_offsets(const int32_t *tile_counts /*[T]*/, int32_t T, int64_t capacity,
                     int32_t *offsets /*[T+1]*/, int32_t *item_offsets /*[T+1]|NULL*/, int32_t *total /*[4]*/,
                     eg_stream_t stream);
@@ -277,7 +280,7 @@ int eg_project_visibility(const float *means, int32_t N, const float *cams /*[V,
                           eg_stream_t stream);
 
 /* ---- nearest neighbours + orientation regularisers (train_gaussians.py:108-131).
- * eg_knn: exact K <= 16 nearest neighbours (self excluded, ascending distance, ties by index) of N 3D
+ * eg_knn: exact K <= 32 nearest neighbours (self excluded, ascending distance, ties by index) of N 3D
  * points on a uniform grid: origin/cell/dims chosen by the caller (bounding box of the points, ~2
  * points per cell).  Scratch: cell_of[N], cell_counts[C] (zero on entry, returned to zero),
  * cell_start[C+1], sorted[N] with C = dims[0]*dims[1]*dims[2].  Replaces k_nearest_sklearn
@@ -286,12 +289,15 @@ int eg_knn(const float *points /*[N,3]*/, int32_t N, int32_t K, const float *ori
            const int32_t *dims_host /*[3]*/, int32_t *cell_of, int32_t *cell_counts, int32_t *cell_start,
            int32_t *sorted, int32_t *out_idx /*[N,K]*/, float *out_d2 /*[N,K]|NULL squared distances*/,
            eg_stream_t stream);
-/* compute_direction_loss (edge_gs.py:346-373, every method but 'enforce_half'): sum_out[0] += sum over
- * (i,k) of |m_i . unit(mu_i - mu_nn(i,k))| (loss = 1 - sum/(N K)); g_means += and g_quats = the
- * gradient of that SUM (the caller scales by -lambda/(N K)). */
+/* compute_direction_loss (edge_gs.py:346-373): sum_out[0] += sum over the counted (i,k) of
+ * |m_i . unit(mu_i - mu_nn(i,k))|; g_means += and g_quats = the gradient of that SUM.  top_k <= 0 or >= K:
+ * every listed neighbour counts (loss = 1 - sum/(N K), the caller scales by -lambda/(N K)); 0 < top_k < K
+ * ('enforce_half', :366-369, K = 2 k listed, top_k = k): only the top_k best-aligned neighbours of each
+ * Gaussian count (loss = 1 - sum/(N top_k)).  K <= 32. */
 int eg_direction_loss(const float *means, const float *quats, const float *log_scales,
-                      const int32_t *nn_idx /*[N,K]*/, int32_t N, int32_t K, float *g_means /*[N,3] accumulated*/,
-                      float *g_quats /*[N,4] written*/, float *sum_out, eg_stream_t stream);
+                      const int32_t *nn_idx /*[N,K]*/, int32_t N, int32_t K, int32_t top_k,
+                      float *g_means /*[N,3] accumulated*/, float *g_quats /*[N,4] written*/, float *sum_out,
+                      eg_stream_t stream);
 /* compute_ratio_loss (edge_gs.py:375-380): sum_out[0] += sum_i second/largest scale (loss = sum/N);
  * g_scales = gradient of the sum w.r.t. the log-scales. */
 int eg_ratio_loss(const float *log_scales, int32_t N, float *g_scales /*[N,3] written*/, float *sum_out,

@@ -80,6 +80,29 @@ def rasterize(means, quats, scales, opacities, colors, viewmat, K, width, height
                 _op_in=opacities, _colors=colors, _vm=vm, _K=Kc, _size=(width, height), _eps2d=eps2d, _aa=antialiased)
 
 
+def borderline_pixels(fw: Dict[str, np.ndarray], rel_alpha: float = 1e-4, rel_T: float = 2e-4) -> np.ndarray:
+    """uint8 [H,W]: pixels whose walk passes within the margins of a float threshold (see eg_oracle.c)."""
+    width, height = fw["_size"]
+    flat = np.ascontiguousarray(np.concatenate([fw["flatten_ids"], np.zeros(1, np.int32)]))
+    mask = np.zeros((height, width), np.uint8)
+    load().ego_borderline_pixels(_opt(fw["means2d"]), _opt(fw["conics"]), _opt(fw["opacities"]), width, height,
+                                 _opt(np.ascontiguousarray(fw["isect_offsets"].reshape(-1))), _opt(flat),
+                                 C.c_int64(fw["M"]), C.c_double(rel_alpha), C.c_double(rel_T), _opt(mask))
+    return mask
+
+
+def project_borderline(means, quats, scales, viewmat, K, width, height, near_plane=0.01, eps2d=0.3,
+                       rel: float = 2e-5) -> np.ndarray:
+    """uint8 [N]: Gaussians whose integer decisions (radius ceil, culls, tile box) hinge on float rounding."""
+    f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32)  # noqa: E731
+    means, quats, scales = map(f32, (means, quats, scales))
+    mask = np.zeros(means.shape[0], np.uint8)
+    load().ego_project_borderline(_opt(means), _opt(quats), _opt(scales), _opt(f32(viewmat).reshape(16)),
+                                  _opt(f32(K).reshape(9)), means.shape[0], width, height, C.c_double(near_plane),
+                                  C.c_double(eps2d), C.c_double(rel), _opt(mask))
+    return mask
+
+
 def backward(fw: Dict[str, np.ndarray], v_render: np.ndarray, v_alphas: Optional[np.ndarray] = None):
     """Gradients of the call w.r.t. means, quats, scales, opacities, colors (+ means2d grad / absgrad)."""
     lib = load()
@@ -106,7 +129,7 @@ def backward(fw: Dict[str, np.ndarray], v_render: np.ndarray, v_alphas: Optional
                         width, height, C.c_float(fw["_eps2d"]), _opt(fw["radii"]), _opt(v_m2d), None, _opt(v_con),
                         _opt(v_comp), _opt(g_means), _opt(g_quats), _opt(g_scales))
     return dict(means=g_means, quats=g_quats, scales=g_scales, opacities=v_opac, colors=v_col, means2d=v_m2d,
-                absgrad=v_abs)
+                absgrad=v_abs, conics=v_con, opacities_eff=v_op)
 
 
 class CpuTrainer:

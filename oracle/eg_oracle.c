@@ -431,6 +431,108 @@ double ego_train_step(float *means, float *log_scales, float *quats, float *logi
   return loss;
 }
 
+/* ---------------------------------------------------------------- float-borderline analysis -------
+ * The path branches on float comparisons (radius = ceil(3 sqrt(lambda)), the near / on-screen culls,
+ * alpha >= 1/255, alpha raw <= 0.999, next_T <= 1e-4).  Two correct fp32 implementations with a
+ * different exp or a different operation order may take different branches where the compared value sits
+ * within rounding distance of its threshold; everywhere else they must agree to the float tolerance.
+ * These two routines evaluate the SAME formulas in double precision on the same fp32 inputs and mark
+ * what lies within a stated relative margin of a threshold, so that the parity tests can (a) take such
+ * Gaussians out of the scene and (b) give such pixels zero loss weight -- and then assert the tolerance
+ * on EVERY remaining element, instead of admitting an unexplained fraction of outliers. */
+void ego_project_borderline(const float *means, const float *quats, const float *scales, const float *vm,
+                            const float *K, int N, int width, int height, double near_plane, double eps2d,
+                            double rel, uint8_t *mask /*[N] out*/) {
+  const double Rv[9] = {vm[0], vm[1], vm[2], vm[4], vm[5], vm[6], vm[8], vm[9], vm[10]};
+  const double tv[3] = {vm[3], vm[7], vm[11]};
+  const double fx = K[0], cx = K[2], fy = K[4], cy = K[5];
+  const int tw = (width + TILE - 1) / TILE, th = (height + TILE - 1) / TILE;
+#pragma omp parallel for schedule(static)
+  for (int g = 0; g < N; ++g) {
+    const float *mu = means + 3 * g, *q = quats + 4 * g, *sc = scales + 3 * g;
+    uint8_t flag = 0;
+    const double x = Rv[0] * mu[0] + Rv[1] * mu[1] + Rv[2] * mu[2] + tv[0];
+    const double y = Rv[3] * mu[0] + Rv[4] * mu[1] + Rv[5] * mu[2] + tv[1];
+    const double z = Rv[6] * mu[0] + Rv[7] * mu[1] + Rv[8] * mu[2] + tv[2];
+    if (fabs(z - near_plane) <= rel * near_plane) flag = 1;
+    if (z < near_plane) { mask[g] = flag; continue; }
+    double w = q[0], qx = q[1], qy = q[2], qz = q[3];
+    const double qi = 1.0 / sqrt(w * w + qx * qx + qy * qy + qz * qz);
+    w *= qi; qx *= qi; qy *= qi; qz *= qi;
+    const double R[9] = {1 - 2 * (qy * qy + qz * qz), 2 * (qx * qy - w * qz), 2 * (qx * qz + w * qy),
+                         2 * (qx * qy + w * qz), 1 - 2 * (qx * qx + qz * qz), 2 * (qy * qz - w * qx),
+                         2 * (qx * qz - w * qy), 2 * (qy * qz + w * qx), 1 - 2 * (qx * qx + qy * qy)};
+    double W[9];
+    for (int i = 0; i < 3; ++i)
+      for (int k = 0; k < 3; ++k) W[3 * i + k] = (Rv[3 * i] * R[k] + Rv[3 * i + 1] * R[3 + k] + Rv[3 * i + 2] * R[6 + k]) * sc[k];
+    const double lim_x = 1.3 * (0.5 * width / fx), lim_y = 1.3 * (0.5 * height / fy);
+    const double rz = 1.0 / z, xr = x * rz, yr = y * rz;
+    if (fabs(fabs(xr) - lim_x) <= rel * lim_x || fabs(fabs(yr) - lim_y) <= rel * lim_y) flag = 1; /* fov-clamp gate */
+    const double tx = z * fmin(lim_x, fmax(-lim_x, xr)), ty = z * fmin(lim_y, fmax(-lim_y, yr));
+    const double J00 = fx * rz, J11 = fy * rz, J02 = -fx * tx * rz * rz, J12 = -fy * ty * rz * rz;
+    double p0[3], p1[3];
+    for (int k = 0; k < 3; ++k) { p0[k] = J00 * W[k] + J02 * W[6 + k]; p1[k] = J11 * W[3 + k] + J12 * W[6 + k]; }
+    const double c00 = p0[0] * p0[0] + p0[1] * p0[1] + p0[2] * p0[2], c01 = p0[0] * p1[0] + p0[1] * p1[1] + p0[2] * p1[2];
+    const double c11 = p1[0] * p1[0] + p1[1] * p1[1] + p1[2] * p1[2];
+    const double b00 = c00 + eps2d, b11 = c11 + eps2d, det1 = b00 * b11 - c01 * c01;
+    if (det1 <= 0.0) { mask[g] = 1; continue; }
+    const double bh = 0.5 * (b00 + b11), disc = bh * bh - det1;
+    if (fabs(disc - 0.01) <= rel * 0.01) flag = 1; /* max(0.01, .) switches: its derivative does */
+    const double v = 3.0 * sqrt(bh + sqrt(fmax(0.01, disc)));
+    if (fabs(v - floor(v + 0.5)) <= rel * v) flag = 1; /* ceil() is about to flip */
+    const double r = ceil(v), u = fx * x * rz + cx, vv = fy * y * rz + cy;
+    const double edges[4] = {u + r, u - r - width, vv + r, vv - r - height};
+    for (int e = 0; e < 4; ++e)
+      if (fabs(edges[e]) <= rel * (r + width + height)) flag = 1; /* on-screen cull */
+    /* tile box: floor / ceil of (c -+ r) / 16 about to flip (only matters inside the grid) */
+    const double tb[4] = {(u - r) / TILE, (u + r) / TILE, (vv - r) / TILE, (vv + r) / TILE};
+    const double hi[4] = {(double)tw, (double)tw, (double)th, (double)th};
+    for (int e = 0; e < 4; ++e)
+      if (tb[e] > -0.5 && tb[e] < hi[e] + 0.5 && fabs(tb[e] - floor(tb[e] + 0.5)) <= rel * (fabs(tb[e]) + 1.0)) flag = 1;
+    mask[g] = flag;
+  }
+}
+
+/* per pixel: does its front-to-back walk (ego_composite_fwd, in double) pass within the margins of a
+ * threshold?  bit 0: alpha vs 1/255 or raw alpha vs 0.999 or sigma vs 0 (rel_alpha); bit 1: next_T vs
+ * 1e-4 (rel_T).  The walk goes on past a borderline stop, so a flagged pixel is flagged whichever way
+ * an fp32 implementation decides. */
+void ego_borderline_pixels(const float *means2d, const float *conics, const float *opac, int width, int height,
+                           const int32_t *offsets, const int32_t *flatten_ids, int64_t M, double rel_alpha,
+                           double rel_T, uint8_t *mask /*[H*W] out*/) {
+  const int tw = (width + TILE - 1) / TILE, th = (height + TILE - 1) / TILE, T = tw * th;
+  const double amin = 1.0 / 255.0, amax = 0.999, tstop = 1e-4;
+#pragma omp parallel for schedule(dynamic, 1)
+  for (int t = 0; t < T; ++t) {
+    const int64_t start = offsets[t], end = (t == T - 1) ? M : offsets[t + 1];
+    const int ty = t / tw, tx = t % tw;
+    for (int di = 0; di < TILE; ++di)
+      for (int dj = 0; dj < TILE; ++dj) {
+        const int i = ty * TILE + di, j = tx * TILE + dj;
+        if (i >= height || j >= width) continue;
+        const double px = (double)j + 0.5, py = (double)i + 0.5;
+        double Tt = 1.0;
+        uint8_t flag = 0;
+        for (int64_t idx = start; idx < end; ++idx) {
+          const int g = flatten_ids[idx];
+          const double dx = (double)means2d[2 * g] - px, dy = (double)means2d[2 * g + 1] - py;
+          const double a = conics[3 * g], b = conics[3 * g + 1], c = conics[3 * g + 2];
+          const double sigma = 0.5 * (a * dx * dx + c * dy * dy) + b * dx * dy;
+          const double araw = (double)opac[g] * exp(-sigma);
+          if (fabs(araw - amin) <= rel_alpha * amin || fabs(araw - amax) <= rel_alpha * amax || sigma < 1e-6) flag |= 1;
+          const double alpha = fmin(amax, araw);
+          if (sigma < 0.0 || alpha < amin) continue;
+          const double next_T = Tt * (1.0 - alpha);
+          if (fabs(next_T - tstop) <= rel_T * tstop) flag |= 2;
+          if (next_T <= tstop * (1.0 - rel_T)) break; /* stopped beyond doubt */
+          if (next_T <= tstop) continue;              /* borderline stop: look at what follows as well */
+          Tt = next_T;
+        }
+        mask[(size_t)i * width + j] = flag;
+      }
+  }
+}
+
 int ego_num_threads(void) {
   int n = 1;
 #ifdef _OPENMP

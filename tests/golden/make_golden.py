@@ -285,6 +285,49 @@ def filter_projection(views, keep):
     np.savez_compressed(os.path.join(OUT, "filter_projection.npz"), means=means, views=np.array(keep), **out)
 
 
+def regularizers(views):
+    """update_nearest_neighbors / compute_direction_loss / compute_ratio_loss (edge_gs.py:326-380) run
+    as-is (sklearn KD-tree, autograd) on a seeded 2400-Gaussian state that looks like a trained one:
+    means along a few line segments plus noise, anisotropic scales, random quaternions.  Three settings:
+    the shipped one (enforce_full, k = 5), Replica's k = 10, and 'enforce_half' with k = 5 and k = 10."""
+    cams = [views[0]["camera"]]
+    n = 2400
+    g = torch.Generator().manual_seed(21)
+    t = torch.rand(n, 1, generator=g)
+    seg = torch.randint(0, 8, (n,), generator=g)
+    a, b = torch.rand(8, 3, generator=g), torch.rand(8, 3, generator=g)
+    pts = a[seg] * (1 - t) + b[seg] * t + 0.004 * torch.randn(n, 3, generator=g)
+    pts[: n // 6] = torch.rand(n // 6, 3, generator=g)  # plus a uniform background
+    out = {"means": pts.numpy().astype(np.float32)}
+    m = _make_model(cams, n=n, seed=22)
+    with torch.no_grad():
+        m.gauss_params["means"].copy_(pts)
+        m.gauss_params["scales"].copy_(torch.log(0.004 * (1 + 4 * torch.rand(n, 3, generator=g))))
+        m.gauss_params["quats"].mul_(0.5 + torch.rand(n, 1, generator=g))  # un-normalised, like after training
+    out["quats"] = m.quats.detach().numpy().copy()
+    out["log_scales"] = m.scales.detach().numpy().copy()
+    for method, k in (("enforce_full", 5), ("enforce_full", 10), ("enforce_half", 5), ("enforce_half", 10)):
+        m.dir_loss_num_nn, m.dir_loss_enforce_method = k, method
+        m.update_nearest_neighbors()
+        tag = f"{method}_{k}"
+        out[f"nn_{tag}"] = np.asarray(m.nn_indices).astype(np.int32)
+        for p in m.gauss_params.values():
+            p.grad = None
+        loss = m.compute_direction_loss()
+        loss.backward()
+        out[f"dir_loss_{tag}"] = np.float64(loss.item())
+        out[f"dir_gmeans_{tag}"] = m.means.grad.numpy().copy()
+        out[f"dir_gquats_{tag}"] = m.quats.grad.numpy().copy()
+        assert m.scales.grad is None or float(m.scales.grad.abs().max()) == 0.0  # argmax: no gradient to the scales
+    for p in m.gauss_params.values():
+        p.grad = None
+    r = m.compute_ratio_loss()
+    r.backward()
+    out["ratio_loss"] = np.float64(r.item())
+    out["ratio_gscales"] = m.scales.grad.numpy().copy()
+    np.savez_compressed(os.path.join(OUT, "regularizers.npz"), **out)
+
+
 def train_fixture(views):
     """A small end-to-end training problem cut from the reference's own data: 16 of the 50 DexiNed
     edge maps of scan 00004926 at half resolution (2x2 block mean, sparse), their cameras, and 4000 of
@@ -337,7 +380,11 @@ if __name__ == "__main__":
     if "--only-filter" in sys.argv:
         filter_projection(views, keep)
         raise SystemExit(0)
+    if "--only-regularizers" in sys.argv:
+        regularizers(views)
+        raise SystemExit(0)
     filter_projection(views, keep)
+    regularizers(views)
     train_fixture(views)
     train_config()
     quats()

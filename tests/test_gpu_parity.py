@@ -1,7 +1,15 @@
 """GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on identical inputs.
 
 Tolerances (BASELINE.json north_star): floats 1e-4 relative; tile / pixel indexing bit-exact
-(on identical float inputs -- the binning tests feed the ORACLE's floats to the HIP kernels).
+(on identical float inputs -- the binning tests here and the compositing tests in
+test_gpu_oracle_floats.py feed the ORACLE's floats to the HIP kernels).
+
+Single-step comparisons assert 1e-4 on EVERY element: the float-borderline branches of the path are
+handled by a quantified exclusion (tests/util.py) -- Gaussians whose integer decisions hinge on rounding
+are taken out of the scene, pixels within a stated margin of a threshold get zero loss weight on both
+sides.  Only the multi-step TRAJECTORY tests (protocol checks: step counts, alternation, absgrad
+accumulation) keep a looser, documented tolerance, because after the first Adam step the two
+implementations no longer hold bit-identical parameters.
 """
 import math
 
@@ -9,7 +17,8 @@ import numpy as np
 import pytest
 import torch
 
-from tests.util import assert_close, rel_err, to_np
+from tests.util import (assert_close, borderline_pixel_mask, check_fused_step_vs_c_oracle, clean_scene, masked_weights,
+                        oracle_forward, oracle_raw_grads, record, rel_err, strict_inputs, to_np)
 
 pytestmark = pytest.mark.gpu
 
@@ -167,9 +176,7 @@ def _run_pair(env, sc, view=0, colors=None, absgrad=True, mode="antialiased", lo
     return outs
 
 
-def _l1_loss(sc, synth, view, strategy):
-    w = synth.weight_map(strategy, sc.gt[view], ratio=1.0, generator=torch.Generator().manual_seed(5))
-
+def _l1_loss(sc, w, view):
     def fn(render, alpha, dev):
         rgb = torch.clamp(render[0, ..., :3], 0.0, 1.0)  # edge_gs.py:278-279
         return (w.to(dev) * (rgb[:, :, 0] - sc.gt[view].to(dev)).abs()).sum()  # train_gaussians.py:84-94
@@ -179,45 +186,76 @@ def _l1_loss(sc, synth, view, strategy):
 @pytest.mark.parametrize("strategy,mode", [("weighted", "antialiased"), ("whole", "antialiased"),
                                            ("bg_edge_ratio", "antialiased"), ("weighted", "classic")])
 def test_rasterization_matches_oracle(env, strategy, mode):
+    """The drop-in operator against the dense PyTorch oracle (autograd backward): every output of the call."""
     _lib, synth, O = env
-    sc = _scene(synth, n=3000)
-    cpu, gpu = _run_pair(env, sc, view=0, mode=mode, loss_fn=_l1_loss(sc, synth, 0, strategy))
+    sc, fw, border, w, removed = strict_inputs(_scene(synth, n=3000), 0, strategy, seed=5)
+    if mode == "classic":  # no compensation: different opacities, so its own borderline pixels
+        from oracle import c_oracle as CO
+        fw = CO.rasterize(sc.means.numpy(), sc.quats.numpy(), torch.exp(sc.log_scales).numpy(),
+                          torch.sigmoid(sc.logit_opacities).squeeze(-1).numpy(), np.ones((sc.means.shape[0], 1), np.float32),
+                          sc.viewmats[0].numpy(), sc.Ks[0].numpy(), sc.width, sc.height, antialiased=False)
+        border = borderline_pixel_mask(fw, sc.gt[0])
+        w = masked_weights(synth.weight_map(strategy, sc.gt[0], 1.0, torch.Generator().manual_seed(5)), border)
+    cpu, gpu = _run_pair(env, sc, view=0, mode=mode, loss_fn=_l1_loss(sc, w, 0))
     io, ig = cpu["info"], gpu["info"]
-    # integer outputs: identical wherever the float inputs of the integer decisions agree
-    ro, rg = to_np(io["radii"]), to_np(ig["radii"])
-    assert (ro != rg).mean() < 2e-3
-    same_bins = np.array_equal(ro, rg) and np.array_equal(to_np(io["flatten_ids"]), to_np(ig["flatten_ids"]))
-    assert np.array_equal(to_np(io["tiles_per_gauss"])[ro == rg], to_np(ig["tiles_per_gauss"])[ro == rg])
-    if same_bins:
-        assert np.array_equal(to_np(io["isect_offsets"]), to_np(ig["isect_offsets"]))
-        assert (to_np(io["last_ids"]) != to_np(ig["last_ids"])).mean() < 1e-3
+    # integer outputs: the scene holds no Gaussian whose radius / cull / tile box hinges on rounding
+    assert np.array_equal(to_np(io["radii"]), to_np(ig["radii"]))
+    assert np.array_equal(to_np(io["tiles_per_gauss"]), to_np(ig["tiles_per_gauss"]))
+    assert np.array_equal(to_np(io["isect_offsets"]), to_np(ig["isect_offsets"]))
+    fo, fg = to_np(io["flatten_ids"]), to_np(ig["flatten_ids"])
+    # depths are computed with a different operation order (fused multiply-add) on the device: two Gaussians of one
+    # tile whose depths agree to the last bit may swap places.  Everything but such swaps must be identical.
+    diff = fo != fg
+    if diff.any():
+        dep = to_np(io["depths"])[0]
+        assert np.allclose(dep[fo[diff]], dep[fg[diff]], rtol=3e-7, atol=0), "sorted lists differ beyond depth ulps"
+    # pixel indexing: the Gaussian that contributed last, on every pixel outside the borderline set
+    ok = ~border
+    lo = torch.from_numpy(fo)[io["last_ids"][0].long()]
+    lg = torch.from_numpy(fg)[ig["last_ids"][0].cpu().long()]
+    touched = (cpu["alpha"][0, ..., 0] > 0)
+    n_idx = int((lo[ok & touched] != lg[ok & touched]).sum())
+    assert n_idx == 0, f"{n_idx} pixels disagree on the last contributing Gaussian"
     # float outputs
     assert cpu["render"].shape == gpu["render"].shape == (1, sc.height, sc.width, 3)
-    assert_close(gpu["render"], cpu["render"], max_bad=2e-3, name="render")
-    assert_close(gpu["alpha"], cpu["alpha"], max_bad=2e-3, name="alpha")
-    assert np.abs(to_np(gpu["render"]) - to_np(cpu["render"])).max() < 1.2 / 255
+    e = {"render": rel_err(gpu["render"][0][ok], cpu["render"][0][ok]), "alpha": rel_err(gpu["alpha"][0][ok], cpu["alpha"][0][ok])}
+    assert_close(gpu["render"][0][ok], cpu["render"][0][ok], name="render")
+    assert_close(gpu["alpha"][0][ok], cpu["alpha"][0][ok], name="alpha")
     assert abs(float(gpu["loss"]) - float(cpu["loss"])) <= 1e-4 * abs(float(cpu["loss"]))
     for k in ("means", "q", "ls", "lo"):
-        assert_close(gpu[k].grad, cpu[k].grad, max_bad=5e-3, name=f"grad {k}")
-        assert rel_err(gpu[k].grad, cpu[k].grad) < 2e-3, k
-    assert_close(ig["means2d"].grad, io["means2d"].grad, max_bad=5e-3, name="v_means2d")
+        e[f"grad {k}"] = rel_err(gpu[k].grad, cpu[k].grad)
+        assert_close(gpu[k].grad, cpu[k].grad, name=f"grad {k}")
+    e["v_means2d"] = rel_err(ig["means2d"].grad, io["means2d"].grad)
+    e["absgrad"] = rel_err(ig["means2d"].absgrad, io["means2d"].absgrad)
+    assert_close(ig["means2d"].grad, io["means2d"].grad, name="v_means2d")
     assert ig["means2d"].absgrad.shape == (1, sc.means.shape[0], 2)
-    assert_close(ig["means2d"].absgrad, io["means2d"].absgrad, max_bad=5e-3, name="absgrad")
+    assert_close(ig["means2d"].absgrad, io["means2d"].absgrad, name="absgrad")
+    record("rasterization_vs_torch_oracle", strategy=strategy, mode=mode, removed_borderline_gaussians=removed,
+           borderline_pixels=int(border.sum()), pixels=int(border.numel()), max_rel_err=e,
+           last_contributor_mismatches=n_idx, depth_ulp_swaps=int(diff.sum()))
 
 
 def test_rasterization_general_colors(env):
     _lib, synth, O = env
-    sc = _scene(synth, n=1500, w=96, h=80)
-    colors = torch.rand(1500, 3, generator=torch.Generator().manual_seed(9))
-    wr = torch.rand(80, 96, 3, generator=torch.Generator().manual_seed(10))
+    sc, removed = clean_scene(_scene(synth, n=1500, w=96, h=80), [0])
+    n = sc.means.shape[0]
+    colors = torch.rand(n, 3, generator=torch.Generator().manual_seed(9))
+    keep = (~borderline_pixel_mask(oracle_forward(sc, 0))).float()  # borderline pixels: zero upstream gradient
+    wr = torch.rand(80, 96, 3, generator=torch.Generator().manual_seed(10)) * keep[..., None]
 
     def fn(render, alpha, dev):
-        return (render[0] * wr.to(dev)).sum() * 1e-3 + (alpha[0, ..., 0] ** 2).sum() * 1e-3
+        return (render[0] * wr.to(dev)).sum() * 1e-3 + ((alpha[0, ..., 0] ** 2) * keep.to(dev)).sum() * 1e-3
     cpu, gpu = _run_pair(env, sc, colors=colors, loss_fn=fn)
-    assert_close(gpu["render"], cpu["render"], max_bad=2e-3, name="render")
+    ok = keep.bool()
+    assert_close(gpu["render"][0][ok], cpu["render"][0][ok], name="render")
+    e = {}
     for k in ("means", "q", "ls", "lo", "col"):
-        assert_close(gpu[k].grad, cpu[k].grad, max_bad=5e-3, name=f"grad {k}")
-    assert_close(gpu["info"]["means2d"].absgrad, cpu["info"]["means2d"].absgrad, max_bad=5e-3, name="absgrad")
+        e[k] = rel_err(gpu[k].grad, cpu[k].grad)
+        assert_close(gpu[k].grad, cpu[k].grad, name=f"grad {k}")
+    e["absgrad"] = rel_err(gpu["info"]["means2d"].absgrad, cpu["info"]["means2d"].absgrad)
+    assert_close(gpu["info"]["means2d"].absgrad, cpu["info"]["means2d"].absgrad, name="absgrad")
+    record("general_colors_vs_torch_oracle", removed_borderline_gaussians=removed, borderline_pixels=int((~ok).sum()),
+           max_rel_err=e)
 
 
 def test_boundary_protocol(env, golden_dir):
@@ -351,11 +389,11 @@ def test_grad_step_equals_autograd_path(env, segmented):
     binning layouts of the step (count / scan / emit, and the one-pass segmented layout)."""
     _lib, synth, O = env
     from edgegaussians_amd import EdgeTrainer, rasterization
-    sc = _scene(synth, n=2500, w=160, h=112, views=2)
+    sc, _fw, _border, w, _ = strict_inputs(_scene(synth, n=2500, w=160, h=112, views=2), 1, "weighted")
     tr = EdgeTrainer(sc.means, sc.log_scales, sc.quats, sc.logit_opacities, sc.viewmats, sc.Ks, sc.gt,
                      sc.width, sc.height, segmented=segmented)
     tr.ensure_capacity()
-    w = synth.weight_map("weighted", sc.gt[1]).cuda()
+    w = w.cuda()
     tr.grad_step(1, w)
     gm, gq, gs, go = [t.clone() for t in tr.grad_views()]
     N = sc.means.shape[0]
@@ -369,12 +407,12 @@ def test_grad_step_equals_autograd_path(env, segmented):
     loss = (w * (torch.clamp(render[0, ..., 0], 0, 1) - sc.gt[1].cuda()).abs()).sum()
     loss.backward()
     assert abs(tr.pop_loss() - float(loss)) <= 1e-5 * abs(float(loss))
-    assert_close(gm, means.grad, rtol=1e-4, max_bad=1e-3, name="means")
-    assert_close(gq, q.grad, rtol=1e-4, max_bad=1e-3, name="quats")
-    assert_close(gs, ls.grad, rtol=1e-4, max_bad=1e-3, name="scales")
-    assert_close(go, lo.grad.view(-1), rtol=1e-4, max_bad=1e-3, name="opacities")
+    assert_close(gm, means.grad, rtol=1e-4, name="means")
+    assert_close(gq, q.grad, rtol=1e-4, name="quats")
+    assert_close(gs, ls.grad, rtol=1e-4, name="scales")
+    assert_close(go, lo.grad.view(-1), rtol=1e-4, name="opacities")
     inc = tr.grads.view(-1)[11 * N:]
-    assert_close(inc, info["means2d"].absgrad[0].norm(dim=-1), rtol=1e-4, max_bad=1e-3, name="absgrad inc")
+    assert_close(inc, info["means2d"].absgrad[0].norm(dim=-1), rtol=1e-4, name="absgrad inc")
     # the step does not materialise the images unless asked to; when asked they are the operator's
     assert tr.render is None and tr.alphas is None and tr.last_ids is None and tr.vpix is None
     tk = EdgeTrainer(sc.means, sc.log_scales, sc.quats, sc.logit_opacities, sc.viewmats, sc.Ks, sc.gt,
@@ -386,12 +424,13 @@ def test_grad_step_equals_autograd_path(env, segmented):
     assert torch.equal(tk.grad_views()[0], gm), "same gradients with and without images"
 
 
-def _grad_step_vs_oracle(env, sc, view, strategy="whole"):
-    """fused eg_train_step (no Adam) against the CPU oracle's autograd on the same inputs."""
+def _grad_step_vs_torch_oracle(env, sc, view, label, strategy="whole"):
+    """fused eg_train_step (no Adam) against the dense PyTorch oracle's AUTOGRAD (a backward derived
+    independently of every hand-written one) on the same inputs; 1e-4 on every element."""
     _lib, synth, O = env
     from edgegaussians_amd import EdgeTrainer
+    sc, fw, border, w, removed = strict_inputs(sc, view, strategy)
     N = sc.means.shape[0]
-    w = synth.weight_map(strategy, sc.gt[view], generator=torch.Generator().manual_seed(3))
     tr = EdgeTrainer(sc.means, sc.log_scales, sc.quats, sc.logit_opacities, sc.viewmats, sc.Ks, sc.gt,
                      sc.width, sc.height)
     tr.ensure_capacity()
@@ -407,35 +446,41 @@ def _grad_step_vs_oracle(env, sc, view, strategy="whole"):
     info["means2d"].retain_grad()
     loss = O.edge_step_loss(render[0, ..., 0], sc.gt[view], w)
     loss.backward()
-    assert abs(loss_g - float(loss)) <= 2e-4 * abs(float(loss)), (loss_g, float(loss))
+    assert abs(loss_g - float(loss)) <= 1e-4 * abs(float(loss)), (loss_g, float(loss))
     want = [p[0].grad, p[1].grad, p[2].grad, p[3].grad.view(-1), info["means2d"].absgrad[0].norm(dim=-1)]
-    stopped = float((alpha < 1 - 1.1e-4).float().mean())
-    return got, want, stopped, render, tr
+    stopped = float((alpha > 1 - 1.1e-4).float().mean())
+    names = ("means", "quats", "scales", "opac", "absgrad")
+    errs = {k: rel_err(a, b) for a, b, k in zip(got, want, names)}
+    record("fused_grad_step_vs_torch_oracle", scene=label, removed_borderline_gaussians=removed,
+           borderline_pixels=int(border.sum()), pixels=int(border.numel()), stopped_pixel_frac=stopped, max_rel_err=errs)
+    for a, b, k in zip(got, want, names):
+        assert_close(a, b, rtol=1e-4, name=f"{label} {k}")
+    return stopped
 
 
 def test_fused_backward_big_footprints(env):
-    """Gaussians above the 8192-pixel footprint limit take the wavefront-per-Gaussian kernel."""
+    """Footprints of thousands of pixels (one Gaussian takes most lanes of its wavefront)."""
     _lib, synth, O = env
     sc = synth.make_scene(200, 2, 320, 256, seed=4, spread_opacity=True, scale=0.12, anisotropy=3.0)
-    got, want, _, _, _ = _grad_step_vs_oracle(env, sc, 0)
-    for a, b, name in zip(got, want, ("means", "quats", "scales", "opac", "absgrad")):
-        assert_close(a, b, rtol=2e-4, max_bad=5e-3, name=name)
+    _grad_step_vs_torch_oracle(env, sc, 0, "big_footprints")
 
 
 def test_fused_step_with_transmittance_stops(env):
-    """Opaque, heavily overlapping Gaussians: most pixels hit the T <= 1e-4 stop, which is the only
+    """Opaque, heavily overlapping Gaussians: a share of the pixels hits the T <= 1e-4 stop, which is the only
     order-dependent part of the unit-colour path (slice re-walk in the forward, last-contributor
     test in the footprint backward)."""
     _lib, synth, O = env
     sc = synth.make_scene(4000, 2, 128, 96, seed=6, spread_opacity=False, scale=0.03, anisotropy=2.0)
     sc.logit_opacities[:] = torch.logit(torch.tensor(0.97))
-    got, want, frac_unsat, render, tr = _grad_step_vs_oracle(env, sc, 1)
-    assert frac_unsat < 0.97, "scene must saturate a share of the pixels"
-    # a saturated pixel's gradient is ~1e-4 of an open one and hinges on the float-borderline stop
-    # position, so compare norm-wise with a looser per-element allowance
-    for a, b, name in zip(got, want, ("means", "quats", "scales", "opac", "absgrad")):
-        assert rel_err(a, b) < 5e-3, (name, rel_err(a, b))
-        assert_close(a, b, rtol=1e-3, max_bad=2e-2, name=name)
+    stopped = _grad_step_vs_torch_oracle(env, sc, 1, "transmittance_stops")
+    assert stopped > 0.03, "scene must saturate a share of the pixels"
+
+
+def test_fused_step_small_scene_vs_c_oracle(env):
+    """gradients + one whole step against the sequential C oracle on the standard small scene (both views)."""
+    _lib, synth, O = env
+    for view, strategy in ((0, "weighted"), (1, "bg_edge_ratio")):
+        check_fused_step_vs_c_oracle(_scene(synth, n=3000), view, strategy, f"small_scene_view{view}")
 
 
 def test_data_parallel_leg_on_gpu_single_rank(env):
@@ -479,33 +524,6 @@ def test_data_parallel_leg_on_gpu_single_rank(env):
     assert abs(a.pop_loss() - b.pop_loss()) < 1e-6
 
 
-def test_fused_step_vs_c_oracle_at_config1_size(env):
-    """BASELINE config 1 (30 k Gaussians, 512x512) end to end against the plain-C oracle: two training
-    iterations (different views, different strategies), loss / M / parameter updates / absgrads."""
-    _lib, synth, O = env
-    from edgegaussians_amd import EdgeTrainer, LRSchedule, rasterization
-    from oracle import c_oracle as CO
-    n, W, H = 30_000, 512, 512
-    sc = synth.make_scene(n, 3, W, H, seed=0, anisotropy=5.0, spread_opacity=True)
-    sched = LRSchedule(scales_start=0, quats_start=0, opacities_start=0)
-    ct = CO.CpuTrainer(sc.means.numpy(), sc.log_scales.numpy(), sc.quats.numpy(), sc.logit_opacities.numpy(), sched.at(0))
-    tr = EdgeTrainer(sc.means, sc.log_scales, sc.quats, sc.logit_opacities, sc.viewmats, sc.Ks, sc.gt, W, H, schedule=sched)
-    tr.ensure_capacity()
-    for s, (v, strat) in enumerate([(0, "whole"), (2, "bg_edge_ratio")]):
-        w = synth.weight_map(strat, sc.gt[v], generator=torch.Generator().manual_seed(s))
-        lc, M = ct.train_step(sc.viewmats[v].numpy(), sc.Ks[v].numpy(), W, H, sc.gt[v].numpy(), w.numpy())
-        tr.train_step(v, w.cuda())
-        lg = tr.pop_loss()
-        assert abs(lg - lc) <= 2e-4 * abs(lc), (s, lg, lc)
-        assert tr.last_m() <= M  # tight tile boxes only drop (Gaussian, tile) pairs
-    assert not tr.overflowed()
-    for name, mine, theirs in (("means", tr.means, ct.means), ("scales", tr.log_scales, ct.log_scales),
-                               ("quats", tr.quats, ct.quats), ("opacities", tr.logit_opacities, ct.logit)):
-        init = {"means": sc.means, "scales": sc.log_scales, "quats": sc.quats, "opacities": sc.logit_opacities.view(-1)}[name]
-        assert_close(mine.cpu() - init, torch.from_numpy(theirs) - init, rtol=2e-3, max_bad=2e-2, name=f"delta {name}")
-    assert_close(tr.absgrads, ct.absgrads, max_bad=5e-3, name="absgrads")
-
-
 # ------------------------------------------------------------------ edge cases and full-size properties
 def test_empty_and_degenerate_scenes(env):
     """M = 0 (everything culled), N = 1, and an image smaller than one tile: no faults, exact zeros."""
@@ -533,8 +551,9 @@ def test_empty_and_degenerate_scenes(env):
     # N = 1, image 9x7 (smaller than a tile)
     one = synth.make_scene(1, 1, 9, 7, seed=1, scale=0.3, spread_opacity=True)
     one.means[0] = torch.tensor([0.5, 0.5, 0.5])
-    cpu, gpu = _run_pair(env, one, loss_fn=lambda render, alpha, dev: (render[0, ..., 0] ** 2).sum())
-    assert_close(gpu["render"], cpu["render"], max_bad=0.02, name="render 1-gaussian")
+    ok1 = ~borderline_pixel_mask(oracle_forward(one, 0))
+    cpu, gpu = _run_pair(env, one, loss_fn=lambda render, alpha, dev: ((render[0, ..., 0] ** 2) * ok1.to(dev)).sum())
+    assert_close(gpu["render"][0][ok1], cpu["render"][0][ok1], name="render 1-gaussian")
     assert_close(gpu["means"].grad, cpu["means"].grad, rtol=2e-4, name="grad 1-gaussian")
 
 
@@ -543,8 +562,10 @@ def test_full_size_properties_config2(env):
     size-independent properties of the path instead."""
     _lib, synth, O = env
     from edgegaussians_amd import EdgeTrainer, rasterization
-    n, W, H = 100_000, 512, 512
-    sc = synth.make_scene(n, 2, W, H, seed=0, anisotropy=5.0, spread_opacity=True)
+    W, H = 512, 512
+    sc, _fw, _border, w_strict, _removed = strict_inputs(
+        synth.make_scene(100_000, 2, W, H, seed=0, anisotropy=5.0, spread_opacity=True), 0, "weighted")
+    n = sc.means.shape[0]
     dev = "cuda"
     p = [t.clone().to(dev).requires_grad_(True) for t in (sc.means, sc.quats, sc.log_scales, sc.logit_opacities)]
     r, a, info = rasterization(p[0], p[1], torch.exp(p[2]), torch.sigmoid(p[3]).squeeze(-1), torch.ones(n, 3, device=dev),
@@ -565,7 +586,7 @@ def test_full_size_properties_config2(env):
     same = (ids[1:] == ids[:-1])
     assert bool((flat[1:][same] > flat[:-1][same]).all())  # ties: ascending Gaussian id (stable)
     # (3) fused path == operator path on the same inputs: loss and gradients
-    w = synth.weight_map("weighted", sc.gt[0]).to(dev)
+    w = w_strict.to(dev)
     loss = (w * (torch.clamp(r[0, ..., 0], 0, 1) - sc.gt[0].to(dev)).abs()).sum()
     loss.backward()
     tr = EdgeTrainer(sc.means, sc.log_scales, sc.quats, sc.logit_opacities, sc.viewmats, sc.Ks, sc.gt, W, H)
@@ -576,8 +597,8 @@ def test_full_size_properties_config2(env):
     gm, gq, gs, go = tr.grad_views()
     for got, want, name in ((gm, p[0].grad, "means"), (gq, p[1].grad, "quats"), (gs, p[2].grad, "scales"),
                             (go, p[3].grad.view(-1), "opac")):
-        assert_close(got, want, rtol=1e-4, max_bad=2e-3, name=name)
-    assert_close(tr.grads.view(-1)[11 * n:], info["means2d"].absgrad[0].norm(dim=-1), rtol=1e-4, max_bad=2e-3, name="absgrad")
+        assert_close(got, want, rtol=1e-4, name=name)
+    assert_close(tr.grads.view(-1)[11 * n:], info["means2d"].absgrad[0].norm(dim=-1), rtol=1e-4, name="absgrad")
     # (4) determinism of everything that is not a float atomic: two forwards are bit-identical
     r2, a2, info2 = rasterization(p[0].detach(), p[1].detach(), torch.exp(p[2]).detach(), torch.sigmoid(p[3]).squeeze(-1).detach(),
                                   torch.ones(n, 3, device=dev), sc.viewmats[:1].to(dev), sc.Ks[:1].to(dev), W, H,
@@ -591,23 +612,11 @@ def test_large_tile_grids_take_the_fallback_binning_paths(env, W, H):
     to direct atomics; 8192 < T <= 16384: projection keeps LDS counters, emit falls back.  Fused step vs the
     plain-C oracle."""
     _lib, synth, O = env
-    from edgegaussians_amd import EdgeTrainer, LRSchedule
-    from oracle import c_oracle as CO
     T = math.ceil(W / 16) * math.ceil(H / 16)
     assert T > 8192
     sc = synth.make_scene(6000, 1, W, H, seed=2, spread_opacity=True, scale=0.006)
-    sched = LRSchedule(scales_start=0, quats_start=0, opacities_start=0)
-    ct = CO.CpuTrainer(sc.means.numpy(), sc.log_scales.numpy(), sc.quats.numpy(), sc.logit_opacities.numpy(), sched.at(0))
-    tr = EdgeTrainer(sc.means, sc.log_scales, sc.quats, sc.logit_opacities, sc.viewmats, sc.Ks, sc.gt, W, H, schedule=sched)
-    tr.ensure_capacity()
-    w = synth.weight_map("weighted", sc.gt[0])
-    lc, M = ct.train_step(sc.viewmats[0].numpy(), sc.Ks[0].numpy(), W, H, sc.gt[0].numpy(), w.numpy())
-    tr.train_step(0, w.cuda())
-    lg = tr.pop_loss()
-    assert abs(lg - lc) <= 2e-4 * abs(lc) and 0 < tr.last_m() <= M and not tr.overflowed()
+    tr, _, _ = check_fused_step_vs_c_oracle(sc, 0, "weighted", f"large_grid_{W}x{H}")
     assert int(tr.tile_counts.abs().sum()) == 0  # emit returned every counter to zero
-    assert_close(tr.absgrads, ct.absgrads, max_bad=5e-3, name="absgrads")
-    assert_close(tr.means.cpu() - sc.means, torch.from_numpy(ct.means) - sc.means, rtol=2e-3, max_bad=2e-2, name="delta means")
 
 
 # ------------------------------------------------------------------ 8(f): kNN + orientation regularisers
@@ -667,6 +676,37 @@ def test_direction_and_ratio_losses_match_autograd(env):
     r, gs = R.ratio_loss(ls.cuda())
     assert abs(float(r) - float(r_ref)) < 1e-6
     assert_close(gs, s2.grad, rtol=1e-5, name="ratio dlogscales")
+
+
+@pytest.mark.parametrize("method,k", [("enforce_full", 5), ("enforce_full", 10), ("enforce_half", 5), ("enforce_half", 10)])
+def test_regularisers_match_reference_functions(env, golden_dir, method, k):
+    """eg_knn / eg_direction_loss / eg_ratio_loss against the REFERENCE's own update_nearest_neighbors,
+    compute_direction_loss, compute_ratio_loss (edge_gs.py:326-380: sklearn KD-tree + torch autograd), run in
+    the build container on a seeded trained-like state (tests/golden/make_golden.py:regularizers)."""
+    import os
+    from edgegaussians_amd import regularizers as R
+    d = np.load(os.path.join(golden_dir, "regularizers.npz"))
+    means, quats, ls = (torch.from_numpy(d[x]).cuda() for x in ("means", "quats", "log_scales"))
+    tag = f"{method}_{k}"
+    nn_ref = d[f"nn_{tag}"]
+    nn = R.reference_nn_indices(means, k, method)
+    assert nn.shape == nn_ref.shape == (means.shape[0], 2 * k if method == "enforce_half" else k)
+    same_rows = (to_np(nn) == nn_ref).all(axis=1)
+    # index work: exact, except rows in which two neighbours are equidistant to the last bit (KD-tree vs grid order)
+    assert same_rows.mean() > 0.999, same_rows.mean()
+    nn_use = torch.from_numpy(nn_ref).cuda()  # the reference's table: the loss comparison is then input-identical
+    loss, gm, gq = R.direction_loss(means, quats, ls, nn_use, k if method == "enforce_half" else 0)
+    e = {"loss": abs(float(loss) - float(d[f"dir_loss_{tag}"])) / abs(float(d[f"dir_loss_{tag}"])),
+         "gmeans": rel_err(gm, d[f"dir_gmeans_{tag}"]), "gquats": rel_err(gq, d[f"dir_gquats_{tag}"])}
+    assert e["loss"] < 1e-5
+    assert_close(gm, d[f"dir_gmeans_{tag}"], rtol=1e-4, name="dir dmeans")
+    assert_close(gq, d[f"dir_gquats_{tag}"], rtol=1e-4, name="dir dquats")
+    r, gs = R.ratio_loss(ls)
+    e["ratio"] = abs(float(r) - float(d["ratio_loss"])) / float(d["ratio_loss"])
+    e["gscales"] = rel_err(gs, d["ratio_gscales"])
+    assert e["ratio"] < 1e-5
+    assert_close(gs, d["ratio_gscales"], rtol=1e-5, name="ratio dlogscales")
+    record("regularisers_vs_reference_functions", method=method, k=k, nn_rows_identical=float(same_rows.mean()), max_rel_err=e)
 
 
 def test_regulariser_step_advances_only_three_optimizers(env):
@@ -858,7 +898,7 @@ def test_spatial_row_order_is_a_pure_relabelling(env):
     la, lb = ta.pop_loss(), tb.pop_loss()
     assert abs(la - lb) <= 1e-5 * abs(la)
     for ga, gb, name in zip(ta.grad_views(), tb.grad_views(), ("means", "quats", "scales", "opacities")):
-        assert_close(tb._in_reference_order(gb), ga, rtol=1e-4, max_bad=1e-3, name=f"grad {name}")
+        assert_close(tb._in_reference_order(gb), ga, rtol=1e-4, name=f"grad {name}")
     # three optimizer steps, then the densify / cull events with the same (reference-order) noise
     for t in (ta, tb):
         for s in range(3):
@@ -932,14 +972,23 @@ def test_binning_layouts_agree_and_segment_overflow_is_flagged(env):
     la, lb = ta.pop_loss(), tb.pop_loss()
     assert abs(la - lb) <= 1e-6 * abs(la)
     for k, v in ta.state_dict().items():
-        assert_close(tb.state_dict()[k], v, rtol=1e-5, max_bad=1e-3, name=k)
+        assert_close(tb.state_dict()[k], v, rtol=1e-6, name=k)
     assert int(tb.tile_counts.abs().sum()) == 0, "the segment cursors must be back at zero"
-    # overflow: segments far too small for the busiest tiles
+    # overflow: segments far too small for the busiest tiles -> excess dropped, STICKY flag raised, cursors clean
     tb._alloc_isect(tb.capacity, 128)
     assert tb.max_tile_seen > 128
     tb.train_step(0, w)
-    assert tb.overflowed() and math.isfinite(tb.pop_loss())
+    tb.train_step(1, w)
+    assert tb.overflowed()
+    torch.cuda.synchronize()
     assert int(tb.tile_counts.abs().sum()) == 0
+    # the read-back notices, grows the segments, restores the state and replays both steps
+    ta.train_step(0, w); ta.train_step(1, w)
+    la, lb = ta.pop_loss(), tb.pop_loss()
+    assert tb.overflow_events >= 1 and not tb.overflowed() and tb.seg_cap > 128
+    assert abs(la - lb) <= 1e-6 * abs(la)
+    for k, v in ta.state_dict().items():
+        assert_close(tb.state_dict()[k], v, rtol=1e-6, name=f"after replay: {k}")
 
 
 def test_segmented_layout_with_a_giant_tile(env):
@@ -961,7 +1010,7 @@ def test_segmented_layout_with_a_giant_tile(env):
     la, lb = ta.pop_loss(), tb.pop_loss()
     assert math.isfinite(la) and abs(la - lb) <= 1e-5 * abs(la)
     for k, v in ta.state_dict().items():
-        assert_close(tb.state_dict()[k], v, rtol=1e-5, max_bad=2e-3, name=k)
+        assert_close(tb.state_dict()[k], v, rtol=1e-6, name=k)
 
 
 @pytest.mark.parametrize("case", [
@@ -977,10 +1026,14 @@ def test_fused_step_vs_operator_on_random_scenes(env, case):
     _lib, synth, O = env
     from edgegaussians_amd import EdgeTrainer, rasterization
     n, w, h, scale, aniso, seed = case
-    sc = synth.make_scene(n, 2, w, h, seed=seed, spread_opacity=True, scale=scale, anisotropy=aniso)
+    sc, _fw, _border, wm, removed = strict_inputs(
+        synth.make_scene(n, 2, w, h, seed=seed, spread_opacity=True, scale=scale, anisotropy=aniso), 1, "weighted")
+    if removed:  # keep the case's Gaussian count meaningful (n = 1, 7): nothing borderline may be in it
+        assert n > 100
+    n = sc.means.shape[0]
     tr = EdgeTrainer(sc.means, sc.log_scales, sc.quats, sc.logit_opacities, sc.viewmats, sc.Ks, sc.gt, w, h)
     tr.ensure_capacity()
-    wm = synth.weight_map("weighted", sc.gt[1]).cuda()
+    wm = wm.cuda()
     tr.grad_step(1, wm)
     assert not tr.overflowed()
     got = [t.clone() for t in tr.grad_views()]
@@ -998,8 +1051,103 @@ def test_fused_step_vs_operator_on_random_scenes(env, case):
     floor = 1e-6 * max(float(r.abs().max()) for r in ref)  # a gradient that is zero up to round-off stays "equal"
     for a, b, name in zip(got, ref, ("means", "quats", "scales", "opac")):
         assert torch.isfinite(a).all()
-        assert_close(a, b, rtol=2e-4, max_bad=5e-3, name=f"{name} {case}", atol_floor=floor)
-    assert_close(inc, info["means2d"].absgrad[0].norm(dim=-1), rtol=2e-4, max_bad=5e-3, name=f"absgrad {case}")
+        assert_close(a, b, rtol=1e-4, name=f"{name} {case}", atol_floor=floor)
+    assert_close(inc, info["means2d"].absgrad[0].norm(dim=-1), rtol=1e-4, name=f"absgrad {case}")
+
+
+def _overflow_scene(synth):
+    sc = synth.make_scene(6000, 2, 200, 136, seed=3, spread_opacity=False, scale=0.02, anisotropy=5.0)
+    return sc
+
+
+def test_overflow_between_capacity_sweeps_is_replayed(env):
+    """Opacities climb from 0.08 to 0.9 between two capacity sweeps (tight tile boxes grow with ln(255 o)): M
+    outgrows buffers sized with NO slack.  The sticky device flag is noticed at the read-back, the buffers
+    grow, the state is restored and the journalled steps run again: same result as a run that was oversized
+    from the start."""
+    _lib, synth, O = env
+    from edgegaussians_amd import EdgeTrainer, LRSchedule
+    sc = _overflow_scene(synth)
+    sched = LRSchedule(scales_start=0, quats_start=0, opacities_start=0)
+    mk = lambda: EdgeTrainer(sc.means, sc.log_scales, sc.quats, sc.logit_opacities, sc.viewmats, sc.Ks, sc.gt,  # noqa: E731
+                             sc.width, sc.height, schedule=sched)
+    ta, tb = mk(), mk()
+    ta.ensure_capacity(slack=1.0)
+    ta._alloc_isect(ta.capacity * 16, ta.seg_cap * 16)       # the oversized run
+    tb.ensure_capacity(slack=1.0)                             # sized for opacity 0.08 ...
+    tb._alloc_isect(tb.m_max_seen + 64, (tb.max_tile_seen // 128 + 1) * 128)  # ... exactly
+    m0 = tb.m_max_seen
+    w = [synth.weight_map("weighted", sc.gt[v]).cuda() for v in range(2)]
+    tight = (tb.m_max_seen + 64, (tb.max_tile_seen // 128 + 1) * 128)
+    for t in (ta, tb):
+        t.train_step(0, w[0])                                 # fits
+        assert math.isfinite(t.pop_loss()) and t.overflow_events == 0
+        t.logit_opacities.fill_(float(torch.logit(torch.tensor(0.9))))   # "training" raises the opacities
+    tb._alloc_isect(*tight)                                   # (undo the read-back's look-ahead growth)
+    for t in (ta, tb):
+        for s in range(4):
+            t.train_step(s % 2, w[s % 2])
+    assert tb.overflowed() and not ta.overflowed()
+    la, lb = ta.pop_loss(), tb.pop_loss()
+    assert tb.overflow_events >= 1 and ta.overflow_events == 0 and not tb.overflowed()
+    assert tb.last_m() > m0 + 64, "the scene must really have outgrown the first sizing"
+    assert abs(la - lb) <= 1e-6 * abs(la)
+    for k, v in ta.state_dict().items():
+        assert_close(tb.state_dict()[k], v, rtol=1e-6, name=k)
+    assert_close(tb.absgrads, ta.absgrads, rtol=1e-6, name="absgrads")
+    assert tb.adam_step == ta.adam_step and tb.step == ta.step and tb.absgrads_normalize_factor == ta.absgrads_normalize_factor
+
+
+def test_overflow_without_journal_raises(env):
+    _lib, synth, O = env
+    from edgegaussians_amd import EdgeTrainer
+    from edgegaussians_amd.trainer import IsectOverflow
+    sc = _overflow_scene(synth)
+    tr = EdgeTrainer(sc.means, sc.log_scales, sc.quats, sc.logit_opacities, sc.viewmats, sc.Ks, sc.gt, sc.width, sc.height,
+                     replay_on_overflow=False)
+    tr.ensure_capacity(slack=1.0)
+    tr._alloc_isect(tr.m_max_seen + 64, (tr.max_tile_seen // 128 + 1) * 128)
+    w = synth.weight_map("weighted", sc.gt[0]).cuda()
+    tr.logit_opacities.fill_(float(torch.logit(torch.tensor(0.9))))
+    tr.train_step(0, w)
+    tr.logit_opacities.fill_(float(torch.logit(torch.tensor(0.08))))
+    tr.train_step(1, w)   # this step fits again: only a STICKY flag still knows about the first one
+    with pytest.raises(IsectOverflow):
+        tr.pop_loss()
+    # the data-parallel leg (grad_step) has no journal either
+    tr.logit_opacities.fill_(float(torch.logit(torch.tensor(0.9))))
+    tr._alloc_isect(tr.m_max_seen + 64, (tr.max_tile_seen // 128 + 1) * 128)
+    tr.grad_step(0, w)
+    with pytest.raises(IsectOverflow):
+        tr.pop_loss()
+
+
+def test_train_loop_survives_a_capacity_crossing(env):
+    """train() across an opacity ramp with buffers sized without slack: the epoch-end read-back repairs the
+    overflow (the loop never looked at the flag)."""
+    _lib, synth, O = env
+    from edgegaussians_amd import EdgeTrainer, train
+    sc = _overflow_scene(synth)
+    tr = EdgeTrainer(sc.means, sc.log_scales, sc.quats, sc.logit_opacities, sc.viewmats, sc.Ks, sc.gt, sc.width, sc.height)
+    tr.ensure_capacity(slack=1.0)
+    tr._alloc_isect(tr.m_max_seen + 64, (tr.max_tile_seen // 128 + 1) * 128)
+    optim = {"means": {"start_lr": 2e-3, "milestones": [], "gamma": 1.0}, "scales": {"start_lr": 1e-4, "start_at_epoch": 0},
+             "quats": {"start_lr": 1e-3, "start_at_epoch": 0}, "opacities": {"start_lr": 0.3, "start_at_epoch": 0}}
+    training_cfg = {"num_epochs": 3, "optim": optim, "loss": {
+        "orientation_losses": {"start_dir_loss_at_epoch": 99, "start_ratio_loss_at_epoch": 99, "dir_loss_num_nn": 5,
+                               "dir_loss_scale_factor": 0.01, "ratio_loss_scale_factor": 0.01},
+        "projection_losses": {"lambda_annealing": "constant", "lambda_start": 1, "lambda_end": 1,
+                              "loss_before_alternating": "whole", "less_freq_loss": "bg_edge_ratio",
+                              "more_freq_loss": "whole", "start_alternating_at_epoch": 99,
+                              "bg_edge_pixel_ratio_annealing": "constant", "bg_edge_pixel_ratio_start": 1,
+                              "bg_edge_pixel_ratio_end": 1, "sampling_whole_num_epochs_ratio": 5}}}
+    # a target that wants everything opaque: with lr 0.3 on the logits the opacities run up within an epoch
+    tr.gt.fill_(1.0)
+    hist = train(tr, {"if_duplicate_high_pos_grad": False, "if_cull_low_opacity": False,
+                      "if_cull_gaussians_not_projecting": False}, training_cfg, lambda e: [0, 1] * 20)
+    assert len(hist) == 3 and all(math.isfinite(x) for x in hist)
+    assert tr.overflow_events >= 1 and not tr.overflowed()
+    assert float(torch.sigmoid(tr.logit_opacities).mean()) > 0.5
 
 
 def test_bench_line_contract(env):
