@@ -44,7 +44,7 @@ class StepArgs(C.Structure):
         ("tile_counts", _vp), ("offsets", _vp), ("item_offsets", _vp), ("total", _vp),
         ("tile_mask", _vp), ("ticket", _vp),
         ("workspace", _vp), ("max_items", _i64),
-        ("keys", _vp), ("flatten_ids", _vp), ("capacity", _i64), ("max_tile_hint", _i32),
+        ("keys", _vp), ("flatten_ids", _vp), ("capacity", _i64), ("max_tile_hint", _i32), ("rewalk_hint", _i32),
         ("seg_cap", _i32), ("tile_end", _vp), ("item_end", _vp), ("item_tile", _vp),
         ("render", _vp), ("alphas", _vp), ("vpix", _vp), ("loss", _vp), ("gtstop", _vp),
         ("last_ids", _vp),
@@ -63,9 +63,9 @@ _SIGS = {
     "eg_sort_pairs": [_vp, _vp, _i32, _i64, _vp, _vp, _i32, _vp],
     "eg_project_emit": [_vp] * 6 + [_i32, _i32, _i32, _u32, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _vp],
     "eg_sort_segments": [_vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp],
-    "eg_composite_fwd_segments": [_vp] * 7 + [_i32, _i32, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _i64, _vp, _vp, _vp],
+    "eg_composite_fwd_segments": [_vp] * 7 + [_i32, _i32, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _i64, _vp, _vp, _i32, _vp],
     "eg_composite_fwd": [_vp, _vp, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp,
-                         _vp, _vp, _i64, _vp, _vp, _vp],
+                         _vp, _vp, _i64, _vp, _vp, _i32, _vp],
     "eg_composite_bwd": [_vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp],
     "eg_composite_bwd_colors": [_vp, _vp, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "eg_project_bwd": [_vp] * 6 + [_i32, _i32, _i32, _f, _u32] + [_vp] * 9 + [_vp],
@@ -85,7 +85,7 @@ _SIGS = {
     "eg_train_step": [C.POINTER(StepArgs), _vp],
 }
 EXPORTS = sorted(list(_SIGS) + ["eg_last_error_string", "eg_version", "eg_device_count",
-                                 "eg_composite_workspace_bytes", "eg_timing_begin", "eg_timing_end",
+                                 "eg_composite_workspace_bytes", "eg_composite_workspace_ctl_bytes", "eg_timing_begin", "eg_timing_end",
                                  "eg_timing_stage_count", "eg_timing_stage_name"])
 
 _lib: Optional[C.CDLL] = None
@@ -114,11 +114,21 @@ def load(require_device: bool = True) -> C.CDLL:
         lib.eg_timing_stage_name.restype = C.c_char_p
         lib.eg_composite_workspace_bytes.restype = _i64
         lib.eg_composite_workspace_bytes.argtypes = [_i64, _i64]
+        lib.eg_composite_workspace_ctl_bytes.restype = _i64
+        lib.eg_composite_workspace_ctl_bytes.argtypes = [_i64, _i64]
         _lib = lib
     if require_device and not torch.cuda.is_available():
         raise RuntimeError("edgegaussians_amd needs a gfx950 GPU (torch.cuda.is_available() is False); "
                            "there is no CPU fallback in the product path")
     return _lib
+
+
+def composite_workspace(max_items: int, n_tiles: int, device) -> torch.Tensor:
+    """Scratch of the slice-parallel forward for (max_items, n_tiles), control words zeroed (include/edgegs.h)."""
+    lib = load()
+    ws = torch.empty(lib.eg_composite_workspace_bytes(max_items, n_tiles), dtype=torch.uint8, device=device)
+    ws[:lib.eg_composite_workspace_ctl_bytes(max_items, n_tiles)].zero_()
+    return ws
 
 
 def call(name: str, *args) -> None:

@@ -103,7 +103,8 @@ tile_offsets_kernel(const int *__restrict__ counts, int T, long long capacity, i
   for (int base = 0; base < T; base += 1024) {
     const int i = base + tid;
     const int c = (i < T) ? counts[i] : 0;
-    const int it = (c + 127) >> 7;  // 128-Gaussian slices (kSlice in composite.hip)
+    const int it = max(1, (c + 127) >> 7);  // 128-Gaussian slices (kSlice in composite.hip); an empty tile owns one
+                                            // (empty) item: the forward finalises its pixels there
     int tot, itot;
     const int e = block_excl_scan_1024(c, wave_sums, tot);
     const int ie = block_excl_scan_1024(it, wave_sums, itot);
@@ -212,9 +213,9 @@ tile_emit_kernel(const float2 *__restrict__ means2d, const int *__restrict__ rad
 // ---------------------------------------------------------------------------------------------
 // segmented sort: one workgroup per tile on unique 64-bit keys in LDS.
 // Two variants are launched back to back; each tile is handled by exactly one of them:
-//   small: 256 threads,  2 x 2048 keys (34 KiB LDS)  -- tiles with n <= 2048
-//   large: 1024 threads, 2 x 8192 keys (136 KiB LDS) -- tiles with n > 2048; bucket+rank up to 8192
-//          keys, in-LDS bitonic network up to 16384, hybrid global/LDS network beyond (any n, slow)
+//   small: 256 threads,  4096 keys (34 KiB LDS)   -- tiles with n <= 4096 (16 keys per thread in registers)
+//   large: 1024 threads, 16384 keys (136 KiB LDS) -- tiles with n > 4096; bucket+rank / in-LDS bitonic network
+//          up to 16384 keys, hybrid global/LDS network beyond (any n, slow)
 
 // all compare-exchanges of bitonic stages k = k_lo .. k_hi restricted to strides < P, on s[0..P)
 // (ascending-only network: first substage of each k mirrors inside the k-block, then half-cleaners)
@@ -297,8 +298,8 @@ tile_sort_kernel(unsigned long long *__restrict__ keys, const int *__restrict__ 
                  long long capacity, int small_cap, int *__restrict__ flatten_ids,
                  long long *__restrict__ isect_ids, const SegTable seg) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long s[];
-  unsigned long long *kin = s, *kout = s + CAP;
-  int *hist = (int *)(s + 2 * CAP);  // [THREADS] counts -> exclusive starts
+  unsigned long long *kout = s;      // [CAP] keys scattered by bucket (the fast path keeps its input in registers)
+  int *hist = (int *)(s + CAP);      // [THREADS] counts -> exclusive starts
   int *cursor = hist + THREADS;      // [THREADS]
   __shared__ unsigned wave_tmp[32], wave_tmp2[32];  // two hops per tile, never the same array twice in a row
 
@@ -310,7 +311,7 @@ tile_sort_kernel(unsigned long long *__restrict__ keys, const int *__restrict__ 
   if (seg.cursor) {
     if (!LARGE) {
       const int kept = min(seg.cursor[tile], seg.seg_cap);  // every thread reads it; reset after the barrier
-      const int first = seg.item_first[tile], items = min((kept + 127) >> 7, max(0, seg.max_items - first));
+      const int first = seg.item_first[tile], items = min(max(1, (kept + 127) >> 7), max(0, seg.max_items - first));
       __syncthreads();
       if (tid == 0) {
         seg.cursor[tile] = 0;  // ready for the next step
@@ -337,14 +338,21 @@ tile_sort_kernel(unsigned long long *__restrict__ keys, const int *__restrict__ 
   const unsigned long long kInf = ~0ull;
 
   if (n <= CAP) {
-    // ---- bucket + rank
+    // ---- bucket + rank.  A thread keeps its (up to CAP / THREADS) keys in registers across the three passes
+    // (range, histogram, scatter), so LDS only holds the scattered copy: twice the keys per byte of LDS
+    constexpr int KPT = CAP / THREADS;
+    unsigned long long kr[KPT];
     unsigned dmin = 0xffffffffu, dmax = 0u;
-    for (int i = tid; i < n; i += THREADS) {
-      const unsigned long long k = seg[i];
-      kin[i] = k;
-      const unsigned d = (unsigned)(k >> 32);
-      dmin = min(dmin, d);
-      dmax = max(dmax, d);
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) {
+      const int i = tid + j * THREADS;
+      kr[j] = kInf;
+      if (j * THREADS < n && i < n) {
+        kr[j] = seg[i];
+        const unsigned d = (unsigned)(kr[j] >> 32);
+        dmin = min(dmin, d);
+        dmax = max(dmax, d);
+      }
     }
     hist[tid] = 0;
     cursor[tid] = 0;
@@ -361,11 +369,12 @@ tile_sort_kernel(unsigned long long *__restrict__ keys, const int *__restrict__ 
 #pragma unroll
     for (int w = 0; w < NW; ++w) { dmin = min(dmin, wave_tmp[w]); dmax = max(dmax, wave_tmp[16 + w]); }
     const float scale = (float)THREADS / ((float)(dmax - dmin) + 1.f);
-    for (int i = tid; i < n; i += THREADS) {
-      const unsigned d = (unsigned)(kin[i] >> 32);
-      const int bk = min(THREADS - 1, (int)((float)(d - dmin) * scale));
-      atomicAdd(&hist[bk], 1);
-    }
+#pragma unroll
+    for (int j = 0; j < KPT; ++j)
+      if (j * THREADS < n && tid + j * THREADS < n) {
+        const unsigned d = (unsigned)(kr[j] >> 32);
+        atomicAdd(&hist[min(THREADS - 1, (int)((float)(d - dmin) * scale))], 1);
+      }
     __syncthreads();
     // exclusive scan of the bucket counts and their maximum, again one hop and one barrier
     const int cnt = hist[tid];
@@ -390,12 +399,13 @@ tile_sort_kernel(unsigned long long *__restrict__ keys, const int *__restrict__ 
     if (fill <= (unsigned)kMaxBucketFill) {
       hist[tid] = pre + (incl - cnt);
       __syncthreads();
-      for (int i = tid; i < n; i += THREADS) {
-        const unsigned long long k = kin[i];
-        const unsigned d = (unsigned)(k >> 32);
-        const int bk = min(THREADS - 1, (int)((float)(d - dmin) * scale));
-        kout[hist[bk] + atomicAdd(&cursor[bk], 1)] = k;
-      }
+#pragma unroll
+      for (int j = 0; j < KPT; ++j)
+        if (j * THREADS < n && tid + j * THREADS < n) {
+          const unsigned d = (unsigned)(kr[j] >> 32);
+          const int bk = min(THREADS - 1, (int)((float)(d - dmin) * scale));
+          kout[hist[bk] + atomicAdd(&cursor[bk], 1)] = kr[j];
+        }
       __syncthreads();
       for (int i = tid; i < n; i += THREADS) {
         const unsigned long long k = kout[i];
@@ -410,7 +420,12 @@ tile_sort_kernel(unsigned long long *__restrict__ keys, const int *__restrict__ 
       }
       continue;
     }
-    // degenerate depth distribution: bitonic network on kin
+    // degenerate depth distribution: bitonic network on the keys (kin := LDS buffer `kout`)
+    unsigned long long *kin = kout;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < KPT; ++j)
+      if (j * THREADS < n && tid + j * THREADS < n) kin[tid + j * THREADS] = kr[j];
     int P = 1;
     while (P < n) P <<= 1;
     for (int i = n + tid; i < P; i += THREADS) kin[i] = kInf;
@@ -424,23 +439,9 @@ tile_sort_kernel(unsigned long long *__restrict__ keys, const int *__restrict__ 
     continue;
   }
 
-  // ---- oversized segment (n > CAP): bitonic network over both buffers (2 CAP keys) in LDS, and the
-  // hybrid global/LDS network beyond that.  Virtual size P (power of two), indices >= n behave as
-  // +inf and never move (the network only ever moves larger keys to higher indices).
-  constexpr int BCAP = 2 * CAP;
-  if (n <= BCAP) {
-    int P = 1;
-    while (P < n) P <<= 1;
-    for (int i = tid; i < P; i += THREADS) s[i] = (i < n) ? seg[i] : kInf;
-    __syncthreads();
-    bitonic_lds<THREADS>(s, P, 2, P, tid);
-    for (int i = tid; i < n; i += THREADS) {
-      const unsigned long long key = s[i];
-      flatten_ids[start + i] = (int)(unsigned)(key & 0xffffffffull);
-      if (isect_ids) isect_ids[start + i] = ((long long)tile << 32) | (long long)(key >> 32);
-    }
-    continue;
-  }
+  // ---- oversized segment (n > CAP): hybrid global/LDS bitonic network.  Virtual size P (power of two),
+  // indices >= n behave as +inf and never move (the network only ever moves larger keys to higher indices).
+  constexpr int BCAP = CAP;
   long long P = BCAP;
   while (P < n) P <<= 1;
   // (a) sort every BCAP chunk completely
@@ -543,9 +544,9 @@ static bool g_sort_attr_set = false;
 static int launch_tile_sort(uint64_t *keys, const int32_t *offsets, int32_t T, int64_t capacity,
                             int32_t *flatten_ids, int64_t *isect_ids, int32_t max_tile_hint, const SegTable seg,
                             eg_stream_t stream) {
-  // small: 256 threads / buckets, 2 x 2048 keys; large: 1024 threads / buckets, 2 x 8192 keys
-  constexpr int kSmall = 2048, kLarge = 8192;
-  constexpr size_t kSmallLds = 2 * kSmall * 8 + 2 * 256 * 4, kLargeLds = 2 * kLarge * 8 + 2 * 1024 * 4;
+  // small: 256 threads / buckets, 4096 keys; large: 1024 threads / buckets, 16384 keys
+  constexpr int kSmall = 4096, kLarge = 16384;
+  constexpr size_t kSmallLds = kSmall * 8 + 2 * 256 * 4, kLargeLds = kLarge * 8 + 2 * 1024 * 4;
   if (!g_sort_attr_set) {
     (void)hipFuncSetAttribute((const void *)tile_sort_kernel<1024, kLarge, true>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLargeLds);

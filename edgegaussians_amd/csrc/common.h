@@ -20,7 +20,7 @@ int check_launch(const char *what);
 
 // kernel-granular timing marks of the training step (step.hip): no-ops unless a timing window is open
 enum TimingMark {
-  kMarkStart = 0, kMarkProjectBin, kMarkEmit, kMarkSort, kMarkSlice, kMarkCombine, kMarkRewalk, kMarkFootprint,
+  kMarkStart = 0, kMarkProjectBin, kMarkEmit, kMarkSort, kMarkSlice, kMarkRewalk, kMarkFootprint,
   kMarkProjectBwd, kNumMarks
 };
 void timing_mark(int mark, hipStream_t stream);

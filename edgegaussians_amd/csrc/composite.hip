@@ -8,17 +8,20 @@
 // Work decomposition: the reference's scenes put nearly all Gaussians into the ~13x13 central tiles
 // (the object spans ~200 px), so "one workgroup per tile" leaves >80 % of the 256 CUs idle while a
 // few workgroups walk thousands of Gaussians serially (measured: 1.2 ms).  Both passes therefore
-// run one 256-thread workgroup per ITEM = (tile, slice of <= 256 depth-sorted Gaussians); the item
-// table is the second scan produced by eg_tile_offsets.
+// run one 256-thread workgroup per ITEM = (tile, slice of <= 128 depth-sorted Gaussians); the item
+// table is the second scan produced by eg_tile_offsets (an empty tile owns one empty item, which
+// finalises its pixels).
 //
-// Forward (unit colours), two kernels:
+// Forward (unit colours), one kernel + a (usually idle) fix-up:
 //   slice  : item -> per-pixel product P = prod(1 - alpha) over the slice and the index of the last
 //            contributing Gaussian; Gaussians staged through LDS as packed 32-byte records, inner loop
 //            = two broadcast ds_read_b128 + ~15 VALU; a conservative sigma threshold (ln(255 o) +
-//            margin) skips the exp for pairs that cannot reach alpha >= 1/255, the exact test follows
-//   combine: tile -> T = prod over its slices in depth order; the transmittance stop (T <= 1e-4) is
-//            detected on the slice products and resolved exactly by re-walking only the slice in
-//            which it happens; fused clamp + weighted L1 + upstream gradient
+//            margin) skips the exp for pairs that cannot reach alpha >= 1/255, the exact test follows.
+//            The LAST workgroup of a tile to finish (per-tile ticket) combines: T = prod over the tile's
+//            slices in depth order, fused clamp + weighted L1 + upstream gradient.  A tile with one slice
+//            (most tiles at the reference's sizes) never writes its products at all.
+//   re-walk: the transmittance stop (T <= 1e-4) is only DETECTED on the slice products; the slice in which
+//            it falls is put on a compact list and resolved exactly by this kernel
 // (front-to-back compositing is associative: (C1,T1) o (C2,T2) = (C1 + T1 C2, T1 T2); with unit
 // colours C = 1 - T, so only T travels).  General colours use the classic one-workgroup-per-tile
 // kernel below.
@@ -374,88 +377,7 @@ __device__ __forceinline__ PairEval eval_pair(const float4 X, const float4 Cq, c
   return r;
 }
 
-// forward phase A: per (tile, slice) transmittance products.
-// Staging: thread t fetches Gaussian t of the slice, computes its conservative alpha >= 1/255 extent
-// (ex, ey) and appends the packed record to the list of every quadrant it can touch (ballot +
-// popcount compaction, 4 lists x 256 records in LDS).  Each wave then walks only ITS list.
-__global__ void __launch_bounds__(256)
-composite_slice_fwd_kernel(const float4 *__restrict__ splat, const TileTable tt, const int *__restrict__ total,
-                           const int *__restrict__ flat, int tw, int th, float *__restrict__ sliceP,
-                           int *__restrict__ sliceL, unsigned char *__restrict__ sliceQ) {
-  __shared__ QuadLists ql;
-  static_assert(kSlice <= kTilePix, "one staging thread per Gaussian of the slice");
-  __shared__ int sTile[5];
-  const int b = blockIdx.x;
-  if (b >= total[2]) return;
-  const int tile = tt.item_tile ? tt.item_tile[b] : item_tile_coop(tt.item_first, tw * th, b, sTile);
-  const int tid = threadIdx.x, wv = tid >> 6;
-  const int ty = tile / tw, tx = tile - ty * tw;
-  int di, dj;
-  quad_pixel(tid, di, dj);
-  const float px = (float)(tx * kTile + dj) + 0.5f, py = (float)(ty * kTile + di) + 0.5f;
-  const int start = tt.start[tile] + (b - tt.item_first[tile]) * kSlice;
-  const int end = min(tt.end[tile], start + kSlice);
-  const int idx = start + tid;
-
-  float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), rB = s0;
-  bool hitq[4] = {false, false, false, false};
-  if (idx < end) {
-    const int g = flat[idx];
-    s0 = splat[2 * g];
-    const float4 s1 = splat[2 * g + 1];
-    const float thr = __logf(255.f * s1.y) + kThrMargin;
-    rB = make_float4(s1.x, s1.y, thr, __int_as_float(tid));
-    const float det = s0.z * s1.x - s0.w * s0.w;
-    if (thr > 0.f && det > 0.f) {
-      const float k2 = 2.f * thr * __builtin_amdgcn_rcpf(det);  // hardware rcp / sqrt: the inflation covers 1 ulp
-      const float ex = __builtin_amdgcn_sqrtf(k2 * s1.x) * 1.001f + 0.01f;
-      const float ey = __builtin_amdgcn_sqrtf(k2 * s0.z) * 1.001f + 0.01f;
-      const float X0 = (float)(tx * kTile), Y0 = (float)(ty * kTile);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float qx = X0 + (float)((q & 1) << 3), qy = Y0 + (float)((q >> 1) << 3);
-        // pixel centres of the quadrant span [q + 0.5, q + 7.5]: AABB reject, then the exact
-        // ellipse-vs-rectangle test (thin diagonal ellipses miss most of their AABB)
-        hitq[q] = (s0.x - ex <= qx + 7.5f) && (s0.x + ex >= qx + 0.5f) && (s0.y - ey <= qy + 7.5f) &&
-                  (s0.y + ey >= qy + 0.5f) &&
-                  ellipse_hits_rect(s0.x, s0.y, s0.z, s0.w, s1.x, thr, qx + 0.5f, qy + 0.5f, qx + 7.5f, qy + 7.5f);
-      }
-    }
-  }
-  if (tid < kSlice)  // which quadrants each Gaussian of the slice reaches: reused by the exact-stop re-walk
-    sliceQ[(size_t)b * kSlice + tid] = (unsigned char)((int)hitq[0] | ((int)hitq[1] << 1) | ((int)hitq[2] << 2) |
-                                                       ((int)hitq[3] << 3));
-  const int n_mine = build_quad_lists(ql, hitq, s0, rB, tid);
-
-  const float4 *lX = ql.X[wv], *lC = ql.C[wv], *lD = ql.D[wv], *lE = ql.E[wv];
-  const v2f px2 = {px, px}, py2 = {py, py};
-  float P = 1.f;
-  int L = -1;
-  // Walk, two pairs (four Gaussians) per iteration: all LDS reads of a group are issued before the
-  // first use.  No branches: every listed Gaussian reaches some pixel of the quadrant (exact test
-  // above), so a wave-level skip never fires and exec-mask bookkeeping is pure overhead; a rejected
-  // pair multiplies by 1.
-  for (int t = 0; t < n_mine; t += 4) {
-    float4 X[2], Cq[2], D[2], E[2];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      X[u] = lX[(t >> 1) + u]; Cq[u] = lC[(t >> 1) + u]; D[u] = lD[(t >> 1) + u]; E[u] = lE[(t >> 1) + u];
-    }
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const PairEval ev = eval_pair(X[u], Cq[u], D[u], E[u], px2, py2);
-      P *= ev.k0 ? 1.f - ev.a0 : 1.f;  // depth order kept: (P * m0) * m1
-      P *= ev.k1 ? 1.f - ev.a1 : 1.f;
-      L = ev.k0 ? t + 2 * u : L;       // list position (wave-uniform value); translated once after the walk
-      L = ev.k1 ? t + 2 * u + 1 : L;
-    }
-  }
-  if (L >= 0) L = start + __float_as_int(((const float *)&lE[L >> 1])[2 + (L & 1)]);
-  sliceP[(size_t)b * kTilePix + tid] = P;
-  sliceL[(size_t)b * kTilePix + tid] = L;
-}
-
-// per-pixel epilogue shared by the combine and re-walk kernels: outputs, fused clamp + weighted L1
+// per-pixel epilogue shared by the slice (combine) and re-walk kernels: outputs, fused clamp + weighted L1
 // (edge_gs.py:279,288-324) and the packed record the footprint backward reads.  Returns the loss term.
 // Per-pixel record the fused forward leaves for the footprint backward (12 bytes, one dwordx3 load):
 // v * T_final, and -- only for pixels whose front-to-back walk ended on the transmittance rule -- the
@@ -516,60 +438,166 @@ __device__ __forceinline__ void block_loss_add(float l, float *sRed, float *__re
   }
 }
 
-// per-pixel hand-off from combine to re-walk: the slice in which the stop falls and the state before it
+// per-pixel hand-off from the combine to the re-walk kernel: the slice in which the stop falls and the state
+// before it
 struct StopInfo {
   int slice;     // tile-local slice index, -1 = this pixel is final
   float T;       // transmittance before that slice
   int last;      // last contributor before that slice
 };
 
-// forward phase B: per tile, T = product of the slice products in depth order.  A pixel whose running
-// T * P_s drops to <= 1e-4 has its transmittance stop INSIDE slice s: it is handed to the re-walk
-// kernel (item flag + StopInfo); every other pixel is finalised here.
+// Scratch of the slice-parallel forward.  The control words must be ZERO before the first use; every launch
+// sequence hands them back zeroed (tile tickets by the combining workgroup, item flags and the list counter by
+// the re-walk kernel), so a workspace is zeroed once, when it is allocated.
+struct SliceWs {
+  int *tile_ticket;     // [T]   slices of the tile that have finished
+  int *item_flags;      // [max_items] 1 = the item is on the re-walk list
+  int *ctl;             // [4]   {list length, exit ticket of the re-walk kernel, list length of the last step, -}
+  float *sliceP;        // [max_items][256] transmittance product of the slice (written only by tiles with > 1 slice)
+  int *sliceL;          // [max_items][256] its last contributor (global index into the sorted ids, -1 none)
+  StopInfo *stopinfo;   // [T][256]
+  int2 *rewalk;         // [max_items] (item, tile)
+  unsigned char *sliceQ;  // [max_items][128] quadrant verdicts
+};
+
+// forward phase A: per (tile, slice) transmittance products -- and, in the tile's last workgroup, phase B.
+// Staging: thread t fetches Gaussian t of the slice, computes its conservative alpha >= 1/255 extent
+// (ex, ey) and appends the packed record to the list of every quadrant it can touch (ballot +
+// popcount compaction, 4 lists x 128 records in LDS).  Each wave then walks only ITS list.
+// Phase B (T = product of the slice products in depth order): the slice workgroups of a tile publish their
+// products with device-scope stores and take a ticket on the tile; whoever draws the last ticket reads all
+// of them back (device-scope loads: another XCD's L2 may hold the line) and finalises the pixels.  A pixel
+// whose running T * P_s drops to <= 1e-4 has its transmittance stop INSIDE slice s: the item goes on the
+// re-walk list with the pixel's state before it.
 template <int CH>
 __global__ void __launch_bounds__(256)
-composite_combine_fwd_kernel(const TileTable tt, const int *__restrict__ flat, int width,
-                             int height, int tw, int th, const float *__restrict__ sliceP,
-                             const int *__restrict__ sliceL, int *__restrict__ item_flags,
-                             StopInfo *__restrict__ stopinfo, float *__restrict__ render,
-                             float *__restrict__ alphas, int *__restrict__ last_ids,
-                             const float *__restrict__ gt, const float *__restrict__ wmap, float loss_scale,
-                             float *__restrict__ vpix, float *__restrict__ loss_out,
-                             StopRec *__restrict__ gtstop) {
+composite_slice_fwd_kernel(const float4 *__restrict__ splat, const TileTable tt, const int *__restrict__ total,
+                           const int *__restrict__ flat, int width, int height, int tw, int th, const SliceWs ws,
+                           float *__restrict__ render, float *__restrict__ alphas, int *__restrict__ last_ids,
+                           const float *__restrict__ gt, const float *__restrict__ wmap, float loss_scale,
+                           float *__restrict__ vpix, float *__restrict__ loss_out, StopRec *__restrict__ gtstop) {
+  __shared__ QuadLists ql;
+  static_assert(kSlice <= kTilePix, "one staging thread per Gaussian of the slice");
+  __shared__ int sTile[5];
+  __shared__ int s_last;
   __shared__ float sRed[4];
-  const int tile = blockIdx.x, tid = threadIdx.x;
+  const int b = blockIdx.x;
+  if (b >= total[2]) return;
+  const int tile = tt.item_tile ? tt.item_tile[b] : item_tile_coop(tt.item_first, tw * th, b, sTile);
+  const int tid = threadIdx.x, wv = tid >> 6;
   const int ty = tile / tw, tx = tile - ty * tw;
   int di, dj;
-  quad_pixel(tid, di, dj);  // same thread -> pixel map as the slice kernel
+  quad_pixel(tid, di, dj);
   const int i = ty * kTile + di, j = tx * kTile + dj;
   const bool inside = (i < height) && (j < width);
+  const float px = (float)j + 0.5f, py = (float)i + 0.5f;
   const int i0 = tt.item_first[tile], ns = tt.item_end[tile] - i0;
-  // the pixel's target and loss weight do not depend on the slices: fetch them under the slice loads
+  const int start = tt.start[tile] + (b - i0) * kSlice;
+  const int end = min(tt.end[tile], start + kSlice);
+  const int idx = start + tid;
+
+  float P = 1.f;
+  int L = -1;
+  if (end > start) {  // (an empty tile's single item has nothing to walk)
+    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), rB = s0;
+    bool hitq[4] = {false, false, false, false};
+    if (idx < end) {
+      const int g = flat[idx];
+      s0 = splat[2 * g];
+      const float4 s1 = splat[2 * g + 1];
+      const float thr = __logf(255.f * s1.y) + kThrMargin;
+      rB = make_float4(s1.x, s1.y, thr, __int_as_float(tid));
+      const float det = s0.z * s1.x - s0.w * s0.w;
+      if (thr > 0.f && det > 0.f) {
+        const float k2 = 2.f * thr * __builtin_amdgcn_rcpf(det);  // hardware rcp / sqrt: the inflation covers 1 ulp
+        const float ex = __builtin_amdgcn_sqrtf(k2 * s1.x) * 1.001f + 0.01f;
+        const float ey = __builtin_amdgcn_sqrtf(k2 * s0.z) * 1.001f + 0.01f;
+        const float X0 = (float)(tx * kTile), Y0 = (float)(ty * kTile);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float qx = X0 + (float)((q & 1) << 3), qy = Y0 + (float)((q >> 1) << 3);
+          // pixel centres of the quadrant span [q + 0.5, q + 7.5]: AABB reject, then the exact
+          // ellipse-vs-rectangle test (thin diagonal ellipses miss most of their AABB)
+          hitq[q] = (s0.x - ex <= qx + 7.5f) && (s0.x + ex >= qx + 0.5f) && (s0.y - ey <= qy + 7.5f) &&
+                    (s0.y + ey >= qy + 0.5f) &&
+                    ellipse_hits_rect(s0.x, s0.y, s0.z, s0.w, s1.x, thr, qx + 0.5f, qy + 0.5f, qx + 7.5f, qy + 7.5f);
+        }
+      }
+    }
+    if (tid < kSlice)  // which quadrants each Gaussian of the slice reaches: reused by the exact-stop re-walk
+      ws.sliceQ[(size_t)b * kSlice + tid] = (unsigned char)((int)hitq[0] | ((int)hitq[1] << 1) | ((int)hitq[2] << 2) |
+                                                            ((int)hitq[3] << 3));
+    const int n_mine = build_quad_lists(ql, hitq, s0, rB, tid);
+
+    const float4 *lX = ql.X[wv], *lC = ql.C[wv], *lD = ql.D[wv], *lE = ql.E[wv];
+    const v2f px2 = {px, px}, py2 = {py, py};
+    // Walk, two pairs (four Gaussians) per iteration: all LDS reads of a group are issued before the
+    // first use.  No branches: every listed Gaussian reaches some pixel of the quadrant (exact test
+    // above), so a wave-level skip never fires and exec-mask bookkeeping is pure overhead; a rejected
+    // pair multiplies by 1.
+    for (int t = 0; t < n_mine; t += 4) {
+      float4 X[2], Cq[2], D[2], E[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        X[u] = lX[(t >> 1) + u]; Cq[u] = lC[(t >> 1) + u]; D[u] = lD[(t >> 1) + u]; E[u] = lE[(t >> 1) + u];
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const PairEval ev = eval_pair(X[u], Cq[u], D[u], E[u], px2, py2);
+        P *= ev.k0 ? 1.f - ev.a0 : 1.f;  // depth order kept: (P * m0) * m1
+        P *= ev.k1 ? 1.f - ev.a1 : 1.f;
+        L = ev.k0 ? t + 2 * u : L;       // list position (wave-uniform value); translated once after the walk
+        L = ev.k1 ? t + 2 * u + 1 : L;
+      }
+    }
+    if (L >= 0) L = start + __float_as_int(((const float *)&lE[L >> 1])[2 + (L & 1)]);
+  }
+
+  // the pixel's target and loss weight do not depend on the slices: in flight under the ticket round trip
   const bool has_loss = wmap != nullptr;
   const float w_p = (has_loss && inside) ? wmap[i * width + j] : 0.f;
   const float gt_p = (has_loss && inside) ? gt[i * width + j] : 0.f;
-  for (int s = tid; s < ns; s += 256) item_flags[i0 + s] = 0;
-  __syncthreads();
 
   float T = 1.f;
   int last = 0, stop_slice = -1;
-  for (int s4 = 0; s4 < ns && stop_slice < 0; s4 += 4) {
-    // four slices' records in flight per wait (the walk over a tile's ~20 slices is latency-bound)
-    float P[4];
-    int L[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const bool ok = s4 + u < ns;
-      P[u] = ok ? sliceP[(size_t)(i0 + s4 + u) * kTilePix + tid] : 1.f;
-      L[u] = ok ? sliceL[(size_t)(i0 + s4 + u) * kTilePix + tid] : -1;
+  if (ns == 1) {  // the tile's only slice: nothing to publish, nothing to wait for
+    if (L >= 0) {
+      if (P <= kTStop) stop_slice = 0; else { T = P; last = L; }
     }
+  } else {
+    // publish at device scope (the other slices of this tile may run on other XCDs, whose L2s do not snoop
+    // this one), drain, take the tile's ticket
+    __hip_atomic_store(&ws.sliceP[(size_t)b * kTilePix + tid], P, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&ws.sliceL[(size_t)b * kTilePix + tid], L, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      const bool lastwg = atomicAdd(&ws.tile_ticket[tile], 1) == ns - 1;
+      if (lastwg) atomicExch(&ws.tile_ticket[tile], 0);  // ready for the next step
+      s_last = lastwg;
+    }
+    __syncthreads();
+    if (!s_last) return;  // (whole workgroup)
+    for (int s4 = 0; s4 < ns && stop_slice < 0; s4 += 4) {
+      // four slices' records in flight per wait (the walk over a tile's slices is latency-bound)
+      float Ps[4];
+      int Ls[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      if (L[u] < 0 || stop_slice >= 0) continue;
-      const float nT = T * P[u];
-      if (nT <= kTStop) { stop_slice = s4 + u; continue; }
-      T = nT;
-      last = L[u];
+      for (int u = 0; u < 4; ++u) {
+        const bool ok = s4 + u < ns;
+        const size_t o = (size_t)(i0 + (ok ? s4 + u : 0)) * kTilePix + tid;
+        Ps[u] = __hip_atomic_load(&ws.sliceP[o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        Ls[u] = __hip_atomic_load(&ws.sliceL[o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!ok) { Ps[u] = 1.f; Ls[u] = -1; }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (Ls[u] < 0 || stop_slice >= 0) continue;
+        const float nT = T * Ps[u];
+        if (nT <= kTStop) { stop_slice = s4 + u; continue; }
+        T = nT;
+        last = Ls[u];
+      }
     }
   }
   StopInfo si;
@@ -577,10 +605,11 @@ composite_combine_fwd_kernel(const TileTable tt, const int *__restrict__ flat, i
   si.T = T;
   si.last = last;
   if (__syncthreads_or(si.slice >= 0)) {  // only tiles that hand pixels over need the per-pixel records
-    stopinfo[(size_t)tile * kTilePix + tid] = si;
-    if (si.slice >= 0) item_flags[i0 + si.slice] = tile + 1;  // flag = owning tile + 1 (benign race: same value)
+    ws.stopinfo[(size_t)tile * kTilePix + tid] = si;
+    // first pixel to flag a slice puts it on the list (the re-walk kernel returns the flag to zero)
+    if (si.slice >= 0 && atomicExch(&ws.item_flags[i0 + si.slice], 1) == 0)
+      ws.rewalk[atomicAdd(&ws.ctl[0], 1)] = make_int2(i0 + si.slice, tile);
   }
-
   float l = 0.f;
   if (inside && stop_slice < 0)
     l = finalize_pixel<CH>(i * width + j, T, last, false, flat, render, alphas, last_ids, has_loss, gt_p, w_p,
@@ -588,39 +617,35 @@ composite_combine_fwd_kernel(const TileTable tt, const int *__restrict__ flat, i
   if (wmap && loss_out) block_loss_add(l, sRed, loss_out);
 }
 
-// forward phase C: exact transmittance stop.  One workgroup per flagged (tile, slice) item: the slice's
-// records are staged through LDS once and the pixels whose stop falls in this slice walk it
-// sequentially from their known T; should float rounding move the crossing past the slice end, the
-// same lanes carry on through the following slices.
+// forward phase C: exact transmittance stop.  A small grid strides over the compact list of flagged
+// (tile, slice) items: the slice's records are staged through LDS once and the pixels whose stop falls in this
+// slice walk it sequentially from their known T; should float rounding move the crossing past the slice end,
+// the same lanes carry on through the following slices.  In scenes without stops the launch reads one word.
 template <int CH>
 __global__ void __launch_bounds__(256)
-composite_rewalk_fwd_kernel(const float4 *__restrict__ splat, const TileTable tt, const int *__restrict__ total,
-                            const int *__restrict__ flat, int width, int height, int tw, int th,
-                            const int *__restrict__ item_flags, const StopInfo *__restrict__ stopinfo,
-                            const unsigned char *__restrict__ sliceQ,
+composite_rewalk_fwd_kernel(const float4 *__restrict__ splat, const TileTable tt,
+                            const int *__restrict__ flat, int width, int height, int tw, int th, const SliceWs ws,
                             float *__restrict__ render, float *__restrict__ alphas, int *__restrict__ last_ids,
                             const float *__restrict__ gt, const float *__restrict__ wmap, float loss_scale,
                             float *__restrict__ vpix, float *__restrict__ loss_out, StopRec *__restrict__ gtstop) {
   __shared__ QuadLists ql;
   __shared__ float sRed[4];
-  // a fixed small grid strides over the items: in scenes without stops this whole launch is a scan of
-  // the flag array
   const int tid = threadIdx.x, wv = tid >> 6;
   int di, dj;
   quad_pixel(tid, di, dj);
-  const int n_items = total[2];
-  for (int b = blockIdx.x; b < n_items; b += gridDim.x) {
-  const int flag = item_flags[b];
-  if (flag == 0) continue;
+  const int n_list = ws.ctl[0];
+  if ((int)blockIdx.x >= n_list) return;  // the usual case: an empty list costs one load per workgroup
+  for (int k = blockIdx.x; k < n_list; k += gridDim.x) {
   __syncthreads();
-  const int tile = flag - 1;  // the combine kernel left the owning tile in the flag
+  const int2 it = ws.rewalk[k];
+  const int b = it.x, tile = it.y;
   const int ty = tile / tw, tx = tile - ty * tw;
   const int i = ty * kTile + di, j = tx * kTile + dj;
   const float px = (float)j + 0.5f, py = (float)i + 0.5f;
   const v2f px2 = {px, px}, py2 = {py, py};
   const int ib = tt.item_first[tile];
   const int s0 = b - ib, ns = tt.item_end[tile] - ib;
-  const StopInfo si = stopinfo[(size_t)tile * kTilePix + tid];
+  const StopInfo si = ws.stopinfo[(size_t)tile * kTilePix + tid];
   const bool mine = si.slice == s0;
   float T = si.T;
   int last = si.last;
@@ -637,7 +662,7 @@ composite_rewalk_fwd_kernel(const float4 *__restrict__ splat, const TileTable tt
       g0 = splat[2 * g];
       const float4 g1 = splat[2 * g + 1];
       rB = make_float4(g1.x, g1.y, __logf(255.f * g1.y) + kThrMargin, __int_as_float(tid));
-      const int m = sliceQ[(size_t)(ib + s) * kSlice + tid];
+      const int m = ws.sliceQ[(size_t)(ib + s) * kSlice + tid];
 #pragma unroll
       for (int q = 0; q < 4; ++q) hitq[q] = (m >> q) & 1;
     }
@@ -682,7 +707,16 @@ composite_rewalk_fwd_kernel(const float4 *__restrict__ splat, const TileTable tt
                            wmap ? gt[i * width + j] : 0.f, wmap ? wmap[i * width + j] : 0.f, loss_scale, vpix, gtstop,
                            splat);
   if (wmap && loss_out) block_loss_add(l, sRed, loss_out);
-  }  // item loop
+  if (tid == 0) ws.item_flags[b] = 0;  // off the list
+  }  // list loop
+  // the last of the workgroups that had work empties the list for the next step: every one of them has read its
+  // length by now, and a workgroup that starts later reads zero and leaves (only these take the ticket: a burst of
+  // a thousand same-address atomics from idle workgroups cost 10 us per step)
+  if (tid == 0 && atomicAdd(&ws.ctl[1], 1) == min((int)gridDim.x, n_list) - 1) {
+    ws.ctl[2] = max(ws.ctl[2], n_list);  // largest list since the caller last looked (its launch-shape hint)
+    atomicExch(&ws.ctl[0], 0);
+    atomicExch(&ws.ctl[1], 0);
+  }
 }
 
 // backward, unit colours, one workgroup per item: lane = Gaussian of the slice, loop = active pixels
@@ -1146,38 +1180,56 @@ composite_bwd_colors_kernel(const float4 *__restrict__ splat, const float *__res
 
 using namespace eg;
 
-// workspace layout: sliceP f32[max_items][256] | sliceL i32[max_items][256] | item_flags i32[max_items]
-//                   | stopinfo {i32,f32,i32}[T][256]
-extern "C" int64_t eg_composite_workspace_bytes(int64_t max_items, int64_t n_tiles) {
+// workspace layout: control words first (they must be zero before the first use, see SliceWs):
+//   tile_ticket i32[T] | item_flags i32[max_items] | ctl i32[4]
+// then  sliceP f32[max_items][256] | sliceL i32[max_items][256] | stopinfo {i32,f32,i32}[T][256]
+//       | rewalk int2[max_items] | sliceQ u8[max_items][128]
+extern "C" int64_t eg_composite_workspace_ctl_bytes(int64_t max_items, int64_t n_tiles) {
   if (max_items < 0 || n_tiles < 0) return 0;
-  return max_items * kTilePix * (int64_t)(sizeof(float) + sizeof(int32_t)) + max_items * (int64_t)sizeof(int32_t) +
-         n_tiles * kTilePix * (int64_t)sizeof(StopInfo) + max_items * (int64_t)kSlice;
+  return (n_tiles + max_items + 4) * (int64_t)sizeof(int32_t);
 }
 
-// unit colours: slice-parallel forward (slice products -> combine -> exact-stop re-walk)
+extern "C" int64_t eg_composite_workspace_bytes(int64_t max_items, int64_t n_tiles) {
+  if (max_items < 0 || n_tiles < 0) return 0;
+  return eg_composite_workspace_ctl_bytes(max_items, n_tiles) +
+         max_items * kTilePix * (int64_t)(sizeof(float) + sizeof(int32_t)) +
+         n_tiles * kTilePix * (int64_t)sizeof(StopInfo) + max_items * (int64_t)sizeof(int2) + max_items * (int64_t)kSlice;
+}
+
+static SliceWs carve_workspace(void *workspace, int64_t max_items, int n_tiles) {
+  SliceWs ws;
+  ws.tile_ticket = (int *)workspace;
+  ws.item_flags = ws.tile_ticket + n_tiles;
+  ws.ctl = ws.item_flags + max_items;
+  ws.sliceP = (float *)(ws.ctl + 4);
+  ws.sliceL = (int *)(ws.sliceP + (size_t)max_items * kTilePix);
+  ws.stopinfo = (StopInfo *)(ws.sliceL + (size_t)max_items * kTilePix);
+  ws.rewalk = (int2 *)(ws.stopinfo + (size_t)n_tiles * kTilePix);
+  ws.sliceQ = (unsigned char *)(ws.rewalk + max_items);
+  return ws;
+}
+
+// unit colours: slice-parallel forward (slice products + combine by the tile's last workgroup -> exact-stop re-walk)
 static int launch_sliced_fwd(const float4 *splat, const TileTable tt, int channels, const int32_t *flatten_ids,
                              int width, int height, float *render, float *alphas, int32_t *last_ids, const float *gt,
                              const float *wmap, float loss_scale, float *vpix, float *loss_out, const int32_t *total,
-                             int64_t max_items, void *workspace, float *gtstop, hipStream_t s) {
+                             int64_t max_items, void *workspace, float *gtstop, int rewalk_hint, hipStream_t s) {
   const int tw = cdiv(width, kTile), th = cdiv(height, kTile);
-  float *sliceP = (float *)workspace;
-  int *sliceL = (int *)(sliceP + (size_t)max_items * kTilePix);
-  int *item_flags = sliceL + (size_t)max_items * kTilePix;
-  StopInfo *stopinfo = (StopInfo *)(item_flags + max_items);
-  unsigned char *sliceQ = (unsigned char *)(stopinfo + (size_t)tw * th * kTilePix);
-  composite_slice_fwd_kernel<<<(unsigned)max_items, 256, 0, s>>>(splat, tt, total, flatten_ids, tw, th, sliceP, sliceL,
-                                                                sliceQ);
-  timing_mark(kMarkSlice, s);
+  const SliceWs ws = carve_workspace(workspace, max_items, tw * th);
+  // the re-walk grid strides over the compact list: sized from the caller's hint (launching 1024 workgroups that
+  // find an empty list costs 4.5 us, 64 cost 1.3 us); any grid is correct
+  int64_t want = rewalk_hint < 0 ? 256 : (rewalk_hint == 0 ? 64 : 2 * (int64_t)rewalk_hint);
+  want = want < 64 ? 64 : (want > 1024 ? 1024 : want);
+  const unsigned rewalk_grid = (unsigned)(max_items < want ? max_items : want);
 #define EG_LAUNCH_CB(CH)                                                                                          \
   do {                                                                                                            \
-    composite_combine_fwd_kernel<CH><<<tw * th, 256, 0, s>>>(tt, flatten_ids, width, height, tw, th, sliceP,      \
-                                                            sliceL, item_flags, stopinfo, render, alphas,        \
-                                                            last_ids, gt, wmap, loss_scale, vpix, loss_out,       \
-                                                            (StopRec *)gtstop);                                   \
-    timing_mark(kMarkCombine, s);                                                                                 \
-    composite_rewalk_fwd_kernel<CH><<<(unsigned)max_items, 256, 0, s>>>(                                          \
-        splat, tt, total, flatten_ids, width, height, tw, th, item_flags, stopinfo, sliceQ, render, alphas,       \
-        last_ids, gt, wmap, loss_scale, vpix, loss_out, (StopRec *)gtstop);                                       \
+    composite_slice_fwd_kernel<CH><<<(unsigned)max_items, 256, 0, s>>>(                                           \
+        splat, tt, total, flatten_ids, width, height, tw, th, ws, render, alphas, last_ids, gt, wmap, loss_scale, \
+        vpix, loss_out, (StopRec *)gtstop);                                                                       \
+    timing_mark(kMarkSlice, s);                                                                                   \
+    composite_rewalk_fwd_kernel<CH><<<rewalk_grid, 256, 0, s>>>(splat, tt, flatten_ids, width, height, tw, th,   \
+                                                                ws, render, alphas, last_ids, gt, wmap,           \
+                                                                loss_scale, vpix, loss_out, (StopRec *)gtstop);   \
     timing_mark(kMarkRewalk, s);                                                                                  \
   } while (0)
   if (channels == 1) EG_LAUNCH_CB(1); else EG_LAUNCH_CB(3);
@@ -1190,7 +1242,7 @@ extern "C" int eg_composite_fwd(const float *splat, const float *colors, int32_t
                                 float *alphas, int32_t *last_ids, const float *gt, const float *wmap,
                                 float loss_scale, float *vpix, float *loss_out, const int32_t *item_offsets,
                                 const int32_t *total, int64_t max_items, void *workspace, float *gtstop,
-                                eg_stream_t stream) {
+                                int32_t rewalk_hint, eg_stream_t stream) {
   EG_REQUIRE(width > 0 && height > 0, "bad sizes");
   EG_REQUIRE(channels == 1 || channels == 3, "channels must be 1 or 3");
   EG_REQUIRE(splat && offsets, "null pointer");
@@ -1203,7 +1255,7 @@ extern "C" int eg_composite_fwd(const float *splat, const float *colors, int32_t
   if (!colors && item_offsets && total && workspace && max_items > 0) {
     const TileTable tt = {offsets, offsets + 1, item_offsets, item_offsets + 1, nullptr};
     return launch_sliced_fwd((const float4 *)splat, tt, channels, flatten_ids, width, height, render, alphas, last_ids,
-                             gt, wmap, loss_scale, vpix, loss_out, total, max_items, workspace, gtstop, s);
+                             gt, wmap, loss_scale, vpix, loss_out, total, max_items, workspace, gtstop, rewalk_hint, s);
   }
 #define EG_LAUNCH_FWD(CH, UNIT)                                                                              \
   composite_fwd_kernel<CH, UNIT><<<tw * th, 256, 0, s>>>((const float4 *)splat, colors, offsets, flatten_ids, \
@@ -1221,7 +1273,7 @@ extern "C" int eg_composite_fwd_segments(const float *splat, const int32_t *tile
                                          int32_t height, float *render, float *alphas, int32_t *last_ids,
                                          const float *gt, const float *wmap, float loss_scale, float *vpix,
                                          float *loss_out, const int32_t *total, int64_t max_items, void *workspace,
-                                         float *gtstop, eg_stream_t stream) {
+                                         float *gtstop, int32_t rewalk_hint, eg_stream_t stream) {
   EG_REQUIRE(width > 0 && height > 0 && max_items > 0, "bad sizes");
   EG_REQUIRE(splat && tile_start && tile_end && item_first && item_end && item_tile && flatten_ids && total &&
                  workspace,
@@ -1231,7 +1283,8 @@ extern "C" int eg_composite_fwd_segments(const float *splat, const int32_t *tile
   EG_REQUIRE(!gtstop || wmap, "gtstop needs the fused loss");
   const TileTable tt = {tile_start, tile_end, item_first, item_end, item_tile};
   return launch_sliced_fwd((const float4 *)splat, tt, 1, flatten_ids, width, height, render, alphas, last_ids, gt, wmap,
-                           loss_scale, vpix, loss_out, total, max_items, workspace, gtstop, as_stream(stream));
+                           loss_scale, vpix, loss_out, total, max_items, workspace, gtstop, rewalk_hint,
+                           as_stream(stream));
 }
 
 extern "C" int eg_composite_bwd(const float *splat, const int32_t *offsets, const int32_t *flatten_ids,

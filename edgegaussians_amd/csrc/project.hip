@@ -228,7 +228,7 @@ project_fwd_kernel(const float *__restrict__ means, const float *__restrict__ qu
       int sum = 0, isum = 0, cmax = 0;
       for (int t = t0; t < t1; ++t) {
         const int c = __hip_atomic_load(&tile_counts[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        sum += c; isum += (c + 127) >> 7; cmax = max(cmax, c);
+        sum += c; isum += max(1, (c + 127) >> 7); cmax = max(cmax, c);  // an empty tile owns one (empty) item
       }
       int tot, itot;
       int e = block_excl_scan<256>(sum, s_tmp, tot);
@@ -237,7 +237,7 @@ project_fwd_kernel(const float *__restrict__ means, const float *__restrict__ qu
         const int c = __hip_atomic_load(&tile_counts[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         scan_offsets[t] = (int)min((long long)e, scan_capacity);
         scan_item_offsets[t] = ie;
-        e += c; ie += (c + 127) >> 7;
+        e += c; ie += max(1, (c + 127) >> 7);
       }
 #pragma unroll
       for (int d = 32; d >= 1; d >>= 1) cmax = max(cmax, __shfl_xor(cmax, d, 64));
@@ -606,7 +606,7 @@ project_emit_kernel(const float *__restrict__ means, const float *__restrict__ q
   for (int t = t0; t < t1; ++t) {
     const int pop = LDS_HIST ? s_hist[t] : __hip_atomic_load(&cursor[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int kept = min(pop, seg_cap);
-    isum += (kept + 127) >> 7; msum += kept; cmax = max(cmax, pop);
+    isum += max(1, (kept + 127) >> 7); msum += kept; cmax = max(cmax, pop);  // an empty tile owns one (empty) item
   }
   int itot, mtot;
   int ie = block_excl_scan<kPE>(isum, s_tmp, itot);
@@ -614,7 +614,7 @@ project_emit_kernel(const float *__restrict__ means, const float *__restrict__ q
   for (int t = t0; t < t1; ++t) {
     const int pop = LDS_HIST ? s_hist[t] : __hip_atomic_load(&cursor[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (LDS_HIST) s_base[t] = ie; else out.item_first[t] = min(ie, out.max_items);
-    ie += (min(pop, seg_cap) + 127) >> 7;
+    ie += max(1, (min(pop, seg_cap) + 127) >> 7);
   }
   if (LDS_HIST) {
     __syncthreads();

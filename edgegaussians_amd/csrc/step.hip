@@ -8,8 +8,9 @@
 //   update_absgrads()          -> fused in the projection VJP
 //   4x Adam.step(), zero_grad  -> fused in the projection VJP (single-GPU) or left to eg_adam_multi after
 //                                 the RCCL all-reduce (multi-GPU)
-// 10 launches per step (project+count+scan, emit, sort x2, slice, combine, re-walk, footprint x2,
-// project-bwd+Adam) instead of ~60 (torch glue + gsplat + CUB passes + 4 unfused Adams).
+// 6 launches per step in the segmented layout (project+emit+scan, sort, slice+combine, re-walk [a bare launch
+// when no pixel stops], footprint, project-bwd+Adam; a second sort launch only when a tile holds > 4096 keys)
+// instead of ~60 (torch glue + gsplat + CUB passes + 4 unfused Adams).
 #include <cstdarg>
 #include <cstdio>
 
@@ -58,8 +59,7 @@ extern "C" int eg_device_count(void) {
 namespace eg {
 constexpr int kStages = kNumMarks - 1;  // one stage ends at every mark after kMarkStart
 static const char *kStageNames[kStages] = {"project_bin", "tile_emit", "tile_sort", "composite_slice_fwd",
-                                           "composite_combine_fwd", "composite_rewalk_fwd", "footprint_bwd",
-                                           "project_bwd_adam"};
+                                           "composite_rewalk_fwd", "footprint_bwd", "project_bwd_adam"};
 static hipEvent_t *g_ev = nullptr;  // [(kStages + 1) * g_ev_steps]
 static int g_ev_steps = 0, g_ev_next = 0;
 static hipEvent_t *g_ev_cur = nullptr;  // events of the step being enqueued (nullptr outside a window)
@@ -142,7 +142,7 @@ extern "C" int eg_train_step(const eg_step_args *a, eg_stream_t stream) {
     rc = eg_composite_fwd_segments(a->splat, a->offsets, a->tile_end, a->item_offsets, a->item_end, a->item_tile,
                                    a->flatten_ids, a->width, a->height, a->render, a->alphas, a->last_ids, a->gt,
                                    a->wmap, a->loss_scale, a->vpix, a->loss, a->total, a->max_items, a->workspace,
-                                   a->gtstop, stream);
+                                   a->gtstop, a->rewalk_hint, stream);
     if (rc) return rc;
   } else {
   // tile_counts is zero on entry (caller zero-initialises it once): the projection counts it up and its
@@ -161,10 +161,10 @@ extern "C" int eg_train_step(const eg_step_args *a, eg_stream_t stream) {
   EG_MARK(kMarkSort);
   rc = eg_composite_fwd(a->splat, nullptr, 1, a->offsets, a->flatten_ids, a->width, a->height, a->render,
                         a->alphas, a->last_ids, a->gt, a->wmap, a->loss_scale, a->vpix, a->loss, a->item_offsets,
-                        a->total, a->max_items, a->workspace, a->gtstop, stream);
+                        a->total, a->max_items, a->workspace, a->gtstop, a->rewalk_hint, stream);
   if (rc) return rc;
   }
-  // (slice / combine / re-walk marks are recorded inside eg_composite_fwd)
+  // (slice / re-walk marks are recorded inside eg_composite_fwd)
   // backward: footprint compositing VJP, then projection VJP + absgrad (+ Adam)
   rc = eg_composite_bwd_footprint(a->splat, a->N, a->width, a->height, a->gtstop, a->g2d, stream);
   if (rc) return rc;

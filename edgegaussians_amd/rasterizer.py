@@ -115,12 +115,11 @@ class _Compositing(torch.autograd.Function):
             col = None if unit_colors else ptr(colors_c[c] if colors_c.dim() == 3 else colors_c)
             ws = None
             if unit_colors and n_items[c] > 0:  # slice-parallel forward needs its scratch
-                nbytes = _lib.load().eg_composite_workspace_bytes(n_items[c], offsets[c].shape[0] - 1)
-                ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+                ws = _lib.composite_workspace(n_items[c], offsets[c].shape[0] - 1, dev)
             call("eg_composite_fwd", ptr(splat[c]), col, D, ptr(offsets[c]), ptr(flatten_ids[c]), width, height,
                  ptr(render[c]), ptr(alphas[c]), ptr(last_ids[c]), None, None, 1.0, None, None,
                  ptr(item_offsets[c]) if ws is not None else None, ptr(totals[c]) if ws is not None else None,
-                 n_items[c], ptr(ws), None, stream())
+                 n_items[c], ptr(ws), None, -1, stream())
         ctx.save_for_backward(means2d, splat, colors_c, alphas, last_ids, *offsets, *flatten_ids, *item_offsets,
                               *totals)
         ctx.cfg = (width, height, absgrad, unit_colors, Cn, tuple(n_items))

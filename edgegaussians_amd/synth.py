@@ -113,12 +113,18 @@ def make_scene(n_gauss: int, n_views: int, width: int, height: int, seed: int = 
         op = torch.full((n_gauss, 1), 0.08)
     logit = torch.logit(op)
     if cameras_npz is not None:
+        # real poses (the reference's scan, tests/golden/cameras_00004926.npz), intrinsics rescaled to the
+        # requested size.  The fixture's principal point is (W - 1) / 2 = 399.5 in pixel-INDEX coordinates, so
+        # it is rescaled about the pixel-centre convention: c' = (c + 0.5) s - 0.5  (800 -> 512: 255.5)
         d = np.load(cameras_npz)
-        s = width / float(d["width"])
+        sx, sy = width / float(d["width"]), height / float(d["height"])
         Ks = torch.from_numpy(d["Ks"]).clone()[:n_views]
-        Ks[:, 0, :] *= s
-        Ks[:, 1, :] *= height / float(d["height"])
+        Ks[:, 0, 0] *= sx
+        Ks[:, 1, 1] *= sy
+        Ks[:, 0, 2] = (Ks[:, 0, 2] + 0.5) * sx - 0.5
+        Ks[:, 1, 2] = (Ks[:, 1, 2] + 0.5) * sy - 0.5
         vms = torch.from_numpy(d["viewmats"]).clone()[:n_views]
+        assert vms.shape[0] == n_views, f"the fixture holds {vms.shape[0]} poses, {n_views} were asked for"
     else:
         vms, Ks = lookat_cameras(n_views, width, height, g)
     gt = wireframe_edge_maps(vms, Ks, width, height)

@@ -92,6 +92,7 @@ class EdgeTrainer:
         self._journal: List = []
         self._snap: Optional[Dict] = None
         self.overflow_events = 0
+        self.rewalk_hint = -1  # re-walk list length seen at the last read-back (launch-shape hint; -1 = unknown)
         # noise of duplicate() comes from a dedicated generator seeded with (seed, event number): identical
         # on every data-parallel rank whatever else the ranks drew (edge_gs.py:462-467 uses the global RNG)
         self.seed = int(seed)
@@ -185,8 +186,7 @@ class EdgeTrainer:
             self.tile_end = torch.zeros(self.T, dtype=torch.int32, device=self.dev)
             self.item_end = torch.zeros(self.T, dtype=torch.int32, device=self.dev)
             self.item_tile = torch.zeros(self.max_items, dtype=torch.int32, device=self.dev)
-        self.workspace = torch.empty(_lib.load().eg_composite_workspace_bytes(self.max_items, self.T), dtype=torch.uint8,
-                                     device=self.dev)
+        self.workspace = _lib.composite_workspace(self.max_items, self.T, self.dev)
         self._args_cache = {}
 
     # ------------------------------------------------------------------ loss weight maps
@@ -275,6 +275,7 @@ class EdgeTrainer:
             a.splat, a.g2d = ptr(self.splat), ptr(self.g2d)
             a.gtstop = ptr(self.gtstop)
             a.max_tile_hint = getattr(self, "max_tile_seen", 0)
+            a.rewalk_hint = self.rewalk_hint
             a.seg_cap = self.seg_cap
             if self.seg_cap:
                 a.tile_end, a.item_end, a.item_tile = ptr(self.tile_end), ptr(self.item_end), ptr(self.item_tile)
@@ -418,7 +419,7 @@ class EdgeTrainer:
         call("eg_composite_fwd", ptr(self.splat), None, 1, ptr(self.offsets), ptr(self.flatten_ids), W, H,
              ptr(self.render), ptr(self.alphas), ptr(self.last_ids), ptr(self.gt[view]), ptr(wmap),
              self.loss_scale, ptr(self.vpix), ptr(self.loss_acc), ptr(self.item_offsets), ptr(self.total),
-             self.max_items, ptr(self.workspace), ptr(self.gtstop), st)
+             self.max_items, ptr(self.workspace), ptr(self.gtstop), self.rewalk_hint, st)
         mark("composite_fwd")
         call("eg_backward_fused", ptr(self.means), ptr(self.quats), ptr(self.log_scales),
              ptr(self.logit_opacities), vm, K, N, W, H, 0.3, fl, ptr(self.splat), ptr(self.gtstop), ptr(self.g2d),
@@ -528,7 +529,15 @@ class EdgeTrainer:
             m_last, _, _items, tile_max = (int(x) for x in self.total.tolist())
         self._journal.clear()
         self.loss_acc.zero_()
-        # the stream is drained anyway: refresh the tile-sort launch hint from the last step's scan
+        # the stream is drained anyway: refresh the launch-shape hints -- the longest exact-stop re-walk list since
+        # the last read-back (control word 2 of the compositing workspace) ...
+        ctl2 = self.workspace[4 * (self.T + self.max_items + 2):4 * (self.T + self.max_items + 3)].view(torch.int32)
+        seen = int(ctl2.item())
+        ctl2.zero_()
+        if seen != self.rewalk_hint:
+            self.rewalk_hint = seen
+            self._args_cache = {}
+        # ... and the tile-sort launch hint from the last step's scan
         if tile_max > getattr(self, "max_tile_seen", 0):
             self.max_tile_seen = tile_max
             self._args_cache = {}

@@ -142,7 +142,8 @@ int eg_composite_fwd_segments(const float *splat, const int32_t *tile_start, con
                               float *render /*[H,W]|NULL*/, float *alphas /*[H,W]|NULL*/,
                               int32_t *last_ids /*[H,W]|NULL*/, const float *gt, const float *wmap, float loss_scale,
                               float *vpix /*[H,W]|NULL*/, float *loss_out /*[1]*/, const int32_t *total,
-                              int64_t max_items, void *workspace, float *gtstop /*[H,W,3]*/, eg_stream_t stream);
+                              int64_t max_items, void *workspace, float *gtstop /*[H,W,3]*/,
+                              int32_t rewalk_hint, eg_stream_t stream);
 
 /* ---- G7: alpha compositing forward (replaces gsplat rasterize_to_pixels fwd).
  * channels = 1 or 3.  colors == NULL means "all ones" (the reference's colours, edge_gs.py:247).
@@ -151,11 +152,15 @@ int eg_composite_fwd_segments(const float *splat, const int32_t *tile_start, con
  * vpix[p] = loss_scale * wmap_p * sign(c0_p - gt_p) (the upstream gradient of eg_composite_bwd).
  * Slice-parallel mode (unit colours only): pass item_offsets + total from eg_tile_offsets, an upper
  * bound max_items >= total[2] (e.g. ceil(capacity/128) + T) and a workspace of
- * eg_composite_workspace_bytes(max_items, T) bytes; one workgroup runs per (tile, 128-Gaussian slice).
- * With item_offsets == NULL (or per-Gaussian colours) one workgroup walks each tile.
+ * eg_composite_workspace_bytes(max_items, T) bytes; one workgroup runs per (tile, 128-Gaussian slice; an
+ * empty tile owns one empty item).  The first eg_composite_workspace_ctl_bytes(max_items, T) bytes of the
+ * workspace are control words (per-tile tickets, item flags, the re-walk list counter): the caller ZEROES
+ * them once when the workspace is allocated -- with these (max_items, T) -- and every call hands them back
+ * zeroed.  With item_offsets == NULL (or per-Gaussian colours) one workgroup walks each tile.
  * When gtstop != NULL (the fused training step, whose backward reads nothing else) render, alphas,
  * last_ids and vpix may each be NULL and are then not materialised. */
 int64_t eg_composite_workspace_bytes(int64_t max_items, int64_t n_tiles);
+int64_t eg_composite_workspace_ctl_bytes(int64_t max_items, int64_t n_tiles);
 int eg_composite_fwd(const float *splat, const float *colors /*[N,channels]|NULL*/, int32_t channels,
                      const int32_t *offsets, const int32_t *flatten_ids, int32_t width, int32_t height,
                      float *render /*[H,W,channels]|NULL*/, float *alphas /*[H,W]|NULL*/,
@@ -166,6 +171,9 @@ int eg_composite_fwd(const float *splat, const float *colors /*[N,channels]|NULL
                      float *gtstop /*[H,W,3] 32-bit words|NULL: {vpix * T_final (f32), id of the last contributor
                                      if the pixel's walk stopped on T <= 1e-4 else -1 (i32), that Gaussian's
                                      depth bits (u32)} for eg_backward_fused*/,
+                     int32_t rewalk_hint /*how many (tile, slice) items needed the exact-stop re-walk lately: sizes that
+                     kernel's grid, never affects the result; 0 = none seen, < 0 = unknown.  The workspace's control
+                     word [n_tiles + max_items + 2] holds the largest list length since the caller last zeroed it*/,
                      eg_stream_t stream);
 
 /* ---- G8: compositing backward for unit colours (replaces gsplat rasterize_to_pixels bwd for the
@@ -320,12 +328,13 @@ typedef struct {
   int32_t *tile_counts, *offsets, *item_offsets, *total; /* [T], [T+1], [T+1], [4] */
   uint32_t *tile_mask;                                   /* [N] */
   int32_t *ticket;                                       /* [1], zero-initialised once */
-  void *workspace;   /* eg_composite_workspace_bytes(max_items, T) bytes */
+  void *workspace;   /* eg_composite_workspace_bytes(max_items, T) bytes, control prefix zeroed at allocation */
   int64_t max_items; /* >= ceil(capacity/128) + T */
   uint64_t *keys;
   int32_t *flatten_ids;
   int64_t capacity;
   int32_t max_tile_hint;                /* see eg_sort_pairs; 0 = unknown */
+  int32_t rewalk_hint;                  /* see eg_composite_fwd; 0 = none seen, < 0 = unknown */
   int32_t seg_cap;                      /* > 0: segmented binning (eg_project_emit ...): keys / flatten_ids are
                                            [T * seg_cap], offsets / item_offsets serve as tile_start / item_first */
   int32_t *tile_end, *item_end, *item_tile; /* [T], [T], [max_items]; used when seg_cap > 0 */

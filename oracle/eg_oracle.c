@@ -488,7 +488,8 @@ void ego_project_borderline(const float *means, const float *quats, const float 
     const double tb[4] = {(u - r) / TILE, (u + r) / TILE, (vv - r) / TILE, (vv + r) / TILE};
     const double hi[4] = {(double)tw, (double)tw, (double)th, (double)th};
     for (int e = 0; e < 4; ++e)
-      if (tb[e] > -0.5 && tb[e] < hi[e] + 0.5 && fabs(tb[e] - floor(tb[e] + 0.5)) <= rel * (fabs(tb[e]) + 1.0)) flag = 1;
+      /* (the fp32 error of (c -+ r) / 16 is a few ulps of c: a tenth of the margin the radius gets) */
+      if (tb[e] > -0.5 && tb[e] < hi[e] + 0.5 && fabs(tb[e] - floor(tb[e] + 0.5)) <= 0.1 * rel * (fabs(tb[e]) + 1.0)) flag = 1;
     mask[g] = flag;
   }
 }

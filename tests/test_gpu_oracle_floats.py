@@ -83,10 +83,10 @@ def _composite_fwd(_lib, splat, offs, flat, W, H, sliced, gt=None, wmap=None):
     n_items = 0
     if sliced:
         item_offsets, total, n_items = _items(offs, T)
-        ws = torch.empty(_lib.load().eg_composite_workspace_bytes(max(n_items, 1), T), dtype=torch.uint8, device="cuda")
+        ws = _lib.composite_workspace(max(n_items, 1), T, "cuda")
     call("eg_composite_fwd", ptr(splat), None, 1, ptr(offs), ptr(flat), W, H, ptr(render), ptr(alphas), ptr(last),
          ptr(gt), ptr(wmap), 1.0, ptr(vpix), ptr(loss), ptr(item_offsets), ptr(total), max(n_items, 1) if sliced else 0,
-         ptr(ws), ptr(gtstop), stream())
+         ptr(ws), ptr(gtstop), -1, stream())
     torch.cuda.synchronize()
     return dict(render=render[..., 0], alphas=alphas, last=last, vpix=vpix, loss=loss, gtstop=gtstop,
                 item_offsets=item_offsets, total=total, n_items=n_items)

