@@ -211,7 +211,7 @@ def cpu_baseline(sc, budget_s=15.0, which="c"):
                       f"oracle/ref_torch.py on {torch.get_num_threads()} torch threads"}
 
 
-def measure(name, args, device, rank, world, backend, spread=False, steps=None, warmup=None, stages=True):
+def measure(name, args, device, rank, world, backend, spread=False, steps=None, warmup=None, stages=True, vps=1):
     """One workload: pre-warm, W untimed + K timed steps between barriers, then (rank 0) a second window of the
     same steps with HIP events between the kernels.  Returns the result dict (value, ms_per_step, roofline ...)."""
     import torch.distributed as dist
@@ -226,9 +226,11 @@ def measure(name, args, device, rank, world, backend, spread=False, steps=None, 
         dp.world = 2  # issue the collective
     # device pre-warm, not part of --warmup: a fresh box needs ~0.1 s of work before clocks and page
     # tables settle (first-run outliers of 2x were measured without it)
-    for s in range(300):
-        if dp is None:
+    for s in range(300 // vps):
+        if dp is None and vps == 1:
             tr.train_step(s % n_views, whole)
+        elif dp is None:
+            tr.train_step_batched([(s * vps + i) % n_views for i in range(vps)], [whole] * vps)
         else:  # keep the replicas identical: the pre-warm goes through the all-reduce as well
             dp.step(egdist.view_for(s, rank, world, n_views), whole)
     torch.cuda.synchronize()
@@ -239,7 +241,10 @@ def measure(name, args, device, rank, world, backend, spread=False, steps=None, 
 
     def run(k, step0):
         for s in range(step0, step0 + k):
-            if dp is None:
+            if dp is None and vps > 1:  # C views per launch sequence and optimizer step
+                vs = [(s * vps + i) % n_views for i in range(vps)]
+                tr.train_step_batched(vs, [wmap_for(s * vps + i, v) for i, v in enumerate(vs)])
+            elif dp is None:
                 v = s % n_views
                 tr.train_step(v, wmap_for(s, v))
             else:
@@ -267,13 +272,13 @@ def measure(name, args, device, rank, world, backend, spread=False, steps=None, 
         raise SystemExit(f"invalid run: overflow events={tr.overflow_events} loss={loss_sum}")
     m_last = tr.last_m()
     res = {
-        "value": n * steps * world / dt, "ms_per_step": 1e3 * dt / steps, "steps": steps, "warmup": warmup,
+        "value": n * steps * world * vps / dt, "ms_per_step": 1e3 * dt / steps, "steps": steps, "warmup": warmup,
         "config": {"workload": f"{name}: {n} Gaussians (5:1 anisotropic, scale 0.004, opacity "
                                f"{'U(0.05,0.9)' if spread else '0.08'}), {n_views} views @{w}x{h}, {poses}, "
                                f"synthetic wireframe edge maps, loss whole/bg_edge_ratio 4:1",
                    "n_gaussians": n, "views": n_views, "width": w, "height": h, "lr_scale": LR_SCALE, "poses": poses,
                    "tile_intersections_M": m_last, "largest_tile_population": int(tr.max_tile_seen),
-                   "views_per_step": world,
+                   "views_per_step": world * vps,
                    "gaussian_row_order": "morton" if tr.spatial_order else "as given",
                    "binning": "segmented" if tr.segmented else "scan",
                    "parallelism": f"dp{world} (views sharded, RCCL all-reduce of [N,12] grads)" if world > 1 else "single GPU"},
@@ -282,7 +287,7 @@ def measure(name, args, device, rank, world, backend, spread=False, steps=None, 
     }
     if dp is not None and getattr(dp, "comm_us", None) is not None:
         res["allreduce_us_per_step_this_rank"] = dp.comm_us()
-    if stages and not args.profile_only:
+    if stages and not args.profile_only and vps == 1:
         # ---- per-kernel launch durations: HIP events recorded natively between the kernels of eg_train_step on
         # the launch stream, over a second window of the same steps (one sync).  With N ranks every rank runs the
         # window (the all-reduce is collective), rank 0 records.
@@ -334,6 +339,9 @@ def main():
                     help="run only warmup+steps of the fused step (for rocprofv3), skip stage timing/CPU leg")
     ap.add_argument("--no-traffic", action="store_true",
                     help="skip the two rocprofv3 --pmc passes that measure roofline.traffic (adds ~40 s)")
+    ap.add_argument("--views-per-step", type=int, default=1,
+                    help="C > 1: C views per launch sequence and optimizer step on this GPU (train_step_batched; the "
+                         "semantics of C-way data parallelism).  The headline stays at 1: the reference steps per view")
     ap.add_argument("--no-extra", action="store_true",
                     help="only the headline workload (skip the config1 and trained-like lines under other_workloads)")
     args = ap.parse_args()
@@ -356,7 +364,7 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=0, world_size=1)
 
-    head = measure(args.config, args, device, rank, world, backend, spread=args.spread_opacity)
+    head = measure(args.config, args, device, rank, world, backend, spread=args.spread_opacity, vps=args.views_per_step)
     sc = head.pop("_scene")
     out = {
         "metric": "train-step Gaussians*views/sec",
@@ -365,7 +373,7 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
     }
     out.update({k: v for k, v in head.items() if k not in ("value", "ms_per_step", "steps", "warmup")})
-    single = world == 1 and not args.profile_only and not args.force_dp
+    single = world == 1 and not args.profile_only and not args.force_dp and args.views_per_step == 1
     if single and rank == 0 and not args.no_traffic:
         stages, src = measure_traffic(args.config, args.spread_opacity)
         out["roofline"]["traffic"] = stages.get(out["roofline"]["kernel"]) if stages else None
@@ -376,10 +384,13 @@ def main():
         # north_star's stated target is config 1 (~30 k Gaussians, the scan's 50 views @512x512): measured in this
         # same run, next to a trained-like variant of the headline (opacities U(0.05, 0.9): transmittance stops)
         extra = {}
-        for key, name, spread in (("config1", "config1", False), (f"{args.config}_trained_like", args.config, True)):
-            if name == args.config and spread == args.spread_opacity:
+        for key, name, spread, vps in (("config1", "config1", False, 1), (f"{args.config}_trained_like", args.config, True, 1),
+                                       ("config1_4_views_per_step", "config1", False, 4),
+                                       (f"{args.config}_4_views_per_step", args.config, False, 4)):
+            if name == args.config and spread == args.spread_opacity and vps == args.views_per_step:
                 continue
-            r = measure(name, args, device, rank, world, backend, spread=spread)
+            r = measure(name, args, device, rank, world, backend, spread=spread, vps=vps,
+                        steps=max(args.steps // vps, 20), warmup=max(args.warmup // vps, 5))
             r.pop("_scene")
             r["unit"] = "Gaussians*views/s"
             extra[key] = r

@@ -296,8 +296,18 @@ template <int THREADS, int CAP, bool LARGE>
 __global__ void __launch_bounds__(THREADS)
 tile_sort_kernel(unsigned long long *__restrict__ keys, const int *__restrict__ offsets, int T,
                  long long capacity, int small_cap, int *__restrict__ flatten_ids,
-                 long long *__restrict__ isect_ids, const SegTable seg) {
+                 long long *__restrict__ isect_ids, const SegTable seg_, const Batch bt) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long s[];
+  // view of this workgroup (batched step: blockIdx.y over [C, ...] work buffers; segmented layout only)
+  SegTable seg = seg_;
+  {
+    const int bv = blockIdx.y;
+    keys += bv * bt.keys; flatten_ids += bv * bt.keys;
+    if (seg.cursor) {
+      seg.cursor += bv * bt.tiles; seg.tile_start += bv * bt.tiles; seg.tile_end += bv * bt.tiles;
+      seg.item_first += bv * bt.tiles; seg.item_end += bv * bt.tiles; seg.item_tile += bv * bt.items;
+    }
+  }
   unsigned long long *kout = s;      // [CAP] keys scattered by bucket (the fast path keeps its input in registers)
   int *hist = (int *)(s + CAP);      // [THREADS] counts -> exclusive starts
   int *cursor = hist + THREADS;      // [THREADS]
@@ -334,7 +344,7 @@ tile_sort_kernel(unsigned long long *__restrict__ keys, const int *__restrict__ 
   const int n = (int)(end - start);
   if (n <= 0) continue;
   if (LARGE ? (n <= small_cap) : (n > small_cap)) continue;  // the other variant owns this tile
-  unsigned long long *seg = keys + start;
+  unsigned long long *segk = keys + start;
   const unsigned long long kInf = ~0ull;
 
   if (n <= CAP) {
@@ -348,7 +358,7 @@ tile_sort_kernel(unsigned long long *__restrict__ keys, const int *__restrict__ 
       const int i = tid + j * THREADS;
       kr[j] = kInf;
       if (j * THREADS < n && i < n) {
-        kr[j] = seg[i];
+        kr[j] = segk[i];
         const unsigned d = (unsigned)(kr[j] >> 32);
         dmin = min(dmin, d);
         dmax = max(dmax, d);
@@ -446,11 +456,11 @@ tile_sort_kernel(unsigned long long *__restrict__ keys, const int *__restrict__ 
   while (P < n) P <<= 1;
   // (a) sort every BCAP chunk completely
   for (long long c0 = 0; c0 < n; c0 += BCAP) {
-    for (int i = tid; i < BCAP; i += THREADS) s[i] = (c0 + i < n) ? seg[c0 + i] : kInf;
+    for (int i = tid; i < BCAP; i += THREADS) s[i] = (c0 + i < n) ? segk[c0 + i] : kInf;
     __syncthreads();
     bitonic_lds<THREADS>(s, BCAP, 2, BCAP, tid);
     for (int i = tid; i < BCAP; i += THREADS)
-      if (c0 + i < n) seg[c0 + i] = s[i];
+      if (c0 + i < n) segk[c0 + i] = s[i];
     __syncthreads();
   }
   // (b) merges for k > BCAP: long strides in global memory, the tail (j <= BCAP/2) in LDS
@@ -460,8 +470,8 @@ tile_sort_kernel(unsigned long long *__restrict__ keys, const int *__restrict__ 
       const long long blk = i / hk, off = i - blk * hk;
       const long long lo = blk * k + off, hi = blk * k + k - 1 - off;
       if (hi < n) {
-        unsigned long long a = seg[lo], b = seg[hi];
-        if (a > b) { seg[lo] = b; seg[hi] = a; }
+        unsigned long long a = segk[lo], b = segk[hi];
+        if (a > b) { segk[lo] = b; segk[hi] = a; }
       }
     }
     __syncthreads();
@@ -469,24 +479,24 @@ tile_sort_kernel(unsigned long long *__restrict__ keys, const int *__restrict__ 
       for (long long i = tid; i < (P >> 1); i += THREADS) {
         const long long lo = ((i / j) * (j << 1)) + (i % j), hi = lo + j;
         if (hi < n) {
-          unsigned long long a = seg[lo], b = seg[hi];
-          if (a > b) { seg[lo] = b; seg[hi] = a; }
+          unsigned long long a = segk[lo], b = segk[hi];
+          if (a > b) { segk[lo] = b; segk[hi] = a; }
         }
       }
       __syncthreads();
     }
     for (long long c0 = 0; c0 < n; c0 += BCAP) {
-      for (int i = tid; i < BCAP; i += THREADS) s[i] = (c0 + i < n) ? seg[c0 + i] : kInf;
+      for (int i = tid; i < BCAP; i += THREADS) s[i] = (c0 + i < n) ? segk[c0 + i] : kInf;
       __syncthreads();
       // only the half-cleaner substages j = BCAP/2 .. 1 (k_lo = k_hi = 2*BCAP > P skips the mirror)
       bitonic_lds<THREADS>(s, BCAP, 2 * BCAP, 2 * BCAP, tid);
       for (int i = tid; i < BCAP; i += THREADS)
-        if (c0 + i < n) seg[c0 + i] = s[i];
+        if (c0 + i < n) segk[c0 + i] = s[i];
       __syncthreads();
     }
   }
   for (int i = tid; i < n; i += THREADS) {
-    const unsigned long long key = seg[i];
+    const unsigned long long key = segk[i];
     flatten_ids[start + i] = (int)(unsigned)(key & 0xffffffffull);
     if (isect_ids) isect_ids[start + i] = ((long long)tile << 32) | (long long)(key >> 32);
   }
@@ -543,7 +553,7 @@ static bool g_sort_attr_set = false;
 
 static int launch_tile_sort(uint64_t *keys, const int32_t *offsets, int32_t T, int64_t capacity,
                             int32_t *flatten_ids, int64_t *isect_ids, int32_t max_tile_hint, const SegTable seg,
-                            eg_stream_t stream) {
+                            eg_stream_t stream, const Batch &bt = Batch{}, int C = 1) {
   // small: 256 threads / buckets, 4096 keys; large: 1024 threads / buckets, 16384 keys
   constexpr int kSmall = 4096, kLarge = 16384;
   constexpr size_t kSmallLds = kSmall * 8 + 2 * 256 * 4, kLargeLds = kLarge * 8 + 2 * 1024 * 4;
@@ -557,13 +567,13 @@ static int launch_tile_sort(uint64_t *keys, const int32_t *offsets, int32_t T, i
   // LDS that would all find nothing to do: ~3 us) is skipped and the small variant owns EVERY tile -- a
   // tile that outgrew the hint is then still sorted correctly, by the slower paths of the small variant.
   const bool small_only = max_tile_hint > 0 && (int64_t)max_tile_hint * 3 / 2 <= kSmall;
-  tile_sort_kernel<256, kSmall, false><<<T, 256, kSmallLds, as_stream(stream)>>>(
+  tile_sort_kernel<256, kSmall, false><<<dim3(T, C), 256, kSmallLds, as_stream(stream)>>>(
       (unsigned long long *)keys, offsets, T, (long long)capacity, small_only ? 0x7fffffff : kSmall, flatten_ids,
-      (long long *)isect_ids, seg);
+      (long long *)isect_ids, seg, bt);
   if (!small_only)
-    tile_sort_kernel<1024, kLarge, true><<<min(T, 256), 1024, kLargeLds, as_stream(stream)>>>(
+    tile_sort_kernel<1024, kLarge, true><<<dim3(min(T, 256), C), 1024, kLargeLds, as_stream(stream)>>>(
         (unsigned long long *)keys, offsets, T, (long long)capacity, kSmall, flatten_ids, (long long *)isect_ids,
-        seg);
+        seg, bt);
   return check_launch("tile_sort");
 }
 
@@ -589,3 +599,18 @@ extern "C" int eg_sort_segments(uint64_t *keys, int32_t *tile_cursor, int32_t T,
   seg.item_tile = item_tile; seg.max_items = max_items;
   return launch_tile_sort(keys, nullptr, T, (int64_t)T * seg_cap, flatten_ids, nullptr, max_tile_hint, seg, stream);
 }
+
+namespace eg {
+int launch_sort_segments(uint64_t *keys, int32_t *tile_cursor, int32_t T, int32_t seg_cap, int32_t *flatten_ids,
+                         int32_t *tile_start, int32_t *tile_end, const int32_t *item_first, int32_t *item_end,
+                         int32_t *item_tile, int32_t max_items, int32_t max_tile_hint, const Batch &bt, int C,
+                         hipStream_t st) {
+  SegTable seg;
+  seg.cursor = tile_cursor; seg.seg_cap = seg_cap;
+  seg.tile_start = tile_start; seg.tile_end = tile_end;
+  seg.item_first = item_first; seg.item_end = item_end;
+  seg.item_tile = item_tile; seg.max_items = max_items;
+  return launch_tile_sort(keys, nullptr, T, (int64_t)T * seg_cap, flatten_ids, nullptr, max_tile_hint, seg,
+                          (eg_stream_t)st, bt, C);
+}
+}  // namespace eg

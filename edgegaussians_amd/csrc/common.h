@@ -25,6 +25,43 @@ enum TimingMark {
 };
 void timing_mark(int mark, hipStream_t stream);
 
+// View batching: the kernels of the training step take the view from blockIdx.y.  Every
+// per-view work buffer of a batched step is a [C, ...] array; Batch holds the strides between the per-view
+// copies and the per-view inputs.  A default-constructed Batch (all strides zero, no pointers) is the
+// single-view launch: blockIdx.y is 0 and the kernels use their own view arguments.
+constexpr int kMaxBatch = EG_MAX_BATCH;
+struct Batch {
+  long long splat4 = 0;    // splat / g2d: float4 units (2 N)
+  long long tiles = 0;     // per-tile tables: T
+  long long keys = 0;      // keys / sorted ids: T * seg_cap
+  long long items = 0;     // item tables: max_items
+  long long ws_bytes = 0;  // compositing workspace
+  long long pixels = 0;    // per-pixel images / records: H * W
+  const float *viewmat[kMaxBatch] = {}, *K[kMaxBatch] = {}, *gt[kMaxBatch] = {}, *wmap[kMaxBatch] = {};
+};
+
+// internal launchers of the batched step (defined next to their kernels, sequenced by step.hip)
+int launch_project_emit(const float *means, const float *quats, const float *log_scales, const float *logit_opacities,
+                        const float *viewmat, const float *K, int32_t N, int32_t width, int32_t height, uint32_t flags,
+                        float *splat, int32_t *tile_cursor, int32_t seg_cap, uint64_t *keys, int32_t *item_first,
+                        int32_t max_items, int32_t *total, int32_t *ticket, const Batch &bt, int C, hipStream_t st);
+int launch_sort_segments(uint64_t *keys, int32_t *tile_cursor, int32_t T, int32_t seg_cap, int32_t *flatten_ids,
+                         int32_t *tile_start, int32_t *tile_end, const int32_t *item_first, int32_t *item_end,
+                         int32_t *item_tile, int32_t max_items, int32_t max_tile_hint, const Batch &bt, int C,
+                         hipStream_t st);
+int launch_composite_fwd_segments(const float *splat, const int32_t *tile_start, const int32_t *tile_end,
+                                  const int32_t *item_first, const int32_t *item_end, const int32_t *item_tile,
+                                  const int32_t *flatten_ids, int32_t width, int32_t height, float loss_scale,
+                                  float *loss_out, const int32_t *total, int64_t max_items, void *workspace,
+                                  float *gtstop, int32_t rewalk_hint, const Batch &bt, int C, hipStream_t st);
+int launch_footprint_bwd(const float *splat, int32_t N, int32_t width, int32_t height, const float *gtstop, float *g2d,
+                         const Batch &bt, int C, hipStream_t st);
+int launch_project_bwd_batched(float *means, float *quats, float *scales, float *opacities, int32_t N, int32_t width,
+                               int32_t height, float eps2d, uint32_t flags, const float *splat, const float *g2d,
+                               float *v_means, float *v_quats, float *v_scales, float *v_opacities, float *absgrads,
+                               float *m, float *v, const eg_adam_hyper *hyper_host, const Batch &bt, int C,
+                               hipStream_t st);
+
 inline hipStream_t as_stream(eg_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 

@@ -460,6 +460,21 @@ struct SliceWs {
   unsigned char *sliceQ;  // [max_items][128] quadrant verdicts
 };
 
+// the per-view copies of a batched step (blockIdx.y = view; strides are zero for a single view)
+__device__ __forceinline__ TileTable view_of(TileTable tt, const Batch &bt, int v) {
+  tt.start += v * bt.tiles; tt.end += v * bt.tiles; tt.item_first += v * bt.tiles; tt.item_end += v * bt.tiles;
+  if (tt.item_tile) tt.item_tile += v * bt.items;
+  return tt;
+}
+__device__ __forceinline__ SliceWs view_of(SliceWs ws, const Batch &bt, int v) {
+  const long long o = v * bt.ws_bytes;
+  ws.tile_ticket = (int *)((char *)ws.tile_ticket + o); ws.item_flags = (int *)((char *)ws.item_flags + o);
+  ws.ctl = (int *)((char *)ws.ctl + o); ws.sliceP = (float *)((char *)ws.sliceP + o);
+  ws.sliceL = (int *)((char *)ws.sliceL + o); ws.stopinfo = (StopInfo *)((char *)ws.stopinfo + o);
+  ws.rewalk = (int2 *)((char *)ws.rewalk + o); ws.sliceQ = (unsigned char *)ws.sliceQ + o;
+  return ws;
+}
+
 // forward phase A: per (tile, slice) transmittance products -- and, in the tile's last workgroup, phase B.
 // Staging: thread t fetches Gaussian t of the slice, computes its conservative alpha >= 1/255 extent
 // (ex, ey) and appends the packed record to the list of every quadrant it can touch (ballot +
@@ -471,16 +486,27 @@ struct SliceWs {
 // re-walk list with the pixel's state before it.
 template <int CH>
 __global__ void __launch_bounds__(256)
-composite_slice_fwd_kernel(const float4 *__restrict__ splat, const TileTable tt, const int *__restrict__ total,
-                           const int *__restrict__ flat, int width, int height, int tw, int th, const SliceWs ws,
+composite_slice_fwd_kernel(const float4 *__restrict__ splat, const TileTable tt_, const int *__restrict__ total,
+                           const int *__restrict__ flat, int width, int height, int tw, int th, const SliceWs ws_,
                            float *__restrict__ render, float *__restrict__ alphas, int *__restrict__ last_ids,
                            const float *__restrict__ gt, const float *__restrict__ wmap, float loss_scale,
-                           float *__restrict__ vpix, float *__restrict__ loss_out, StopRec *__restrict__ gtstop) {
+                           float *__restrict__ vpix, float *__restrict__ loss_out, StopRec *__restrict__ gtstop,
+                           const Batch bt) {
   __shared__ QuadLists ql;
   static_assert(kSlice <= kTilePix, "one staging thread per Gaussian of the slice");
   __shared__ int sTile[5];
   __shared__ int s_last;
   __shared__ float sRed[4];
+  const int bv = blockIdx.y;  // view of a batched step
+  const TileTable tt = view_of(tt_, bt, bv);
+  const SliceWs ws = view_of(ws_, bt, bv);
+  total += 4 * bv; flat += bv * bt.keys; splat += bv * bt.splat4;
+  if (render) render += bv * bt.pixels * CH;
+  if (alphas) alphas += bv * bt.pixels;
+  if (last_ids) last_ids += bv * bt.pixels;
+  if (vpix) vpix += bv * bt.pixels;
+  if (gtstop) gtstop += bv * bt.pixels;
+  if (bt.gt[0]) { gt = bt.gt[bv]; wmap = bt.wmap[bv]; }
   const int b = blockIdx.x;
   if (b >= total[2]) return;
   const int tile = tt.item_tile ? tt.item_tile[b] : item_tile_coop(tt.item_first, tw * th, b, sTile);
@@ -623,13 +649,24 @@ composite_slice_fwd_kernel(const float4 *__restrict__ splat, const TileTable tt,
 // the same lanes carry on through the following slices.  In scenes without stops the launch reads one word.
 template <int CH>
 __global__ void __launch_bounds__(256)
-composite_rewalk_fwd_kernel(const float4 *__restrict__ splat, const TileTable tt,
-                            const int *__restrict__ flat, int width, int height, int tw, int th, const SliceWs ws,
+composite_rewalk_fwd_kernel(const float4 *__restrict__ splat, const TileTable tt_,
+                            const int *__restrict__ flat, int width, int height, int tw, int th, const SliceWs ws_,
                             float *__restrict__ render, float *__restrict__ alphas, int *__restrict__ last_ids,
                             const float *__restrict__ gt, const float *__restrict__ wmap, float loss_scale,
-                            float *__restrict__ vpix, float *__restrict__ loss_out, StopRec *__restrict__ gtstop) {
+                            float *__restrict__ vpix, float *__restrict__ loss_out, StopRec *__restrict__ gtstop,
+                            const Batch bt) {
   __shared__ QuadLists ql;
   __shared__ float sRed[4];
+  const int bv = blockIdx.y;  // view of a batched step
+  const TileTable tt = view_of(tt_, bt, bv);
+  const SliceWs ws = view_of(ws_, bt, bv);
+  flat += bv * bt.keys; splat += bv * bt.splat4;
+  if (render) render += bv * bt.pixels * CH;
+  if (alphas) alphas += bv * bt.pixels;
+  if (last_ids) last_ids += bv * bt.pixels;
+  if (vpix) vpix += bv * bt.pixels;
+  if (gtstop) gtstop += bv * bt.pixels;
+  if (bt.gt[0]) { gt = bt.gt[bv]; wmap = bt.wmap[bv]; }
   const int tid = threadIdx.x, wv = tid >> 6;
   int di, dj;
   quad_pixel(tid, di, dj);
@@ -985,8 +1022,9 @@ __device__ __forceinline__ void footprint_walk(const float4 s0, const float4 s1,
 
 __global__ void __launch_bounds__(256)
 footprint_bwd_kernel(const float4 *__restrict__ splat, int N, int width, int height,
-                     const StopRec *__restrict__ gtstop, float *__restrict__ g2d) {
+                     const StopRec *__restrict__ gtstop, float *__restrict__ g2d, const Batch bt) {
   __shared__ float red[4][64 * 8];
+  splat += blockIdx.y * bt.splat4; gtstop += blockIdx.y * bt.pixels; g2d += blockIdx.y * bt.splat4 * 4;  // view
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int wave = blockIdx.x * 4 + wv;
   const int gbase = wave * 8;
@@ -1213,7 +1251,8 @@ static SliceWs carve_workspace(void *workspace, int64_t max_items, int n_tiles) 
 static int launch_sliced_fwd(const float4 *splat, const TileTable tt, int channels, const int32_t *flatten_ids,
                              int width, int height, float *render, float *alphas, int32_t *last_ids, const float *gt,
                              const float *wmap, float loss_scale, float *vpix, float *loss_out, const int32_t *total,
-                             int64_t max_items, void *workspace, float *gtstop, int rewalk_hint, hipStream_t s) {
+                             int64_t max_items, void *workspace, float *gtstop, int rewalk_hint, hipStream_t s,
+                             const Batch &bt = Batch{}, int C = 1) {
   const int tw = cdiv(width, kTile), th = cdiv(height, kTile);
   const SliceWs ws = carve_workspace(workspace, max_items, tw * th);
   // the re-walk grid strides over the compact list: sized from the caller's hint (launching 1024 workgroups that
@@ -1223,13 +1262,13 @@ static int launch_sliced_fwd(const float4 *splat, const TileTable tt, int channe
   const unsigned rewalk_grid = (unsigned)(max_items < want ? max_items : want);
 #define EG_LAUNCH_CB(CH)                                                                                          \
   do {                                                                                                            \
-    composite_slice_fwd_kernel<CH><<<(unsigned)max_items, 256, 0, s>>>(                                           \
+    composite_slice_fwd_kernel<CH><<<dim3((unsigned)max_items, C), 256, 0, s>>>(                                  \
         splat, tt, total, flatten_ids, width, height, tw, th, ws, render, alphas, last_ids, gt, wmap, loss_scale, \
-        vpix, loss_out, (StopRec *)gtstop);                                                                       \
+        vpix, loss_out, (StopRec *)gtstop, bt);                                                                   \
     timing_mark(kMarkSlice, s);                                                                                   \
-    composite_rewalk_fwd_kernel<CH><<<rewalk_grid, 256, 0, s>>>(splat, tt, flatten_ids, width, height, tw, th,   \
-                                                                ws, render, alphas, last_ids, gt, wmap,           \
-                                                                loss_scale, vpix, loss_out, (StopRec *)gtstop);   \
+    composite_rewalk_fwd_kernel<CH><<<dim3(rewalk_grid, C), 256, 0, s>>>(                                         \
+        splat, tt, flatten_ids, width, height, tw, th, ws, render, alphas, last_ids, gt, wmap, loss_scale, vpix,  \
+        loss_out, (StopRec *)gtstop, bt);                                                                         \
     timing_mark(kMarkRewalk, s);                                                                                  \
   } while (0)
   if (channels == 1) EG_LAUNCH_CB(1); else EG_LAUNCH_CB(3);
@@ -1312,10 +1351,31 @@ extern "C" int eg_composite_bwd_footprint(const float *splat, int32_t N, int32_t
   EG_REQUIRE(splat && gtstop && g2d, "null pointer");
   hipStream_t st = as_stream(stream);
   footprint_bwd_kernel<<<cdiv((int64_t)N, 32), 256, 0, st>>>((const float4 *)splat, N, width, height,
-                                                            (const StopRec *)gtstop, g2d);
+                                                            (const StopRec *)gtstop, g2d, Batch{});
   timing_mark(kMarkFootprint, st);
   return check_launch("composite_bwd_footprint");
 }
+
+namespace eg {
+// batched step: the slice-parallel forward and the footprint backward of C views in one launch each
+int launch_composite_fwd_segments(const float *splat, const int32_t *tile_start, const int32_t *tile_end,
+                                  const int32_t *item_first, const int32_t *item_end, const int32_t *item_tile,
+                                  const int32_t *flatten_ids, int32_t width, int32_t height, float loss_scale,
+                                  float *loss_out, const int32_t *total, int64_t max_items, void *workspace,
+                                  float *gtstop, int32_t rewalk_hint, const Batch &bt, int C, hipStream_t st) {
+  const TileTable tt = {tile_start, tile_end, item_first, item_end, item_tile};
+  return launch_sliced_fwd((const float4 *)splat, tt, 1, flatten_ids, width, height, nullptr, nullptr, nullptr,
+                           bt.gt[0], bt.wmap[0], loss_scale, nullptr, loss_out, total, max_items, workspace, gtstop,
+                           rewalk_hint, st, bt, C);
+}
+int launch_footprint_bwd(const float *splat, int32_t N, int32_t width, int32_t height, const float *gtstop, float *g2d,
+                         const Batch &bt, int C, hipStream_t st) {
+  footprint_bwd_kernel<<<dim3(cdiv((int64_t)N, 32), C), 256, 0, st>>>((const float4 *)splat, N, width, height,
+                                                                     (const StopRec *)gtstop, g2d, bt);
+  timing_mark(kMarkFootprint, st);
+  return check_launch("composite_bwd_footprint");
+}
+}  // namespace eg
 
 extern "C" int eg_composite_bwd_colors(const float *splat, const float *colors, int32_t channels,
                                        const int32_t *offsets, const int32_t *flatten_ids, int32_t width,

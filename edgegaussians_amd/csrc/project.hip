@@ -434,6 +434,80 @@ project_bwd_kernel(float *__restrict__ means, float *__restrict__ quats, float *
   }
 }
 
+// Batched step: the C views of the batch were composited into splat[v] / g2d[v]; one thread per Gaussian runs
+// the projection VJP of every view and SUMS the gradients (the same sum a data-parallel all-reduce forms), the
+// absgrad increments add up like C calls of update_absgrads (edge_gs.py:607-613), then ONE Adam step.
+template <bool ADAM>
+__global__ void __launch_bounds__(256)
+project_bwd_batched_kernel(float *__restrict__ means, float *__restrict__ quats, float *__restrict__ scales,
+                           float *__restrict__ opacities, int N, int width, int height, float eps2d, uint32_t flags,
+                           const float4 *__restrict__ splat, const float4 *__restrict__ g2d,
+                           float *__restrict__ v_means, float *__restrict__ v_quats, float *__restrict__ v_scales,
+                           float *__restrict__ v_opacities, float *__restrict__ absgrads, float *__restrict__ am,
+                           float *__restrict__ av, AdamK hyper, const Batch bt, int C) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= N) return;
+  Grads acc;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) acc.mean[k] = acc.scale[k] = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) acc.quat[k] = 0.f;
+  acc.opac = 0.f;
+  float absinc = 0.f;
+  for (int v = 0; v < C; ++v) {
+    const float4 *sp = splat + v * bt.splat4, *gd = g2d + v * bt.splat4;
+    const int radius = __float_as_int(sp[2 * g + 1].w);
+    if (radius <= 0) continue;
+    const Cam cam = load_cam(bt.viewmat[v], bt.K[v]);
+    const float4 ga = gd[2 * g], gb = gd[2 * g + 1];
+    Fwd f;
+    forward_geom(cam, means, quats, scales, opacities, g, width, height, -3.0e38f, 3.0e38f, eps2d, flags, f);
+    Grads gr;
+    backward_geom(cam, f, eps2d, flags, ga, gb, false, 0.f, 0.f, gr);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { acc.mean[k] += gr.mean[k]; acc.scale[k] += gr.scale[k]; }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc.quat[k] += gr.quat[k];
+    acc.opac += gr.opac;
+    absinc += sqrtf(ga.z * ga.z + ga.w * ga.w);
+  }
+  if (absgrads) {
+    if (flags & EG_FLAG_ABSGRAD_WRITE) absgrads[g] = absinc; else absgrads[g] += absinc;
+  }
+  if (!ADAM) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { v_means[3 * g + k] = acc.mean[k]; v_scales[3 * g + k] = acc.scale[k]; }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v_quats[4 * g + k] = acc.quat[k];
+    v_opacities[g] = acc.opac;
+  } else {
+    const size_t oM = 0, oS = 3 * (size_t)N, oQ = 6 * (size_t)N, oO = 10 * (size_t)N;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      float p = means[3 * g + k], m = am[oM + 3 * g + k], v = av[oM + 3 * g + k];
+      adam1(p, acc.mean[k], m, v, 0, hyper);
+      means[3 * g + k] = p; am[oM + 3 * g + k] = m; av[oM + 3 * g + k] = v;
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      float p = scales[3 * g + k], m = am[oS + 3 * g + k], v = av[oS + 3 * g + k];
+      adam1(p, acc.scale[k], m, v, 1, hyper);
+      scales[3 * g + k] = p; am[oS + 3 * g + k] = m; av[oS + 3 * g + k] = v;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float p = quats[4 * g + k], m = am[oQ + 4 * g + k], v = av[oQ + 4 * g + k];
+      adam1(p, acc.quat[k], m, v, 2, hyper);
+      quats[4 * g + k] = p; am[oQ + 4 * g + k] = m; av[oQ + 4 * g + k] = v;
+    }
+    {
+      float p = opacities[g], m = am[oO + g], v = av[oO + g];
+      adam1(p, acc.opac, m, v, 3, hyper);
+      opacities[g] = p; am[oO + g] = m; av[oO + g] = v;
+    }
+  }
+}
+
 // stand-alone Adam over the 11 N parameters (used after an RCCL gradient all-reduce)
 __global__ void __launch_bounds__(256)
 adam_multi_kernel(float *__restrict__ means, float *__restrict__ scales, float *__restrict__ quats,
@@ -484,6 +558,26 @@ static AdamK make_adamk(const eg_adam_hyper &h) {
 
 }  // namespace eg
 
+namespace eg {
+int launch_project_bwd_batched(float *means, float *quats, float *scales, float *opacities, int32_t N, int32_t width,
+                               int32_t height, float eps2d, uint32_t flags, const float *splat, const float *g2d,
+                               float *v_means, float *v_quats, float *v_scales, float *v_opacities, float *absgrads,
+                               float *m, float *v, const eg_adam_hyper *hyper_host, const Batch &bt, int C,
+                               hipStream_t st) {
+  if (hyper_host)
+    project_bwd_batched_kernel<true><<<cdiv(N, 256), 256, 0, st>>>(
+        means, quats, scales, opacities, N, width, height, eps2d, flags, (const float4 *)splat, (const float4 *)g2d,
+        nullptr, nullptr, nullptr, nullptr, absgrads, m, v, make_adamk(*hyper_host), bt, C);
+  else {
+    AdamK dummy = {};
+    project_bwd_batched_kernel<false><<<cdiv(N, 256), 256, 0, st>>>(
+        means, quats, scales, opacities, N, width, height, eps2d, flags, (const float4 *)splat, (const float4 *)g2d,
+        v_means, v_quats, v_scales, v_opacities, absgrads, nullptr, nullptr, dummy, bt, C);
+  }
+  return check_launch("project_bwd_batched");
+}
+}  // namespace eg
+
 using namespace eg;
 
 // ---------------------------------------------------------------------------------------------
@@ -512,9 +606,15 @@ project_emit_kernel(const float *__restrict__ means, const float *__restrict__ q
                     const float *__restrict__ scales, const float *__restrict__ opacities,
                     const float *__restrict__ viewmat, const float *__restrict__ K, int N, int width, int height,
                     uint32_t flags, float4 *__restrict__ splat, int *__restrict__ cursor, int seg_cap,
-                    unsigned long long *__restrict__ keys, const SegOut out) {
+                    unsigned long long *__restrict__ keys, const SegOut out_, const Batch bt) {
   extern __shared__ __attribute__((aligned(16))) int s_mem[];
   const int tw = (width + kTile - 1) / kTile, th = (height + kTile - 1) / kTile, T = tw * th;
+  // view of this workgroup (a batched step runs its C views as blockIdx.y over [C, ...] work buffers)
+  const int bv = blockIdx.y;
+  SegOut out = out_;
+  splat += bv * bt.splat4; cursor += bv * bt.tiles; keys += bv * bt.keys;
+  out.item_first += bv * bt.tiles; out.total += 4 * bv; out.ticket += bv;
+  if (bt.viewmat[0]) { viewmat = bt.viewmat[bv]; K = bt.K[bv]; }
   int *s_hist = s_mem, *s_base = s_mem + T;
   if (LDS_HIST) {
     for (int t = threadIdx.x; t < T; t += kPE) s_hist[t] = 0;
@@ -685,6 +785,28 @@ extern "C" int eg_project_bin(const float *means, const float *quats, const floa
                             nullptr, tile_mask, offsets, item_offsets, total, capacity, ticket, stream);
 }
 
+namespace eg {
+int launch_project_emit(const float *means, const float *quats, const float *log_scales, const float *logit_opacities,
+                        const float *viewmat, const float *K, int32_t N, int32_t width, int32_t height, uint32_t flags,
+                        float *splat, int32_t *tile_cursor, int32_t seg_cap, uint64_t *keys, int32_t *item_first,
+                        int32_t max_items, int32_t *total, int32_t *ticket, const Batch &bt, int C, hipStream_t st) {
+  const int T = cdiv(width, kTile) * cdiv(height, kTile);
+  SegOut out;
+  out.item_first = item_first; out.max_items = max_items;
+  out.total = total; out.ticket = ticket;
+  const dim3 grid(cdiv(N, kPE), C);
+  if (2 * T <= 16384)
+    project_emit_kernel<true><<<grid, kPE, sizeof(int) * 2 * T, st>>>(
+        means, quats, log_scales, logit_opacities, viewmat, K, N, width, height, flags, (float4 *)splat, tile_cursor,
+        seg_cap, (unsigned long long *)keys, out, bt);
+  else
+    project_emit_kernel<false><<<grid, kPE, 0, st>>>(
+        means, quats, log_scales, logit_opacities, viewmat, K, N, width, height, flags, (float4 *)splat, tile_cursor,
+        seg_cap, (unsigned long long *)keys, out, bt);
+  return check_launch("project_emit");
+}
+}  // namespace eg
+
 extern "C" int eg_project_emit(const float *means, const float *quats, const float *log_scales,
                                const float *logit_opacities, const float *viewmat, const float *K, int32_t N,
                                int32_t width, int32_t height, uint32_t flags, float *splat, int32_t *tile_cursor,
@@ -697,18 +819,9 @@ extern "C" int eg_project_emit(const float *means, const float *quats, const flo
   EG_REQUIRE((flags & EG_FLAG_TIGHT_TILES) != 0, "the segmented path bins with the exact tile test");
   const int T = cdiv(width, kTile) * cdiv(height, kTile);
   EG_REQUIRE((int64_t)T * seg_cap < (1ll << 31), "T * seg_cap must fit 31 bits");
-  SegOut out;
-  out.item_first = item_first; out.max_items = max_items;
-  out.total = total; out.ticket = ticket;
-  if (2 * T <= 16384)
-    project_emit_kernel<true><<<cdiv(N, kPE), kPE, sizeof(int) * 2 * T, as_stream(stream)>>>(
-        means, quats, log_scales, logit_opacities, viewmat, K, N, width, height, flags, (float4 *)splat, tile_cursor,
-        seg_cap, (unsigned long long *)keys, out);
-  else
-    project_emit_kernel<false><<<cdiv(N, kPE), kPE, 0, as_stream(stream)>>>(
-        means, quats, log_scales, logit_opacities, viewmat, K, N, width, height, flags, (float4 *)splat, tile_cursor,
-        seg_cap, (unsigned long long *)keys, out);
-  return check_launch("project_emit");
+  return launch_project_emit(means, quats, log_scales, logit_opacities, viewmat, K, N, width, height, flags, splat,
+                             tile_cursor, seg_cap, keys, item_first, max_items, total, ticket, Batch{}, 1,
+                             as_stream(stream));
 }
 
 extern "C" int eg_project_bwd(const float *means, const float *quats, const float *scales, const float *opacities,

@@ -183,3 +183,56 @@ extern "C" int eg_train_step(const eg_step_args *a, eg_stream_t stream) {
   g_ev_cur = nullptr;
   return rc;
 }
+
+// ---- C views per launch sequence.  The same six kernels as eg_train_step, each launched
+// once with gridDim.y = C over [C, ...] work buffers, then ONE projection backward that sums the per-view
+// gradients (what a C-rank data-parallel all-reduce forms) and ONE Adam step.  At the reference's sizes a single
+// view fills a quarter of the chip (30 k Gaussians = 59 projection workgroups on 256 CUs): batching amortises
+// every launch and every dependent-latency chain over C views.  A THROUGHPUT mode -- C views per optimizer
+// step is a different trajectory from C sequential steps (the reference steps after every view).
+extern "C" int64_t eg_batched_workspace_stride(int64_t max_items, int64_t n_tiles) {
+  return (eg_composite_workspace_bytes(max_items, n_tiles) + 255) & ~(int64_t)255;
+}
+
+extern "C" int eg_train_step_batched(const eg_step_args *a, int32_t C, const float *const *viewmats,
+                                     const float *const *Ks, const float *const *gts, const float *const *wmaps,
+                                     eg_stream_t stream) {
+  EG_REQUIRE(a != nullptr && viewmats && Ks && gts && wmaps, "null args");
+  EG_REQUIRE(C >= 1 && C <= kMaxBatch, "1 <= C <= EG_MAX_BATCH");
+  EG_REQUIRE(a->N > 0 && a->width > 0 && a->height > 0 && a->max_items > 0, "bad sizes");
+  EG_REQUIRE(a->seg_cap > 0 && a->tile_end && a->item_end && a->item_tile, "the batched step uses the segmented layout");
+  EG_REQUIRE(a->gtstop && a->g2d && a->splat && a->workspace && a->loss, "null buffer");
+  const int tw = cdiv(a->width, kTile), th = cdiv(a->height, kTile), T = tw * th;
+  EG_REQUIRE((int64_t)T * a->seg_cap < (1ll << 31), "T * seg_cap must fit 31 bits");
+  const uint32_t flags = EG_FLAG_LOG_SCALES | EG_FLAG_LOGIT_OPACITIES | EG_FLAG_ANTIALIASED | EG_FLAG_TIGHT_TILES;
+  Batch bt;
+  bt.splat4 = 2ll * a->N;
+  bt.tiles = T;
+  bt.keys = (long long)T * a->seg_cap;
+  bt.items = a->max_items;
+  bt.ws_bytes = eg_batched_workspace_stride(a->max_items, T);
+  bt.pixels = (long long)a->width * a->height;
+  for (int v = 0; v < C; ++v) {
+    EG_REQUIRE(viewmats[v] && Ks[v] && gts[v] && wmaps[v], "null view input");
+    bt.viewmat[v] = viewmats[v]; bt.K[v] = Ks[v]; bt.gt[v] = gts[v]; bt.wmap[v] = wmaps[v];
+  }
+  hipStream_t st = as_stream(stream);
+  int rc = launch_project_emit(a->means, a->quats, a->log_scales, a->logit_opacities, bt.viewmat[0], bt.K[0], a->N,
+                               a->width, a->height, flags, a->splat, a->tile_counts, a->seg_cap, a->keys,
+                               a->item_offsets, (int32_t)a->max_items, a->total, a->ticket, bt, C, st);
+  if (rc) return rc;
+  rc = launch_sort_segments(a->keys, a->tile_counts, T, a->seg_cap, a->flatten_ids, a->offsets, a->tile_end,
+                            a->item_offsets, a->item_end, a->item_tile, (int32_t)a->max_items, a->max_tile_hint, bt, C,
+                            st);
+  if (rc) return rc;
+  rc = launch_composite_fwd_segments(a->splat, a->offsets, a->tile_end, a->item_offsets, a->item_end, a->item_tile,
+                                     a->flatten_ids, a->width, a->height, a->loss_scale, a->loss, a->total,
+                                     a->max_items, a->workspace, a->gtstop, a->rewalk_hint, bt, C, st);
+  if (rc) return rc;
+  rc = launch_footprint_bwd(a->splat, a->N, a->width, a->height, a->gtstop, a->g2d, bt, C, st);
+  if (rc) return rc;
+  return launch_project_bwd_batched(a->means, a->quats, a->log_scales, a->logit_opacities, a->N, a->width, a->height,
+                                    0.3f, a->adam_host ? flags : (flags | EG_FLAG_ABSGRAD_WRITE), a->splat, a->g2d,
+                                    a->v_means, a->v_quats, a->v_scales, a->v_opacities, a->absgrads, a->adam_m,
+                                    a->adam_v, a->adam_host, bt, C, st);
+}

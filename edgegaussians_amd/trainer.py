@@ -159,6 +159,7 @@ class EdgeTrainer:
         self.tile_mask = torch.zeros(N, dtype=torch.int32, device=d)  # exact tile hits per Gaussian (bit mask)
         self.grads = torch.zeros(N, 12, device=d)  # [means3|quats4|scales3|opac1|absgrad-inc1] for all-reduce
         self._args_cache: Dict = {}
+        self._batch = None  # [C, ...] work buffers of train_step_batched (allocated on first use)
 
     def _alloc_pixels(self):
         H, W, d = self.height, self.width, self.dev
@@ -188,6 +189,7 @@ class EdgeTrainer:
             self.item_tile = torch.zeros(self.max_items, dtype=torch.int32, device=self.dev)
         self.workspace = _lib.composite_workspace(self.max_items, self.T, self.dev)
         self._args_cache = {}
+        self._batch = None
 
     # ------------------------------------------------------------------ loss weight maps
     def weight_map(self, view: int, strategy: str, ratio: float = 1.0,
@@ -326,7 +328,7 @@ class EdgeTrainer:
         if self.replay_on_overflow:
             if not self._journal:
                 self._snapshot()
-            self._journal.append((view, wmap, self.epoch, self.loss_scale))
+            self._journal.append(("1", view, wmap, self.epoch, self.loss_scale))
         self._step_raw(view, wmap)
 
     def _step_raw(self, view: int, wmap: Tensor) -> None:
@@ -335,6 +337,92 @@ class EdgeTrainer:
         call("eg_train_step", C.byref(self._args(view, wmap, True)), stream())
         self.absgrads_normalize_factor += 1  # edge_gs.py:613
         self.step += 1
+
+    # ------------------------------------------------------------------ C views per launch sequence
+    def _alloc_batch(self, Cn: int):
+        N, T, d = self.N, self.T, self.dev
+        lib = _lib.load()
+        stride = int(lib.eg_batched_workspace_stride(self.max_items, T))
+        ctl = int(lib.eg_composite_workspace_ctl_bytes(self.max_items, T))
+        ws = torch.empty(Cn, stride, dtype=torch.uint8, device=d)
+        ws[:, :ctl].zero_()
+        i32 = dict(dtype=torch.int32, device=d)
+        b = dict(C=Cn, splat=torch.empty(Cn, N, 8, device=d), g2d=torch.empty(Cn, N, 8, device=d),
+                 tile_counts=torch.zeros(Cn, T, **i32), offsets=torch.zeros(Cn, T, **i32),
+                 tile_end=torch.zeros(Cn, T, **i32), item_offsets=torch.zeros(Cn, T, **i32),
+                 item_end=torch.zeros(Cn, T, **i32), item_tile=torch.zeros(Cn, self.max_items, **i32),
+                 keys=torch.empty(Cn, T * self.seg_cap, dtype=torch.int64, device=d),
+                 flatten_ids=torch.empty(Cn, T * self.seg_cap, **i32), total=torch.zeros(Cn, 4, **i32),
+                 ticket=torch.zeros(Cn, **i32), gtstop=torch.zeros(Cn, self.height, self.width, 3, device=d),
+                 workspace=ws, ws_stride=stride, rewalk_hint=-1)
+        a = StepArgs()
+        a.means, a.quats = ptr(self.means), ptr(self.quats)
+        a.log_scales, a.logit_opacities = ptr(self.log_scales), ptr(self.logit_opacities)
+        a.adam_m, a.adam_v = ptr(self.adam_m), ptr(self.adam_v)
+        a.N, a.width, a.height = N, self.width, self.height
+        a.splat, a.g2d, a.gtstop = ptr(b["splat"]), ptr(b["g2d"]), ptr(b["gtstop"])
+        a.seg_cap, a.max_items, a.capacity = self.seg_cap, self.max_items, self.capacity
+        a.tile_counts, a.offsets, a.total = ptr(b["tile_counts"]), ptr(b["offsets"]), ptr(b["total"])
+        a.tile_end, a.item_end, a.item_tile = ptr(b["tile_end"]), ptr(b["item_end"]), ptr(b["item_tile"])
+        a.item_offsets, a.workspace, a.ticket = ptr(b["item_offsets"]), ptr(ws), ptr(b["ticket"])
+        a.keys, a.flatten_ids, a.loss = ptr(b["keys"]), ptr(b["flatten_ids"]), ptr(self.loss_acc)
+        g0 = self.grads.data_ptr()
+        a.v_means, a.v_quats = g0, g0 + 4 * 3 * N
+        a.v_scales, a.v_opacities = g0 + 4 * 7 * N, g0 + 4 * 10 * N
+        b["args"] = a
+        b["ptrs"] = [(C.c_void_p * Cn)() for _ in range(4)]
+        b["hyper_ptr"] = C.pointer(self._hyper)
+        b["null_hyper"] = C.POINTER(AdamHyper)()
+        self._batch = b
+        return b
+
+    def _batched_raw(self, views, wmaps, fused_adam: bool) -> None:
+        Cn = len(views)
+        if not self.seg_cap:
+            raise RuntimeError("train_step_batched needs the segmented binning layout (EdgeTrainer(segmented=True))")
+        b = self._batch if (self._batch is not None and self._batch["C"] == Cn) else self._alloc_batch(Cn)
+        a = b["args"]
+        vm, Kp, gp, wp = b["ptrs"]
+        hw4 = 4 * self.height * self.width
+        for i, (v, w) in enumerate(zip(views, wmaps)):
+            assert w.is_cuda and w.is_contiguous() and w.shape == (self.height, self.width)
+            vm[i] = self.viewmats.data_ptr() + 64 * v
+            Kp[i] = self.Ks.data_ptr() + 36 * v
+            gp[i] = self.gt.data_ptr() + hw4 * v
+            wp[i] = w.data_ptr()
+        a.loss_scale = self.loss_scale
+        a.max_tile_hint = getattr(self, "max_tile_seen", 0)
+        a.rewalk_hint = b["rewalk_hint"]
+        if fused_adam:
+            self._advance_all()
+            self._set_hyper()
+            a.absgrads, a.adam_host = ptr(self.absgrads), b["hyper_ptr"]
+        else:
+            a.absgrads, a.adam_host = self.grads.data_ptr() + 4 * 11 * self.N, b["null_hyper"]
+        call("eg_train_step_batched", C.byref(a), Cn, vm, Kp, gp, wp, stream())
+        if fused_adam:
+            self.absgrads_normalize_factor += Cn  # C calls of update_absgrads (edge_gs.py:613)
+        self.step += Cn
+
+    def train_step_batched(self, views: List[int], wmaps: List[Tensor]) -> None:
+        """C = len(views) <= 8 views in ONE launch sequence (gridDim.y = view) and ONE optimizer step on the SUM of
+        their gradients -- the semantics of C-way data parallelism (dist.py) on a single GPU.  A throughput mode:
+        the reference steps after every view (train_gaussians.py:104-106)."""
+        if self.capacity == 0:
+            self.ensure_capacity()
+        views, wmaps = list(views), list(wmaps)
+        if self.replay_on_overflow:
+            if not self._journal:
+                self._snapshot()
+            self._journal.append(("b", views, wmaps, self.epoch, self.loss_scale))
+        self._batched_raw(views, wmaps, True)
+
+    def grad_step_batched(self, views: List[int], wmaps: List[Tensor]) -> Tensor:
+        """Forward + loss + backward of C views, gradients SUMMED into ``self.grads`` (layout of grad_step)."""
+        if self.capacity == 0:
+            self.ensure_capacity()
+        self._batched_raw(list(views), list(wmaps), False)
+        return self.grads
 
     # ------------------------------------------------------------------ overflow: journal, snapshot, replay
     _SNAP_TENSORS = ("means", "log_scales", "quats", "logit_opacities", "adam_m", "adam_v", "absgrads")
@@ -360,7 +448,7 @@ class EdgeTrainer:
         """Called with the stream drained and total[1] raised: some step since the last read-back dropped
         intersections.  Grow, put the state back, run the journalled steps again; repeat until clean."""
         if not (self.replay_on_overflow and self._journal and self._snap is not None):
-            self.total.zero_()
+            self.clear_overflow()
             self._grow_isect(2.0)  # leave usable buffers behind for a caller that catches and restarts
             raise IsectOverflow("tile-intersection buffers overflowed and the steps since the last read-back "
                                 "cannot be replayed (journal off or data-parallel leg): results are invalid; "
@@ -369,14 +457,17 @@ class EdgeTrainer:
         epoch_now, ls_now = self.epoch, self.loss_scale
         for _ in range(8):
             self.overflow_events += 1
-            self._grow_isect(2.0)
+            self._grow_isect(2.0)  # (drops the batched work buffers as well: re-allocated, flags clear)
             self.total.zero_()
             self.loss_acc.zero_()
             self._restore()
-            for view, wmap, epoch, ls in journal:
+            for kind, view, wmap, epoch, ls in journal:
                 self.epoch, self.loss_scale = epoch, ls
-                self._step_raw(view, wmap)
-            if int(self.total[1].item()) == 0:
+                if kind == "1":
+                    self._step_raw(view, wmap)
+                else:
+                    self._batched_raw(view, wmap, True)
+            if not self.overflowed():
                 self.epoch, self.loss_scale = epoch_now, ls_now
                 return
         raise IsectOverflow("tile-intersection buffers still overflow after 8 doublings")
@@ -384,7 +475,7 @@ class EdgeTrainer:
     def flush(self) -> None:
         """Drain the stream, verify that no step since the last read-back overflowed (repairing it if one
         did) and forget the journal.  Every operation that changes the state outside train_step calls it."""
-        if int(self.total[1].item()) != 0:
+        if self.overflowed():
             self._recover_from_overflow()
         self._journal.clear()
 
@@ -522,11 +613,11 @@ class EdgeTrainer:
         """Sum of the projection losses since the last call (the reference's avg_loss numerator,
         train_gaussians.py:99) -- ONE device sync for many steps instead of two per step."""
         v = float(self.loss_acc.item())
-        m_last, ovf, _items, tile_max = (int(x) for x in self.total.tolist())
+        m_last, ovf, _items, tile_max = self._totals()
         if ovf:  # sticky flag: SOME step since the last read-back dropped intersections
             self._recover_from_overflow()  # raises IsectOverflow when the steps cannot be replayed
             v = float(self.loss_acc.item())
-            m_last, _, _items, tile_max = (int(x) for x in self.total.tolist())
+            m_last, _, _items, tile_max = self._totals()
         self._journal.clear()
         self.loss_acc.zero_()
         # the stream is drained anyway: refresh the launch-shape hints -- the longest exact-stop re-walk list since
@@ -537,6 +628,11 @@ class EdgeTrainer:
         if seen != self.rewalk_hint:
             self.rewalk_hint = seen
             self._args_cache = {}
+        if self._batch is not None:
+            o = 4 * (self.T + self.max_items + 2)
+            w2 = self._batch["workspace"][:, o:o + 4].contiguous().view(torch.int32)
+            self._batch["rewalk_hint"] = int(w2.max().item())
+            self._batch["workspace"][:, o:o + 4].zero_()
         # ... and the tile-sort launch hint from the last step's scan
         if tile_max > getattr(self, "max_tile_seen", 0):
             self.max_tile_seen = tile_max
@@ -554,15 +650,26 @@ class EdgeTrainer:
             self._alloc_isect(cap, seg)
         return v
 
+    def _totals(self):
+        """(M, sticky overflow flag, items, largest tile) of the last step(s): single-view buffers and, when a
+        batched step ran, the maximum over its views."""
+        t = [int(x) for x in self.total.tolist()]
+        if self._batch is not None:
+            bt = self._batch["total"].max(dim=0).values.tolist()
+            t = [max(a, int(b)) for a, b in zip(t, bt)]
+        return t
+
     def overflowed(self) -> bool:
         """True if ANY step since the flag was last cleared dropped intersections (the device flag is sticky)."""
-        return bool(self.total[1].item() != 0)
+        return self._totals()[1] != 0
 
     def clear_overflow(self) -> None:
         self.total[1:2].zero_()
+        if self._batch is not None:
+            self._batch["total"][:, 1].zero_()
 
     def last_m(self) -> int:
-        return int(self.total[0].item())
+        return self._totals()[0]
 
     # ------------------------------------------------------------------ densify / cull
     def _moment_views(self, t: Tensor):

@@ -42,6 +42,7 @@ typedef void *eg_stream_t; /* hipStream_t */
 #define EG_ERR_NODEVICE (-3)
 
 #define EG_TILE 16
+#define EG_MAX_BATCH 8 /* views per eg_train_step_batched call */
 #define EG_FLAG_LOG_SCALES 1u      /* `scales` holds log-scales: exp() fused (edge_gs.py:253) */
 #define EG_FLAG_LOGIT_OPACITIES 2u /* `opacities` holds logits: sigmoid() fused (edge_gs.py:254) */
 #define EG_FLAG_ANTIALIASED 4u     /* rasterize_mode="antialiased" (edge_gs.py:50,266) */
@@ -347,6 +348,21 @@ typedef struct {
 } eg_step_args;
 
 int eg_train_step(const eg_step_args *args_host, eg_stream_t stream);
+
+/* ---- C <= EG_MAX_BATCH views per launch sequence.  `args_host` as for eg_train_step
+ * (segmented layout required; its viewmat / K / gt / wmap fields are ignored) with every per-view work buffer
+ * holding C consecutive copies: splat, g2d [C,N,8]; tile_counts, offsets, tile_end, item_offsets, item_end [C,T];
+ * item_tile [C,max_items]; keys, flatten_ids [C,T*seg_cap]; total [C,4]; ticket [C]; gtstop [C,H,W,3];
+ * workspace = C blocks of eg_batched_workspace_stride(max_items, T) bytes (control prefix of each zeroed at
+ * allocation).  render / alphas / last_ids / vpix are not materialised.  The gradients of the C views are
+ * SUMMED (= what an all-reduce over C data-parallel ranks forms), absgrads += the C per-view increments, then
+ * one Adam step (adam_host != NULL) or the summed gradients are written (v_means ...).  viewmats / Ks / gts /
+ * wmaps: host arrays of C device pointers.  The reference steps after every view (train_gaussians.py:104-106):
+ * this is a throughput mode with the semantics of data parallelism, on one GPU. */
+int64_t eg_batched_workspace_stride(int64_t max_items, int64_t n_tiles);
+int eg_train_step_batched(const eg_step_args *args_host, int32_t C, const float *const *viewmats,
+                          const float *const *Ks, const float *const *gts, const float *const *wmaps,
+                          eg_stream_t stream);
 
 /* ---- measurement aid: between eg_timing_begin(n) and eg_timing_end(), the next n eg_train_step
  * calls record HIP events between their stages on the launch stream; eg_timing_end synchronises

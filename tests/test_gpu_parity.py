@@ -1150,6 +1150,48 @@ def test_train_loop_survives_a_capacity_crossing(env):
     assert float(torch.sigmoid(tr.logit_opacities).mean()) > 0.5
 
 
+@pytest.mark.parametrize("Cn", [1, 3, 8])
+def test_batched_views_equal_the_sum_of_single_view_steps(env, Cn):
+    """C views in one launch sequence (gridDim.y = view).  Guarantee = the data-parallel one:
+    summed gradient == sum of the per-view gradients at the same parameters (same kernels, so to rounding of the
+    final sum), loss == sum of losses, absgrad increment == sum of increments; and the batched optimizer step ==
+    eg_adam_multi on that sum."""
+    _lib, synth, O = env
+    from edgegaussians_amd import EdgeTrainer, LRSchedule
+    sc = _scene(synth, n=4000, w=200, h=136, views=8)
+    sched = LRSchedule(scales_start=0, quats_start=0, opacities_start=0)
+    mk = lambda: EdgeTrainer(sc.means, sc.log_scales, sc.quats, sc.logit_opacities, sc.viewmats, sc.Ks, sc.gt,  # noqa: E731
+                             sc.width, sc.height, schedule=sched)
+    ta, tb = mk(), mk()
+    ta.ensure_capacity(); tb.ensure_capacity()
+    views = [5, 0, 3, 7, 1, 2, 6, 4][:Cn]
+    strat = ["weighted", "whole", "bg_edge_ratio"]
+    wm = [synth.weight_map(strat[i % 3], sc.gt[v], generator=torch.Generator().manual_seed(i)).cuda() for i, v in enumerate(views)]
+    N = sc.means.shape[0]
+    acc = torch.zeros_like(ta.grads)
+    losses = []
+    for v, w in zip(views, wm):
+        acc += ta.grad_step(v, w)
+        losses.append(ta.pop_loss())
+    gb = tb.grad_step_batched(views, wm).clone()
+    lb = tb.pop_loss()
+    assert abs(lb - sum(losses)) <= 1e-5 * abs(sum(losses)) and not tb.overflowed()
+    for name, sl in (("means", slice(0, 3 * N)), ("quats", slice(3 * N, 7 * N)), ("scales", slice(7 * N, 10 * N)),
+                     ("opac", slice(10 * N, 11 * N)), ("absgrad", slice(11 * N, 12 * N))):
+        assert_close(gb.view(-1)[sl], acc.view(-1)[sl], rtol=1e-5, name=f"batched {name}")
+    # the batched optimizer step == Adam on the summed gradient
+    ta.grads.copy_(acc)
+    ta.apply_adam()
+    tb.train_step_batched(views, wm)
+    assert tb.adam_step == ta.adam_step == 1 and tb.step == 2 * Cn
+    for k, v in ta.state_dict().items():
+        assert_close(tb.state_dict()[k], v, rtol=1e-6, name=f"batched step {k}")
+    assert_close(tb.absgrads, ta.absgrads, rtol=1e-5, name="batched absgrads")
+    assert tb.absgrads_normalize_factor == 1 + Cn
+    assert math.isfinite(tb.pop_loss())
+    assert int(tb._batch["tile_counts"].abs().sum()) == 0 and int(tb._batch["ticket"].abs().sum()) == 0
+
+
 def test_bench_line_contract(env):
     """bench.py prints ONE JSON line, last on stdout, with the fields the driver and the judge read."""
     import json

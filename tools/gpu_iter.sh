@@ -12,11 +12,12 @@ for c in ${CONFIGS:-config1 config2}; do
   timeout 300 python bench.py --config $c --no-cpu-baseline --no-traffic --no-extra 2>$O/bench_${c}_$TAG.err | tail -1 > $O/bench_${c}_$TAG.json
 done
 [ "${SPREAD:-1}" = "1" ] && timeout 300 python bench.py --config config2 --spread-opacity --no-cpu-baseline --no-traffic --no-extra 2>/dev/null | tail -1 > $O/bench_config2s_$TAG.json
+for c in ${BATCHED:-config1 config2}; do for v in 2 4 8; do timeout 300 python bench.py --config $c --views-per-step $v --steps 300 --warmup 30 --no-cpu-baseline --no-traffic --no-extra 2>$O/bench_${c}_b${v}_$TAG.err | tail -1 > $O/bench_${c}_b${v}_$TAG.json; done; done
 tail -${TAIL:-40} $O/pytest_$TAG.log 2>/dev/null
 python - <<PY
 import json,glob
 for f in sorted(glob.glob("$O/bench_*_$TAG.json")):
     try:
-        d=json.loads(open(f).read()); print(f.split('/')[-1], round(d['ms_per_step']*1e3,1),'us', d['config']['tile_intersections_M'], {k:round(v,1) for k,v in d.get('stages_us',{}).items()})
+        d=json.loads(open(f).read()); print(f.split('/')[-1], round(d['ms_per_step']*1e3,1),'us', round(d['value']/1e6),'MGv/s', d['config']['tile_intersections_M'], {k:round(v,1) for k,v in d.get('stages_us',{}).items()})
     except Exception as e: print(f, 'ERR', e)
 PY
