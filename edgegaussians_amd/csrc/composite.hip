@@ -405,23 +405,23 @@ __device__ __forceinline__ float finalize_pixel(int p, float T, int last, bool s
 #pragma unroll
     for (int k = 0; k < CH; ++k) render[(size_t)p * CH + k] = pix;
   }
-  float l = 0.f;
+  float l = 0.f, v = 1.f;  // without the fused loss the record carries T_final itself (upstream gradient 1)
   if (has_loss) {  // gt_p, w: this pixel's target and weight, loaded by the caller ahead of its own work
     const float c0 = fminf(fmaxf(pix, 0.f), 1.f);
     const float d = c0 - gt_p;
     l = w * fabsf(d);
     const float sgn = (d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f);
-    const float v = loss_scale * w * sgn;  // pix is in [0,1): the clamp always passes the gradient
+    v = loss_scale * w * sgn;  // pix is in [0,1): the clamp always passes the gradient
     if (vpix) vpix[p] = v;
-    if (gtstop) {
-      // v * T_final, and -- only for pixels whose walk stopped on the transmittance rule -- the id of
-      // the last contributing Gaussian
-      StopRec r;
-      r.gT = (T < 1.f) ? v * T : 0.f;
-      r.stop_id = stopped ? flat[last] : -1;
-      r.stop_depth = stopped ? (unsigned)__float_as_int(splat[2 * r.stop_id + 1].z) : 0u;
-      gtstop[p] = r;
-    }
+  }
+  if (gtstop) {
+    // v * T_final, and -- only for pixels whose walk stopped on the transmittance rule -- the id of
+    // the last contributing Gaussian
+    StopRec r;
+    r.gT = (T < 1.f) ? v * T : 0.f;
+    r.stop_id = stopped ? flat[last] : -1;
+    r.stop_depth = stopped ? (unsigned)__float_as_int(splat[2 * r.stop_id + 1].z) : 0u;
+    gtstop[p] = r;
   }
   return l;
 }
@@ -1287,8 +1287,8 @@ extern "C" int eg_composite_fwd(const float *splat, const float *colors, int32_t
   EG_REQUIRE(splat && offsets, "null pointer");
   EG_REQUIRE((render && alphas && last_ids) || gtstop, "render / alphas / last_ids are optional only with gtstop");
   EG_REQUIRE(!wmap || gt, "wmap needs gt");
-  EG_REQUIRE(!gtstop || (wmap && !colors && item_offsets && total && workspace && max_items > 0),
-             "gtstop needs the fused loss and the slice-parallel unit-colour mode");
+  EG_REQUIRE(!gtstop || (!colors && item_offsets && total && workspace && max_items > 0),
+             "gtstop needs the slice-parallel unit-colour mode");
   const int tw = cdiv(width, kTile), th = cdiv(height, kTile);
   hipStream_t s = as_stream(stream);
   if (!colors && item_offsets && total && workspace && max_items > 0) {

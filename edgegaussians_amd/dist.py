@@ -3,8 +3,8 @@
 The reference is single-process / single-GPU (no torch.distributed call site) and
 steps the optimizer after every single view (train_gaussians.py:104-106,311).  The path shards
 naturally over VIEWS: every rank holds the full Gaussian state (11 floats/Gaussian +
-Adam moments), takes a different view of the step's view batch, and the only exchange is ONE
-all-reduce(sum) over a single fused [N,12] fp32 buffer per step
+Adam moments), takes different views of the step's view batch, and the only exchange is an
+all-reduce(sum) over a fused [N,12] fp32 buffer
     [ dL/dmeans 3 | dL/dquats 4 | dL/dlog_scales 3 | dL/dlogit_opacity 1 | absgrad increment 1 ]
 after which every rank applies the identical fused Adam -- replicas stay bit-identical because the
 all-reduce result is identical on every rank.  This is a THROUGHPUT mode: a P-view batch per
@@ -12,13 +12,20 @@ optimizer step is a different trajectory from P sequential steps; what is guaran
 is  all-reduced gradient == sum of the single-GPU per-view gradients at the same parameters.
 
 Backend "nccl" IS RCCL on ROCm; on the MI355X xGMI mesh a 1.4-24 MB buffer (N = 30k-500k) is
-latency- to per-link-bound, so it is sent as one collective rather than per-parameter buckets.
-The same code runs under "gloo" on CPU tensors (tests/test_dist_gloo.py).
+latency- to per-link-bound, so it is sent as one collective per half step rather than per-parameter
+buckets.  Hiding it: with C >= 2 views per rank and step (`views_per_rank`, the rank's views run as ONE
+batched launch sequence, EdgeTrainer.grad_step_batched) the step is split into two half batches whose
+gradients land in two buffers: the all-reduce of the first half runs on RCCL's stream while the second
+half is being rasterised; only the second, shorter-lived collective is exposed.  With one view per rank
+there is nothing to overlap with (the next forward needs the updated parameters) and the collective is
+exposed in full -- `comm_us()` reports the exposed time either way.
+The same code runs under "gloo" on CPU tensors (tests/test_dist_gloo.py) and, staged through the host,
+with several ranks sharing one GPU (GPU test, RCCL refuses that).
 """
 from __future__ import annotations
 
 import os
-from typing import Callable, Optional, Protocol
+from typing import List, Optional, Protocol, Sequence, Union
 
 import torch
 import torch.distributed as dist
@@ -47,25 +54,90 @@ def init_from_env(backend: Optional[str] = None) -> tuple:
     return rank, local, world
 
 
-def view_for(step: int, rank: int, world: int, n_views: int) -> int:
-    """Round-robin view sharding: the step's batch is views {step*world + r}, r = 0..world-1."""
-    return (step * world + rank) % n_views
+def view_for(step: int, rank: int, world: int, n_views: int, views_per_rank: int = 1, slot: int = 0) -> int:
+    """Round-robin view sharding: the step's batch is views {(step*world + r) * C + slot}, r = 0..world-1."""
+    return ((step * world + rank) * views_per_rank + slot) % n_views
 
 
 class DataParallelStep:
-    def __init__(self, worker: GradWorker, group=None):
+    def __init__(self, worker: GradWorker, group=None, time_comm: bool = False):
         self.worker = worker
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.time_comm = time_comm
+        self._ev: List = []
 
-    def step(self, view: int, wmap: torch.Tensor) -> None:
-        grads = self.worker.grad_step(view, wmap)
-        if self.world > 1:
-            if grads.is_cuda and dist.get_backend(self.group) == "gloo":
-                # test mode only (several ranks sharing one GPU, RCCL refuses that): stage through the host
-                host = grads.cpu()
-                dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
-                grads.copy_(host)
-            else:
-                dist.all_reduce(grads, op=dist.ReduceOp.SUM, group=self.group)
+    # ------------------------------------------------------------------ the collective
+    def _all_reduce(self, t: torch.Tensor, async_op: bool = False):
+        if self.world <= 1:
+            return None
+        if t.is_cuda and dist.get_backend(self.group) == "gloo":
+            # test mode only (several ranks sharing one GPU, RCCL refuses that): stage through the host
+            host = t.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+            t.copy_(host)
+            return None
+        return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+
+    def all_reduce_scalar(self, x: float) -> float:
+        """Sum of a host scalar over the ranks (the epoch's loss sum feeds the regulariser weights,
+        train_gaussians.py:113,125: every replica must use the same value)."""
+        if self.world <= 1 or not dist.is_initialized():
+            return x
+        dev = "cuda" if dist.get_backend(self.group) == "nccl" else "cpu"
+        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return float(t.item())
+
+    def _mark(self):
+        if self.time_comm and torch.cuda.is_available():
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            return e
+        return None
+
+    # ------------------------------------------------------------------ one optimizer step
+    def step(self, view: Union[int, Sequence[int]], wmap) -> None:
+        """`view`, `wmap`: this rank's view (+ weight map) of the step -- or lists of C views / maps, which run
+        as batched launch sequences with the first half's all-reduce hidden behind the second half."""
+        if isinstance(view, int):
+            grads = self.worker.grad_step(view, wmap)
+            e0 = self._mark()
+            self._all_reduce(grads)
+            e1 = self._mark()
+            if e0 is not None:
+                self._ev.append((e0, e1))
+            self.worker.apply_adam()
+            return
+        views, wmaps = list(view), list(wmap)
+        if len(views) == 1 or self.world <= 1:
+            grads = self.worker.grad_step_batched(views, wmaps)
+            e0 = self._mark()
+            self._all_reduce(grads)
+            e1 = self._mark()
+            if e0 is not None:
+                self._ev.append((e0, e1))
+            self.worker.apply_adam()
+            return
+        h = len(views) // 2
+        ga = self.worker.grad_step_batched(views[:h], wmaps[:h], slot=1)   # first half -> second buffer
+        work = self._all_reduce(ga, async_op=True)                         # ... reduced on RCCL's stream while
+        gb = self.worker.grad_step_batched(views[h:], wmaps[h:], slot=0)   # the second half is rasterised
+        e0 = self._mark()
+        self._all_reduce(gb)
+        if work is not None:
+            work.wait()  # the compute stream waits (no host block)
+        e1 = self._mark()
+        if e0 is not None:
+            self._ev.append((e0, e1))
+        gb.add_(ga)
         self.worker.apply_adam()
+
+    def comm_us(self) -> Optional[float]:
+        """Mean EXPOSED all-reduce time per step on this rank's compute stream, microseconds (time_comm=True)."""
+        if not self._ev:
+            return None
+        torch.cuda.synchronize()
+        us = [1e3 * a.elapsed_time(b) for a, b in self._ev]
+        self._ev = []
+        return sum(us) / len(us)

@@ -75,24 +75,34 @@ class _Projection(torch.autograd.Function):
         width, height, eps2d, flags = ctx.cfg
         Cn, N = vm.shape[0], means.shape[0]
         dev = means.device
-        z2 = torch.zeros(Cn, N, 2, device=dev)
-        z1 = torch.zeros(Cn, N, 1, device=dev)
-        vm2d = v_means2d if v_means2d is not None else z2
-        vcon = v_conics if v_conics is not None else torch.zeros(Cn, N, 3, device=dev)
-        g2d = torch.cat([vm2d, z2, vcon, z1], dim=-1).contiguous()
+        base = getattr(v_means2d, "_base", None) if v_means2d is not None else None
+        if (base is not None and v_conics is not None and getattr(v_conics, "_base", None) is base
+                and tuple(base.shape) == (Cn, N, 8) and base.is_contiguous() and base.dtype == torch.float32
+                and v_means2d.storage_offset() == base.storage_offset()
+                and v_conics.storage_offset() == base.storage_offset() + 4):
+            g2d = base  # both are views of the compositing backward's packed record: no re-pack
+        else:
+            z2 = torch.zeros(Cn, N, 2, device=dev)
+            z1 = torch.zeros(Cn, N, 1, device=dev)
+            vm2d = v_means2d if v_means2d is not None else z2
+            vcon = v_conics if v_conics is not None else torch.zeros(Cn, N, 3, device=dev)
+            g2d = torch.cat([vm2d, z2, vcon, z1], dim=-1).contiguous()
         vcomp = (v_comps if v_comps is not None else torch.zeros(Cn, N, device=dev)).contiguous()
         vdep = v_depths.contiguous() if v_depths is not None else None
-        v_means = torch.zeros(N, 3, device=dev)
-        v_quats = torch.zeros(N, 4, device=dev)
-        v_scales = torch.zeros(N, 3, device=dev)
-        tm, tq, ts = torch.empty_like(v_means), torch.empty_like(v_quats), torch.empty_like(v_scales)
+        v_means = torch.empty(N, 3, device=dev)
+        v_quats = torch.empty(N, 4, device=dev)
+        v_scales = torch.empty(N, 3, device=dev)
+        tm, tq, ts = (v_means, v_quats, v_scales) if Cn == 1 else (torch.empty_like(v_means), torch.empty_like(v_quats),
+                                                                  torch.empty_like(v_scales))
         for c in range(Cn):
             call("eg_project_bwd", ptr(means), ptr(quats), ptr(scales), ptr(opac), ptr(vm[c]), ptr(Kc[c]),
                  N, width, height, eps2d, flags, ptr(splat[c]), ptr(g2d[c]), ptr(vcomp[c]),
                  ptr(vdep[c]) if vdep is not None else None, ptr(tm), ptr(tq), ptr(ts), None, None, stream())
-            v_means += tm
-            v_quats += tq
-            v_scales += ts
+            if Cn > 1:
+                if c == 0:
+                    v_means.copy_(tm); v_quats.copy_(tq); v_scales.copy_(ts)
+                else:
+                    v_means += tm; v_quats += tq; v_scales += ts
         return (v_means, v_quats, v_scales) + (None,) * 10
 
 
@@ -101,16 +111,21 @@ class _Compositing(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, means2d, conics, colors, opacities, width, height, offsets, flatten_ids, absgrad,
-                unit_colors, item_offsets, totals, n_items):
+                unit_colors, item_offsets, totals, n_items, packed_splat):
         Cn, N = means2d.shape[0], means2d.shape[1]
         dev = means2d.device
         D = colors.shape[-1]
-        z2 = torch.zeros(Cn, N, 2, device=dev)
-        splat = torch.cat([means2d, conics, opacities[..., None], z2], dim=-1).contiguous()
+        # the projection kernel already wrote the packed record (x y a b c o*comp depth radius) the compositing
+        # kernels read: the same floats as (means2d, conics, opacities), so no torch.cat re-pack per call
+        splat = packed_splat
         colors_c = colors.contiguous()
         render = torch.empty(Cn, height, width, D, device=dev)
         alphas = torch.empty(Cn, height, width, 1, device=dev)
         last_ids = torch.empty(Cn, height, width, dtype=torch.int32, device=dev)
+        # unit colours: the sliced forward leaves the per-pixel record {T_final, stop id, stop depth} that the
+        # order-independent footprint backward reads (deterministic, no atomics, no zero-fill of the gradients)
+        sliced = unit_colors and all(n > 0 for n in n_items)
+        gtstop = torch.empty(Cn, height, width, 3, device=dev) if sliced else None
         for c in range(Cn):
             col = None if unit_colors else ptr(colors_c[c] if colors_c.dim() == 3 else colors_c)
             ws = None
@@ -119,9 +134,10 @@ class _Compositing(torch.autograd.Function):
             call("eg_composite_fwd", ptr(splat[c]), col, D, ptr(offsets[c]), ptr(flatten_ids[c]), width, height,
                  ptr(render[c]), ptr(alphas[c]), ptr(last_ids[c]), None, None, 1.0, None, None,
                  ptr(item_offsets[c]) if ws is not None else None, ptr(totals[c]) if ws is not None else None,
-                 n_items[c], ptr(ws), None, -1, stream())
+                 n_items[c], ptr(ws), ptr(gtstop[c]) if sliced else None, -1, stream())
         ctx.save_for_backward(means2d, splat, colors_c, alphas, last_ids, *offsets, *flatten_ids, *item_offsets,
                               *totals)
+        ctx.gtstop = gtstop
         ctx.cfg = (width, height, absgrad, unit_colors, Cn, tuple(n_items))
         ctx.mark_non_differentiable(last_ids)
         return render, alphas, last_ids
@@ -135,11 +151,22 @@ class _Compositing(torch.autograd.Function):
         item_offsets, totals = saved[5 + 2 * Cn:5 + 3 * Cn], saved[5 + 3 * Cn:5 + 4 * Cn]
         N, D = means2d.shape[1], colors.shape[-1]
         dev = means2d.device
+        need_vcol = ctx.needs_input_grad[2]
+        v_colors = None
+        if unit_colors and not need_vcol and ctx.gtstop is not None:
+            # footprint backward: every Gaussian sums over its own footprint in the {v * T_final, stop} record
+            rec = ctx.gtstop.clone()
+            rec[..., 0] *= (v_render.sum(-1) + v_alphas[..., 0])
+            g2d = torch.empty(Cn, N, 8, device=dev)
+            for c in range(Cn):
+                call("eg_composite_bwd_footprint", ptr(splat[c]), N, width, height, ptr(rec[c]), ptr(g2d[c]), stream())
+            if absgrad:
+                means2d.absgrad = g2d[..., 2:4].contiguous()
+            # views of the one [C,N,8] record: the projection backward recognises them and skips the re-pack
+            return (g2d[..., 0:2], g2d[..., 4:7], None, g2d[..., 7]) + (None,) * 10
         g2d = torch.zeros(Cn, N, 8, device=dev)
         v_render = v_render.contiguous()
         v_alphas = v_alphas.contiguous()
-        need_vcol = ctx.needs_input_grad[2]
-        v_colors = None
         if unit_colors and not need_vcol:
             vpix = (v_render.sum(-1) + v_alphas[..., 0]).contiguous()
             for c in range(Cn):
@@ -159,11 +186,12 @@ class _Compositing(torch.autograd.Function):
         if absgrad:
             means2d.absgrad = g2d[..., 2:4].contiguous()
         return (g2d[..., 0:2].contiguous(), g2d[..., 4:7].contiguous(), v_colors, g2d[..., 7].contiguous(),
-                None, None, None, None, None, None, None, None, None)
+                None, None, None, None, None, None, None, None, None, None)
 
 
 def isect_tiles_and_sort(means2d: Tensor, radii: Tensor, depths: Tensor, counts: Tensor, width: int,
-                         height: int, want_isect_ids: bool = True, max_tile_hint: Optional[int] = None
+                         height: int, want_isect_ids: bool = True, max_tile_hint: Optional[int] = None,
+                         extra_flag: Optional[Tensor] = None
                          ) -> Tuple[Tensor, Tensor, Optional[Tensor], int, Tensor, Tensor, int]:
     """Per camera: offsets[T+1] (scan of `counts`), keys -> sorted flatten_ids (+ int64 isect ids).
 
@@ -176,7 +204,12 @@ def isect_tiles_and_sort(means2d: Tensor, radii: Tensor, depths: Tensor, counts:
     item_offsets = torch.empty(T + 1, dtype=torch.int32, device=dev)
     total = torch.zeros(4, dtype=torch.int32, device=dev)  # total[1] (overflow) is sticky: start from zero
     call("eg_tile_offsets", ptr(counts), T, 1 << 40, ptr(offsets), ptr(item_offsets), ptr(total), stream())
-    M, _ovf, n_items, nmax = (int(v) for v in total.tolist())
+    if extra_flag is not None:  # a device scalar the caller wants back with this (only) read-back
+        vals = torch.cat([total, extra_flag.to(torch.int32).reshape(1)]).tolist()
+        isect_tiles_and_sort.last_extra = int(vals[4])
+        M, _ovf, n_items, nmax = (int(v) for v in vals[:4])
+    else:
+        M, _ovf, n_items, nmax = (int(v) for v in total.tolist())
     keys = torch.empty(max(M, 1), dtype=torch.int64, device=dev)
     flat = torch.empty(max(M, 1), dtype=torch.int32, device=dev)
     ids = torch.empty(max(M, 1), dtype=torch.int64, device=dev) if want_isect_ids else None
@@ -238,10 +271,13 @@ def rasterization(
     offs_l, flat_l, ids_l, item_l, tot_l, nit_l = [], [], [], [], [], []
     m_base = 0
     info_offsets = []
+    # the reference always passes torch.ones(N,3) without grad (edge_gs.py:247, a fresh tensor every step): decide
+    # "unit colours" on the device and read the verdict back with M (the one host sync gsplat also has)
+    unit_flag = None if colors.requires_grad else (colors == 1).all()
     with torch.no_grad():
         for c in range(Cn):
             offsets, flat, ids, M, item_offsets, total, n_items = isect_tiles_and_sort(
-                means2d[c], radii[c], depths[c], counts[c], width, height)
+                means2d[c], radii[c], depths[c], counts[c], width, height, extra_flag=unit_flag if c == 0 else None)
             item_l.append(item_offsets)
             tot_l.append(total)
             nit_l.append(n_items)
@@ -251,12 +287,11 @@ def rasterization(
             info_offsets.append((offsets[:-1] + m_base).reshape(th, tw))
             m_base += M
 
-    # the reference always passes torch.ones(N,3) without grad (edge_gs.py:247): take the
-    # order-independent unit-colour kernels when that is what we were given
-    unit = (not colors.requires_grad) and bool((colors == 1).all().item())
+    # ... and take the order-independent unit-colour kernels when that is what we were given
+    unit = unit_flag is not None and bool(isect_tiles_and_sort.last_extra)
     render, alphas, last_ids = _Compositing.apply(
         means2d, conics, colors, opac.contiguous(), width, height, tuple(offs_l), tuple(flat_l), bool(absgrad),
-        unit, tuple(item_l), tuple(tot_l), tuple(nit_l))
+        unit, tuple(item_l), tuple(tot_l), tuple(nit_l), _splat)
 
     info = {
         "camera_ids": None, "gaussian_ids": None,

@@ -158,8 +158,10 @@ class EdgeTrainer:
         self.g2d = torch.empty(N, 8, device=d)  # written (not accumulated) by the footprint backward
         self.tile_mask = torch.zeros(N, dtype=torch.int32, device=d)  # exact tile hits per Gaussian (bit mask)
         self.grads = torch.zeros(N, 12, device=d)  # [means3|quats4|scales3|opac1|absgrad-inc1] for all-reduce
+        self._grads_b = None
         self._args_cache: Dict = {}
-        self._batch = None  # [C, ...] work buffers of train_step_batched (allocated on first use)
+        self._batches: Dict = {}  # C -> [C, ...] work buffers of train_step_batched (allocated on first use)
+        self._grads_b = None      # second gradient buffer (data-parallel half-step overlap)
 
     def _alloc_pixels(self):
         H, W, d = self.height, self.width, self.dev
@@ -189,7 +191,7 @@ class EdgeTrainer:
             self.item_tile = torch.zeros(self.max_items, dtype=torch.int32, device=self.dev)
         self.workspace = _lib.composite_workspace(self.max_items, self.T, self.dev)
         self._args_cache = {}
-        self._batch = None
+        self._batches = {}
 
     # ------------------------------------------------------------------ loss weight maps
     def weight_map(self, view: int, strategy: str, ratio: float = 1.0,
@@ -366,22 +368,25 @@ class EdgeTrainer:
         a.tile_end, a.item_end, a.item_tile = ptr(b["tile_end"]), ptr(b["item_end"]), ptr(b["item_tile"])
         a.item_offsets, a.workspace, a.ticket = ptr(b["item_offsets"]), ptr(ws), ptr(b["ticket"])
         a.keys, a.flatten_ids, a.loss = ptr(b["keys"]), ptr(b["flatten_ids"]), ptr(self.loss_acc)
-        g0 = self.grads.data_ptr()
-        a.v_means, a.v_quats = g0, g0 + 4 * 3 * N
-        a.v_scales, a.v_opacities = g0 + 4 * 7 * N, g0 + 4 * 10 * N
         b["args"] = a
         b["ptrs"] = [(C.c_void_p * Cn)() for _ in range(4)]
         b["hyper_ptr"] = C.pointer(self._hyper)
         b["null_hyper"] = C.POINTER(AdamHyper)()
-        self._batch = b
+        self._batches[Cn] = b
         return b
 
-    def _batched_raw(self, views, wmaps, fused_adam: bool) -> None:
+    def _batched_raw(self, views, wmaps, fused_adam: bool, slot: int = 0) -> Tensor:
         Cn = len(views)
         if not self.seg_cap:
             raise RuntimeError("train_step_batched needs the segmented binning layout (EdgeTrainer(segmented=True))")
-        b = self._batch if (self._batch is not None and self._batch["C"] == Cn) else self._alloc_batch(Cn)
+        b = self._batches.get(Cn) or self._alloc_batch(Cn)
         a = b["args"]
+        if slot and self._grads_b is None:
+            self._grads_b = torch.zeros_like(self.grads)
+        out = self._grads_b if slot else self.grads
+        g0, N = out.data_ptr(), self.N
+        a.v_means, a.v_quats = g0, g0 + 4 * 3 * N
+        a.v_scales, a.v_opacities = g0 + 4 * 7 * N, g0 + 4 * 10 * N
         vm, Kp, gp, wp = b["ptrs"]
         hw4 = 4 * self.height * self.width
         for i, (v, w) in enumerate(zip(views, wmaps)):
@@ -398,11 +403,12 @@ class EdgeTrainer:
             self._set_hyper()
             a.absgrads, a.adam_host = ptr(self.absgrads), b["hyper_ptr"]
         else:
-            a.absgrads, a.adam_host = self.grads.data_ptr() + 4 * 11 * self.N, b["null_hyper"]
+            a.absgrads, a.adam_host = g0 + 4 * 11 * N, b["null_hyper"]
         call("eg_train_step_batched", C.byref(a), Cn, vm, Kp, gp, wp, stream())
         if fused_adam:
             self.absgrads_normalize_factor += Cn  # C calls of update_absgrads (edge_gs.py:613)
         self.step += Cn
+        return out
 
     def train_step_batched(self, views: List[int], wmaps: List[Tensor]) -> None:
         """C = len(views) <= 8 views in ONE launch sequence (gridDim.y = view) and ONE optimizer step on the SUM of
@@ -417,12 +423,13 @@ class EdgeTrainer:
             self._journal.append(("b", views, wmaps, self.epoch, self.loss_scale))
         self._batched_raw(views, wmaps, True)
 
-    def grad_step_batched(self, views: List[int], wmaps: List[Tensor]) -> Tensor:
-        """Forward + loss + backward of C views, gradients SUMMED into ``self.grads`` (layout of grad_step)."""
+    def grad_step_batched(self, views: List[int], wmaps: List[Tensor], slot: int = 0) -> Tensor:
+        """Forward + loss + backward of C views, gradients SUMMED into ``self.grads`` (layout of grad_step), or
+        into a second buffer of the same layout (slot = 1: the data-parallel driver reduces one half step while
+        the other is computed)."""
         if self.capacity == 0:
             self.ensure_capacity()
-        self._batched_raw(list(views), list(wmaps), False)
-        return self.grads
+        return self._batched_raw(list(views), list(wmaps), False, slot)
 
     # ------------------------------------------------------------------ overflow: journal, snapshot, replay
     _SNAP_TENSORS = ("means", "log_scales", "quats", "logit_opacities", "adam_m", "adam_v", "absgrads")
@@ -628,11 +635,11 @@ class EdgeTrainer:
         if seen != self.rewalk_hint:
             self.rewalk_hint = seen
             self._args_cache = {}
-        if self._batch is not None:
+        for b in self._batches.values():
             o = 4 * (self.T + self.max_items + 2)
-            w2 = self._batch["workspace"][:, o:o + 4].contiguous().view(torch.int32)
-            self._batch["rewalk_hint"] = int(w2.max().item())
-            self._batch["workspace"][:, o:o + 4].zero_()
+            w2 = b["workspace"][:, o:o + 4].contiguous().view(torch.int32)
+            b["rewalk_hint"] = int(w2.max().item())
+            b["workspace"][:, o:o + 4].zero_()
         # ... and the tile-sort launch hint from the last step's scan
         if tile_max > getattr(self, "max_tile_seen", 0):
             self.max_tile_seen = tile_max
@@ -654,9 +661,9 @@ class EdgeTrainer:
         """(M, sticky overflow flag, items, largest tile) of the last step(s): single-view buffers and, when a
         batched step ran, the maximum over its views."""
         t = [int(x) for x in self.total.tolist()]
-        if self._batch is not None:
-            bt = self._batch["total"].max(dim=0).values.tolist()
-            t = [max(a, int(b)) for a, b in zip(t, bt)]
+        for b in self._batches.values():
+            bt = b["total"].max(dim=0).values.tolist()
+            t = [max(a, int(x)) for a, x in zip(t, bt)]
         return t
 
     def overflowed(self) -> bool:
@@ -665,8 +672,8 @@ class EdgeTrainer:
 
     def clear_overflow(self) -> None:
         self.total[1:2].zero_()
-        if self._batch is not None:
-            self._batch["total"][:, 1].zero_()
+        for b in self._batches.values():
+            b["total"][:, 1].zero_()
 
     def last_m(self) -> int:
         return self._totals()[0]

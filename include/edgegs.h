@@ -159,7 +159,9 @@ int eg_composite_fwd_segments(const float *splat, const int32_t *tile_start, con
  * them once when the workspace is allocated -- with these (max_items, T) -- and every call hands them back
  * zeroed.  With item_offsets == NULL (or per-Gaussian colours) one workgroup walks each tile.
  * When gtstop != NULL (the fused training step, whose backward reads nothing else) render, alphas,
- * last_ids and vpix may each be NULL and are then not materialised. */
+ * last_ids and vpix may each be NULL and are then not materialised.  Without wmap the gtstop record carries
+ * T_final itself (upstream gradient 1): the caller scales word 0 by its per-pixel upstream gradient before
+ * eg_composite_bwd_footprint (what the gsplat-compatible operator's backward does). */
 int64_t eg_composite_workspace_bytes(int64_t max_items, int64_t n_tiles);
 int64_t eg_composite_workspace_ctl_bytes(int64_t max_items, int64_t n_tiles);
 int eg_composite_fwd(const float *splat, const float *colors /*[N,channels]|NULL*/, int32_t channels,

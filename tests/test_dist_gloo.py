@@ -109,3 +109,71 @@ def test_allreduced_gradient_equals_sum_of_per_view_gradients():
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
     assert dict(ret) == {0: True, 1: True}
+
+
+# ------------------------------------------------------------------ the same driver over EdgeTrainer on the GPU box
+def _gpu_worker(rank, world, port, ret):
+    """Two ranks sharing cuda:0 (gloo, gradients staged through the host: RCCL refuses two ranks on one device).
+    Under test: DataParallelStep over the HIP path -- single views and C = 2 / 3 views per rank (batched launch
+    sequences, the first half's all-reduce issued before the second half is computed)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK="0")
+    from edgegaussians_amd import EdgeTrainer, LRSchedule
+    torch.cuda.set_device(0)
+    r, _, w = egdist.init_from_env("gloo")
+    assert (r, w) == (rank, world)
+    V = 8
+    sc = synth.make_scene(3000, V, 160, 112, seed=4, spread_opacity=True, scale=0.02)
+    sched = LRSchedule(scales_start=0, quats_start=0, opacities_start=0)
+    mk = lambda: EdgeTrainer(sc.means, sc.log_scales, sc.quats, sc.logit_opacities, sc.viewmats, sc.Ks, sc.gt,  # noqa: E731
+                             sc.width, sc.height, schedule=sched, seed=7)
+    tr, ref = mk(), mk()
+    tr.ensure_capacity()
+    ref.ensure_capacity()
+    dp = egdist.DataParallelStep(tr)
+    wmaps = [synth.weight_map("weighted" if v % 2 else "whole", sc.gt[v]).cuda() for v in range(V)]
+    ok, step = True, 0
+    for Cn in (1, 1, 2, 3):
+        # single-process ground truth at the replicas' current parameters: the sum over the step's whole view batch
+        for name in ("means", "log_scales", "quats", "logit_opacities"):
+            getattr(ref, name).copy_(getattr(tr, name))
+        want = torch.zeros_like(tr.grads)
+        for rr in range(world):
+            for slot in range(Cn):
+                vv = egdist.view_for(step, rr, world, V, Cn, slot)
+                want += ref.grad_step(vv, wmaps[vv])
+        mine = [egdist.view_for(step, rank, world, V, Cn, slot) for slot in range(Cn)]
+        if Cn == 1:
+            dp.step(mine[0], wmaps[mine[0]])
+        else:
+            dp.step(mine, [wmaps[v] for v in mine])
+        got = tr.grads.clone()
+        scale = float(want.abs().max())
+        ok &= bool(((got - want).abs() <= 1e-5 * scale + 1e-5 * want.abs()).all())
+        for t in (tr.means, tr.log_scales, tr.quats, tr.logit_opacities, tr.absgrads, tr.adam_m):
+            h = t.detach().cpu()
+            h0 = h.clone()
+            dist.broadcast(h0, src=0)
+            ok &= bool(torch.equal(h0, h))  # replicas bit-identical
+        step += 1
+    ok &= tr.adam_step == 4 and not tr.overflowed()
+    # a densify event draws its noise from the seeded per-trainer generator: replicas must stay identical
+    tr.absgrads.copy_(torch.arange(tr.N, device="cuda").float())
+    tr.duplicate_high_pos_gradients(0.9, 3, 0.05)
+    h = tr.means.detach().cpu()
+    h0 = h.clone()
+    dist.broadcast(h0, src=0)
+    ok &= bool(torch.equal(h0, h)) and tr.N > 3000
+    ret[rank] = ok
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_data_parallel_driver_over_the_hip_path_two_ranks_one_gpu():
+    assert torch.cuda.is_available()
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_gpu_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert dict(ret) == {0: True, 1: True}

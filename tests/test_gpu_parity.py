@@ -1189,7 +1189,7 @@ def test_batched_views_equal_the_sum_of_single_view_steps(env, Cn):
     assert_close(tb.absgrads, ta.absgrads, rtol=1e-5, name="batched absgrads")
     assert tb.absgrads_normalize_factor == 1 + Cn
     assert math.isfinite(tb.pop_loss())
-    assert int(tb._batch["tile_counts"].abs().sum()) == 0 and int(tb._batch["ticket"].abs().sum()) == 0
+    assert int(tb._batches[Cn]["tile_counts"].abs().sum()) == 0 and int(tb._batches[Cn]["ticket"].abs().sum()) == 0
 
 
 def test_bench_line_contract(env):

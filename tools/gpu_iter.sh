@@ -21,3 +21,5 @@ for f in sorted(glob.glob("$O/bench_*_$TAG.json")):
         d=json.loads(open(f).read()); print(f.split('/')[-1], round(d['ms_per_step']*1e3,1),'us', round(d['value']/1e6),'MGv/s', d['config']['tile_intersections_M'], {k:round(v,1) for k,v in d.get('stages_us',{}).items()})
     except Exception as e: print(f, 'ERR', e)
 PY
+if [ "${OPER:-0}" = "1" ]; then for c in config1 config2; do timeout 300 python bench.py --config $c --path operator 2>$O/bench_${c}_oper_$TAG.err | tail -1 > $O/bench_${c}_oper_$TAG.json; python -c "
+import json; d=json.loads(open('$O/bench_${c}_oper_$TAG.json').read()); print('$c operator', round(d['ms_per_step']*1e3,1),'us')"; done; fi
