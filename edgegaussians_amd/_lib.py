@@ -77,12 +77,14 @@ _SIGS = {
     "eg_mask_scan": [_vp, _i32, _vp, _vp, _vp],
     "eg_compact_rows": [_vp, _vp, _vp, _i32, _i32, _vp, _vp],
     "eg_append_rows": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _f, _vp, _vp],
+    "eg_ratio_wmap": [_vp, _f, _i32, _vp, _i32, _i32, _vp, _vp],
     "eg_project_hits": [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _vp, _vp],
     "eg_project_visibility": [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _vp, _vp],
     "eg_knn": [_vp, _i32, _i32, C.POINTER(_f), _f, C.POINTER(_i32), _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "eg_direction_loss": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp],
     "eg_ratio_loss": [_vp, _i32, _vp, _vp, _vp],
     "eg_train_step": [C.POINTER(StepArgs), _vp],
+    "eg_train_steps": [C.POINTER(StepArgs), _i32, C.POINTER(_i32), C.POINTER(_vp), _vp, _vp, _vp, _vp],
     "eg_train_step_batched": [C.POINTER(StepArgs), _i32, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), _vp],
 }
 EXPORTS = sorted(list(_SIGS) + ["eg_last_error_string", "eg_version", "eg_device_count",

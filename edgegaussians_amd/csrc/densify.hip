@@ -110,6 +110,18 @@ project_visibility_kernel(const float *__restrict__ means, int N, const float *_
   visib[g] += acc;
 }
 
+// bg_edge_ratio weight map (edge_gs.py:298-314 in weight-map form): w_p = [gt_p >= thr] / n_edge + [p sampled] / n_sel.
+// The sample is the first n_sel entries of a random permutation (distinct indices), drawn by the caller.
+__global__ void __launch_bounds__(256)
+ratio_wmap_edge_kernel(const float *__restrict__ gt, float thr, float inv_edge, int HW, float *__restrict__ out) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < HW) out[p] = (gt[p] >= thr) ? inv_edge : 0.f;
+}
+__global__ void __launch_bounds__(256)
+ratio_wmap_sel_kernel(const long long *__restrict__ perm, int n_sel, int HW, float inv_sel, float *__restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_sel) out[(int)(perm[i] % HW)] += inv_sel;  // distinct pixels: no atomics
+}
 }  // namespace eg
 
 using namespace eg;
@@ -161,4 +173,16 @@ extern "C" int eg_project_visibility(const float *means, int32_t N, const float 
   project_visibility_kernel<<<cdiv(N, 256), 256, 0, as_stream(stream)>>>(means, N, cams, V, edge_maps, width,
                                                                         height, visib);
   return check_launch("project_visibility");
+}
+
+// weight map of the 'bg_edge_ratio' strategy from the edge image and a caller-drawn random permutation (int64
+// indices, at least n_sel of them): out[p] = [gt_p >= thr] / n_edge + [p among the first n_sel] / n_sel.
+extern "C" int eg_ratio_wmap(const float *gt, float thr, int32_t n_edge, const int64_t *perm, int32_t n_sel,
+                             int32_t HW, float *out, eg_stream_t stream) {
+  EG_REQUIRE(HW > 0 && n_sel >= 0 && n_edge >= 0 && gt && out && (perm || n_sel == 0), "bad arguments");
+  hipStream_t st = as_stream(stream);
+  ratio_wmap_edge_kernel<<<cdiv(HW, 256), 256, 0, st>>>(gt, thr, 1.f / (float)(n_edge > 0 ? n_edge : 1), HW, out);
+  if (n_sel > 0)
+    ratio_wmap_sel_kernel<<<cdiv(n_sel, 256), 256, 0, st>>>((const long long *)perm, n_sel, HW, 1.f / (float)n_sel, out);
+  return check_launch("ratio_wmap");
 }

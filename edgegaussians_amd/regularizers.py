@@ -17,26 +17,58 @@ from torch import Tensor
 from ._lib import call, ptr, stream
 
 
-def knn(points: Tensor, k: int, want_dist: bool = False) -> Tuple[Tensor, Tensor]:
+def make_grid(points: Tensor, margin: float = 0.0):
+    """Uniform search grid over the points' bounding box (one host sync): (origin, cell edge, dims).  With
+    `margin` > 0 the box is inflated by that fraction so that the grid can be REUSED while the points move: a
+    point that leaves the box is clamped into a boundary cell, which keeps the search exact (every cell still
+    lies at least as far from a query as its index distance says) and only costs speed."""
+    pts = points.detach()
+    N = pts.shape[0]
+    lo_h, hi_h = pts.min(dim=0).values.tolist(), pts.max(dim=0).values.tolist()
+    ext = [max(h - l, 1e-6) for l, h in zip(lo_h, hi_h)]
+    lo_h = [l - margin * e for l, e in zip(lo_h, ext)]
+    ext = [e * (1.0 + 2.0 * margin) for e in ext]
+    vol = ext[0] * ext[1] * ext[2]
+    # ~8 points per cell if they fill the box: the 27 cells around a query then hold its K <= 32 neighbours and the
+    # first round settles it (a range look-up costs ~10 candidate evaluations: fewer, fuller cells win)
+    cell = max((vol * 8.0 / max(N, 1)) ** (1.0 / 3.0), max(ext) / 512.0)
+    lo_t = torch.tensor(lo_h, device=pts.device)
+
+    def dims_of(c):
+        return [max(1, min(512, int(math.ceil(e / c)))) for e in ext]
+
+    # trained Gaussians sit on curves, not in the volume: shrink the cells until an OCCUPIED cell holds ~8 points
+    # (a query thread walks every point of the 27 cells around it), within 2^24 cells of scratch
+    for _ in range(4):
+        d = dims_of(cell)
+        ids = ((pts - lo_t) / cell).floor().long().clamp_(min=0)
+        ids = (ids[:, 2].clamp_(max=d[2] - 1) * d[1] + ids[:, 1].clamp_(max=d[1] - 1)) * d[0] + ids[:, 0].clamp_(max=d[0] - 1)
+        occ = N / max(int(torch.unique(ids).numel()), 1)
+        if occ <= 16.0:
+            break
+        smaller = cell * max((8.0 / occ) ** 0.5, 0.25)
+        ds = dims_of(smaller)
+        if smaller < max(ext) / 512.0 or ds[0] * ds[1] * ds[2] > (1 << 24):
+            break
+        cell = smaller
+    return lo_h, float(cell), dims_of(cell)
+
+
+def knn(points: Tensor, k: int, want_dist: bool = False, grid=None) -> Tuple[Tensor, Tensor]:
     """Indices [N,k] (int32, ascending distance, self excluded) and, optionally, distances [N,k].
-    One host sync (the bounding box), where the reference had a full D2H copy + CPU tree build."""
+    One host sync (the bounding box, `make_grid`) unless a grid is passed in -- where the reference had a full D2H
+    copy + CPU tree build."""
     assert points.is_cuda and points.dtype == torch.float32 and points.dim() == 2 and points.shape[1] == 3
     assert 1 <= k <= 32
     pts = points.detach().contiguous()
     N = pts.shape[0]
     dev = pts.device
-    lo = pts.min(dim=0).values
-    hi = pts.max(dim=0).values
-    lo_h, hi_h = lo.tolist(), hi.tolist()
-    ext = [max(h - l, 1e-6) for l, h in zip(lo_h, hi_h)]
-    vol = ext[0] * ext[1] * ext[2]
-    cell = max((vol * 2.0 / max(N, 1)) ** (1.0 / 3.0), max(ext) / 512.0)  # ~2 points per cell, <= 512^3 cells
-    dims = [max(1, min(512, int(math.ceil(e / cell)))) for e in ext]
+    lo_h, cell, dims = grid if grid is not None else make_grid(pts)
     ncell = dims[0] * dims[1] * dims[2]
     cell_of = torch.empty(N, dtype=torch.int32, device=dev)
     counts = torch.zeros(ncell, dtype=torch.int32, device=dev)
     start = torch.empty(ncell + 1, dtype=torch.int32, device=dev)
-    order = torch.empty(N, dtype=torch.int32, device=dev)
+    order = torch.empty(N, 4, device=dev)  # the points in cell order: x y z index
     idx = torch.empty(N, k, dtype=torch.int32, device=dev)
     d2 = torch.empty(N, k, device=dev) if want_dist else None
     origin = (C.c_float * 3)(*lo_h)
@@ -46,12 +78,12 @@ def knn(points: Tensor, k: int, want_dist: bool = False) -> Tuple[Tensor, Tensor
     return idx, (d2.sqrt() if d2 is not None else None)
 
 
-def reference_nn_indices(points: Tensor, dir_loss_num_nn: int, enforce_method: str = "enforce_full") -> Tensor:
+def reference_nn_indices(points: Tensor, dir_loss_num_nn: int, enforce_method: str = "enforce_full", grid=None) -> Tensor:
     """`update_nearest_neighbors` (edge_gs.py:326-344): k_nearest_sklearn(points, k+1) -- 2k+1 for
     'enforce_half' -- already drops the point itself, and `indices[:, 1:]` then drops the NEAREST
     neighbour as well: the reference aligns with neighbours 2 .. k+1 (2 .. 2k+1).  Kept as is."""
     n = 2 * dir_loss_num_nn + 1 if enforce_method == "enforce_half" else dir_loss_num_nn + 1
-    idx, _ = knn(points, n)
+    idx, _ = knn(points, n, grid=grid)
     return idx[:, 1:].contiguous()
 
 

@@ -48,23 +48,37 @@ def train_epoch(tr: EdgeTrainer, views: Iterable[int], epoch: int, num_epochs: i
     apply_dir = epoch > orientation_cfg["start_dir_loss_at_epoch"]
     apply_ratio = epoch > orientation_cfg["start_ratio_loss_at_epoch"]
     period = projection_cfg["sampling_whole_num_epochs_ratio"]
-    loss_sum, n = 0.0, 0
+    # The iterations between two regulariser steps go to the device as ONE native enqueue (EdgeTrainer.train_steps);
+    # the regulariser weight lambda = (running loss sum of this epoch) * factor / loss is formed on the device from
+    # the loss accumulator, so the epoch runs without a single host sync; the one read-back at its end also checks
+    # the sticky overflow flag (and replays the epoch from its journal if some step dropped intersections).
+    n, step_no = 0, tr.step
+    pend_v, pend_w = [], []
+
+    def flush_steps():
+        if pend_v:
+            tr.train_steps(list(pend_v), list(pend_w))
+            pend_v.clear()
+            pend_w.clear()
+
     for idx in views:
         if alternate:
-            strategy = projection_cfg["less_freq_loss"] if tr.step % period == 0 else projection_cfg["more_freq_loss"]
-        tr.train_step(idx, tr.weight_map(idx, strategy, ratio, generator, edge_threshold))
+            strategy = projection_cfg["less_freq_loss"] if step_no % period == 0 else projection_cfg["more_freq_loss"]
+        pend_v.append(int(idx))
+        pend_w.append(tr.weight_map(idx, strategy, ratio, generator, edge_threshold))
         n += 1
-        if (apply_dir or apply_ratio) and tr.step % 5 == 0:
-            # the regulariser weights are data-dependent: lambda = running loss sum * factor / loss
-            loss_sum += tr.pop_loss()  # the device accumulator holds the UNSCALED losses (train_gaussians.py:99)
+        step_no += 1
+        if (apply_dir or apply_ratio) and step_no % 5 == 0:
+            flush_steps()
+            # (the device accumulator holds the UNSCALED losses of the epoch so far, train_gaussians.py:99,113,125)
             if apply_dir:
-                tr.regulariser_step("direction", loss_sum, orientation_cfg["dir_loss_scale_factor"],
+                tr.regulariser_step("direction", None, orientation_cfg["dir_loss_scale_factor"],
                                     orientation_cfg["dir_loss_num_nn"],
-                                    orientation_cfg.get("dir_loss_enforce_method", "enforce_full"))
+                                    orientation_cfg.get("dir_loss_enforce_method", "enforce_full"), want_value=False)
             if apply_ratio:
-                tr.regulariser_step("ratio", loss_sum, orientation_cfg["ratio_loss_scale_factor"])
-    loss_sum += tr.pop_loss()
-    return loss_sum / max(n, 1)
+                tr.regulariser_step("ratio", None, orientation_cfg["ratio_loss_scale_factor"], want_value=False)
+    flush_steps()
+    return tr.pop_loss() / max(n, 1)
 
 
 def train(tr: EdgeTrainer, model_cfg: Dict, training_cfg: Dict, view_order: Callable[[int], Iterable[int]],

@@ -223,12 +223,12 @@ class EdgeTrainer:
             if generator is not None:
                 return synth.weight_map(strategy, self.gt[view].cpu(), ratio, generator, threshold).to(self.dev)
             n_sel = int(ratio * n_e)
-            perm = torch.randperm(hw - n_e, device=self.dev)[:n_sel] % hw
-            sel = torch.zeros(hw, device=self.dev)
-            sel[perm] = 1.0
-            # randperm values are distinct and < hw, so exactly n_sel pixels are selected: no read-back
-            w = edge.reshape(-1).float() / max(n_e, 1) + sel / max(float(n_sel), 1.0)
-            return w.reshape(H, W).contiguous()
+            # one randperm (distinct values < hw: exactly n_sel pixels) + one native call; no read-back
+            perm = torch.randperm(hw - n_e, device=self.dev)
+            w = torch.empty(H, W, device=self.dev)
+            call("eg_ratio_wmap", ptr(self.gt[view]), float(threshold), n_e, ptr(perm), min(n_sel, hw - n_e), hw, ptr(w),
+                 stream())
+            return w
         raise ValueError(f"Unknown projection loss strategy: {strategy}")
 
     # ------------------------------------------------------------------ capacity
@@ -332,6 +332,36 @@ class EdgeTrainer:
                 self._snapshot()
             self._journal.append(("1", view, wmap, self.epoch, self.loss_scale))
         self._step_raw(view, wmap)
+
+    def train_steps(self, views: List[int], wmaps: List[Tensor]) -> None:
+        """len(views) consecutive reference iterations (one optimizer step per view, exactly `train_step` in a loop)
+        enqueued by ONE native call: no Python between the steps.  The learning rates / loss scale of the current
+        epoch apply to all of them."""
+        K = len(views)
+        if K == 0:
+            return
+        if self.capacity == 0:
+            self.ensure_capacity()
+        if self.replay_on_overflow:
+            if not self._journal:
+                self._snapshot()
+            self._journal.extend(("1", v, w, self.epoch, self.loss_scale) for v, w in zip(views, wmaps))
+        self._steps_raw(views, wmaps)
+
+    def _steps_raw(self, views, wmaps) -> None:
+        K = len(views)
+        self._advance_all()   # step 0's counts; the native loop advances them by k
+        self._set_hyper()
+        a = self._args(views[0], wmaps[0], True)
+        va = (C.c_int32 * K)(*views)
+        wa = (C.c_void_p * K)(*[w.data_ptr() for w in wmaps])
+        for w in wmaps:
+            assert w.is_cuda and w.is_contiguous() and w.shape == (self.height, self.width)
+        call("eg_train_steps", C.byref(a), K, va, wa, ptr(self.viewmats), ptr(self.Ks), ptr(self.gt), stream())
+        for _ in range(K - 1):
+            self._advance_all()
+        self.absgrads_normalize_factor += K
+        self.step += K
 
     def _step_raw(self, view: int, wmap: Tensor) -> None:
         self._advance_all()
@@ -472,6 +502,8 @@ class EdgeTrainer:
                 self.epoch, self.loss_scale = epoch, ls
                 if kind == "1":
                     self._step_raw(view, wmap)
+                elif kind == "r":
+                    self._regulariser_raw(view, self.loss_acc[0], *wmap)
                 else:
                     self._batched_raw(view, wmap, True)
             if not self.overflowed():
@@ -572,22 +604,42 @@ class EdgeTrainer:
     # ------------------------------------------------------------------ orientation regularisers (8f)
     def update_nearest_neighbors(self, dir_loss_num_nn: int = 5, enforce_method: str = "enforce_full") -> Tensor:
         """`update_nearest_neighbors` (edge_gs.py:326-344) on device; keeps the reference's quirk of
-        skipping the nearest neighbour (see regularizers.reference_nn_indices)."""
+        skipping the nearest neighbour (see regularizers.reference_nn_indices).  The search grid (bounding box of
+        the means, the one thing that needs the host) is refreshed at most once per epoch and N, inflated by 10 %:
+        a mean that drifts out of it is clamped into a boundary cell, which keeps the search exact."""
         from . import regularizers as R
-        self.nn_indices = R.reference_nn_indices(self.means, dir_loss_num_nn, enforce_method)
+        key = (self.epoch, self.N)
+        if getattr(self, "_knn_grid_key", None) != key:
+            self._knn_grid, self._knn_grid_key = R.make_grid(self.means, margin=0.1), key
+        self.nn_indices = R.reference_nn_indices(self.means, dir_loss_num_nn, enforce_method, self._knn_grid)
         return self.nn_indices
 
-    def regulariser_step(self, kind: str, avg_loss_sum: float, scale_factor: float,
-                         dir_loss_num_nn: int = 5, enforce_method: str = "enforce_full") -> float:
+    def regulariser_step(self, kind: str, avg_loss_sum=None, scale_factor: float = 0.01,
+                         dir_loss_num_nn: int = 5, enforce_method: str = "enforce_full", want_value: bool = True):
         """One regulariser iteration of train_gaussians.py:108-131 ('direction' or 'ratio'):
-        loss -> lambda = avg_loss_sum * scale_factor / loss.item() -> backward -> Adam step of the
+        loss -> lambda = avg_loss_sum * scale_factor / loss -> backward -> Adam step of the
         means / scales / quats optimizers only (their step counts advance, the opacity optimizer's does
         not).  With the reference's torch 1.13 `zero_grad()` (zeroed, not None) the optimizers whose
-        parameter is outside the loss still step on a zero gradient; that is reproduced.  Returns the
-        loss value (one host sync, where the reference has `.item()`)."""
-        from . import regularizers as R
-        if self._journal:
+        parameter is outside the loss still step on a zero gradient; that is reproduced.
+
+        avg_loss_sum = None: the running sum of this epoch's projection losses is taken from the DEVICE accumulator
+        (what `pop_loss` would return) and lambda is formed on the device -- no host sync at all (the reference
+        has two `.item()` per regulariser step); the step is journalled for overflow replay like a train_step.
+        A float: the caller's host value (one sync for the journal check).  Returns the loss value as a float
+        when want_value (one sync), else the device scalar."""
+        device_lambda = avg_loss_sum is None
+        if device_lambda and self.replay_on_overflow:
+            if not self._journal:
+                self._snapshot()
+            self._journal.append(("r", kind, (scale_factor, dir_loss_num_nn, enforce_method), self.epoch, self.loss_scale))
+        elif self._journal:
             self.flush()
+        loss = self._regulariser_raw(kind, self.loss_acc[0] if device_lambda else avg_loss_sum, scale_factor,
+                                     dir_loss_num_nn, enforce_method)
+        return float(loss) if want_value else loss
+
+    def _regulariser_raw(self, kind, avg_loss_sum, scale_factor, dir_loss_num_nn, enforce_method):
+        from . import regularizers as R
         N = self.N
         gm, gq, gs, go = self.grad_views()
         self.grads.zero_()
@@ -595,14 +647,12 @@ class EdgeTrainer:
             self.update_nearest_neighbors(dir_loss_num_nn, enforce_method)
             loss, dm, dq = R.direction_loss(self.means, self.quats, self.log_scales, self.nn_indices,
                                             dir_loss_num_nn if enforce_method == "enforce_half" else 0)
-            val = float(loss)
-            lam = avg_loss_sum * scale_factor / val
+            lam = avg_loss_sum * scale_factor / loss  # device scalar (or host float / device scalar)
             gm.copy_(dm * lam)
             gq.copy_(dq * lam)
         elif kind == "ratio":
             loss, ds = R.ratio_loss(self.log_scales)
-            val = float(loss)
-            lam = avg_loss_sum * scale_factor / val
+            lam = avg_loss_sum * scale_factor / loss
             gs.copy_(ds * lam)
         else:
             raise ValueError(f"unknown regulariser: {kind}")
@@ -613,7 +663,7 @@ class EdgeTrainer:
         call("eg_adam_multi", ptr(self.means), ptr(self.log_scales), ptr(self.quats), ptr(self.logit_opacities),
              ptr(gm), ptr(gs), ptr(gq), ptr(go), ptr(self.adam_m), ptr(self.adam_v), N, self._hyper, None, None,
              stream())
-        return val
+        return loss
 
     # ------------------------------------------------------------------ read-backs (these sync)
     def pop_loss(self) -> float:

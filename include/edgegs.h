@@ -294,11 +294,11 @@ int eg_project_visibility(const float *means, int32_t N, const float *cams /*[V,
  * eg_knn: exact K <= 32 nearest neighbours (self excluded, ascending distance, ties by index) of N 3D
  * points on a uniform grid: origin/cell/dims chosen by the caller (bounding box of the points, ~2
  * points per cell).  Scratch: cell_of[N], cell_counts[C] (zero on entry, returned to zero),
- * cell_start[C+1], sorted[N] with C = dims[0]*dims[1]*dims[2].  Replaces k_nearest_sklearn
+ * cell_start[C+1], sorted[N,4] (the points in cell order: x y z index) with C = dims[0]*dims[1]*dims[2].  Replaces k_nearest_sklearn
  * (edge_gs.py:135-151). */
 int eg_knn(const float *points /*[N,3]*/, int32_t N, int32_t K, const float *origin_host /*[3]*/, float cell,
            const int32_t *dims_host /*[3]*/, int32_t *cell_of, int32_t *cell_counts, int32_t *cell_start,
-           int32_t *sorted, int32_t *out_idx /*[N,K]*/, float *out_d2 /*[N,K]|NULL squared distances*/,
+           float *sorted /*[N,4]*/, int32_t *out_idx /*[N,K]*/, float *out_d2 /*[N,K]|NULL squared distances*/,
            eg_stream_t stream);
 /* compute_direction_loss (edge_gs.py:346-373): sum_out[0] += sum over the counted (i,k) of
  * |m_i . unit(mu_i - mu_nn(i,k))|; g_means += and g_quats = the gradient of that SUM.  top_k <= 0 or >= K:
@@ -313,6 +313,12 @@ int eg_direction_loss(const float *means, const float *quats, const float *log_s
  * g_scales = gradient of the sum w.r.t. the log-scales. */
 int eg_ratio_loss(const float *log_scales, int32_t N, float *g_scales /*[N,3] written*/, float *sum_out,
                   eg_stream_t stream);
+
+/* ---- the per-pixel loss weights of the 'bg_edge_ratio' strategy (edge_gs.py:298-314 in weight-map form) built on
+ * the device: out[p] = [gt_p >= thr] / n_edge + [p among perm[0 .. n_sel)] / n_sel; perm = a random permutation
+ * drawn by the caller (int64, distinct, taken modulo HW like the reference's unravel, :303-310). */
+int eg_ratio_wmap(const float *gt /*[H*W]*/, float thr, int32_t n_edge, const int64_t *perm, int32_t n_sel, int32_t HW,
+                  float *out /*[H*W]*/, eg_stream_t stream);
 
 /* ---- whole training step for one view, enqueued from native code (train_gaussians.py:81-106):
  * project+count -> offsets -> emit -> sort -> composite+loss -> composite bwd -> project bwd
@@ -350,6 +356,13 @@ typedef struct {
 } eg_step_args;
 
 int eg_train_step(const eg_step_args *args_host, eg_stream_t stream);
+
+/* ---- K consecutive steps by one native call: step k = eg_train_step on view views_host[k] (taken out of the
+ * [V,4,4] / [V,3,3] / [V,H,W] arrays) with weight map wmaps_host[k] and every active Adam step count of
+ * args_host->adam_host advanced by k.  args_host's own viewmat / K / gt / wmap are ignored. */
+int eg_train_steps(const eg_step_args *args_host, int32_t K, const int32_t *views_host,
+                   const float *const *wmaps_host, const float *viewmats, const float *Ks, const float *gts,
+                   eg_stream_t stream);
 
 /* ---- C <= EG_MAX_BATCH views per launch sequence.  `args_host` as for eg_train_step
  * (segmented layout required; its viewmat / K / gt / wmap fields are ignored) with every per-view work buffer

@@ -1192,6 +1192,33 @@ def test_batched_views_equal_the_sum_of_single_view_steps(env, Cn):
     assert int(tb._batches[Cn]["tile_counts"].abs().sum()) == 0 and int(tb._batches[Cn]["ticket"].abs().sum()) == 0
 
 
+def test_device_weight_maps_match_the_host_construction(env):
+    """EdgeTrainer.weight_map on the device (eg_ratio_wmap for 'bg_edge_ratio') against synth.weight_map (the host
+    construction pinned to the reference by tests/test_golden.py): same values for the deterministic strategies; for
+    the sampled one the edge part is identical and the sample is n_sel DISTINCT pixels of weight 1/n_sel."""
+    _lib, synth, O = env
+    from edgegaussians_amd import EdgeTrainer
+    sc = _scene(synth, n=500, w=200, h=136, views=2)
+    tr = EdgeTrainer(sc.means, sc.log_scales, sc.quats, sc.logit_opacities, sc.viewmats, sc.Ks, sc.gt, sc.width, sc.height)
+    for strat in ("whole", "weighted"):
+        assert_close(tr.weight_map(1, strat), synth.weight_map(strat, sc.gt[1]), rtol=1e-6, name=strat)
+    edge = sc.gt[1] >= 0.5
+    n_e, hw = int(edge.sum()), edge.numel()
+    for ratio in (1.0, 0.5, 3.0):
+        w = tr.weight_map(1, "bg_edge_ratio", ratio).cpu()
+        n_sel = int(ratio * n_e)
+        sel_part = w - edge.float() / n_e
+        picked = sel_part > 0.5 / n_sel
+        assert int(picked.sum()) == n_sel, (int(picked.sum()), n_sel)
+        assert_close(sel_part[picked], torch.full((n_sel,), 1.0 / n_sel), rtol=1e-5, name="sample weight")
+        assert float(sel_part[~picked].abs().max()) < 1e-9
+        assert abs(float(w.sum()) - 2.0) < 1e-4
+        # the reference's quirk (edge_gs.py:303-310): indices are drawn from [0, #bg) and unravelled over the whole image
+        assert int(torch.nonzero(picked.view(-1)).max()) < hw - n_e
+    a, b = tr.weight_map(1, "bg_edge_ratio", 1.0), tr.weight_map(1, "bg_edge_ratio", 1.0)
+    assert not torch.equal(a, b), "every call draws a fresh sample"
+
+
 def test_bench_line_contract(env):
     """bench.py prints ONE JSON line, last on stdout, with the fields the driver and the judge read."""
     import json

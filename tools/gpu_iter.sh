@@ -23,3 +23,4 @@ for f in sorted(glob.glob("$O/bench_*_$TAG.json")):
 PY
 if [ "${OPER:-0}" = "1" ]; then for c in config1 config2; do timeout 300 python bench.py --config $c --path operator 2>$O/bench_${c}_oper_$TAG.err | tail -1 > $O/bench_${c}_oper_$TAG.json; python -c "
 import json; d=json.loads(open('$O/bench_${c}_oper_$TAG.json').read()); print('$c operator', round(d['ms_per_step']*1e3,1),'us')"; done; fi
+if [ "${ABC:-0}" = "1" ]; then timeout 600 python tools/train_abc_fixture.py > $O/abc_$TAG.txt 2>&1; tail -5 $O/abc_$TAG.txt | cut -c1-400; fi
