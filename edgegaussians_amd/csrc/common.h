@@ -53,9 +53,22 @@ int launch_composite_fwd_segments(const float *splat, const int32_t *tile_start,
                                   const int32_t *item_first, const int32_t *item_end, const int32_t *item_tile,
                                   const int32_t *flatten_ids, int32_t width, int32_t height, float loss_scale,
                                   float *loss_out, const int32_t *total, int64_t max_items, void *workspace,
-                                  float *gtstop, int32_t rewalk_hint, const Batch &bt, int C, hipStream_t st);
+                                  float *gtstop, int32_t rewalk_hint, const Batch &bt, int C, hipStream_t st,
+                                  int32_t max_tile_hint);
+int composite_fwd_segments_hinted(const float *splat, const int32_t *tile_start, const int32_t *tile_end,
+                                  const int32_t *item_first, const int32_t *item_end, const int32_t *item_tile,
+                                  const int32_t *flatten_ids, int32_t width, int32_t height, float *render, float *alphas,
+                                  int32_t *last_ids, const float *gt, const float *wmap, float loss_scale, float *vpix,
+                                  float *loss_out, const int32_t *total, int64_t max_items, void *workspace,
+                                  float *gtstop, int32_t rewalk_hint, int32_t max_tile_hint, hipStream_t st);
 int launch_footprint_bwd(const float *splat, int32_t N, int32_t width, int32_t height, const float *gtstop, float *g2d,
                          const Batch &bt, int C, hipStream_t st);
+int launch_project_bwd_emit(float *means, float *quats, float *scales, float *opacities, const float *viewmat,
+                            const float *K, const float *next_viewmat, const float *next_K, int32_t N, int32_t width,
+                            int32_t height, float eps2d, uint32_t flags, float *splat, const float *g2d, float *absgrads,
+                            float *m, float *v, const eg_adam_hyper &hyper, int32_t *tile_cursor, int32_t seg_cap,
+                            uint64_t *keys, int32_t *item_first, int32_t max_items, int32_t *total, int32_t *ticket,
+                            hipStream_t st);
 int launch_project_bwd_batched(float *means, float *quats, float *scales, float *opacities, int32_t N, int32_t width,
                                int32_t height, float eps2d, uint32_t flags, const float *splat, const float *g2d,
                                float *v_means, float *v_quats, float *v_scales, float *v_opacities, float *absgrads,

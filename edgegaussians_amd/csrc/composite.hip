@@ -475,6 +475,62 @@ __device__ __forceinline__ SliceWs view_of(SliceWs ws, const Batch &bt, int v) {
   return ws;
 }
 
+// Phase B for one tile (256 threads = its 256 pixels): T = product of the slice products in depth order, the
+// hand-over of stopping pixels to the re-walk list, the per-pixel epilogue.  `T`, `last`, `stop_slice` come in
+// holding the result of a single-slice tile; with ns > 1 the slices' records are read back -- at DEVICE scope when
+// they were published inside the same launch (another XCD's L2 may hold the line), plainly after a kernel boundary.
+template <int CH, bool DEVICE_SCOPE>
+__device__ __forceinline__ void combine_tail(int tile, int tid, int i0, int ns, bool inside, int p, float T, int last,
+                                             int stop_slice, const SliceWs &ws, const int *__restrict__ flat,
+                                             float *__restrict__ render, float *__restrict__ alphas,
+                                             int *__restrict__ last_ids, bool has_loss, float gt_p, float w_p,
+                                             float loss_scale, float *__restrict__ vpix, float *__restrict__ loss_out,
+                                             StopRec *__restrict__ gtstop, float *sRed) {
+  if (ns > 1) {
+    for (int s8 = 0; s8 < ns && stop_slice < 0; s8 += 8) {
+      // eight slices' records in flight per wait (the walk over a tile's slices is a chain of round trips)
+      float Ps[8];
+      int Ls[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const bool ok = s8 + u < ns;
+        const size_t o = (size_t)(i0 + (ok ? s8 + u : 0)) * kTilePix + tid;
+        if (DEVICE_SCOPE) {
+          Ps[u] = __hip_atomic_load(&ws.sliceP[o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          Ls[u] = __hip_atomic_load(&ws.sliceL[o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+          Ps[u] = ws.sliceP[o];
+          Ls[u] = ws.sliceL[o];
+        }
+        if (!ok) { Ps[u] = 1.f; Ls[u] = -1; }
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (Ls[u] < 0 || stop_slice >= 0) continue;
+        const float nT = T * Ps[u];
+        if (nT <= kTStop) { stop_slice = s8 + u; continue; }
+        T = nT;
+        last = Ls[u];
+      }
+    }
+  }
+  StopInfo si;
+  si.slice = inside ? stop_slice : -1;
+  si.T = T;
+  si.last = last;
+  if (__syncthreads_or(si.slice >= 0)) {  // only tiles that hand pixels over need the per-pixel records
+    ws.stopinfo[(size_t)tile * kTilePix + tid] = si;
+    // first pixel to flag a slice puts it on the list (the re-walk kernel returns the flag to zero)
+    if (si.slice >= 0 && atomicExch(&ws.item_flags[i0 + si.slice], 1) == 0)
+      ws.rewalk[atomicAdd(&ws.ctl[0], 1)] = make_int2(i0 + si.slice, tile);
+  }
+  float l = 0.f;
+  if (inside && stop_slice < 0)
+    l = finalize_pixel<CH>(p, T, last, false, flat, render, alphas, last_ids, has_loss, gt_p, w_p, loss_scale, vpix,
+                           gtstop, nullptr);  // pixels finalised here did not stop
+  if (has_loss && loss_out) block_loss_add(l, sRed, loss_out);
+}
+
 // forward phase A: per (tile, slice) transmittance products -- and, in the tile's last workgroup, phase B.
 // Staging: thread t fetches Gaussian t of the slice, computes its conservative alpha >= 1/255 extent
 // (ex, ey) and appends the packed record to the list of every quadrant it can touch (ballot +
@@ -484,7 +540,11 @@ __device__ __forceinline__ SliceWs view_of(SliceWs ws, const Batch &bt, int v) {
 // of them back (device-scope loads: another XCD's L2 may hold the line) and finalises the pixels.  A pixel
 // whose running T * P_s drops to <= 1e-4 has its transmittance stop INSIDE slice s: the item goes on the
 // re-walk list with the pixel's state before it.
-template <int CH>
+// FUSED = false (many items: several rounds of workgroups per CU): a workgroup of a multi-slice tile stores its
+// record plainly and leaves at once -- draining device-scope stores and a returning ticket atomic cost every
+// workgroup ~4 us of residency, which multiplies by the number of rounds -- and composite_combine_fwd_kernel
+// does phase B after the kernel boundary.  Single-slice tiles are finalised here in both modes.
+template <int CH, bool FUSED>
 __global__ void __launch_bounds__(256)
 composite_slice_fwd_kernel(const float4 *__restrict__ splat, const TileTable tt_, const int *__restrict__ total,
                            const int *__restrict__ flat, int width, int height, int tw, int th, const SliceWs ws_,
@@ -590,6 +650,10 @@ composite_slice_fwd_kernel(const float4 *__restrict__ splat, const TileTable tt_
     if (L >= 0) {
       if (P <= kTStop) stop_slice = 0; else { T = P; last = L; }
     }
+  } else if (!FUSED) {
+    ws.sliceP[(size_t)b * kTilePix + tid] = P;
+    ws.sliceL[(size_t)b * kTilePix + tid] = L;
+    return;
   } else {
     // publish at device scope (the other slices of this tile may run on other XCDs, whose L2s do not snoop
     // this one), drain, take the tile's ticket
@@ -604,43 +668,43 @@ composite_slice_fwd_kernel(const float4 *__restrict__ splat, const TileTable tt_
     }
     __syncthreads();
     if (!s_last) return;  // (whole workgroup)
-    for (int s4 = 0; s4 < ns && stop_slice < 0; s4 += 4) {
-      // four slices' records in flight per wait (the walk over a tile's slices is latency-bound)
-      float Ps[4];
-      int Ls[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const bool ok = s4 + u < ns;
-        const size_t o = (size_t)(i0 + (ok ? s4 + u : 0)) * kTilePix + tid;
-        Ps[u] = __hip_atomic_load(&ws.sliceP[o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        Ls[u] = __hip_atomic_load(&ws.sliceL[o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (!ok) { Ps[u] = 1.f; Ls[u] = -1; }
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        if (Ls[u] < 0 || stop_slice >= 0) continue;
-        const float nT = T * Ps[u];
-        if (nT <= kTStop) { stop_slice = s4 + u; continue; }
-        T = nT;
-        last = Ls[u];
-      }
-    }
   }
-  StopInfo si;
-  si.slice = inside ? stop_slice : -1;
-  si.T = T;
-  si.last = last;
-  if (__syncthreads_or(si.slice >= 0)) {  // only tiles that hand pixels over need the per-pixel records
-    ws.stopinfo[(size_t)tile * kTilePix + tid] = si;
-    // first pixel to flag a slice puts it on the list (the re-walk kernel returns the flag to zero)
-    if (si.slice >= 0 && atomicExch(&ws.item_flags[i0 + si.slice], 1) == 0)
-      ws.rewalk[atomicAdd(&ws.ctl[0], 1)] = make_int2(i0 + si.slice, tile);
-  }
-  float l = 0.f;
-  if (inside && stop_slice < 0)
-    l = finalize_pixel<CH>(i * width + j, T, last, false, flat, render, alphas, last_ids, has_loss, gt_p, w_p,
-                           loss_scale, vpix, gtstop, nullptr);  // pixels finalised here did not stop
-  if (wmap && loss_out) block_loss_add(l, sRed, loss_out);
+  combine_tail<CH, true>(tile, tid, i0, ns, inside, i * width + j, T, last, stop_slice, ws, flat, render, alphas,
+                         last_ids, has_loss, gt_p, w_p, loss_scale, vpix, loss_out, gtstop, sRed);
+}
+
+// phase B as its own launch (FUSED = false): one workgroup per tile with more than one slice
+template <int CH>
+__global__ void __launch_bounds__(256)
+composite_combine_fwd_kernel(const TileTable tt_, const int *__restrict__ flat, int width, int height, int tw,
+                             const SliceWs ws_, float *__restrict__ render, float *__restrict__ alphas,
+                             int *__restrict__ last_ids, const float *__restrict__ gt, const float *__restrict__ wmap,
+                             float loss_scale, float *__restrict__ vpix, float *__restrict__ loss_out,
+                             StopRec *__restrict__ gtstop, const Batch bt) {
+  __shared__ float sRed[4];
+  const int bv = blockIdx.y;  // view of a batched step
+  const TileTable tt = view_of(tt_, bt, bv);
+  const SliceWs ws = view_of(ws_, bt, bv);
+  flat += bv * bt.keys;
+  if (render) render += bv * bt.pixels * CH;
+  if (alphas) alphas += bv * bt.pixels;
+  if (last_ids) last_ids += bv * bt.pixels;
+  if (vpix) vpix += bv * bt.pixels;
+  if (gtstop) gtstop += bv * bt.pixels;
+  if (bt.gt[0]) { gt = bt.gt[bv]; wmap = bt.wmap[bv]; }
+  const int tile = blockIdx.x, tid = threadIdx.x;
+  const int i0 = tt.item_first[tile], ns = tt.item_end[tile] - i0;
+  if (ns <= 1) return;  // finalised by its slice workgroup
+  const int ty = tile / tw, tx = tile - ty * tw;
+  int di, dj;
+  quad_pixel(tid, di, dj);  // same thread -> pixel map as the slice kernel
+  const int i = ty * kTile + di, j = tx * kTile + dj;
+  const bool inside = (i < height) && (j < width);
+  const bool has_loss = wmap != nullptr;
+  const float w_p = (has_loss && inside) ? wmap[i * width + j] : 0.f;
+  const float gt_p = (has_loss && inside) ? gt[i * width + j] : 0.f;
+  combine_tail<CH, false>(tile, tid, i0, ns, inside, i * width + j, 1.f, 0, -1, ws, flat, render, alphas, last_ids,
+                          has_loss, gt_p, w_p, loss_scale, vpix, loss_out, gtstop, sRed);
 }
 
 // forward phase C: exact transmittance stop.  A small grid strides over the compact list of flagged
@@ -1252,7 +1316,12 @@ static int launch_sliced_fwd(const float4 *splat, const TileTable tt, int channe
                              int width, int height, float *render, float *alphas, int32_t *last_ids, const float *gt,
                              const float *wmap, float loss_scale, float *vpix, float *loss_out, const int32_t *total,
                              int64_t max_items, void *workspace, float *gtstop, int rewalk_hint, hipStream_t s,
-                             const Batch &bt = Batch{}, int C = 1) {
+                             const Batch &bt = Batch{}, int C = 1, int max_tile_hint = 0) {
+  // fused phase B saves a launch and the idle tail of a kernel (~7 us at the reference's sizes, 14 us at 1600x1200)
+  // but the last workgroup of a tile reads its slices back at device scope, one round trip per 8 slices, at the very
+  // end of the tile's critical path: with a 35-slice tile (500 k Gaussians @1200x680) it cost 120 us.  Decided from
+  // the largest tile population the caller has seen; without that knowledge, from the size of the launch.
+  const bool fused = max_tile_hint > 0 ? max_tile_hint <= 24 * kSlice : (int64_t)max_items * C <= 3 * 2048;
   const int tw = cdiv(width, kTile), th = cdiv(height, kTile);
   const SliceWs ws = carve_workspace(workspace, max_items, tw * th);
   // the re-walk grid strides over the compact list: sized from the caller's hint (launching 1024 workgroups that
@@ -1262,9 +1331,19 @@ static int launch_sliced_fwd(const float4 *splat, const TileTable tt, int channe
   const unsigned rewalk_grid = (unsigned)(max_items < want ? max_items : want);
 #define EG_LAUNCH_CB(CH)                                                                                          \
   do {                                                                                                            \
-    composite_slice_fwd_kernel<CH><<<dim3((unsigned)max_items, C), 256, 0, s>>>(                                  \
-        splat, tt, total, flatten_ids, width, height, tw, th, ws, render, alphas, last_ids, gt, wmap, loss_scale, \
-        vpix, loss_out, (StopRec *)gtstop, bt);                                                                   \
+    if (fused)                                                                                                    \
+      composite_slice_fwd_kernel<CH, true><<<dim3((unsigned)max_items, C), 256, 0, s>>>(                          \
+          splat, tt, total, flatten_ids, width, height, tw, th, ws, render, alphas, last_ids, gt, wmap,           \
+          loss_scale, vpix, loss_out, (StopRec *)gtstop, bt);                                                     \
+    else {                                                                                                        \
+      composite_slice_fwd_kernel<CH, false><<<dim3((unsigned)max_items, C), 256, 0, s>>>(                         \
+          splat, tt, total, flatten_ids, width, height, tw, th, ws, render, alphas, last_ids, gt, wmap,           \
+          loss_scale, vpix, loss_out, (StopRec *)gtstop, bt);                                                     \
+      composite_combine_fwd_kernel<CH><<<dim3(tw * th, C), 256, 0, s>>>(tt, flatten_ids, width, height, tw, ws,   \
+                                                                        render, alphas, last_ids, gt, wmap,       \
+                                                                        loss_scale, vpix, loss_out,               \
+                                                                        (StopRec *)gtstop, bt);                   \
+    }                                                                                                             \
     timing_mark(kMarkSlice, s);                                                                                   \
     composite_rewalk_fwd_kernel<CH><<<dim3(rewalk_grid, C), 256, 0, s>>>(                                         \
         splat, tt, flatten_ids, width, height, tw, th, ws, render, alphas, last_ids, gt, wmap, loss_scale, vpix,  \
@@ -1305,6 +1384,20 @@ extern "C" int eg_composite_fwd(const float *splat, const float *colors, int32_t
 #undef EG_LAUNCH_FWD
   return check_launch("composite_fwd");
 }
+
+namespace eg {
+int composite_fwd_segments_hinted(const float *splat, const int32_t *tile_start, const int32_t *tile_end,
+                                  const int32_t *item_first, const int32_t *item_end, const int32_t *item_tile,
+                                  const int32_t *flatten_ids, int32_t width, int32_t height, float *render, float *alphas,
+                                  int32_t *last_ids, const float *gt, const float *wmap, float loss_scale, float *vpix,
+                                  float *loss_out, const int32_t *total, int64_t max_items, void *workspace,
+                                  float *gtstop, int32_t rewalk_hint, int32_t max_tile_hint, hipStream_t st) {
+  const TileTable tt = {tile_start, tile_end, item_first, item_end, item_tile};
+  return launch_sliced_fwd((const float4 *)splat, tt, 1, flatten_ids, width, height, render, alphas, last_ids, gt, wmap,
+                           loss_scale, vpix, loss_out, total, max_items, workspace, gtstop, rewalk_hint, st, Batch{}, 1,
+                           max_tile_hint);
+}
+}  // namespace eg
 
 extern "C" int eg_composite_fwd_segments(const float *splat, const int32_t *tile_start, const int32_t *tile_end,
                                          const int32_t *item_first, const int32_t *item_end,
@@ -1362,11 +1455,12 @@ int launch_composite_fwd_segments(const float *splat, const int32_t *tile_start,
                                   const int32_t *item_first, const int32_t *item_end, const int32_t *item_tile,
                                   const int32_t *flatten_ids, int32_t width, int32_t height, float loss_scale,
                                   float *loss_out, const int32_t *total, int64_t max_items, void *workspace,
-                                  float *gtstop, int32_t rewalk_hint, const Batch &bt, int C, hipStream_t st) {
+                                  float *gtstop, int32_t rewalk_hint, const Batch &bt, int C, hipStream_t st,
+                                  int32_t max_tile_hint) {
   const TileTable tt = {tile_start, tile_end, item_first, item_end, item_tile};
   return launch_sliced_fwd((const float4 *)splat, tt, 1, flatten_ids, width, height, nullptr, nullptr, nullptr,
                            bt.gt[0], bt.wmap[0], loss_scale, nullptr, loss_out, total, max_items, workspace, gtstop,
-                           rewalk_hint, st, bt, C);
+                           rewalk_hint, st, bt, C, max_tile_hint);
 }
 int launch_footprint_bwd(const float *splat, int32_t N, int32_t width, int32_t height, const float *gtstop, float *g2d,
                          const Batch &bt, int C, hipStream_t st) {

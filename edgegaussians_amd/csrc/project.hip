@@ -46,18 +46,31 @@ struct Fwd {
   float u, v;               // mean2d
 };
 
-__device__ __forceinline__ bool forward_geom(const Cam &cam, const float *__restrict__ means,
-                                             const float *__restrict__ quats, const float *__restrict__ scales,
-                                             const float *__restrict__ opacities, int g, int width, int height,
+// the raw parameters of one Gaussian (as stored: log-scales / logit-opacity when the flags say so)
+struct Raw {
+  float m[3], q[4], s[3], o;
+};
+__device__ __forceinline__ Raw load_raw(const float *__restrict__ means, const float *__restrict__ quats,
+                                        const float *__restrict__ scales, const float *__restrict__ opacities, int g) {
+  Raw r;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { r.m[k] = means[3 * g + k]; r.s[k] = scales[3 * g + k]; }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) r.q[k] = quats[4 * g + k];
+  r.o = opacities[g];
+  return r;
+}
+
+__device__ __forceinline__ bool forward_geom(const Cam &cam, const Raw &raw, int width, int height,
                                              float near_plane, float far_plane, float eps2d, uint32_t flags,
                                              Fwd &f) {
-  const float mx = means[3 * g], my = means[3 * g + 1], mz = means[3 * g + 2];
+  const float mx = raw.m[0], my = raw.m[1], mz = raw.m[2];
   f.x = cam.R[0] * mx + cam.R[1] * my + cam.R[2] * mz + cam.t[0];
   f.y = cam.R[3] * mx + cam.R[4] * my + cam.R[5] * mz + cam.t[1];
   f.z = cam.R[6] * mx + cam.R[7] * my + cam.R[8] * mz + cam.t[2];
   if (f.z < near_plane || f.z > far_plane) return false;
 
-  float w = quats[4 * g], x = quats[4 * g + 1], y = quats[4 * g + 2], z = quats[4 * g + 3];
+  float w = raw.q[0], x = raw.q[1], y = raw.q[2], z = raw.q[3];
   f.qinv = rsqrtf(w * w + x * x + y * y + z * z);
   w *= f.qinv; x *= f.qinv; y *= f.qinv; z *= f.qinv;
   f.qw = w; f.qx = x; f.qy = y; f.qz = z;
@@ -69,10 +82,10 @@ __device__ __forceinline__ bool forward_geom(const Cam &cam, const float *__rest
 
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
-    const float sv = scales[3 * g + k];
+    const float sv = raw.s[k];
     f.s[k] = (flags & EG_FLAG_LOG_SCALES) ? expf(sv) : sv;
   }
-  const float ov = opacities[g];
+  const float ov = raw.o;
   f.o = (flags & EG_FLAG_LOGIT_OPACITIES) ? 1.f / (1.f + expf(-ov)) : ov;
 
   // W = Rv * (Rq * diag(s))
@@ -118,6 +131,15 @@ __device__ __forceinline__ bool forward_geom(const Cam &cam, const float *__rest
   f.b = -f.c01 * inv;
   f.c = f.b00 * inv;
   return true;
+}
+
+__device__ __forceinline__ bool forward_geom(const Cam &cam, const float *__restrict__ means,
+                                             const float *__restrict__ quats, const float *__restrict__ scales,
+                                             const float *__restrict__ opacities, int g, int width, int height,
+                                             float near_plane, float far_plane, float eps2d, uint32_t flags,
+                                             Fwd &f) {
+  return forward_geom(cam, load_raw(means, quats, scales, opacities, g), width, height, near_plane, far_plane, eps2d,
+                      flags, f);
 }
 
 __device__ __forceinline__ int radius_of(const Fwd &f, int width, int height, float radius_clip) {
@@ -600,32 +622,25 @@ struct SegOut {
 };
 
 constexpr int kPE = 512;  // threads per workgroup: 512 halves the per-workgroup histogram sweeps and cursor atomics of 256 (config2 16.6 -> 14.6 us, config3 48 -> 33); 1024 loses that again to the longer barriers
+
+// Projection of Gaussian g (raw parameters in registers) for camera `cam`, packed record, exact tile hits, key
+// emission into the fixed per-tile segments, and -- in the last workgroup of the view -- the scan over the tiles.
+// Shared by project_emit_kernel and by the tail of project_bwd_emit_kernel (which projects the NEXT view with
+// the parameters Adam has just updated).  s_mem: 2 T ints of LDS when LDS_HIST.
 template <bool LDS_HIST>
-__global__ void __launch_bounds__(kPE)
-project_emit_kernel(const float *__restrict__ means, const float *__restrict__ quats,
-                    const float *__restrict__ scales, const float *__restrict__ opacities,
-                    const float *__restrict__ viewmat, const float *__restrict__ K, int N, int width, int height,
-                    uint32_t flags, float4 *__restrict__ splat, int *__restrict__ cursor, int seg_cap,
-                    unsigned long long *__restrict__ keys, const SegOut out_, const Batch bt) {
-  extern __shared__ __attribute__((aligned(16))) int s_mem[];
+__device__ __forceinline__ void emit_body(const Raw &raw, bool live, int g, const Cam &cam, int width, int height,
+                                          uint32_t flags, float4 *__restrict__ splat, int *__restrict__ cursor,
+                                          int seg_cap, unsigned long long *__restrict__ keys, const SegOut &out,
+                                          int *s_mem) {
   const int tw = (width + kTile - 1) / kTile, th = (height + kTile - 1) / kTile, T = tw * th;
-  // view of this workgroup (a batched step runs its C views as blockIdx.y over [C, ...] work buffers)
-  const int bv = blockIdx.y;
-  SegOut out = out_;
-  splat += bv * bt.splat4; cursor += bv * bt.tiles; keys += bv * bt.keys;
-  out.item_first += bv * bt.tiles; out.total += 4 * bv; out.ticket += bv;
-  if (bt.viewmat[0]) { viewmat = bt.viewmat[bv]; K = bt.K[bv]; }
   int *s_hist = s_mem, *s_base = s_mem + T;
   if (LDS_HIST) {
     for (int t = threadIdx.x; t < T; t += kPE) s_hist[t] = 0;
     __syncthreads();
   }
-  const int g = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool live = g < N;
-  const Cam cam = load_cam(viewmat, K);
   Fwd f;
   int radius = 0;
-  if (live && forward_geom(cam, means, quats, scales, opacities, g, width, height, 0.01f, 1e10f, 0.3f, flags, f))
+  if (live && forward_geom(cam, raw, width, height, 0.01f, 1e10f, 0.3f, flags, f))
     radius = radius_of(f, width, height, 0.f);
   const bool aa = flags & EG_FLAG_ANTIALIASED;
   float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
@@ -734,6 +749,91 @@ project_emit_kernel(const float *__restrict__ means, const float *__restrict__ q
     out.total[3] = m;
     *out.ticket = 0;  // ready for the next launch
   }
+}
+
+template <bool LDS_HIST>
+__global__ void __launch_bounds__(kPE)
+project_emit_kernel(const float *__restrict__ means, const float *__restrict__ quats,
+                    const float *__restrict__ scales, const float *__restrict__ opacities,
+                    const float *__restrict__ viewmat, const float *__restrict__ K, int N, int width, int height,
+                    uint32_t flags, float4 *__restrict__ splat, int *__restrict__ cursor, int seg_cap,
+                    unsigned long long *__restrict__ keys, const SegOut out_, const Batch bt) {
+  extern __shared__ __attribute__((aligned(16))) int s_mem[];
+  // view of this workgroup (a batched step runs its C views as blockIdx.y over [C, ...] work buffers)
+  const int bv = blockIdx.y;
+  SegOut out = out_;
+  splat += bv * bt.splat4; cursor += bv * bt.tiles; keys += bv * bt.keys;
+  out.item_first += bv * bt.tiles; out.total += 4 * bv; out.ticket += bv;
+  if (bt.viewmat[0]) { viewmat = bt.viewmat[bv]; K = bt.K[bv]; }
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = g < N;
+  Raw raw = {};
+  if (live) raw = load_raw(means, quats, scales, opacities, g);
+  emit_body<LDS_HIST>(raw, live, g, load_cam(viewmat, K), width, height, flags, splat, cursor, seg_cap, keys, out, s_mem);
+}
+
+// Tail fusion across the step boundary (single-view training, consecutive steps enqueued natively): the
+// projection backward + absgrad + Adam of view k and -- with the parameters still in registers -- the projection,
+// binning and tile scan of view k + 1.  One launch and one read of the parameters instead of two.
+template <bool LDS_HIST>
+__global__ void __launch_bounds__(kPE)
+project_bwd_emit_kernel(float *__restrict__ means, float *__restrict__ quats, float *__restrict__ scales,
+                        float *__restrict__ opacities, const float *__restrict__ viewmat, const float *__restrict__ K,
+                        const float *__restrict__ next_viewmat, const float *__restrict__ next_K, int N, int width,
+                        int height, float eps2d, uint32_t flags, float4 *__restrict__ splat,
+                        const float4 *__restrict__ g2d, float *__restrict__ absgrads, float *__restrict__ am,
+                        float *__restrict__ av, AdamK hyper, int *__restrict__ cursor, int seg_cap,
+                        unsigned long long *__restrict__ keys, const SegOut out) {
+  extern __shared__ __attribute__((aligned(16))) int s_mem[];
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = g < N;
+  Raw raw = {};
+  if (live) {
+    raw = load_raw(means, quats, scales, opacities, g);
+    const Cam cam = load_cam(viewmat, K);
+    Grads gr;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) gr.mean[k] = gr.scale[k] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) gr.quat[k] = 0.f;
+    gr.opac = 0.f;
+    const int radius = __float_as_int(splat[2 * g + 1].w);
+    if (radius > 0) {
+      const float4 ga = g2d[2 * g], gb = g2d[2 * g + 1];
+      Fwd f;
+      forward_geom(cam, raw, width, height, -3.0e38f, 3.0e38f, eps2d, flags, f);
+      backward_geom(cam, f, eps2d, flags, ga, gb, false, 0.f, 0.f, gr);
+      if (absgrads) absgrads[g] += sqrtf(ga.z * ga.z + ga.w * ga.w);
+    }
+    // moment layout: [means 3N | scales 3N | quats 4N | opacities N]
+    const size_t oM = 0, oS = 3 * (size_t)N, oQ = 6 * (size_t)N, oO = 10 * (size_t)N;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      float m = am[oM + 3 * g + k], v = av[oM + 3 * g + k];
+      adam1(raw.m[k], gr.mean[k], m, v, 0, hyper);
+      means[3 * g + k] = raw.m[k]; am[oM + 3 * g + k] = m; av[oM + 3 * g + k] = v;
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      float m = am[oS + 3 * g + k], v = av[oS + 3 * g + k];
+      adam1(raw.s[k], gr.scale[k], m, v, 1, hyper);
+      scales[3 * g + k] = raw.s[k]; am[oS + 3 * g + k] = m; av[oS + 3 * g + k] = v;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float m = am[oQ + 4 * g + k], v = av[oQ + 4 * g + k];
+      adam1(raw.q[k], gr.quat[k], m, v, 2, hyper);
+      quats[4 * g + k] = raw.q[k]; am[oQ + 4 * g + k] = m; av[oQ + 4 * g + k] = v;
+    }
+    {
+      float m = am[oO + g], v = av[oO + g];
+      adam1(raw.o, gr.opac, m, v, 3, hyper);
+      opacities[g] = raw.o; am[oO + g] = m; av[oO + g] = v;
+    }
+  }
+  // the next view, with the updated parameters still in registers (this thread's splat row of view k is dead now)
+  emit_body<LDS_HIST>(raw, live, g, load_cam(next_viewmat, next_K), width, height, flags, splat, cursor, seg_cap, keys,
+                      out, s_mem);
 }
 
 static int launch_project_fwd(const float *means, const float *quats, const float *scales, const float *opacities,
@@ -855,6 +955,31 @@ extern "C" int eg_project_bwd_adam(float *means, float *quats, float *scales, fl
       make_adamk(hyper));
   return check_launch("project_bwd_adam");
 }
+
+namespace eg {
+int launch_project_bwd_emit(float *means, float *quats, float *scales, float *opacities, const float *viewmat,
+                            const float *K, const float *next_viewmat, const float *next_K, int32_t N, int32_t width,
+                            int32_t height, float eps2d, uint32_t flags, float *splat, const float *g2d, float *absgrads,
+                            float *m, float *v, const eg_adam_hyper &hyper, int32_t *tile_cursor, int32_t seg_cap,
+                            uint64_t *keys, int32_t *item_first, int32_t max_items, int32_t *total, int32_t *ticket,
+                            hipStream_t st) {
+  const int T = cdiv(width, kTile) * cdiv(height, kTile);
+  SegOut out;
+  out.item_first = item_first; out.max_items = max_items;
+  out.total = total; out.ticket = ticket;
+  if (2 * T <= 16384)
+    project_bwd_emit_kernel<true><<<cdiv(N, kPE), kPE, sizeof(int) * 2 * T, st>>>(
+        means, quats, scales, opacities, viewmat, K, next_viewmat, next_K, N, width, height, eps2d, flags,
+        (float4 *)splat, (const float4 *)g2d, absgrads, m, v, make_adamk(hyper), tile_cursor, seg_cap,
+        (unsigned long long *)keys, out);
+  else
+    project_bwd_emit_kernel<false><<<cdiv(N, kPE), kPE, 0, st>>>(
+        means, quats, scales, opacities, viewmat, K, next_viewmat, next_K, N, width, height, eps2d, flags,
+        (float4 *)splat, (const float4 *)g2d, absgrads, m, v, make_adamk(hyper), tile_cursor, seg_cap,
+        (unsigned long long *)keys, out);
+  return check_launch("project_bwd_emit");
+}
+}  // namespace eg
 
 extern "C" int eg_backward_fused(float *means, float *quats, float *scales, float *opacities,
                                  const float *viewmat, const float *K, int32_t N, int32_t width, int32_t height,

@@ -128,9 +128,11 @@ extern "C" int eg_train_step(const eg_step_args *a, eg_stream_t stream) {
   if (a->seg_cap > 0) {
     // segmented binning: projection + binning (+ the item scan by its last workgroup) in one pass, then the
     // per-tile sort, which also writes the tile / item tables; there is no emit kernel, its stage stays empty
-    rc = eg_project_emit(a->means, a->quats, a->log_scales, a->logit_opacities, a->viewmat, a->K, a->N, a->width,
-                         a->height, flags, a->splat, a->tile_counts, a->seg_cap, a->keys, a->item_offsets,
-                         (int32_t)a->max_items, a->total, a->ticket, stream);
+    // (the previous step's last kernel may already have projected + binned this view: have_projection)
+    rc = a->have_projection ? EG_OK
+                            : eg_project_emit(a->means, a->quats, a->log_scales, a->logit_opacities, a->viewmat, a->K,
+                                              a->N, a->width, a->height, flags, a->splat, a->tile_counts, a->seg_cap,
+                                              a->keys, a->item_offsets, (int32_t)a->max_items, a->total, a->ticket, stream);
     if (rc) return rc;
     EG_MARK(kMarkProjectBin);
     EG_MARK(kMarkEmit);
@@ -139,10 +141,13 @@ extern "C" int eg_train_step(const eg_step_args *a, eg_stream_t stream) {
                           stream);
     if (rc) return rc;
     EG_MARK(kMarkSort);
-    rc = eg_composite_fwd_segments(a->splat, a->offsets, a->tile_end, a->item_offsets, a->item_end, a->item_tile,
-                                   a->flatten_ids, a->width, a->height, a->render, a->alphas, a->last_ids, a->gt,
-                                   a->wmap, a->loss_scale, a->vpix, a->loss, a->total, a->max_items, a->workspace,
-                                   a->gtstop, a->rewalk_hint, stream);
+    EG_REQUIRE(a->splat && a->offsets && a->flatten_ids && a->total && a->workspace && a->max_items > 0 &&
+                   (a->gtstop ? a->wmap != nullptr : (a->render && a->alphas && a->last_ids)) && (!a->wmap || a->gt),
+               "bad compositing arguments");
+    rc = composite_fwd_segments_hinted(a->splat, a->offsets, a->tile_end, a->item_offsets, a->item_end, a->item_tile,
+                                       a->flatten_ids, a->width, a->height, a->render, a->alphas, a->last_ids, a->gt,
+                                       a->wmap, a->loss_scale, a->vpix, a->loss, a->total, a->max_items, a->workspace,
+                                       a->gtstop, a->rewalk_hint, a->max_tile_hint, st);
     if (rc) return rc;
   } else {
   // tile_counts is zero on entry (caller zero-initialises it once): the projection counts it up and its
@@ -169,7 +174,13 @@ extern "C" int eg_train_step(const eg_step_args *a, eg_stream_t stream) {
   rc = eg_composite_bwd_footprint(a->splat, a->N, a->width, a->height, a->gtstop, a->g2d, stream);
   if (rc) return rc;
   // (the footprint mark is recorded inside eg_composite_bwd_footprint)
-  if (a->adam_host)
+  if (a->adam_host && a->next_viewmat && a->next_K && a->seg_cap > 0)
+    // projection backward + absgrad + Adam of this view, projection + binning + tile scan of the next one
+    rc = launch_project_bwd_emit(a->means, a->quats, a->log_scales, a->logit_opacities, a->viewmat, a->K,
+                                 a->next_viewmat, a->next_K, a->N, a->width, a->height, 0.3f, flags, a->splat, a->g2d,
+                                 a->absgrads, a->adam_m, a->adam_v, *a->adam_host, a->tile_counts, a->seg_cap, a->keys,
+                                 a->item_offsets, (int32_t)a->max_items, a->total, a->ticket, st);
+  else if (a->adam_host)
     rc = eg_project_bwd_adam(a->means, a->quats, a->log_scales, a->logit_opacities, a->viewmat, a->K, a->N,
                              a->width, a->height, 0.3f, flags, a->splat, a->g2d, a->adam_m, a->adam_v, a->absgrads,
                              *a->adam_host, stream);
@@ -227,7 +238,8 @@ extern "C" int eg_train_step_batched(const eg_step_args *a, int32_t C, const flo
   if (rc) return rc;
   rc = launch_composite_fwd_segments(a->splat, a->offsets, a->tile_end, a->item_offsets, a->item_end, a->item_tile,
                                      a->flatten_ids, a->width, a->height, a->loss_scale, a->loss, a->total,
-                                     a->max_items, a->workspace, a->gtstop, a->rewalk_hint, bt, C, st);
+                                     a->max_items, a->workspace, a->gtstop, a->rewalk_hint, bt, C, st,
+                                     a->max_tile_hint);
   if (rc) return rc;
   rc = launch_footprint_bwd(a->splat, a->N, a->width, a->height, a->gtstop, a->g2d, bt, C, st);
   if (rc) return rc;
@@ -256,6 +268,13 @@ extern "C" int eg_train_steps(const eg_step_args *a, int32_t K, const int32_t *v
     s.K = Ks + 9 * (size_t)views_host[k];
     s.gt = gts + hw * (size_t)views_host[k];
     s.wmap = wmaps_host[k];
+    // inside the run the parameters change only through these steps: step k's last kernel projects view k + 1
+    s.have_projection = (k > 0 && a->adam_host && a->seg_cap > 0) ? 1 : a->have_projection;
+    s.next_viewmat = s.next_K = nullptr;
+    if (k + 1 < K && a->adam_host && a->seg_cap > 0) {
+      s.next_viewmat = viewmats + 16 * (size_t)views_host[k + 1];
+      s.next_K = Ks + 9 * (size_t)views_host[k + 1];
+    }
     if (a->adam_host) {
       h = *a->adam_host;
       h.step += k;

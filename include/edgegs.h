@@ -353,6 +353,12 @@ typedef struct {
   /* gradient outputs (used when adam == NULL, e.g. before an RCCL all-reduce) */
   float *v_means, *v_quats, *v_scales, *v_opacities;
   const eg_adam_hyper *adam_host; /* NULL = write gradients instead of stepping */
+  /* tail fusion across the step boundary (segmented layout, adam_host != NULL): when next_viewmat != NULL the
+   * step's last kernel also projects + bins the NEXT view with the parameters it has just updated, and the next
+   * eg_train_step call on that view passes have_projection = 1 to skip its own projection.  Any change to the
+   * parameters or the buffers in between voids the projection (the caller then passes 0). */
+  const float *next_viewmat, *next_K;
+  int32_t have_projection;
 } eg_step_args;
 
 int eg_train_step(const eg_step_args *args_host, eg_stream_t stream);

@@ -1,26 +1,32 @@
 #!/bin/bash
-# Full evidence run on the GPU box: parity tests, bench lines, rocprofv3 kernel stats, PMC traffic.
-#   gpurun --timeout 2400 -- 'bash tools/run_gpu_suite.sh'
-# Everything lands in gpurun_out/; copy what should be judged into profiles/.
+# Full evidence run on the GPU box (round 2): parity tests + report, bench lines (headline with same-run PMC traffic,
+# config1, trained-like, batched views, operator path, config3/4), rocprofv3 kernel stats + launch gaps, SQ counters.
+#   gpurun --timeout 3000 -- 'bash tools/run_gpu_suite.sh'
+# Everything lands in gpurun_out/ev/; copy what should be judged into profiles/ (tools/collect_profiles.py).
 R=${GRAFT_REPO_ROOT:-/root/repo}
-O=$R/gpurun_out
-mkdir -p $O
+O=$R/gpurun_out/ev
+rm -rf $O; mkdir -p $O
 cd $R
-timeout 1200 python -m pytest tests -m gpu -x -q 2>&1 | grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl" | tail -6 > $O/pytest_gpu.log
-timeout 600 python bench.py 2>/dev/null | tail -1 > $O/bench_c2.json
-for c in config1 config3 config4; do
-  timeout 600 python bench.py --config $c --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_${c}.json
+F='^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl'
+rm -f $R/gpurun_out/parity_report.jsonl
+timeout 1500 python -m pytest tests -m gpu -q --tb=short 2>&1 | grep -v "$F" | tail -15 > $O/pytest_gpu.log
+cp $R/gpurun_out/parity_report.jsonl $O/parity_report.jsonl 2>/dev/null
+( time timeout 900 python bench.py ) 2>$O/bench_default.err | tail -1 > $O/bench_default.json
+timeout 600 python bench.py --config config1 --no-extra 2>/dev/null | tail -1 > $O/bench_config1.json
+for c in config3 config4; do
+  timeout 600 python bench.py --config $c --no-cpu-baseline --no-traffic --no-extra 2>/dev/null | tail -1 > $O/bench_${c}.json
 done
-timeout 600 python bench.py --config config2 --spread-opacity --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_c2_spread.json
+timeout 300 python bench.py --force-dp --no-cpu-baseline --no-traffic --no-extra 2>/dev/null | tail -1 > $O/bench_config2_force_dp.json
+timeout 300 python tools/bench_regularizers.py 2>/dev/null | tail -1 > $O/regularizers_timing.json
+timeout 300 python tools/train_abc_fixture.py 2>/dev/null | tail -5 > $O/train_abc_fixture.txt
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_c2 -o r01 -- python $R/bench.py --steps 200 --warmup 20 --profile-only > /dev/null 2>$O/prof.err
-timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/pmc_fetch -o f -- python $R/bench.py --steps 40 --warmup 5 --profile-only > /dev/null 2>$O/pmc_f.err
-timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/pmc_write -o w -- python $R/bench.py --steps 40 --warmup 5 --profile-only > /dev/null 2>$O/pmc_w.err
+for c in config1 config2; do
+  rm -rf /tmp/ev_$c /tmp/evsq_$c
+  timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/ev_$c -o r -- python $R/bench.py --config $c --steps 300 --warmup 20 --profile-only > /dev/null 2>$O/prof_$c.err
+  python $R/tools/rocpd_summary.py /tmp/ev_$c/r_results.db $O/kernel_stats_$c.txt > /dev/null
+  python $R/tools/timeline_gaps.py /tmp/ev_$c/r_results.db > $O/timeline_gaps_$c.txt
+  timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY -d /tmp/evsq_$c -o q -- python $R/bench.py --config $c --steps 40 --warmup 5 --profile-only > /dev/null 2>$O/sq_$c.err
+  python $R/tools/pmc_sq_summary.py $O/sq_counters_$c.txt /tmp/evsq_$c/q_results.db > /dev/null
+done
 cd $R
-python tools/rocpd_summary.py /tmp/prof_c2/r01_results.db $O/kstats.txt > /dev/null
-python tools/timeline_gaps.py /tmp/prof_c2/r01_results.db > $O/gaps.txt
-python tools/pmc_summary.py /tmp/pmc_fetch/f_results.db /tmp/pmc_write/w_results.db $O/pmc_config2.json > /dev/null
-# second bench pass so that roofline.traffic is filled from the PMC file of THIS build
-cp $O/pmc_config2.json $R/profiles/r01_pmc_config2.json
-timeout 600 python bench.py 2>/dev/null | tail -1 > $O/bench_c2.json
-tail -3 $O/pytest_gpu.log; head -c 600 $O/bench_c2.json; echo; head -20 $O/kstats.txt
+tail -4 $O/pytest_gpu.log; head -c 700 $O/bench_default.json; echo; cat $O/bench_default.err | tail -4; head -9 $O/kernel_stats_config2.txt; cat $O/sq_counters_config2.txt | head -8
