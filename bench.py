@@ -284,8 +284,9 @@ def measure(name, args, device, rank, world, backend, spread=False, steps=None, 
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     loss_sum = tr.pop_loss()  # raises IsectOverflow if ANY step since the last read-back dropped intersections
-    if tr.overflow_events or tr.overflowed() or not math.isfinite(loss_sum):
-        raise SystemExit(f"invalid run: overflow events={tr.overflow_events} loss={loss_sum}")
+    if tr.overflow_events or tr.rewalk_misses or tr.overflowed() or not math.isfinite(loss_sum):
+        # (a replayed window would have been timed twice)
+        raise SystemExit(f"invalid run: overflow events={tr.overflow_events} re-walk misses={tr.rewalk_misses} loss={loss_sum}")
     m_last = tr.last_m()
     res = {
         "value": n * steps * world * vps / dt, "ms_per_step": 1e3 * dt / steps, "steps": steps, "warmup": warmup,
@@ -298,6 +299,8 @@ def measure(name, args, device, rank, world, backend, spread=False, steps=None, 
                    "gaussian_row_order": "morton" if tr.spatial_order else "as given",
                    "binning": "segmented" if tr.segmented else "scan",
                    "steps_per_native_enqueue": chunk if (dp is None and vps == 1) else 1,
+                   "exact_stop_rewalk": ("not launched (no pixel reaches the transmittance stop; speculation covered by the "
+                                         "step journal)" if tr._rewalk_arg(dp is None) == -2 else f"launched, list length hint {tr.rewalk_hint}"),
                    "parallelism": f"dp{world} (views sharded, RCCL all-reduce of [N,12] grads)" if world > 1 else "single GPU"},
         "mean_loss": loss_sum / (warmup + steps),
         "host_enqueue_ms_per_step": 1e3 * t_enq / steps,

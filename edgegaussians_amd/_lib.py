@@ -26,6 +26,7 @@ FLAG_LOGIT_OPACITIES = 2
 FLAG_ANTIALIASED = 4
 FLAG_TIGHT_TILES = 8
 FLAG_ABSGRAD_WRITE = 16
+REWALK_SPECULATE = -2  # EG_REWALK_SPECULATE
 
 
 class AdamHyper(C.Structure):

@@ -485,7 +485,7 @@ __device__ __forceinline__ void combine_tail(int tile, int tid, int i0, int ns, 
                                              float *__restrict__ render, float *__restrict__ alphas,
                                              int *__restrict__ last_ids, bool has_loss, float gt_p, float w_p,
                                              float loss_scale, float *__restrict__ vpix, float *__restrict__ loss_out,
-                                             StopRec *__restrict__ gtstop, float *sRed) {
+                                             StopRec *__restrict__ gtstop, float *sRed, bool rewalk_skipped) {
   if (ns > 1) {
     for (int s8 = 0; s8 < ns && stop_slice < 0; s8 += 8) {
       // eight slices' records in flight per wait (the walk over a tile's slices is a chain of round trips)
@@ -519,10 +519,16 @@ __device__ __forceinline__ void combine_tail(int tile, int tid, int i0, int ns, 
   si.T = T;
   si.last = last;
   if (__syncthreads_or(si.slice >= 0)) {  // only tiles that hand pixels over need the per-pixel records
-    ws.stopinfo[(size_t)tile * kTilePix + tid] = si;
-    // first pixel to flag a slice puts it on the list (the re-walk kernel returns the flag to zero)
-    if (si.slice >= 0 && atomicExch(&ws.item_flags[i0 + si.slice], 1) == 0)
-      ws.rewalk[atomicAdd(&ws.ctl[0], 1)] = make_int2(i0 + si.slice, tile);
+    if (rewalk_skipped) {
+      // the caller speculated that no pixel would stop and did not launch the re-walk: tell it (sticky word 3 of
+      // the control block); it restores its state and runs the step again with the re-walk
+      if (tid == 0) atomicExch(&ws.ctl[3], 1);
+    } else {
+      ws.stopinfo[(size_t)tile * kTilePix + tid] = si;
+      // first pixel to flag a slice puts it on the list (the re-walk kernel returns the flag to zero)
+      if (si.slice >= 0 && atomicExch(&ws.item_flags[i0 + si.slice], 1) == 0)
+        ws.rewalk[atomicAdd(&ws.ctl[0], 1)] = make_int2(i0 + si.slice, tile);
+    }
   }
   float l = 0.f;
   if (inside && stop_slice < 0)
@@ -551,7 +557,7 @@ composite_slice_fwd_kernel(const float4 *__restrict__ splat, const TileTable tt_
                            float *__restrict__ render, float *__restrict__ alphas, int *__restrict__ last_ids,
                            const float *__restrict__ gt, const float *__restrict__ wmap, float loss_scale,
                            float *__restrict__ vpix, float *__restrict__ loss_out, StopRec *__restrict__ gtstop,
-                           const Batch bt) {
+                           const Batch bt, int rewalk_skipped) {
   __shared__ QuadLists ql;
   static_assert(kSlice <= kTilePix, "one staging thread per Gaussian of the slice");
   __shared__ int sTile[5];
@@ -670,7 +676,7 @@ composite_slice_fwd_kernel(const float4 *__restrict__ splat, const TileTable tt_
     if (!s_last) return;  // (whole workgroup)
   }
   combine_tail<CH, true>(tile, tid, i0, ns, inside, i * width + j, T, last, stop_slice, ws, flat, render, alphas,
-                         last_ids, has_loss, gt_p, w_p, loss_scale, vpix, loss_out, gtstop, sRed);
+                         last_ids, has_loss, gt_p, w_p, loss_scale, vpix, loss_out, gtstop, sRed, rewalk_skipped != 0);
 }
 
 // phase B as its own launch (FUSED = false): one workgroup per tile with more than one slice
@@ -680,7 +686,7 @@ composite_combine_fwd_kernel(const TileTable tt_, const int *__restrict__ flat, 
                              const SliceWs ws_, float *__restrict__ render, float *__restrict__ alphas,
                              int *__restrict__ last_ids, const float *__restrict__ gt, const float *__restrict__ wmap,
                              float loss_scale, float *__restrict__ vpix, float *__restrict__ loss_out,
-                             StopRec *__restrict__ gtstop, const Batch bt) {
+                             StopRec *__restrict__ gtstop, const Batch bt, int rewalk_skipped) {
   __shared__ float sRed[4];
   const int bv = blockIdx.y;  // view of a batched step
   const TileTable tt = view_of(tt_, bt, bv);
@@ -704,7 +710,7 @@ composite_combine_fwd_kernel(const TileTable tt_, const int *__restrict__ flat, 
   const float w_p = (has_loss && inside) ? wmap[i * width + j] : 0.f;
   const float gt_p = (has_loss && inside) ? gt[i * width + j] : 0.f;
   combine_tail<CH, false>(tile, tid, i0, ns, inside, i * width + j, 1.f, 0, -1, ws, flat, render, alphas, last_ids,
-                          has_loss, gt_p, w_p, loss_scale, vpix, loss_out, gtstop, sRed);
+                          has_loss, gt_p, w_p, loss_scale, vpix, loss_out, gtstop, sRed, rewalk_skipped != 0);
 }
 
 // forward phase C: exact transmittance stop.  A small grid strides over the compact list of flagged
@@ -1326,6 +1332,8 @@ static int launch_sliced_fwd(const float4 *splat, const TileTable tt, int channe
   const SliceWs ws = carve_workspace(workspace, max_items, tw * th);
   // the re-walk grid strides over the compact list: sized from the caller's hint (launching 1024 workgroups that
   // find an empty list costs 4.5 us, 64 cost 1.3 us); any grid is correct
+  // rewalk_hint == EG_REWALK_SPECULATE: no launch at all; a pixel that does stop raises control word 3 instead
+  const int skip = rewalk_hint == EG_REWALK_SPECULATE;
   int64_t want = rewalk_hint < 0 ? 256 : (rewalk_hint == 0 ? 64 : 2 * (int64_t)rewalk_hint);
   want = want < 64 ? 64 : (want > 1024 ? 1024 : want);
   const unsigned rewalk_grid = (unsigned)(max_items < want ? max_items : want);
@@ -1334,20 +1342,21 @@ static int launch_sliced_fwd(const float4 *splat, const TileTable tt, int channe
     if (fused)                                                                                                    \
       composite_slice_fwd_kernel<CH, true><<<dim3((unsigned)max_items, C), 256, 0, s>>>(                          \
           splat, tt, total, flatten_ids, width, height, tw, th, ws, render, alphas, last_ids, gt, wmap,           \
-          loss_scale, vpix, loss_out, (StopRec *)gtstop, bt);                                                     \
+          loss_scale, vpix, loss_out, (StopRec *)gtstop, bt, skip);                                               \
     else {                                                                                                        \
       composite_slice_fwd_kernel<CH, false><<<dim3((unsigned)max_items, C), 256, 0, s>>>(                         \
           splat, tt, total, flatten_ids, width, height, tw, th, ws, render, alphas, last_ids, gt, wmap,           \
-          loss_scale, vpix, loss_out, (StopRec *)gtstop, bt);                                                     \
+          loss_scale, vpix, loss_out, (StopRec *)gtstop, bt, skip);                                               \
       composite_combine_fwd_kernel<CH><<<dim3(tw * th, C), 256, 0, s>>>(tt, flatten_ids, width, height, tw, ws,   \
                                                                         render, alphas, last_ids, gt, wmap,       \
                                                                         loss_scale, vpix, loss_out,               \
-                                                                        (StopRec *)gtstop, bt);                   \
+                                                                        (StopRec *)gtstop, bt, skip);             \
     }                                                                                                             \
     timing_mark(kMarkSlice, s);                                                                                   \
-    composite_rewalk_fwd_kernel<CH><<<dim3(rewalk_grid, C), 256, 0, s>>>(                                         \
-        splat, tt, flatten_ids, width, height, tw, th, ws, render, alphas, last_ids, gt, wmap, loss_scale, vpix,  \
-        loss_out, (StopRec *)gtstop, bt);                                                                         \
+    if (!skip)                                                                                                    \
+      composite_rewalk_fwd_kernel<CH><<<dim3(rewalk_grid, C), 256, 0, s>>>(                                       \
+          splat, tt, flatten_ids, width, height, tw, th, ws, render, alphas, last_ids, gt, wmap, loss_scale,      \
+          vpix, loss_out, (StopRec *)gtstop, bt);                                                                 \
     timing_mark(kMarkRewalk, s);                                                                                  \
   } while (0)
   if (channels == 1) EG_LAUNCH_CB(1); else EG_LAUNCH_CB(3);

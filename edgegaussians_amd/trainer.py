@@ -92,6 +92,7 @@ class EdgeTrainer:
         self._journal: List = []
         self._snap: Optional[Dict] = None
         self.overflow_events = 0
+        self.rewalk_misses = 0  # replays caused by a transmittance stop while the re-walk launch was being skipped
         self.rewalk_hint = -1  # re-walk list length seen at the last read-back (launch-shape hint; -1 = unknown)
         # noise of duplicate() comes from a dedicated generator seeded with (seed, event number): identical
         # on every data-parallel rank whatever else the ranks drew (edge_gs.py:462-467 uses the global RNG)
@@ -279,7 +280,6 @@ class EdgeTrainer:
             a.splat, a.g2d = ptr(self.splat), ptr(self.g2d)
             a.gtstop = ptr(self.gtstop)
             a.max_tile_hint = getattr(self, "max_tile_seen", 0)
-            a.rewalk_hint = self.rewalk_hint
             a.seg_cap = self.seg_cap
             if self.seg_cap:
                 a.tile_end, a.item_end, a.item_tile = ptr(self.tile_end), ptr(self.item_end), ptr(self.item_tile)
@@ -301,6 +301,7 @@ class EdgeTrainer:
         a.gt = self.gt.data_ptr() + 4 * self.height * self.width * view
         a.wmap = wmap.data_ptr()
         a.loss_scale = self.loss_scale
+        a.rewalk_hint = self._rewalk_arg(fused_adam)
         if fused_adam:
             a.absgrads = ptr(self.absgrads)
             a.adam_host = self._args_cache["hyper_ptr"]
@@ -308,6 +309,26 @@ class EdgeTrainer:
             a.absgrads = self.grads.data_ptr() + 4 * 11 * self.N
             a.adam_host = self._args_cache["null_hyper"]
         return a
+
+    def _rewalk_arg(self, journalled: bool) -> int:
+        """The re-walk launch hint of the next enqueue.  While no pixel has reached the transmittance stop (the
+        whole phase before opacities train up, edge_gs.py:93 starts them at 0.08) the launch is skipped
+        altogether -- speculation, covered by the journal: a stop raises a sticky device word, the read-back
+        restores the state and replays the steps with the re-walk on."""
+        if journalled and self.replay_on_overflow and self.rewalk_hint == 0:
+            return _lib.REWALK_SPECULATE
+        return self.rewalk_hint
+
+    def _ctl_words(self):
+        """[(max re-walk list length, missed-re-walk flag)] of every compositing workspace in use (one small D2H each)."""
+        o = 4 * (self.T + self.max_items + 2)
+        out = [self.workspace[o:o + 8].view(torch.int32)]
+        for b in self._batches.values():
+            out.append(b["workspace"][:, o:o + 8].contiguous().view(torch.int32))
+        return out
+
+    def _rewalk_missed(self) -> bool:
+        return any(bool((w.view(-1, 2)[:, 1] != 0).any().item()) for w in self._ctl_words())
 
     def _advance_all(self):
         self.adam_step += 1
@@ -427,7 +448,8 @@ class EdgeTrainer:
             wp[i] = w.data_ptr()
         a.loss_scale = self.loss_scale
         a.max_tile_hint = getattr(self, "max_tile_seen", 0)
-        a.rewalk_hint = b["rewalk_hint"]
+        a.rewalk_hint = (_lib.REWALK_SPECULATE if (fused_adam and self.replay_on_overflow and b["rewalk_hint"] == 0
+                                                   and self.rewalk_hint in (0, -1)) else b["rewalk_hint"])
         if fused_adam:
             self._advance_all()
             self._set_hyper()
@@ -482,8 +504,10 @@ class EdgeTrainer:
         self._alloc_isect(int(self.capacity * factor), seg)
 
     def _recover_from_overflow(self) -> None:
-        """Called with the stream drained and total[1] raised: some step since the last read-back dropped
-        intersections.  Grow, put the state back, run the journalled steps again; repeat until clean."""
+        """Called with the stream drained and a sticky device flag raised: some step since the last read-back
+        dropped intersections (buffers too small) or hit a transmittance stop while the re-walk launch was being
+        skipped.  Grow / switch the re-walk on, put the state back, run the journalled steps again; repeat until
+        clean."""
         if not (self.replay_on_overflow and self._journal and self._snap is not None):
             self.clear_overflow()
             self._grow_isect(2.0)  # leave usable buffers behind for a caller that catches and restarts
@@ -493,9 +517,23 @@ class EdgeTrainer:
         journal = list(self._journal)
         epoch_now, ls_now = self.epoch, self.loss_scale
         for _ in range(8):
-            self.overflow_events += 1
-            self._grow_isect(2.0)  # (drops the batched work buffers as well: re-allocated, flags clear)
+            if self._rewalk_missed():
+                self.rewalk_hint = -1  # stops exist: launch the re-walk from now on (the next read-back sizes it)
+                for b in self._batches.values():
+                    b["rewalk_hint"] = -1
+                for w in self._ctl_words():
+                    w.view(-1, 2)[:, 1].zero_()
+                o = 4 * (self.T + self.max_items + 3)
+                self.workspace[o:o + 4].zero_()
+                for b in self._batches.values():
+                    b["workspace"][:, o:o + 4].zero_()
+                self.rewalk_misses += 1
+            if self.overflowed():
+                self.overflow_events += 1
+                self._grow_isect(2.0)  # (drops the batched work buffers as well: re-allocated, flags clear)
             self.total.zero_()
+            for b in self._batches.values():
+                b["total"].zero_()
             self.loss_acc.zero_()
             self._restore()
             for kind, view, wmap, epoch, ls in journal:
@@ -506,7 +544,7 @@ class EdgeTrainer:
                     self._regulariser_raw(view, self.loss_acc[0], *wmap)
                 else:
                     self._batched_raw(view, wmap, True)
-            if not self.overflowed():
+            if not self.overflowed() and not self._rewalk_missed():
                 self.epoch, self.loss_scale = epoch_now, ls_now
                 return
         raise IsectOverflow("tile-intersection buffers still overflow after 8 doublings")
@@ -514,7 +552,7 @@ class EdgeTrainer:
     def flush(self) -> None:
         """Drain the stream, verify that no step since the last read-back overflowed (repairing it if one
         did) and forget the journal.  Every operation that changes the state outside train_step calls it."""
-        if self.overflowed():
+        if self.overflowed() or self._rewalk_missed():
             self._recover_from_overflow()
         self._journal.clear()
 
@@ -671,7 +709,7 @@ class EdgeTrainer:
         train_gaussians.py:99) -- ONE device sync for many steps instead of two per step."""
         v = float(self.loss_acc.item())
         m_last, ovf, _items, tile_max = self._totals()
-        if ovf:  # sticky flag: SOME step since the last read-back dropped intersections
+        if ovf or self._rewalk_missed():  # sticky flags: SOME step since the last read-back must be repeated
             self._recover_from_overflow()  # raises IsectOverflow when the steps cannot be replayed
             v = float(self.loss_acc.item())
             m_last, _, _items, tile_max = self._totals()

@@ -43,6 +43,7 @@ typedef void *eg_stream_t; /* hipStream_t */
 
 #define EG_TILE 16
 #define EG_MAX_BATCH 8 /* views per eg_train_step_batched call */
+#define EG_REWALK_SPECULATE (-2) /* rewalk_hint: do not launch the exact-stop re-walk; control word 3 reports a miss */
 #define EG_FLAG_LOG_SCALES 1u      /* `scales` holds log-scales: exp() fused (edge_gs.py:253) */
 #define EG_FLAG_LOGIT_OPACITIES 2u /* `opacities` holds logits: sigmoid() fused (edge_gs.py:254) */
 #define EG_FLAG_ANTIALIASED 4u     /* rasterize_mode="antialiased" (edge_gs.py:50,266) */
@@ -175,8 +176,13 @@ int eg_composite_fwd(const float *splat, const float *colors /*[N,channels]|NULL
                                      if the pixel's walk stopped on T <= 1e-4 else -1 (i32), that Gaussian's
                                      depth bits (u32)} for eg_backward_fused*/,
                      int32_t rewalk_hint /*how many (tile, slice) items needed the exact-stop re-walk lately: sizes that
-                     kernel's grid, never affects the result; 0 = none seen, < 0 = unknown.  The workspace's control
-                     word [n_tiles + max_items + 2] holds the largest list length since the caller last zeroed it*/,
+                     kernel's grid, never affects the result; 0 = none seen, -1 = unknown.  The workspace's control
+                     word [n_tiles + max_items + 2] holds the largest list length since the caller last zeroed it.
+                     EG_REWALK_SPECULATE (-2): the caller bets that no pixel reaches the transmittance stop (true
+                     until opacities have trained up) and the re-walk kernel is NOT launched; if a pixel does stop,
+                     the sticky control word [n_tiles + max_items + 3] is raised and the results of that call are
+                     INVALID -- the caller must check the word, restore its state and repeat the call with a
+                     hint >= -1 (what EdgeTrainer's journal does), then zero the word*/,
                      eg_stream_t stream);
 
 /* ---- G8: compositing backward for unit colours (replaces gsplat rasterize_to_pixels bwd for the

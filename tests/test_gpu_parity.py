@@ -1105,6 +1105,42 @@ def test_overflow_between_capacity_sweeps_is_replayed(env):
     assert tb.adam_step == ta.adam_step and tb.step == ta.step and tb.absgrads_normalize_factor == ta.absgrads_normalize_factor
 
 
+def test_rewalk_speculation_miss_is_replayed(env):
+    """While no pixel has reached the transmittance stop the trainer does not even launch the exact-stop re-walk
+    (EG_REWALK_SPECULATE).  Opacities jump to 0.97 between two read-backs: the first stopping pixel raises the sticky
+    miss word, the read-back restores the state and replays the steps with the re-walk on -- same result as a trainer
+    that never speculates."""
+    _lib, synth, O = env
+    from edgegaussians_amd import EdgeTrainer, LRSchedule
+    sc = synth.make_scene(4000, 2, 128, 96, seed=6, spread_opacity=False, scale=0.03, anisotropy=2.0)
+    sched = LRSchedule(scales_start=0, quats_start=0, opacities_start=0)
+    mk = lambda spec: EdgeTrainer(sc.means, sc.log_scales, sc.quats, sc.logit_opacities, sc.viewmats, sc.Ks, sc.gt,  # noqa: E731
+                                  sc.width, sc.height, schedule=sched, replay_on_overflow=spec)
+    ta, tb = mk(False), mk(True)
+    ta.ensure_capacity(slack=4.0); tb.ensure_capacity(slack=4.0)
+    w = [synth.weight_map("weighted", sc.gt[v]).cuda() for v in range(2)]
+    for t in (ta, tb):
+        t.train_step(0, w[0])
+        assert math.isfinite(t.pop_loss())
+    assert tb.rewalk_hint == 0 and tb._rewalk_arg(True) == -2 and ta._rewalk_arg(True) == 0  # tb speculates from now on
+    for t in (ta, tb):
+        t.logit_opacities.fill_(float(torch.logit(torch.tensor(0.97))))
+        t.train_steps([0, 1, 0], [w[0], w[1], w[0]])
+        t.train_step(1, w[1])
+    assert tb._rewalk_missed() and not ta._rewalk_missed()
+    la, lb = ta.pop_loss(), tb.pop_loss()
+    assert getattr(tb, "rewalk_misses", 0) == 1 and tb.rewalk_hint > 0 and not tb._rewalk_missed()
+    assert abs(la - lb) <= 1e-6 * abs(la)
+    for k, v in ta.state_dict().items():
+        assert_close(tb.state_dict()[k], v, rtol=1e-6, name=f"after the replay: {k}")
+    assert_close(tb.absgrads, ta.absgrads, rtol=1e-6, name="absgrads")
+    # ... and the next window runs with the re-walk launched, no further replay
+    for t in (ta, tb):
+        t.train_step(0, w[0])
+    la, lb = ta.pop_loss(), tb.pop_loss()
+    assert abs(la - lb) <= 1e-6 * abs(la) and tb.rewalk_misses == 1
+
+
 def test_overflow_without_journal_raises(env):
     _lib, synth, O = env
     from edgegaussians_amd import EdgeTrainer
