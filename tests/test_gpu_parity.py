@@ -1295,6 +1295,51 @@ def test_native_run_of_steps_equals_single_steps(env):
     assert int(tb.tile_counts.abs().sum()) == 0 and int(tb.ticket.abs().sum()) == 0
 
 
+def test_batched_views_with_stops_and_overflow_replay(env):
+    """The batched launch sequence on a stop-heavy scene (exact-stop re-walk per view, gridDim.y) equals the sum of the
+    single-view steps; and a batched step that overflows buffers sized without slack is replayed from the journal."""
+    _lib, synth, O = env
+    from edgegaussians_amd import EdgeTrainer, LRSchedule
+    sc = synth.make_scene(4000, 4, 128, 96, seed=6, spread_opacity=False, scale=0.03, anisotropy=2.0)
+    sc.logit_opacities[:] = torch.logit(torch.tensor(0.97))
+    sched = LRSchedule(scales_start=0, quats_start=0, opacities_start=0)
+    mk = lambda: EdgeTrainer(sc.means, sc.log_scales, sc.quats, sc.logit_opacities, sc.viewmats, sc.Ks, sc.gt,  # noqa: E731
+                             sc.width, sc.height, schedule=sched)
+    ta, tb = mk(), mk()
+    ta.ensure_capacity(); tb.ensure_capacity()
+    views = [2, 0, 3]
+    wm = [synth.weight_map("weighted", sc.gt[v]).cuda() for v in views]
+    acc = torch.zeros_like(ta.grads)
+    for v, w in zip(views, wm):
+        acc += ta.grad_step(v, w)
+    la = ta.pop_loss()
+    gb = tb.grad_step_batched(views, wm).clone()
+    lb = tb.pop_loss()
+    assert abs(la - lb) <= 1e-5 * abs(la)
+    assert_close(gb, acc, rtol=1e-5, name="batched gradients on a stop-heavy scene")
+    assert max(b["rewalk_hint"] for b in tb._batches.values()) > 0, "the scene must exercise the re-walk"
+    # overflow inside a batched step: buffers sized for opacity 0.08, opacities jump to 0.9
+    sc2 = synth.make_scene(6000, 3, 200, 136, seed=3, spread_opacity=False, scale=0.02, anisotropy=5.0)
+    mk2 = lambda: EdgeTrainer(sc2.means, sc2.log_scales, sc2.quats, sc2.logit_opacities, sc2.viewmats, sc2.Ks, sc2.gt,  # noqa: E731
+                              sc2.width, sc2.height, schedule=sched)
+    t1, t2 = mk2(), mk2()
+    t1.ensure_capacity(slack=1.0)
+    t1._alloc_isect(t1.capacity * 16, t1.seg_cap * 16)
+    t2.ensure_capacity(slack=1.0)
+    t2._alloc_isect(t2.m_max_seen + 64, (t2.max_tile_seen // 128 + 1) * 128)
+    w2 = [synth.weight_map("weighted", sc2.gt[v]).cuda() for v in range(3)]
+    for t in (t1, t2):
+        t.logit_opacities.fill_(float(torch.logit(torch.tensor(0.9))))
+        t.train_step_batched([0, 1, 2], w2)
+        t.train_step_batched([2, 0], w2[:2])
+    assert t2.overflowed() and not t1.overflowed()
+    l1, l2 = t1.pop_loss(), t2.pop_loss()
+    assert t2.overflow_events >= 1 and t1.overflow_events == 0 and not t2.overflowed()
+    assert abs(l1 - l2) <= 1e-6 * abs(l1) and t2.adam_step == t1.adam_step == 2
+    for k, v in t1.state_dict().items():
+        assert_close(t2.state_dict()[k], v, rtol=1e-5, name=f"batched replay: {k}")
+
+
 def test_bench_line_contract(env):
     """bench.py prints ONE JSON line, last on stdout, with the fields the driver and the judge read."""
     import json
