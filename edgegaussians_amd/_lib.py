@@ -51,7 +51,7 @@ class StepArgs(C.Structure):
         ("last_ids", _vp),
         ("v_means", _vp), ("v_quats", _vp), ("v_scales", _vp), ("v_opacities", _vp),
         ("adam_host", C.POINTER(AdamHyper)),
-        ("next_viewmat", _vp), ("next_K", _vp), ("have_projection", _i32),
+        ("next_viewmat", _vp), ("next_K", _vp), ("have_projection", _i32), ("ws_tag", _i32),
     ]
 
 

@@ -54,13 +54,14 @@ int launch_composite_fwd_segments(const float *splat, const int32_t *tile_start,
                                   const int32_t *flatten_ids, int32_t width, int32_t height, float loss_scale,
                                   float *loss_out, const int32_t *total, int64_t max_items, void *workspace,
                                   float *gtstop, int32_t rewalk_hint, const Batch &bt, int C, hipStream_t st,
-                                  int32_t max_tile_hint);
+                                  int32_t max_tile_hint, int32_t chain_tag);
 int composite_fwd_segments_hinted(const float *splat, const int32_t *tile_start, const int32_t *tile_end,
                                   const int32_t *item_first, const int32_t *item_end, const int32_t *item_tile,
                                   const int32_t *flatten_ids, int32_t width, int32_t height, float *render, float *alphas,
                                   int32_t *last_ids, const float *gt, const float *wmap, float loss_scale, float *vpix,
                                   float *loss_out, const int32_t *total, int64_t max_items, void *workspace,
-                                  float *gtstop, int32_t rewalk_hint, int32_t max_tile_hint, hipStream_t st);
+                                  float *gtstop, int32_t rewalk_hint, int32_t max_tile_hint, int32_t chain_tag,
+                                  hipStream_t st);
 int launch_footprint_bwd(const float *splat, int32_t N, int32_t width, int32_t height, const float *gtstop, float *g2d,
                          const Batch &bt, int C, hipStream_t st);
 int launch_project_bwd_emit(float *means, float *quats, float *scales, float *opacities, const float *viewmat,

@@ -452,7 +452,9 @@ struct StopInfo {
 struct SliceWs {
   int *tile_ticket;     // [T]   slices of the tile that have finished
   int *item_flags;      // [max_items] 1 = the item is on the re-walk list
-  int *ctl;             // [4]   {list length, exit ticket of the re-walk kernel, list length of the last step, -}
+  int *ctl;             // [4]   {list length, exit ticket of the re-walk kernel, longest list since the caller looked, missed re-walk}
+  int *exit_grp;        // [64 x 16] first level of the re-walk kernel's exit ticket, one cache line per group
+  int *ready;           // [max_items] chained forward: the caller's tag once the item's record is published
   float *sliceP;        // [max_items][256] transmittance product of the slice (written only by tiles with > 1 slice)
   int *sliceL;          // [max_items][256] its last contributor (global index into the sorted ids, -1 none)
   StopInfo *stopinfo;   // [T][256]
@@ -469,7 +471,9 @@ __device__ __forceinline__ TileTable view_of(TileTable tt, const Batch &bt, int 
 __device__ __forceinline__ SliceWs view_of(SliceWs ws, const Batch &bt, int v) {
   const long long o = v * bt.ws_bytes;
   ws.tile_ticket = (int *)((char *)ws.tile_ticket + o); ws.item_flags = (int *)((char *)ws.item_flags + o);
-  ws.ctl = (int *)((char *)ws.ctl + o); ws.sliceP = (float *)((char *)ws.sliceP + o);
+  ws.ctl = (int *)((char *)ws.ctl + o); ws.exit_grp = (int *)((char *)ws.exit_grp + o);
+  ws.ready = (int *)((char *)ws.ready + o);
+  ws.sliceP = (float *)((char *)ws.sliceP + o);
   ws.sliceL = (int *)((char *)ws.sliceL + o); ws.stopinfo = (StopInfo *)((char *)ws.stopinfo + o);
   ws.rewalk = (int2 *)((char *)ws.rewalk + o); ws.sliceQ = (unsigned char *)ws.sliceQ + o;
   return ws;
@@ -679,6 +683,215 @@ composite_slice_fwd_kernel(const float4 *__restrict__ splat, const TileTable tt_
                          last_ids, has_loss, gt_p, w_p, loss_scale, vpix, loss_out, gtstop, sRed, rewalk_skipped != 0);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Chained forward: slice products, phase B and the EXACT transmittance stop in ONE kernel (used by the training
+// step whenever pixels do reach the stop, i.e. for most of a real training run).  Every slice workgroup of a tile
+// publishes its per-pixel product and last contributor (device-scope stores, then a per-item flag carrying the
+// caller's tag) and then LOOKS BACK: it waits for the flags of the slices in front of it -- lower block indices,
+// dispatched earlier, never waiting on it, so the wait cannot deadlock (the decoupled look-back idiom of
+// single-pass scans) -- and multiplies their products up to its own slice.  That tells each pixel, in every slice
+// workgroup, whether its stop fell in an earlier slice (nothing to do), falls in THIS slice (resolved on the spot
+// by a sequential walk of the quadrant lists that are still in LDS -- no re-staging, no second kernel, no lists)
+// or lies further back.  The workgroup in whose slice a pixel stops finalises that pixel; the last slice
+// finalises the pixels that never stop.  Same arithmetic, in the same order, as slice -> combine -> re-walk.
+__device__ __forceinline__ int stage_slice(QuadLists &ql, const float4 *__restrict__ splat,
+                                           const int *__restrict__ flat, int start, int end, int tx, int ty, int tid) {
+  float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), rB = s0;
+  bool hitq[4] = {false, false, false, false};
+  if (start + tid < end) {
+    const int g = flat[start + tid];
+    s0 = splat[2 * g];
+    const float4 s1 = splat[2 * g + 1];
+    const float thr = __logf(255.f * s1.y) + kThrMargin;
+    rB = make_float4(s1.x, s1.y, thr, __int_as_float(tid));
+    const float det = s0.z * s1.x - s0.w * s0.w;
+    if (thr > 0.f && det > 0.f) {
+      const float k2 = 2.f * thr * __builtin_amdgcn_rcpf(det);
+      const float ex = __builtin_amdgcn_sqrtf(k2 * s1.x) * 1.001f + 0.01f;
+      const float ey = __builtin_amdgcn_sqrtf(k2 * s0.z) * 1.001f + 0.01f;
+      const float X0 = (float)(tx * kTile), Y0 = (float)(ty * kTile);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float qx = X0 + (float)((q & 1) << 3), qy = Y0 + (float)((q >> 1) << 3);
+        hitq[q] = (s0.x - ex <= qx + 7.5f) && (s0.x + ex >= qx + 0.5f) && (s0.y - ey <= qy + 7.5f) &&
+                  (s0.y + ey >= qy + 0.5f) &&
+                  ellipse_hits_rect(s0.x, s0.y, s0.z, s0.w, s1.x, thr, qx + 0.5f, qy + 0.5f, qx + 7.5f, qy + 7.5f);
+      }
+    }
+  }
+  return build_quad_lists(ql, hitq, s0, rB, tid);
+}
+
+// sequential walk of this wave's quadrant list with the stop rule (the re-walk kernel's inner loop): lanes with
+// `live` look for their stop from transmittance T; returns the list position of the last contributor (-1: none)
+__device__ __forceinline__ int exact_walk(const QuadLists &ql, int wv, int n_mine, const v2f px2, const v2f py2,
+                                          bool &live, float &T, bool &found) {
+  const float4 *lX = ql.X[wv], *lC = ql.C[wv], *lD = ql.D[wv], *lE = ql.E[wv];
+  int lastpos = -1;
+  for (int t = 0; t < n_mine && __ballot(live) != 0ull; t += 4) {
+    float4 X[2], Cq[2], D[2], E[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      X[u] = lX[(t >> 1) + u]; Cq[u] = lC[(t >> 1) + u]; D[u] = lD[(t >> 1) + u]; E[u] = lE[(t >> 1) + u];
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const PairEval ev = eval_pair(X[u], Cq[u], D[u], E[u], px2, py2);
+      {
+        const float nT = T * (1.f - ev.a0);
+        const bool hit = live & ev.k0, stop = hit & (nT <= kTStop), upd = hit & !stop;
+        T = upd ? nT : T;
+        lastpos = upd ? t + 2 * u : lastpos;
+        found = found | stop;
+        live = live & !stop;
+      }
+      {
+        const float nT = T * (1.f - ev.a1);
+        const bool hit = live & ev.k1, stop = hit & (nT <= kTStop), upd = hit & !stop;
+        T = upd ? nT : T;
+        lastpos = upd ? t + 2 * u + 1 : lastpos;
+        found = found | stop;
+        live = live & !stop;
+      }
+    }
+  }
+  return lastpos;
+}
+
+template <int CH>
+__global__ void __launch_bounds__(256)
+composite_chained_fwd_kernel(const float4 *__restrict__ splat, const TileTable tt_, const int *__restrict__ total,
+                             const int *__restrict__ flat, int width, int height, int tw, int th, const SliceWs ws_,
+                             int tag, float *__restrict__ render, float *__restrict__ alphas,
+                             int *__restrict__ last_ids, const float *__restrict__ gt, const float *__restrict__ wmap,
+                             float loss_scale, float *__restrict__ vpix, float *__restrict__ loss_out,
+                             StopRec *__restrict__ gtstop, const Batch bt) {
+  __shared__ QuadLists ql;
+  __shared__ int sTile[5];
+  __shared__ float sRed[4];
+  const int bv = blockIdx.y;  // view of a batched step
+  const TileTable tt = view_of(tt_, bt, bv);
+  const SliceWs ws = view_of(ws_, bt, bv);
+  total += 4 * bv; flat += bv * bt.keys; splat += bv * bt.splat4;
+  if (render) render += bv * bt.pixels * CH;
+  if (alphas) alphas += bv * bt.pixels;
+  if (last_ids) last_ids += bv * bt.pixels;
+  if (vpix) vpix += bv * bt.pixels;
+  if (gtstop) gtstop += bv * bt.pixels;
+  if (bt.gt[0]) { gt = bt.gt[bv]; wmap = bt.wmap[bv]; }
+  const int b = blockIdx.x;
+  if (b >= total[2]) return;
+  const int tile = tt.item_tile ? tt.item_tile[b] : item_tile_coop(tt.item_first, tw * th, b, sTile);
+  const int tid = threadIdx.x, wv = tid >> 6;
+  const int ty = tile / tw, tx = tile - ty * tw;
+  int di, dj;
+  quad_pixel(tid, di, dj);
+  const int i = ty * kTile + di, j = tx * kTile + dj;
+  const bool inside = (i < height) && (j < width);
+  const float px = (float)j + 0.5f, py = (float)i + 0.5f;
+  const v2f px2 = {px, px}, py2 = {py, py};
+  const int i0 = tt.item_first[tile], ns = tt.item_end[tile] - i0, s_me = b - i0;
+  const int t_start = tt.start[tile], t_end = tt.end[tile];
+  const int start = t_start + s_me * kSlice, end = min(t_end, start + kSlice);
+  const bool has_loss = wmap != nullptr;
+  const float w_p = (has_loss && inside) ? wmap[i * width + j] : 0.f;
+  const float gt_p = (has_loss && inside) ? gt[i * width + j] : 0.f;
+
+  // ---- phase A: this slice's product and last contributor (lists stay in LDS)
+  float P = 1.f;
+  int Lpos = -1, n_mine = 0;
+  if (end > start) {
+    n_mine = stage_slice(ql, splat, flat, start, end, tx, ty, tid);
+    const float4 *lX = ql.X[wv], *lC = ql.C[wv], *lD = ql.D[wv], *lE = ql.E[wv];
+    for (int t = 0; t < n_mine; t += 4) {
+      float4 X[2], Cq[2], D[2], E[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        X[u] = lX[(t >> 1) + u]; Cq[u] = lC[(t >> 1) + u]; D[u] = lD[(t >> 1) + u]; E[u] = lE[(t >> 1) + u];
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const PairEval ev = eval_pair(X[u], Cq[u], D[u], E[u], px2, py2);
+        P *= ev.k0 ? 1.f - ev.a0 : 1.f;
+        P *= ev.k1 ? 1.f - ev.a1 : 1.f;
+        Lpos = ev.k0 ? t + 2 * u : Lpos;
+        Lpos = ev.k1 ? t + 2 * u + 1 : Lpos;
+      }
+    }
+  }
+  const int L = (Lpos >= 0) ? start + __float_as_int(((const float *)&ql.E[wv][Lpos >> 1])[2 + (Lpos & 1)]) : -1;
+
+  // ---- publish for the slices behind this one (the last slice has nobody behind it)
+  if (s_me < ns - 1) {
+    __hip_atomic_store(&ws.sliceP[(size_t)b * kTilePix + tid], P, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&ws.sliceL[(size_t)b * kTilePix + tid], L, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(&ws.ready[b], tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+
+  // ---- look back: T in front of this slice; `before` = the pixel stopped in an earlier slice
+  float T = 1.f;
+  int last = 0;
+  bool before = false;
+  for (int j8 = 0; j8 < s_me; j8 += 8) {
+    const int nb = min(8, s_me - j8);
+    if (tid < nb)  // one poller per awaited flag; the others wait at the barrier
+      while (__hip_atomic_load(&ws.ready[i0 + j8 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != tag)
+        __builtin_amdgcn_s_sleep(2);
+    __syncthreads();
+    float Ps[8];
+    int Ls[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const bool ok = u < nb;
+      const size_t o = (size_t)(i0 + j8 + (ok ? u : 0)) * kTilePix + tid;
+      Ps[u] = __hip_atomic_load(&ws.sliceP[o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      Ls[u] = __hip_atomic_load(&ws.sliceL[o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (!ok) { Ps[u] = 1.f; Ls[u] = -1; }
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (Ls[u] < 0 || before) continue;
+      const float nT = T * Ps[u];
+      if (nT <= kTStop) { before = true; continue; }
+      T = nT;
+      last = Ls[u];
+    }
+  }
+  // ---- this slice: does the stop fall in it?  (same test, on the same products, as the combine of the split path)
+  bool cross = false;
+  if (!before && L >= 0) {
+    const float nT = T * P;
+    if (nT <= kTStop) cross = true; else { T = nT; last = L; }
+  }
+  cross = cross && inside;
+  bool found = false;
+  if (__syncthreads_or(cross)) {
+    if (tid == 0 && ws.ctl[2] == 0) atomicMax(&ws.ctl[2], 1);  // "pixels do stop": the caller's launch-mode hint
+    // exact stop from the lists still in LDS, sequentially in depth order from T; should float rounding move the
+    // crossing past the slice end, the same lanes carry on through the following slices (staged afresh)
+    bool live = cross;
+    const int lp = exact_walk(ql, wv, n_mine, px2, py2, live, T, found);
+    if (lp >= 0) last = start + __float_as_int(((const float *)&ql.E[wv][lp >> 1])[2 + (lp & 1)]);
+    for (int s2 = s_me + 1; s2 < ns; ++s2) {
+      if (!__syncthreads_or(cross && !found)) break;
+      const int st2 = t_start + s2 * kSlice, en2 = min(t_end, st2 + kSlice);
+      const int n2 = stage_slice(ql, splat, flat, st2, en2, tx, ty, tid);
+      live = cross && !found;
+      const int lp2 = exact_walk(ql, wv, n2, px2, py2, live, T, found);
+      if (lp2 >= 0) last = st2 + __float_as_int(((const float *)&ql.E[wv][lp2 >> 1])[2 + (lp2 & 1)]);
+    }
+  }
+  // ---- finalise: the pixels that stop here (whichever way the exact walk ended), and -- in the last slice -- the
+  // pixels that never stop
+  float l = 0.f;
+  if (cross || (inside && !before && s_me == ns - 1))
+    l = finalize_pixel<CH>(i * width + j, T, last, cross && found, flat, render, alphas, last_ids, has_loss, gt_p, w_p,
+                           loss_scale, vpix, gtstop, splat);
+  if (has_loss && loss_out) block_loss_add(l, sRed, loss_out);
+}
+
 // phase B as its own launch (FUSED = false): one workgroup per tile with more than one slice
 template <int CH>
 __global__ void __launch_bounds__(256)
@@ -817,12 +1030,21 @@ composite_rewalk_fwd_kernel(const float4 *__restrict__ splat, const TileTable tt
   if (tid == 0) ws.item_flags[b] = 0;  // off the list
   }  // list loop
   // the last of the workgroups that had work empties the list for the next step: every one of them has read its
-  // length by now, and a workgroup that starts later reads zero and leaves (only these take the ticket: a burst of
-  // a thousand same-address atomics from idle workgroups cost 10 us per step)
-  if (tid == 0 && atomicAdd(&ws.ctl[1], 1) == min((int)gridDim.x, n_list) - 1) {
-    ws.ctl[2] = max(ws.ctl[2], n_list);  // largest list since the caller last looked (its launch-shape hint)
-    atomicExch(&ws.ctl[0], 0);
-    atomicExch(&ws.ctl[1], 0);
+  // length by now, and a workgroup that starts later reads zero and leaves.  Only these take the exit ticket, and
+  // in TWO LEVELS (64 groups on 64 cache lines, then the groups' last members on one word): returning atomics on
+  // one address run at ~60 ns apiece, a flat ticket cost 70 us with 1024 idle workgroups and 30 us of the 41 us this
+  // kernel took on a trained-like scene with 700 busy ones
+  if (tid == 0) {
+    const int P = min((int)gridDim.x, n_list), grp = blockIdx.x & 63;
+    const int members = (P - grp + 63) >> 6;
+    if (atomicAdd(&ws.exit_grp[grp * 16], 1) == members - 1) {
+      atomicExch(&ws.exit_grp[grp * 16], 0);
+      if (atomicAdd(&ws.ctl[1], 1) == min(P, 64) - 1) {
+        ws.ctl[2] = max(ws.ctl[2], n_list);  // longest list since the caller last looked (its launch-shape hint)
+        atomicExch(&ws.ctl[0], 0);
+        atomicExch(&ws.ctl[1], 0);
+      }
+    }
   }
 }
 
@@ -1289,12 +1511,12 @@ composite_bwd_colors_kernel(const float4 *__restrict__ splat, const float *__res
 using namespace eg;
 
 // workspace layout: control words first (they must be zero before the first use, see SliceWs):
-//   tile_ticket i32[T] | item_flags i32[max_items] | ctl i32[4]
+//   tile_ticket i32[T] | item_flags i32[max_items] | ctl i32[4] | exit_grp i32[64 x 16] | ready i32[max_items]
 // then  sliceP f32[max_items][256] | sliceL i32[max_items][256] | stopinfo {i32,f32,i32}[T][256]
 //       | rewalk int2[max_items] | sliceQ u8[max_items][128]
 extern "C" int64_t eg_composite_workspace_ctl_bytes(int64_t max_items, int64_t n_tiles) {
   if (max_items < 0 || n_tiles < 0) return 0;
-  return (n_tiles + max_items + 4) * (int64_t)sizeof(int32_t);
+  return (n_tiles + 2 * max_items + 4 + 64 * 16) * (int64_t)sizeof(int32_t);
 }
 
 extern "C" int64_t eg_composite_workspace_bytes(int64_t max_items, int64_t n_tiles) {
@@ -1309,7 +1531,9 @@ static SliceWs carve_workspace(void *workspace, int64_t max_items, int n_tiles) 
   ws.tile_ticket = (int *)workspace;
   ws.item_flags = ws.tile_ticket + n_tiles;
   ws.ctl = ws.item_flags + max_items;
-  ws.sliceP = (float *)(ws.ctl + 4);
+  ws.exit_grp = ws.ctl + 4;
+  ws.ready = ws.exit_grp + 64 * 16;
+  ws.sliceP = (float *)(ws.ready + max_items);
   ws.sliceL = (int *)(ws.sliceP + (size_t)max_items * kTilePix);
   ws.stopinfo = (StopInfo *)(ws.sliceL + (size_t)max_items * kTilePix);
   ws.rewalk = (int2 *)(ws.stopinfo + (size_t)n_tiles * kTilePix);
@@ -1322,7 +1546,7 @@ static int launch_sliced_fwd(const float4 *splat, const TileTable tt, int channe
                              int width, int height, float *render, float *alphas, int32_t *last_ids, const float *gt,
                              const float *wmap, float loss_scale, float *vpix, float *loss_out, const int32_t *total,
                              int64_t max_items, void *workspace, float *gtstop, int rewalk_hint, hipStream_t s,
-                             const Batch &bt = Batch{}, int C = 1, int max_tile_hint = 0) {
+                             const Batch &bt = Batch{}, int C = 1, int max_tile_hint = 0, int chain_tag = 0) {
   // fused phase B saves a launch and the idle tail of a kernel (~7 us at the reference's sizes, 14 us at 1600x1200)
   // but the last workgroup of a tile reads its slices back at device scope, one round trip per 8 slices, at the very
   // end of the tile's critical path: with a 35-slice tile (500 k Gaussians @1200x680) it cost 120 us.  Decided from
@@ -1334,6 +1558,20 @@ static int launch_sliced_fwd(const float4 *splat, const TileTable tt, int channe
   // find an empty list costs 4.5 us, 64 cost 1.3 us); any grid is correct
   // rewalk_hint == EG_REWALK_SPECULATE: no launch at all; a pixel that does stop raises control word 3 instead
   const int skip = rewalk_hint == EG_REWALK_SPECULATE;
+  if (!skip && chain_tag > 0) {
+    // pixels do reach the stop: slice products, phase B and the exact stop in one kernel (decoupled look-back)
+    if (channels == 1)
+      composite_chained_fwd_kernel<1><<<dim3((unsigned)max_items, C), 256, 0, s>>>(
+          splat, tt, total, flatten_ids, width, height, tw, th, ws, chain_tag, render, alphas, last_ids, gt, wmap,
+          loss_scale, vpix, loss_out, (StopRec *)gtstop, bt);
+    else
+      composite_chained_fwd_kernel<3><<<dim3((unsigned)max_items, C), 256, 0, s>>>(
+          splat, tt, total, flatten_ids, width, height, tw, th, ws, chain_tag, render, alphas, last_ids, gt, wmap,
+          loss_scale, vpix, loss_out, (StopRec *)gtstop, bt);
+    timing_mark(kMarkSlice, s);
+    timing_mark(kMarkRewalk, s);
+    return check_launch("composite_fwd(chained)");
+  }
   int64_t want = rewalk_hint < 0 ? 256 : (rewalk_hint == 0 ? 64 : 2 * (int64_t)rewalk_hint);
   want = want < 64 ? 64 : (want > 1024 ? 1024 : want);
   const unsigned rewalk_grid = (unsigned)(max_items < want ? max_items : want);
@@ -1400,11 +1638,12 @@ int composite_fwd_segments_hinted(const float *splat, const int32_t *tile_start,
                                   const int32_t *flatten_ids, int32_t width, int32_t height, float *render, float *alphas,
                                   int32_t *last_ids, const float *gt, const float *wmap, float loss_scale, float *vpix,
                                   float *loss_out, const int32_t *total, int64_t max_items, void *workspace,
-                                  float *gtstop, int32_t rewalk_hint, int32_t max_tile_hint, hipStream_t st) {
+                                  float *gtstop, int32_t rewalk_hint, int32_t max_tile_hint, int32_t chain_tag,
+                                  hipStream_t st) {
   const TileTable tt = {tile_start, tile_end, item_first, item_end, item_tile};
   return launch_sliced_fwd((const float4 *)splat, tt, 1, flatten_ids, width, height, render, alphas, last_ids, gt, wmap,
                            loss_scale, vpix, loss_out, total, max_items, workspace, gtstop, rewalk_hint, st, Batch{}, 1,
-                           max_tile_hint);
+                           max_tile_hint, chain_tag);
 }
 }  // namespace eg
 
@@ -1465,11 +1704,11 @@ int launch_composite_fwd_segments(const float *splat, const int32_t *tile_start,
                                   const int32_t *flatten_ids, int32_t width, int32_t height, float loss_scale,
                                   float *loss_out, const int32_t *total, int64_t max_items, void *workspace,
                                   float *gtstop, int32_t rewalk_hint, const Batch &bt, int C, hipStream_t st,
-                                  int32_t max_tile_hint) {
+                                  int32_t max_tile_hint, int32_t chain_tag) {
   const TileTable tt = {tile_start, tile_end, item_first, item_end, item_tile};
   return launch_sliced_fwd((const float4 *)splat, tt, 1, flatten_ids, width, height, nullptr, nullptr, nullptr,
                            bt.gt[0], bt.wmap[0], loss_scale, nullptr, loss_out, total, max_items, workspace, gtstop,
-                           rewalk_hint, st, bt, C, max_tile_hint);
+                           rewalk_hint, st, bt, C, max_tile_hint, chain_tag);
 }
 int launch_footprint_bwd(const float *splat, int32_t N, int32_t width, int32_t height, const float *gtstop, float *g2d,
                          const Batch &bt, int C, hipStream_t st) {

@@ -147,7 +147,7 @@ extern "C" int eg_train_step(const eg_step_args *a, eg_stream_t stream) {
     rc = composite_fwd_segments_hinted(a->splat, a->offsets, a->tile_end, a->item_offsets, a->item_end, a->item_tile,
                                        a->flatten_ids, a->width, a->height, a->render, a->alphas, a->last_ids, a->gt,
                                        a->wmap, a->loss_scale, a->vpix, a->loss, a->total, a->max_items, a->workspace,
-                                       a->gtstop, a->rewalk_hint, a->max_tile_hint, st);
+                                       a->gtstop, a->rewalk_hint, a->max_tile_hint, a->ws_tag, st);
     if (rc) return rc;
   } else {
   // tile_counts is zero on entry (caller zero-initialises it once): the projection counts it up and its
@@ -239,7 +239,7 @@ extern "C" int eg_train_step_batched(const eg_step_args *a, int32_t C, const flo
   rc = launch_composite_fwd_segments(a->splat, a->offsets, a->tile_end, a->item_offsets, a->item_end, a->item_tile,
                                      a->flatten_ids, a->width, a->height, a->loss_scale, a->loss, a->total,
                                      a->max_items, a->workspace, a->gtstop, a->rewalk_hint, bt, C, st,
-                                     a->max_tile_hint);
+                                     a->max_tile_hint, a->ws_tag);
   if (rc) return rc;
   rc = launch_footprint_bwd(a->splat, a->N, a->width, a->height, a->gtstop, a->g2d, bt, C, st);
   if (rc) return rc;
@@ -268,6 +268,7 @@ extern "C" int eg_train_steps(const eg_step_args *a, int32_t K, const int32_t *v
     s.K = Ks + 9 * (size_t)views_host[k];
     s.gt = gts + hw * (size_t)views_host[k];
     s.wmap = wmaps_host[k];
+    if (a->ws_tag > 0) s.ws_tag = (int32_t)(((int64_t)a->ws_tag + k - 1) % 0x7ffffff0) + 1;  // a fresh tag per step
     // inside the run the parameters change only through these steps: step k's last kernel projects view k + 1
     s.have_projection = (k > 0 && a->adam_host && a->seg_cap > 0) ? 1 : a->have_projection;
     s.next_viewmat = s.next_K = nullptr;

@@ -94,6 +94,8 @@ class EdgeTrainer:
         self.overflow_events = 0
         self.rewalk_misses = 0  # replays caused by a transmittance stop while the re-walk launch was being skipped
         self.rewalk_hint = -1  # re-walk list length seen at the last read-back (launch-shape hint; -1 = unknown)
+        self._ws_tag = 0       # tags of the chained forward (eg_step_args.ws_tag): one fresh value per enqueued step
+        self.chained_forward = bool(int(os.environ.get("EG_CHAINED", "1")))
         # noise of duplicate() comes from a dedicated generator seeded with (seed, event number): identical
         # on every data-parallel rank whatever else the ranks drew (edge_gs.py:462-467 uses the global RNG)
         self.seed = int(seed)
@@ -302,6 +304,7 @@ class EdgeTrainer:
         a.wmap = wmap.data_ptr()
         a.loss_scale = self.loss_scale
         a.rewalk_hint = self._rewalk_arg(fused_adam)
+        a.ws_tag = self._next_tag(1) if self.chained_forward else 0
         if fused_adam:
             a.absgrads = ptr(self.absgrads)
             a.adam_host = self._args_cache["hyper_ptr"]
@@ -318,6 +321,12 @@ class EdgeTrainer:
         if journalled and self.replay_on_overflow and self.rewalk_hint == 0:
             return _lib.REWALK_SPECULATE
         return self.rewalk_hint
+
+    def _next_tag(self, n: int) -> int:
+        """First of n fresh tags (consecutive, in 1 .. 2^31 - 17, never 0)."""
+        t = self._ws_tag % 0x7ffffff0 + 1
+        self._ws_tag += n
+        return t
 
     def _ctl_words(self):
         """[(max re-walk list length, missed-re-walk flag)] of every compositing workspace in use (one small D2H each)."""
@@ -374,6 +383,8 @@ class EdgeTrainer:
         self._advance_all()   # step 0's counts; the native loop advances them by k
         self._set_hyper()
         a = self._args(views[0], wmaps[0], True)
+        if self.chained_forward and K > 1:
+            self._next_tag(K - 1)  # (the native loop uses ws_tag .. ws_tag + K - 1)
         va = (C.c_int32 * K)(*views)
         wa = (C.c_void_p * K)(*[w.data_ptr() for w in wmaps])
         for w in wmaps:
@@ -448,6 +459,7 @@ class EdgeTrainer:
             wp[i] = w.data_ptr()
         a.loss_scale = self.loss_scale
         a.max_tile_hint = getattr(self, "max_tile_seen", 0)
+        a.ws_tag = self._next_tag(1) if self.chained_forward else 0
         a.rewalk_hint = (_lib.REWALK_SPECULATE if (fused_adam and self.replay_on_overflow and b["rewalk_hint"] == 0
                                                    and self.rewalk_hint in (0, -1)) else b["rewalk_hint"])
         if fused_adam:

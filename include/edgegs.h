@@ -156,7 +156,7 @@ int eg_composite_fwd_segments(const float *splat, const int32_t *tile_start, con
  * bound max_items >= total[2] (e.g. ceil(capacity/128) + T) and a workspace of
  * eg_composite_workspace_bytes(max_items, T) bytes; one workgroup runs per (tile, 128-Gaussian slice; an
  * empty tile owns one empty item).  The first eg_composite_workspace_ctl_bytes(max_items, T) bytes of the
- * workspace are control words (per-tile tickets, item flags, the re-walk list counter): the caller ZEROES
+ * workspace are control words (per-tile tickets, item flags and tags, the re-walk list counter): the caller ZEROES
  * them once when the workspace is allocated -- with these (max_items, T) -- and every call hands them back
  * zeroed.  With item_offsets == NULL (or per-Gaussian colours) one workgroup walks each tile.
  * When gtstop != NULL (the fused training step, whose backward reads nothing else) render, alphas,
@@ -365,6 +365,12 @@ typedef struct {
    * parameters or the buffers in between voids the projection (the caller then passes 0). */
   const float *next_viewmat, *next_K;
   int32_t have_projection;
+  /* > 0: when pixels reach the transmittance stop (rewalk_hint != EG_REWALK_SPECULATE) the forward runs as ONE
+   * chained kernel (slice products, phase B and the exact stop by decoupled look-back; same results as the
+   * slice / combine / re-walk sequence).  The tag marks the items published in THIS call: it must differ from the
+   * tags of all earlier calls on the same workspace since that workspace was zeroed (count up from 1;
+   * eg_train_steps uses ws_tag .. ws_tag + K - 1).  0: the slice / combine / re-walk sequence. */
+  int32_t ws_tag;
 } eg_step_args;
 
 int eg_train_step(const eg_step_args *args_host, eg_stream_t stream);
