@@ -93,6 +93,7 @@ def build_trainer(name, seed, device, spread_opacity=False):
 STAGE_OF = {"project_emit_kernel": "project_bwd_adam+next_project_bin", "project_bwd_emit_kernel": "project_bwd_adam+next_project_bin",
             "tile_emit_kernel": "tile_emit",
             "tile_sort_kernel": "tile_sort", "composite_slice_fwd_kernel": "composite_slice_fwd",
+            "composite_chained_fwd_kernel": "composite_slice_fwd",  # (the pre-warm window runs before the first read-back)
             "composite_rewalk_fwd_kernel": "composite_rewalk_fwd", "footprint_bwd_kernel": "footprint_bwd",
             "project_bwd_kernel": "project_bwd_adam+next_project_bin"}
 
@@ -220,9 +221,10 @@ def measure(name, args, device, rank, world, backend, spread=False, steps=None, 
     steps = args.steps if steps is None else steps
     warmup = args.warmup if warmup is None else warmup
     n, n_views, w, h = CONFIGS[name]
-    tr, sc, whole, ratio, poses = build_trainer(name, args.seed, device, spread)
+    # --replicas (BASELINE config 5: one scene per GPU): every rank trains its OWN scene (seed + rank), no collective
+    tr, sc, whole, ratio, poses = build_trainer(name, args.seed + (rank if args.replicas else 0), device, spread)
     tr.ensure_capacity()
-    dp = egdist.DataParallelStep(tr) if (world > 1 or args.force_dp) else None
+    dp = egdist.DataParallelStep(tr) if ((world > 1 and not args.replicas) or args.force_dp) else None
     if dp is not None and world == 1:
         dp.world = 2  # issue the collective
     # device pre-warm, not part of --warmup: a fresh box needs ~0.1 s of work before clocks and page
@@ -301,7 +303,9 @@ def measure(name, args, device, rank, world, backend, spread=False, steps=None, 
                    "steps_per_native_enqueue": chunk if (dp is None and vps == 1) else 1,
                    "exact_stop_rewalk": ("not launched (no pixel reaches the transmittance stop; speculation covered by the "
                                          "step journal)" if tr._rewalk_arg(dp is None) == -2 else f"launched, list length hint {tr.rewalk_hint}"),
-                   "parallelism": f"dp{world} (views sharded, RCCL all-reduce of [N,12] grads)" if world > 1 else "single GPU"},
+                   "parallelism": ("single GPU" if world == 1 else
+                                   f"{world} independent replicas, one scene per GPU, no collective (BASELINE config 5)" if args.replicas
+                                   else f"dp{world} (views sharded, RCCL all-reduce of [N,12] grads)")},
         "mean_loss": loss_sum / (warmup + steps),
         "host_enqueue_ms_per_step": 1e3 * t_enq / steps,
     }
@@ -428,6 +432,9 @@ def main():
                     help="run only warmup+steps of the fused step (for rocprofv3), skip stage timing/CPU leg")
     ap.add_argument("--no-traffic", action="store_true",
                     help="skip the two rocprofv3 --pmc passes that measure roofline.traffic (adds ~40 s)")
+    ap.add_argument("--replicas", action="store_true",
+                    help="with --gpus N: N independent replicas (one scene per GPU, different seeds, no collective) -- "
+                         "BASELINE config 5's shape -- instead of view-sharded data parallelism")
     ap.add_argument("--chunk", type=int, default=10,
                     help="steps per native enqueue (EdgeTrainer.train_steps); 1 = one Python call per step")
     ap.add_argument("--views-per-step", type=int, default=1,
