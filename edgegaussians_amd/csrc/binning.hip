@@ -556,7 +556,11 @@ static int launch_tile_sort(uint64_t *keys, const int32_t *offsets, int32_t T, i
                             eg_stream_t stream, const Batch &bt = Batch{}, int C = 1) {
   // small: 256 threads / buckets, 4096 keys; large: 1024 threads / buckets, 16384 keys
   constexpr int kSmall = 4096, kLarge = 16384;
-  constexpr size_t kSmallLds = kSmall * 8 + 2 * 256 * 4, kLargeLds = kLarge * 8 + 2 * 1024 * 4;
+  constexpr size_t kLargeLds = kLarge * 8 + 2 * 1024 * 4;
+  // workgroup of the small variant: the kernel lasts as long as its fullest tile, so tiles of thousands of keys
+  // want 512 threads (config 2: 16.0 -> 13.1 us; 500 k @1200x680: 45 -> 41) -- unless the grid has thousands of
+  // small tiles (200 k @1600x1200: 33 -> 44 with 512), where the extra waves cost more than the fullest tile gains
+  const bool wide = max_tile_hint > 1536 && T <= 4096;
   if (!g_sort_attr_set) {
     (void)hipFuncSetAttribute((const void *)tile_sort_kernel<1024, kLarge, true>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLargeLds);
@@ -567,9 +571,14 @@ static int launch_tile_sort(uint64_t *keys, const int32_t *offsets, int32_t T, i
   // LDS that would all find nothing to do: ~3 us) is skipped and the small variant owns EVERY tile -- a
   // tile that outgrew the hint is then still sorted correctly, by the slower paths of the small variant.
   const bool small_only = max_tile_hint > 0 && (int64_t)max_tile_hint * 3 / 2 <= kSmall;
-  tile_sort_kernel<256, kSmall, false><<<dim3(T, C), 256, kSmallLds, as_stream(stream)>>>(
-      (unsigned long long *)keys, offsets, T, (long long)capacity, small_only ? 0x7fffffff : kSmall, flatten_ids,
-      (long long *)isect_ids, seg, bt);
+  if (wide)
+    tile_sort_kernel<512, kSmall, false><<<dim3(T, C), 512, kSmall * 8 + 2 * 512 * 4, as_stream(stream)>>>(
+        (unsigned long long *)keys, offsets, T, (long long)capacity, small_only ? 0x7fffffff : kSmall, flatten_ids,
+        (long long *)isect_ids, seg, bt);
+  else
+    tile_sort_kernel<256, kSmall, false><<<dim3(T, C), 256, kSmall * 8 + 2 * 256 * 4, as_stream(stream)>>>(
+        (unsigned long long *)keys, offsets, T, (long long)capacity, small_only ? 0x7fffffff : kSmall, flatten_ids,
+        (long long *)isect_ids, seg, bt);
   if (!small_only)
     tile_sort_kernel<1024, kLarge, true><<<dim3(min(T, 256), C), 1024, kLargeLds, as_stream(stream)>>>(
         (unsigned long long *)keys, offsets, T, (long long)capacity, kSmall, flatten_ids, (long long *)isect_ids,

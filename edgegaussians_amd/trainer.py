@@ -645,10 +645,14 @@ class EdgeTrainer:
     def apply_adam(self) -> None:
         self._advance_all()
         self._set_hyper()
-        gm, gq, gs, go = self.grad_views()
-        call("eg_adam_multi", ptr(self.means), ptr(self.log_scales), ptr(self.quats), ptr(self.logit_opacities),
-             ptr(gm), ptr(gs), ptr(gq), ptr(go), ptr(self.adam_m), ptr(self.adam_v), self.N, self._hyper,
-             self.grads.data_ptr() + 4 * 11 * self.N, ptr(self.absgrads), stream())  # += all-reduced absgrad block
+        c = self._args_cache.get("adam_ptrs")
+        if c is None:  # raw pointers of the gradient blocks (rebuilt with the buffers): no tensor views per step
+            g0, N = self.grads.data_ptr(), self.N
+            c = (ptr(self.means), ptr(self.log_scales), ptr(self.quats), ptr(self.logit_opacities),
+                 g0, g0 + 4 * 7 * N, g0 + 4 * 3 * N, g0 + 4 * 10 * N, ptr(self.adam_m), ptr(self.adam_v), g0 + 4 * 11 * N)
+            self._args_cache["adam_ptrs"] = c
+        call("eg_adam_multi", c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7], c[8], c[9], self.N, self._hyper,
+             c[10], ptr(self.absgrads), stream())  # += all-reduced absgrad block
         self.absgrads_normalize_factor += 1
 
     # ------------------------------------------------------------------ orientation regularisers (8f)
