@@ -435,8 +435,8 @@ def main():
     ap.add_argument("--replicas", action="store_true",
                     help="with --gpus N: N independent replicas (one scene per GPU, different seeds, no collective) -- "
                          "BASELINE config 5's shape -- instead of view-sharded data parallelism")
-    ap.add_argument("--chunk", type=int, default=10,
-                    help="steps per native enqueue (EdgeTrainer.train_steps); 1 = one Python call per step")
+    ap.add_argument("--chunk", type=int, default=50,
+                    help="steps per native enqueue (EdgeTrainer.train_steps; default: one epoch of the scan's 50 views); 1 = one Python call per step")
     ap.add_argument("--views-per-step", type=int, default=1,
                     help="C > 1: C views per launch sequence and optimizer step on this GPU (train_step_batched; the "
                          "semantics of C-way data parallelism).  The headline stays at 1: the reference steps per view")
