@@ -80,9 +80,11 @@ _SIGS = {
     "eg_compact_rows": [_vp, _vp, _vp, _i32, _i32, _vp, _vp],
     "eg_append_rows": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _f, _vp, _vp],
     "eg_ratio_wmap": [_vp, _f, _i32, _vp, _i32, _i32, _vp, _vp],
+    "eg_ratio_wmap_seeded": [_vp, _f, _i32, _i32, _i32, C.c_uint64, _i32, _vp, _vp],
     "eg_project_hits": [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _vp, _vp],
     "eg_project_visibility": [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _vp, _vp],
     "eg_knn": [_vp, _i32, _i32, C.POINTER(_f), _f, C.POINTER(_i32), _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "eg_knn_small": [_vp, _i32, _i32, _vp, _vp, _vp, _vp],
     "eg_direction_loss": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp],
     "eg_ratio_loss": [_vp, _i32, _vp, _vp, _vp],
     "eg_train_step": [C.POINTER(StepArgs), _vp],
@@ -91,7 +93,7 @@ _SIGS = {
 }
 EXPORTS = sorted(list(_SIGS) + ["eg_last_error_string", "eg_version", "eg_device_count",
                                  "eg_composite_workspace_bytes", "eg_composite_workspace_ctl_bytes",
-                                 "eg_batched_workspace_stride", "eg_timing_begin", "eg_timing_end",
+                                 "eg_batched_workspace_stride", "eg_knn_small_scratch_bytes", "eg_timing_begin", "eg_timing_end",
                                  "eg_timing_stage_count", "eg_timing_stage_name"])
 
 _lib: Optional[C.CDLL] = None
@@ -124,6 +126,8 @@ def load(require_device: bool = True) -> C.CDLL:
         lib.eg_composite_workspace_ctl_bytes.argtypes = [_i64, _i64]
         lib.eg_batched_workspace_stride.restype = _i64
         lib.eg_batched_workspace_stride.argtypes = [_i64, _i64]
+        lib.eg_knn_small_scratch_bytes.restype = _i64
+        lib.eg_knn_small_scratch_bytes.argtypes = [_i32, _i32]
         _lib = lib
     if require_device and not torch.cuda.is_available():
         raise RuntimeError("edgegaussians_amd needs a gfx950 GPU (torch.cuda.is_available() is False); "

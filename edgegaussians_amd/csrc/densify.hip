@@ -122,6 +122,41 @@ ratio_wmap_sel_kernel(const long long *__restrict__ perm, int n_sel, int HW, flo
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n_sel) out[(int)(perm[i] % HW)] += inv_sel;  // distinct pixels: no atomics
 }
+
+// The same weight map with the sample drawn inside the kernel: pixel p < n_bg is sampled iff pi(p) < n_sel for a
+// keyed pseudo-random PERMUTATION pi of [0, n_bg) -- a 6-round Feistel network on 2 * half_bits >= log2(n_bg) bits,
+// cycle-walked back into the domain (a bijection restricted to the values that land inside stays a bijection).
+// Exactly n_sel distinct pixels, one launch, no sort (torch.randperm on the device is a 7-launch radix sort:
+// ~55 us of device time and ~36 us of host time per step of the 'bg_edge_ratio' strategy).
+__device__ __forceinline__ uint32_t mix32(uint32_t h) {
+  h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+  return h;
+}
+__global__ void __launch_bounds__(256)
+ratio_wmap_seeded_kernel(const float *__restrict__ gt, float thr, float inv_edge, uint32_t n_bg, uint32_t n_sel,
+                         float inv_sel, uint32_t key_lo, uint32_t key_hi, int half_bits, int HW,
+                         float *__restrict__ out) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= HW) return;
+  float w = (gt[p] >= thr) ? inv_edge : 0.f;
+  if ((uint32_t)p < n_bg && n_sel > 0) {
+    const uint32_t mask = (1u << half_bits) - 1u;
+    uint32_t v = (uint32_t)p;
+    do {
+      uint32_t l = v >> half_bits, r = v & mask;
+#pragma unroll
+      for (int round = 0; round < 6; ++round) {
+        const uint32_t f = mix32(r ^ mix32(key_lo + 0x9e3779b9u * (uint32_t)(round + 1)) ^ key_hi) & mask;
+        const uint32_t t = l ^ f;
+        l = r;
+        r = t;
+      }
+      v = (l << half_bits) | r;
+    } while (v >= n_bg);
+    if (v < n_sel) w += inv_sel;
+  }
+  out[p] = w;
+}
 }  // namespace eg
 
 using namespace eg;
@@ -185,4 +220,19 @@ extern "C" int eg_ratio_wmap(const float *gt, float thr, int32_t n_edge, const i
   if (n_sel > 0)
     ratio_wmap_sel_kernel<<<cdiv(n_sel, 256), 256, 0, st>>>((const long long *)perm, n_sel, HW, 1.f / (float)n_sel, out);
   return check_launch("ratio_wmap");
+}
+
+// ... and with the sample drawn on the device from a 64-bit seed: n_sel distinct pixels among the first n_bg flat
+// indices (the reference's quirk, edge_gs.py:303-310: positions in the list of background pixels are unravelled
+// as if they were pixel indices), uniformly at random; a different seed per call gives a fresh sample.
+extern "C" int eg_ratio_wmap_seeded(const float *gt, float thr, int32_t n_edge, int32_t n_bg, int32_t n_sel,
+                                    uint64_t seed, int32_t HW, float *out, eg_stream_t stream) {
+  EG_REQUIRE(HW > 0 && n_sel >= 0 && n_edge >= 0 && n_bg >= 0 && n_bg <= HW && gt && out, "bad arguments");
+  n_sel = min(n_sel, n_bg);
+  int half_bits = 1;
+  while (half_bits < 16 && (1ull << (2 * half_bits)) < (uint64_t)n_bg) ++half_bits;
+  ratio_wmap_seeded_kernel<<<cdiv(HW, 256), 256, 0, as_stream(stream)>>>(
+      gt, thr, 1.f / (float)(n_edge > 0 ? n_edge : 1), (uint32_t)n_bg, (uint32_t)n_sel,
+      n_sel > 0 ? 1.f / (float)n_sel : 0.f, (uint32_t)seed, (uint32_t)(seed >> 32), half_bits, HW, out);
+  return check_launch("ratio_wmap_seeded");
 }

@@ -155,6 +155,79 @@ knn_query_kernel(const float *__restrict__ pts, int N, int K, Grid g, const int 
 }
 
 // ---------------------------------------------------------------------------------------------
+// Exhaustive search for small N (the ABC-NEF runs end at ~10 k Gaussians, three quarters of them faint floaters
+// spread through the volume while the rest sit on curves: no uniform grid fits both, one isolated query held its
+// whole wave for ~800 us).  N^2 distance evaluations are cheap when the whole chip takes part: workgroup (b, s)
+// answers queries 256 b .. 256 b + 255 against candidate chunk s; every lane of a wave reads the SAME candidate
+// (a wave-uniform address: scalar loads, no LDS), ~10 VALU instructions per pair, K-best list in registers;
+// a second kernel merges the S partial lists of a query.  Same (distance, index) order as the grid search.
+template <int KMAX>
+__global__ void __launch_bounds__(256)
+knn_exhaustive_kernel(const float *__restrict__ pts, int N, int chunk, float *__restrict__ part_d,
+                      int *__restrict__ part_i) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int s = blockIdx.y;
+  const int q = min(i, N - 1);
+  const float x = pts[3 * q], y = pts[3 * q + 1], z = pts[3 * q + 2];
+  float bd[KMAX];
+  int bi[KMAX];
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k) { bd[k] = 3.0e38f; bi[k] = -1; }
+  const int c0 = s * chunk, c1 = min(N, c0 + chunk);
+  int j = c0;
+  for (; j + 8 <= c1; j += 8) {  // eight candidates = 24 consecutive floats per round of scalar loads
+    float c[24];
+#pragma unroll
+    for (int u = 0; u < 24; ++u) c[u] = pts[3 * j + u];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const float ex = c[3 * u] - x, ey = c[3 * u + 1] - y, ez = c[3 * u + 2] - z;
+      const float d = ex * ex + ey * ey + ez * ez;
+      if (j + u != i) knn_insert<KMAX>(bd, bi, d, j + u);
+    }
+  }
+  for (; j < c1; ++j) {
+    const float ex = pts[3 * j] - x, ey = pts[3 * j + 1] - y, ez = pts[3 * j + 2] - z;
+    const float d = ex * ex + ey * ey + ez * ez;
+    if (j != i) knn_insert<KMAX>(bd, bi, d, j);
+  }
+  if (i >= N) return;
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k) {
+    part_d[((size_t)s * KMAX + k) * N + i] = bd[k];
+    part_i[((size_t)s * KMAX + k) * N + i] = bi[k];
+  }
+}
+
+template <int KMAX>
+__global__ void __launch_bounds__(256)
+knn_merge_kernel(const float *__restrict__ part_d, const int *__restrict__ part_i, int N, int K, int S,
+                 int *__restrict__ out_idx, float *__restrict__ out_d2) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= N) return;
+  float bd[KMAX];
+  int bi[KMAX];
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k) {
+    bd[k] = part_d[(size_t)k * N + i];
+    bi[k] = part_i[(size_t)k * N + i];
+  }
+  for (int s = 1; s < S; ++s)
+    for (int k = 0; k < K; ++k) {  // the partial lists are ascending: stop at the first entry that does not enter
+      const float d = part_d[((size_t)s * KMAX + k) * N + i];
+      const int j = part_i[((size_t)s * KMAX + k) * N + i];
+      if (j < 0 || !(d < bd[KMAX - 1] || (d == bd[KMAX - 1] && j < bi[KMAX - 1]))) break;
+      knn_insert<KMAX>(bd, bi, d, j);
+    }
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k)
+    if (k < K) {
+      out_idx[(size_t)i * K + k] = bi[k];
+      if (out_d2) out_d2[(size_t)i * K + k] = bd[k];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // direction loss (edge_gs.py:346-373): 1 - mean_i mean_k | m_i . unit(mu_i - mu_nn(i,k)) |
 // with m_i = column argmax_k(scale) of R(q_i).  One thread per Gaussian: value (sum of alignments, the
 // caller forms 1 - sum / (N k)) and UNSCALED gradients d(sum)/d{mu, q} (the caller multiplies by
@@ -310,6 +383,42 @@ extern "C" int eg_knn(const float *points, int32_t N, int32_t K, const float *or
     knn_query_kernel<32><<<cdiv(N, 128), 128, 0, st>>>(points, N, K, g, cell_start, (const float4 *)sorted, out_idx,
                                                          out_d2, r_brute);
   return check_launch("knn");
+}
+
+// candidate chunks per query block of the exhaustive search: enough workgroups to fill the chip (~4 per CU)
+static int knn_small_splits(int N) {
+  const int blocks = cdiv(N, 256);
+  return max(1, min(min(64, cdiv(N, 64)), cdiv(1024, blocks)));
+}
+
+extern "C" int64_t eg_knn_small_scratch_bytes(int32_t N, int32_t K) {
+  if (N <= 0 || K < 1 || K > 32) return 0;
+  const int kmax = K <= 8 ? 8 : (K <= 16 ? 16 : 32);
+  return (int64_t)knn_small_splits(N) * kmax * N * 8;
+}
+
+extern "C" int eg_knn_small(const float *points, int32_t N, int32_t K, void *scratch, int32_t *out_idx,
+                            float *out_d2, eg_stream_t stream) {
+  EG_REQUIRE(N >= 0 && K >= 1 && K <= 32, "bad arguments");
+  if (N == 0) return EG_OK;
+  EG_REQUIRE(points && scratch && out_idx, "null pointer");
+  EG_REQUIRE(N <= (1 << 16), "eg_knn_small: N <= 65536 (use the grid search, eg_knn)");
+  hipStream_t st = as_stream(stream);
+  const int S = knn_small_splits(N), chunk = cdiv(N, S);
+  const int kmax = K <= 8 ? 8 : (K <= 16 ? 16 : 32);
+  float *pd = (float *)scratch;
+  int *pi = (int *)(pd + (size_t)S * kmax * N);
+  const dim3 grid(cdiv(N, 256), S);
+#define EG_KNN_SMALL(KM)                                                                                     \
+  do {                                                                                                       \
+    knn_exhaustive_kernel<KM><<<grid, 256, 0, st>>>(points, N, chunk, pd, pi);                                 \
+    knn_merge_kernel<KM><<<cdiv(N, 256), 256, 0, st>>>(pd, pi, N, K, S, out_idx, out_d2);                    \
+  } while (0)
+  if (kmax == 8) EG_KNN_SMALL(8);
+  else if (kmax == 16) EG_KNN_SMALL(16);
+  else EG_KNN_SMALL(32);
+#undef EG_KNN_SMALL
+  return check_launch("knn_small");
 }
 
 extern "C" int eg_direction_loss(const float *means, const float *quats, const float *log_scales,

@@ -14,7 +14,7 @@ from typing import Tuple
 import torch
 from torch import Tensor
 
-from ._lib import call, ptr, stream
+from ._lib import call, load, ptr, stream
 
 
 def make_grid(points: Tensor, margin: float = 0.0):
@@ -54,15 +54,28 @@ def make_grid(points: Tensor, margin: float = 0.0):
     return lo_h, float(cell), dims_of(cell)
 
 
-def knn(points: Tensor, k: int, want_dist: bool = False, grid=None) -> Tuple[Tensor, Tensor]:
+# up to this many points the exhaustive search (eg_knn_small: N^2 pairs over the whole chip, no grid, no host sync)
+# beats the grid search, whatever the distribution of the points
+KNN_EXHAUSTIVE_MAX = 32768
+
+
+def knn(points: Tensor, k: int, want_dist: bool = False, grid=None, method: str = "auto") -> Tuple[Tensor, Tensor]:
     """Indices [N,k] (int32, ascending distance, self excluded) and, optionally, distances [N,k].
-    One host sync (the bounding box, `make_grid`) unless a grid is passed in -- where the reference had a full D2H
-    copy + CPU tree build."""
+    method "auto": exhaustive search for N <= KNN_EXHAUSTIVE_MAX (no host sync at all), else the uniform-grid
+    search (one host sync for the bounding box, `make_grid`, unless a grid is passed in) -- where the reference
+    had a full D2H copy + CPU tree build.  "grid" / "exhaustive" force one."""
     assert points.is_cuda and points.dtype == torch.float32 and points.dim() == 2 and points.shape[1] == 3
     assert 1 <= k <= 32
     pts = points.detach().contiguous()
     N = pts.shape[0]
     dev = pts.device
+    if method == "exhaustive" or (method == "auto" and N <= KNN_EXHAUSTIVE_MAX):
+        idx = torch.empty(N, k, dtype=torch.int32, device=dev)
+        d2 = torch.empty(N, k, device=dev) if want_dist else None
+        nbytes = int(load().eg_knn_small_scratch_bytes(N, k))
+        scratch = torch.empty(max(nbytes, 8) // 4, dtype=torch.int32, device=dev)
+        call("eg_knn_small", ptr(pts), N, k, ptr(scratch), ptr(idx), ptr(d2) if d2 is not None else None, stream())
+        return idx, (d2.sqrt() if d2 is not None else None)
     lo_h, cell, dims = grid if grid is not None else make_grid(pts)
     ncell = dims[0] * dims[1] * dims[2]
     cell_of = torch.empty(N, dtype=torch.int32, device=dev)
@@ -78,12 +91,13 @@ def knn(points: Tensor, k: int, want_dist: bool = False, grid=None) -> Tuple[Ten
     return idx, (d2.sqrt() if d2 is not None else None)
 
 
-def reference_nn_indices(points: Tensor, dir_loss_num_nn: int, enforce_method: str = "enforce_full", grid=None) -> Tensor:
+def reference_nn_indices(points: Tensor, dir_loss_num_nn: int, enforce_method: str = "enforce_full", grid=None,
+                         method: str = "auto") -> Tensor:
     """`update_nearest_neighbors` (edge_gs.py:326-344): k_nearest_sklearn(points, k+1) -- 2k+1 for
     'enforce_half' -- already drops the point itself, and `indices[:, 1:]` then drops the NEAREST
     neighbour as well: the reference aligns with neighbours 2 .. k+1 (2 .. 2k+1).  Kept as is."""
     n = 2 * dir_loss_num_nn + 1 if enforce_method == "enforce_half" else dir_loss_num_nn + 1
-    idx, _ = knn(points, n, grid=grid)
+    idx, _ = knn(points, n, grid=grid, method=method)
     return idx[:, 1:].contiguous()
 
 

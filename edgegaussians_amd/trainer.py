@@ -226,11 +226,13 @@ class EdgeTrainer:
             if generator is not None:
                 return synth.weight_map(strategy, self.gt[view].cpu(), ratio, generator, threshold).to(self.dev)
             n_sel = int(ratio * n_e)
-            # one randperm (distinct values < hw: exactly n_sel pixels) + one native call; no read-back
-            perm = torch.randperm(hw - n_e, device=self.dev)
+            # one launch: the sample (exactly n_sel distinct pixels) is drawn inside the kernel from a keyed
+            # pseudo-random permutation; the key advances with every draw
+            self._wmap_draws = getattr(self, "_wmap_draws", 0) + 1
+            key = ((self.seed + 1) * 0x9E3779B97F4A7C15 + self._wmap_draws * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
             w = torch.empty(H, W, device=self.dev)
-            call("eg_ratio_wmap", ptr(self.gt[view]), float(threshold), n_e, ptr(perm), min(n_sel, hw - n_e), hw, ptr(w),
-                 stream())
+            call("eg_ratio_wmap_seeded", ptr(self.gt[view]), float(threshold), n_e, hw - n_e, min(n_sel, hw - n_e), key,
+                 hw, ptr(w), stream())
             return w
         raise ValueError(f"Unknown projection loss strategy: {strategy}")
 
@@ -662,6 +664,9 @@ class EdgeTrainer:
         the means, the one thing that needs the host) is refreshed at most once per epoch and N, inflated by 10 %:
         a mean that drifts out of it is clamped into a boundary cell, which keeps the search exact."""
         from . import regularizers as R
+        if self.N <= R.KNN_EXHAUSTIVE_MAX:  # exhaustive search over the whole chip: no grid, no host sync
+            self.nn_indices = R.reference_nn_indices(self.means, dir_loss_num_nn, enforce_method)
+            return self.nn_indices
         key = (self.epoch, self.N)
         if getattr(self, "_knn_grid_key", None) != key:
             self._knn_grid, self._knn_grid_key = R.make_grid(self.means, margin=0.1), key

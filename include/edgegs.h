@@ -306,6 +306,14 @@ int eg_knn(const float *points /*[N,3]*/, int32_t N, int32_t K, const float *ori
            const int32_t *dims_host /*[3]*/, int32_t *cell_of, int32_t *cell_counts, int32_t *cell_start,
            float *sorted /*[N,4]*/, int32_t *out_idx /*[N,K]*/, float *out_d2 /*[N,K]|NULL squared distances*/,
            eg_stream_t stream);
+
+/* eg_knn_small: the same result (exact K <= 32 neighbours, self excluded, ascending (distance, index)) by
+ * exhaustive search split over the whole chip, for N <= 65536: no grid, no host-side bounding box.  Faster than the
+ * grid search up to a few 10^4 points, and insensitive to their distribution (trained Gaussians: dense curves +
+ * isolated floaters).  scratch: eg_knn_small_scratch_bytes(N, K) bytes. */
+int64_t eg_knn_small_scratch_bytes(int32_t N, int32_t K);
+int eg_knn_small(const float *points /*[N,3]*/, int32_t N, int32_t K, void *scratch, int32_t *out_idx /*[N,K]*/,
+                 float *out_d2 /*[N,K] or NULL*/, eg_stream_t stream);
 /* compute_direction_loss (edge_gs.py:346-373): sum_out[0] += sum over the counted (i,k) of
  * |m_i . unit(mu_i - mu_nn(i,k))|; g_means += and g_quats = the gradient of that SUM.  top_k <= 0 or >= K:
  * every listed neighbour counts (loss = 1 - sum/(N K), the caller scales by -lambda/(N K)); 0 < top_k < K
@@ -325,6 +333,12 @@ int eg_ratio_loss(const float *log_scales, int32_t N, float *g_scales /*[N,3] wr
  * drawn by the caller (int64, distinct, taken modulo HW like the reference's unravel, :303-310). */
 int eg_ratio_wmap(const float *gt /*[H*W]*/, float thr, int32_t n_edge, const int64_t *perm, int32_t n_sel, int32_t HW,
                   float *out /*[H*W]*/, eg_stream_t stream);
+
+/* The same map with the sample drawn inside the kernel (one launch, no permutation buffer): the n_sel sampled
+ * pixels are { p < n_bg : pi(p) < n_sel } for a pseudo-random permutation pi of [0, n_bg) keyed by `seed` (Feistel
+ * network + cycle walking): exactly n_sel distinct pixels, uniformly distributed; a new seed gives a new sample. */
+int eg_ratio_wmap_seeded(const float *gt /*[H*W]*/, float thr, int32_t n_edge, int32_t n_bg, int32_t n_sel,
+                         uint64_t seed, int32_t HW, float *out /*[H*W]*/, eg_stream_t stream);
 
 /* ---- whole training step for one view, enqueued from native code (train_gaussians.py:81-106):
  * project+count -> offsets -> emit -> sort -> composite+loss -> composite bwd -> project bwd

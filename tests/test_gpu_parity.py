@@ -620,8 +620,11 @@ def test_large_tile_grids_take_the_fallback_binning_paths(env, W, H):
 
 
 # ------------------------------------------------------------------ 8(f): kNN + orientation regularisers
-@pytest.mark.parametrize("k,clustered", [(6, False), (6, True), (16, False)])
-def test_knn_matches_sklearn(env, k, clustered):
+@pytest.mark.parametrize("method", ["grid", "exhaustive"])
+@pytest.mark.parametrize("k,clustered", [(6, False), (6, True), (16, False), (21, True)])
+def test_knn_matches_sklearn(env, k, clustered, method):
+    """Both searches (uniform grid: eg_knn; exhaustive, the default up to 32 k points: eg_knn_small) against
+    sklearn's KD-tree, which is what the reference calls (edge_gs.py:135-151)."""
     from sklearn.neighbors import NearestNeighbors
     from edgegaussians_amd import regularizers as R
     g = torch.Generator().manual_seed(11)
@@ -633,14 +636,33 @@ def test_knn_matches_sklearn(env, k, clustered):
         pts = a[seg] * (1 - t) + b[seg] * t + 0.003 * torch.randn(n, 3, generator=g)
     else:
         pts = torch.rand(n, 3, generator=g) * torch.tensor([1.0, 0.6, 0.3])
-    idx, dist = R.knn(pts.cuda(), k, want_dist=True)
+    if clustered:  # ... and faint floaters spread through the volume (three quarters of a trained ABC model)
+        pts[n // 2:] = torch.rand(n - n // 2, 3, generator=g) * 1.3 - 0.15
+    idx, dist = R.knn(pts.cuda(), k, want_dist=True, method=method)
     d_ref, i_ref = NearestNeighbors(n_neighbors=k + 1, algorithm="auto", metric="euclidean").fit(pts.numpy()).kneighbors(pts.numpy())
     d_ref, i_ref = d_ref[:, 1:], i_ref[:, 1:]  # k_nearest_sklearn drops the point itself (edge_gs.py:151)
     assert np.allclose(to_np(dist), d_ref, rtol=1e-4, atol=1e-7)
     assert (to_np(idx) == i_ref).mean() > 0.999  # equal up to exact distance ties
     # the reference's neighbour set: ranks 2 .. k+1
-    nn = R.reference_nn_indices(pts.cuda(), k - 1)
+    nn = R.reference_nn_indices(pts.cuda(), k - 1, method=method)
     assert nn.shape == (n, k - 1) and (to_np(nn) == i_ref[:, 1:]).mean() > 0.999
+
+
+def test_knn_exhaustive_equals_grid_search(env):
+    """The two searches order candidates by the same (distance, index) key: identical tables, at sizes on either
+    side of the split-count steps of eg_knn_small (1 .. 64 candidate chunks) and with coincident points."""
+    from edgegaussians_amd import regularizers as R
+    g = torch.Generator().manual_seed(5)
+    for n, k in ((1, 3), (2, 1), (7, 6), (63, 8), (300, 6), (5000, 11), (40000, 6)):
+        pts = torch.rand(n, 3, generator=g)
+        if n >= 300:
+            pts[: n // 10] = pts[n // 10: 2 * (n // 10)]  # exact duplicates: distance ties resolved by index
+        pts = pts.cuda()
+        ia, da = R.knn(pts, k, want_dist=True, method="grid")
+        ib, db = R.knn(pts, k, want_dist=True, method="exhaustive")
+        assert torch.equal(ia, ib), (n, k, int((ia != ib).sum()))
+        assert torch.allclose(da, db, rtol=1e-6, atol=0)
+        assert int((ia >= 0).sum(1).min()) == min(k, n - 1)  # fewer than k other points: the tail stays -1
 
 
 def test_direction_and_ratio_losses_match_autograd(env):
@@ -678,8 +700,9 @@ def test_direction_and_ratio_losses_match_autograd(env):
     assert_close(gs, s2.grad, rtol=1e-5, name="ratio dlogscales")
 
 
+@pytest.mark.parametrize("search", ["grid", "exhaustive"])
 @pytest.mark.parametrize("method,k", [("enforce_full", 5), ("enforce_full", 10), ("enforce_half", 5), ("enforce_half", 10)])
-def test_regularisers_match_reference_functions(env, golden_dir, method, k):
+def test_regularisers_match_reference_functions(env, golden_dir, method, k, search):
     """eg_knn / eg_direction_loss / eg_ratio_loss against the REFERENCE's own update_nearest_neighbors,
     compute_direction_loss, compute_ratio_loss (edge_gs.py:326-380: sklearn KD-tree + torch autograd), run in
     the build container on a seeded trained-like state (tests/golden/make_golden.py:regularizers)."""
@@ -689,7 +712,7 @@ def test_regularisers_match_reference_functions(env, golden_dir, method, k):
     means, quats, ls = (torch.from_numpy(d[x]).cuda() for x in ("means", "quats", "log_scales"))
     tag = f"{method}_{k}"
     nn_ref = d[f"nn_{tag}"]
-    nn = R.reference_nn_indices(means, k, method)
+    nn = R.reference_nn_indices(means, k, method, method=search)
     assert nn.shape == nn_ref.shape == (means.shape[0], 2 * k if method == "enforce_half" else k)
     same_rows = (to_np(nn) == nn_ref).all(axis=1)
     # index work: exact, except rows in which two neighbours are equidistant to the last bit (KD-tree vs grid order)
@@ -706,7 +729,7 @@ def test_regularisers_match_reference_functions(env, golden_dir, method, k):
     e["gscales"] = rel_err(gs, d["ratio_gscales"])
     assert e["ratio"] < 1e-5
     assert_close(gs, d["ratio_gscales"], rtol=1e-5, name="ratio dlogscales")
-    record("regularisers_vs_reference_functions", method=method, k=k, nn_rows_identical=float(same_rows.mean()), max_rel_err=e)
+    record("regularisers_vs_reference_functions", method=method, k=k, search=search, nn_rows_identical=float(same_rows.mean()), max_rel_err=e)
 
 
 def test_regulariser_step_advances_only_three_optimizers(env):
@@ -1260,6 +1283,22 @@ def test_device_weight_maps_match_the_host_construction(env):
         assert int(torch.nonzero(picked.view(-1)).max()) < hw - n_e
     a, b = tr.weight_map(1, "bg_edge_ratio", 1.0), tr.weight_map(1, "bg_edge_ratio", 1.0)
     assert not torch.equal(a, b), "every call draws a fresh sample"
+    # the sample is uniform over [0, #bg): over D draws every pixel is hit ~ D n_sel / n_bg times (binomial)
+    D, n_bg = 400, hw - n_e
+    hits = torch.zeros(hw)
+    for _ in range(D):
+        hits += (tr.weight_map(1, "bg_edge_ratio", 1.0).cpu().view(-1) - edge.float().view(-1) / n_e > 0.5 / n_e).float()
+    p = n_e / n_bg
+    mean, sd = D * p, math.sqrt(D * p * (1 - p))
+    z = (hits[:n_bg] - mean) / sd
+    assert float(hits[n_bg:].sum()) == 0
+    assert abs(float(z.mean())) < 0.05 and 0.9 < float(z.std()) < 1.1, (float(z.mean()), float(z.std()))
+    assert float(z.abs().max()) < 6.0
+    # ... and consecutive draws are independent: the overlap of two samples is ~ n_sel^2 / n_bg
+    s1 = tr.weight_map(1, "bg_edge_ratio", 1.0).cpu().view(-1) - edge.float().view(-1) / n_e > 0.5 / n_e
+    s2 = tr.weight_map(1, "bg_edge_ratio", 1.0).cpu().view(-1) - edge.float().view(-1) / n_e > 0.5 / n_e
+    both, expect = int((s1 & s2).sum()), n_e * n_e / n_bg
+    assert abs(both - expect) < 6 * math.sqrt(expect) + 3, (both, expect)
 
 
 def test_native_run_of_steps_equals_single_steps(env):
