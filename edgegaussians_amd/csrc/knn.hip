@@ -50,6 +50,12 @@ knn_scatter_kernel(const float *__restrict__ pts, const int *__restrict__ cell_o
       make_float4(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2], __int_as_float(i));
 }
 
+// squared distance with a FIXED rounding sequence: the grid search and the exhaustive search must order
+// near-equidistant candidates identically (the compiler otherwise contracts the sum differently per kernel)
+__device__ __forceinline__ float dist2(float ex, float ey, float ez) {
+  return __fmaf_rn(ez, ez, __fmaf_rn(ey, ey, __fmul_rn(ex, ex)));
+}
+
 // sorted insertion of candidate (d, j) into the K-best list (ties keep the lower index first, like a stable
 // sort on (d, j))
 template <int KMAX>
@@ -114,7 +120,7 @@ knn_query_kernel(const float *__restrict__ pts, int N, int K, Grid g, const int 
             const int j = __float_as_int(c4[u].w);
             if (s + u >= s1 || j == i) continue;
             const float ex = c4[u].x - x, ey = c4[u].y - y, ez = c4[u].z - z;
-            knn_insert<KMAX>(bd, bi, ex * ex + ey * ey + ez * ez, j);
+            knn_insert<KMAX>(bd, bi, dist2(ex, ey, ez), j);
           }
         }
       }
@@ -142,7 +148,7 @@ knn_query_kernel(const float *__restrict__ pts, int N, int K, Grid g, const int 
         const int j = __float_as_int(c4[u].w);
         if (s + u >= N || j == i) continue;
         const float ex = c4[u].x - x, ey = c4[u].y - y, ez = c4[u].z - z;
-        knn_insert<KMAX>(bd, bi, ex * ex + ey * ey + ez * ez, j);
+        knn_insert<KMAX>(bd, bi, dist2(ex, ey, ez), j);
       }
     }
   }
@@ -157,73 +163,77 @@ knn_query_kernel(const float *__restrict__ pts, int N, int K, Grid g, const int 
 // ---------------------------------------------------------------------------------------------
 // Exhaustive search for small N (the ABC-NEF runs end at ~10 k Gaussians, three quarters of them faint floaters
 // spread through the volume while the rest sit on curves: no uniform grid fits both, one isolated query held its
-// whole wave for ~800 us).  N^2 distance evaluations are cheap when the whole chip takes part: workgroup (b, s)
-// answers queries 256 b .. 256 b + 255 against candidate chunk s; every lane of a wave reads the SAME candidate
-// (a wave-uniform address: scalar loads, no LDS), ~10 VALU instructions per pair, K-best list in registers;
-// a second kernel merges the S partial lists of a query.  Same (distance, index) order as the grid search.
-template <int KMAX>
+// whole wave for ~800 us).  N^2 distance evaluations are cheap IF the K-best bookkeeping stays off the common path:
+// with one query per lane, some lane of the wave inserts at nearly every candidate and the whole wave pays the
+// ~65-instruction sorted insertion every time (measured: 0.5 ms at N = 10 k).  So the roles are turned round:
+// a LANE holds a CANDIDATE, a wave owns Q queries (coordinates and the K-th distance so far are wave-uniform),
+// and each query's K-best list is spread over the lanes -- lane k holds the k-th best (distance, index).  A
+// candidate enters the list only if it beats the K-th entry (a ballot; ~K ln(N/K) times per query in total), and
+// then in O(1): every lane compares the newcomer with its own entry and its left neighbour's (one DPP shift) and
+// keeps, takes the newcomer, or takes the neighbour's.  ~11 VALU instructions per (query, 64 candidates) otherwise.
+// Same (distance, index) order as the grid search; K <= 32 <= 64 lanes.
+template <int Q>
 __global__ void __launch_bounds__(256)
-knn_exhaustive_kernel(const float *__restrict__ pts, int N, int chunk, float *__restrict__ part_d,
-                      int *__restrict__ part_i) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  const int s = blockIdx.y;
-  const int q = min(i, N - 1);
-  const float x = pts[3 * q], y = pts[3 * q + 1], z = pts[3 * q + 2];
-  float bd[KMAX];
-  int bi[KMAX];
+knn_wave_kernel(const float *__restrict__ pts, int N, int K, int *__restrict__ out_idx, float *__restrict__ out_d2) {
+  const int lane = threadIdx.x & 63;
+  const int q0 = __builtin_amdgcn_readfirstlane((blockIdx.x * 4 + (threadIdx.x >> 6)) * Q);
+  if (q0 >= N) return;
+  float qx[Q], qy[Q], qz[Q], tau[Q], ld[Q];
+  int lj[Q];
 #pragma unroll
-  for (int k = 0; k < KMAX; ++k) { bd[k] = 3.0e38f; bi[k] = -1; }
-  const int c0 = s * chunk, c1 = min(N, c0 + chunk);
-  int j = c0;
-  for (; j + 8 <= c1; j += 8) {  // eight candidates = 24 consecutive floats per round of scalar loads
-    float c[24];
+  for (int q = 0; q < Q; ++q) {
+    const int qi = min(q0 + q, N - 1);
+    qx[q] = pts[3 * qi]; qy[q] = pts[3 * qi + 1]; qz[q] = pts[3 * qi + 2];
+    tau[q] = 3.0e38f; ld[q] = 3.0e38f; lj[q] = -1;
+  }
+  // Candidate blocks of 64 rows are visited OUTWARD from the queries' own block (b0, b0+1, b0-1, b0+2, ...; wrapping):
+  // when the rows are in spatial (Morton) order -- EdgeTrainer(spatial_order=True) -- the true neighbours come
+  // first, the K-th distance is tight after two or three blocks and almost nothing enters the lists afterwards.
+  // (A plain 0..N scan of spatially sorted rows is the worst case: the candidates close in on the query, and
+  // nearly every one of them beats the K-th so far.)
+  const int nb = (N + 63) >> 6, b0 = q0 >> 6;
+  int cn = min(b0 * 64 + lane, N - 1);
+  float cx = pts[3 * cn], cy = pts[3 * cn + 1], cz = pts[3 * cn + 2];
+  int c0 = b0 * 64;
+  for (int it = 0; it < nb; ++it) {
+    const int c = c0 + lane;
+    const float x = cx, y = cy, z = cz;
+    const int off = (it + 2) >> 1;  // block of the NEXT round: in flight while this one is evaluated
+    int bn = ((it + 1) & 1) ? b0 + off : b0 - off;
+    bn += (bn < 0) ? nb : 0;
+    bn -= (bn >= nb) ? nb : 0;
+    const int c0_next = bn * 64;
+    cn = min(c0_next + lane, N - 1);
+    cx = pts[3 * cn]; cy = pts[3 * cn + 1]; cz = pts[3 * cn + 2];
 #pragma unroll
-    for (int u = 0; u < 24; ++u) c[u] = pts[3 * j + u];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const float ex = c[3 * u] - x, ey = c[3 * u + 1] - y, ez = c[3 * u + 2] - z;
-      const float d = ex * ex + ey * ey + ez * ez;
-      if (j + u != i) knn_insert<KMAX>(bd, bi, d, j + u);
+    for (int q = 0; q < Q; ++q) {
+      const float ex = x - qx[q], ey = y - qy[q], ez = z - qz[q];
+      const float d = dist2(ex, ey, ez);
+      unsigned long long mask = __ballot(c < N && d <= tau[q] && c != q0 + q);
+      while (mask) {
+        const int l = __builtin_ctzll(mask);
+        const float dn = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d), l));
+        const int jn = c0 + l;
+        // left neighbour's entry (lane 0 sees (-inf, -1): the newcomer never sorts before it)
+        const float pd = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(-3.0e38f), __float_as_int(ld[q]),
+                                                                    0x138 /* wave_shr:1 */, 0xf, 0xf, false));
+        const int pj = __builtin_amdgcn_update_dpp(-1, lj[q], 0x138, 0xf, 0xf, false);
+        const bool lt_mine = dn < ld[q] || (dn == ld[q] && jn < lj[q]);
+        const bool lt_prev = dn < pd || (dn == pd && jn < pj);
+        ld[q] = lt_prev ? pd : (lt_mine ? dn : ld[q]);
+        lj[q] = lt_prev ? pj : (lt_mine ? jn : lj[q]);
+        tau[q] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ld[q]), K - 1));
+        mask &= mask - 1;
+        mask &= __ballot(d <= tau[q]);
+      }
     }
+    c0 = c0_next;
   }
-  for (; j < c1; ++j) {
-    const float ex = pts[3 * j] - x, ey = pts[3 * j + 1] - y, ez = pts[3 * j + 2] - z;
-    const float d = ex * ex + ey * ey + ez * ez;
-    if (j != i) knn_insert<KMAX>(bd, bi, d, j);
-  }
-  if (i >= N) return;
 #pragma unroll
-  for (int k = 0; k < KMAX; ++k) {
-    part_d[((size_t)s * KMAX + k) * N + i] = bd[k];
-    part_i[((size_t)s * KMAX + k) * N + i] = bi[k];
-  }
-}
-
-template <int KMAX>
-__global__ void __launch_bounds__(256)
-knn_merge_kernel(const float *__restrict__ part_d, const int *__restrict__ part_i, int N, int K, int S,
-                 int *__restrict__ out_idx, float *__restrict__ out_d2) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= N) return;
-  float bd[KMAX];
-  int bi[KMAX];
-#pragma unroll
-  for (int k = 0; k < KMAX; ++k) {
-    bd[k] = part_d[(size_t)k * N + i];
-    bi[k] = part_i[(size_t)k * N + i];
-  }
-  for (int s = 1; s < S; ++s)
-    for (int k = 0; k < K; ++k) {  // the partial lists are ascending: stop at the first entry that does not enter
-      const float d = part_d[((size_t)s * KMAX + k) * N + i];
-      const int j = part_i[((size_t)s * KMAX + k) * N + i];
-      if (j < 0 || !(d < bd[KMAX - 1] || (d == bd[KMAX - 1] && j < bi[KMAX - 1]))) break;
-      knn_insert<KMAX>(bd, bi, d, j);
-    }
-#pragma unroll
-  for (int k = 0; k < KMAX; ++k)
-    if (k < K) {
-      out_idx[(size_t)i * K + k] = bi[k];
-      if (out_d2) out_d2[(size_t)i * K + k] = bd[k];
+  for (int q = 0; q < Q; ++q)
+    if (q0 + q < N && lane < K) {
+      out_idx[(size_t)(q0 + q) * K + lane] = lj[q];
+      if (out_d2) out_d2[(size_t)(q0 + q) * K + lane] = ld[q];
     }
 }
 
@@ -237,8 +247,9 @@ knn_merge_kernel(const float *__restrict__ part_d, const int *__restrict__ part_
 constexpr int kMaxDirNN = 32;
 __global__ void __launch_bounds__(256)
 direction_loss_kernel(const float *__restrict__ means, const float *__restrict__ quats,
-                      const float *__restrict__ log_scales, const int *__restrict__ nn, int N, int K, int top_k,
-                      float *__restrict__ g_means, float *__restrict__ g_quats, float *__restrict__ sum_out) {
+                      const float *__restrict__ log_scales, const int *__restrict__ nn, int nn_stride, int N, int K,
+                      int top_k, float *__restrict__ g_means, float *__restrict__ g_quats,
+                      float *__restrict__ sum_out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   float acc = 0.f;
   if (i < N) {
@@ -259,7 +270,7 @@ direction_loss_kernel(const float *__restrict__ means, const float *__restrict__
     if (top_k > 0 && top_k < K) {
       float al[kMaxDirNN];
       for (int k = 0; k < K; ++k) {
-        const int j = nn[(size_t)i * K + k];
+        const int j = nn[(size_t)i * nn_stride + k];
         float a = -1.f;
         if (j >= 0) {
           const float dx = px - means[3 * j], dy = py - means[3 * j + 1], dz = pz - means[3 * j + 2];
@@ -279,7 +290,7 @@ direction_loss_kernel(const float *__restrict__ means, const float *__restrict__
       }
     }
     for (int k = 0; k < K; ++k) {
-      const int j = nn[(size_t)i * K + k];
+      const int j = nn[(size_t)i * nn_stride + k];
       if (j < 0 || !((chosen >> k) & 1u)) continue;
       const float dx = px - means[3 * j], dy = py - means[3 * j + 1], dz = pz - means[3 * j + 2];
       const float n2 = dx * dx + dy * dy + dz * dz;
@@ -346,6 +357,21 @@ ratio_loss_kernel(const float *__restrict__ log_scales, int N, float *__restrict
   if ((threadIdx.x & 63) == 0 && acc != 0.f) unsafeAtomicAdd(sum_out, acc);
 }
 
+
+// The tail of a regulariser iteration (train_gaussians.py:108-131) on the device: loss value from the kernel's sum,
+// lambda = (running projection-loss sum) * factor / loss, gradients scaled in place.  Same float32 operation
+// order as the tensor expressions it replaces: loss = 1 + w * sum (direction, w = -1 / (N k)) or sum / N (ratio);
+// g = (raw * w) * lambda or (raw / N) * lambda.
+__global__ void __launch_bounds__(256)
+regulariser_scale_kernel(float *__restrict__ g, size_t n, const float *__restrict__ sum,
+                         const float *__restrict__ loss_sum_dev, float loss_sum_host, float factor, float w,
+                         float n_gauss, int ratio, float *__restrict__ loss_out) {
+  const float loss = ratio ? sum[0] / n_gauss : 1.0f + w * sum[0];
+  const float lam = (loss_sum_dev ? loss_sum_dev[0] * factor : loss_sum_host * factor) / loss;
+  const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i == 0 && loss_out) loss_out[0] = loss;
+  if (i < n) g[i] = (ratio ? g[i] / n_gauss : g[i] * w) * lam;
+}
 }  // namespace eg
 
 using namespace eg;
@@ -385,39 +411,26 @@ extern "C" int eg_knn(const float *points, int32_t N, int32_t K, const float *or
   return check_launch("knn");
 }
 
-// candidate chunks per query block of the exhaustive search: enough workgroups to fill the chip (~4 per CU)
-static int knn_small_splits(int N) {
-  const int blocks = cdiv(N, 256);
-  return max(1, min(min(64, cdiv(N, 64)), cdiv(1024, blocks)));
-}
-
 extern "C" int64_t eg_knn_small_scratch_bytes(int32_t N, int32_t K) {
-  if (N <= 0 || K < 1 || K > 32) return 0;
-  const int kmax = K <= 8 ? 8 : (K <= 16 ? 16 : 32);
-  return (int64_t)knn_small_splits(N) * kmax * N * 8;
+  (void)N; (void)K;
+  return 0;  // (the lists live in registers; kept in the ABI for callers that size a buffer)
 }
 
 extern "C" int eg_knn_small(const float *points, int32_t N, int32_t K, void *scratch, int32_t *out_idx,
                             float *out_d2, eg_stream_t stream) {
+  (void)scratch;
   EG_REQUIRE(N >= 0 && K >= 1 && K <= 32, "bad arguments");
   if (N == 0) return EG_OK;
-  EG_REQUIRE(points && scratch && out_idx, "null pointer");
-  EG_REQUIRE(N <= (1 << 16), "eg_knn_small: N <= 65536 (use the grid search, eg_knn)");
+  EG_REQUIRE(points && out_idx, "null pointer");
+  EG_REQUIRE(N <= (1 << 17), "eg_knn_small: N <= 131072 (use the grid search, eg_knn)");
   hipStream_t st = as_stream(stream);
-  const int S = knn_small_splits(N), chunk = cdiv(N, S);
-  const int kmax = K <= 8 ? 8 : (K <= 16 ? 16 : 32);
-  float *pd = (float *)scratch;
-  int *pi = (int *)(pd + (size_t)S * kmax * N);
-  const dim3 grid(cdiv(N, 256), S);
-#define EG_KNN_SMALL(KM)                                                                                     \
-  do {                                                                                                       \
-    knn_exhaustive_kernel<KM><<<grid, 256, 0, st>>>(points, N, chunk, pd, pi);                                 \
-    knn_merge_kernel<KM><<<cdiv(N, 256), 256, 0, st>>>(pd, pi, N, K, S, out_idx, out_d2);                    \
-  } while (0)
-  if (kmax == 8) EG_KNN_SMALL(8);
-  else if (kmax == 16) EG_KNN_SMALL(16);
-  else EG_KNN_SMALL(32);
-#undef EG_KNN_SMALL
+  // queries per wave: more of them amortise the candidate stream, fewer give the chip more waves
+  if (N >= 16384)
+    knn_wave_kernel<8><<<cdiv(N, 32), 256, 0, st>>>(points, N, K, out_idx, out_d2);
+  else if (N >= 4096)
+    knn_wave_kernel<4><<<cdiv(N, 16), 256, 0, st>>>(points, N, K, out_idx, out_d2);
+  else
+    knn_wave_kernel<2><<<cdiv(N, 8), 256, 0, st>>>(points, N, K, out_idx, out_d2);
   return check_launch("knn_small");
 }
 
@@ -428,7 +441,7 @@ extern "C" int eg_direction_loss(const float *means, const float *quats, const f
   EG_REQUIRE(N >= 0 && K >= 1 && K <= kMaxDirNN, "bad sizes (K <= 32)");
   if (N == 0) return EG_OK;
   EG_REQUIRE(means && quats && log_scales && nn_idx && g_means && g_quats && sum_out, "null pointer");
-  direction_loss_kernel<<<cdiv(N, 256), 256, 0, as_stream(stream)>>>(means, quats, log_scales, nn_idx, N, K, top_k,
+  direction_loss_kernel<<<cdiv(N, 256), 256, 0, as_stream(stream)>>>(means, quats, log_scales, nn_idx, K, N, K, top_k,
                                                                    g_means, g_quats, sum_out);
   return check_launch("direction_loss");
 }
@@ -440,4 +453,43 @@ extern "C" int eg_ratio_loss(const float *log_scales, int32_t N, float *g_scales
   EG_REQUIRE(log_scales && g_scales && sum_out, "null pointer");
   ratio_loss_kernel<<<cdiv(N, 256), 256, 0, as_stream(stream)>>>(log_scales, N, g_scales, sum_out);
   return check_launch("ratio_loss");
+}
+
+// One regulariser iteration of train_gaussians.py:108-131 as ONE native enqueue: zero the gradient blocks, loss
+// kernel (raw gradients + sum), lambda and scaling on the device, Adam step of the means / scales / quats optimizers
+// (hyper.group_steps[3] < 0: the opacity optimizer does not step).  grads: the [11 N] block layout of eg_train_step
+// (means 3N | quats 4N | scales 3N | opacities N).  kind 0 = direction (nn: [N, nn_stride] neighbour table, the K
+// columns from nn_offset on are used; top_k as eg_direction_loss), 1 = ratio.  loss_sum: device scalar (the running
+// projection-loss sum) or NULL -> loss_sum_host.  work: 2 floats of scratch (sum, loss value = work[1] afterwards).
+extern "C" int eg_regulariser_step(int32_t kind, float *means, float *quats, float *log_scales,
+                                   float *logit_opacities, float *adam_m, float *adam_v, float *grads, int32_t N,
+                                   const int32_t *nn, int32_t nn_stride, int32_t nn_offset, int32_t K, int32_t top_k,
+                                   const float *loss_sum, float loss_sum_host, float scale_factor, float *work,
+                                   eg_adam_hyper hyper, eg_stream_t stream) {
+  EG_REQUIRE(N >= 0 && (kind == 0 || kind == 1), "bad arguments");
+  if (N == 0) return EG_OK;
+  EG_REQUIRE(means && quats && log_scales && logit_opacities && adam_m && adam_v && grads && work, "null pointer");
+  hipStream_t st = as_stream(stream);
+  float *gm = grads, *gq = grads + 3 * (size_t)N, *gs = grads + 7 * (size_t)N, *go = grads + 10 * (size_t)N;
+  if (hipMemsetAsync(grads, 0, sizeof(float) * 11 * (size_t)N, st) != hipSuccess ||
+      hipMemsetAsync(work, 0, sizeof(float) * 2, st) != hipSuccess)
+    return check_launch("regulariser_step memset");
+  if (kind == 0) {
+    EG_REQUIRE(nn && K >= 1 && K <= kMaxDirNN && nn_offset >= 0 && nn_offset + K <= nn_stride, "bad neighbour table");
+    direction_loss_kernel<<<cdiv(N, 256), 256, 0, st>>>(means, quats, log_scales, nn + nn_offset, nn_stride, N, K,
+                                                        top_k, gm, gq, work);
+    const int used = (top_k > 0 && top_k < K) ? top_k : K;
+    // means and quats are adjacent blocks: one scaling launch over both
+    regulariser_scale_kernel<<<cdiv(7 * (int64_t)N, 256), 256, 0, st>>>(
+        gm, 7 * (size_t)N, work, loss_sum, loss_sum_host, scale_factor, (float)(-1.0 / ((double)N * used)), (float)N, 0,
+        work + 1);
+  } else {
+    ratio_loss_kernel<<<cdiv(N, 256), 256, 0, st>>>(log_scales, N, gs, work);
+    regulariser_scale_kernel<<<cdiv(3 * (int64_t)N, 256), 256, 0, st>>>(gs, 3 * (size_t)N, work, loss_sum, loss_sum_host,
+                                                                      scale_factor, 0.f, (float)N, 1, work + 1);
+  }
+  int rc = check_launch("regulariser_step");
+  if (rc) return rc;
+  return eg_adam_multi(means, log_scales, quats, logit_opacities, gm, gs, gq, go, adam_m, adam_v, N, hyper, nullptr,
+                       nullptr, stream);
 }

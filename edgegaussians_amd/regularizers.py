@@ -59,21 +59,25 @@ def make_grid(points: Tensor, margin: float = 0.0):
 KNN_EXHAUSTIVE_MAX = 32768
 
 
-def knn(points: Tensor, k: int, want_dist: bool = False, grid=None, method: str = "auto") -> Tuple[Tensor, Tensor]:
+def knn(points: Tensor, k: int, want_dist: bool = False, grid=None, method: str = "auto", out: Tensor = None,
+        scratch: Tensor = None) -> Tuple[Tensor, Tensor]:
     """Indices [N,k] (int32, ascending distance, self excluded) and, optionally, distances [N,k].
     method "auto": exhaustive search for N <= KNN_EXHAUSTIVE_MAX (no host sync at all), else the uniform-grid
     search (one host sync for the bounding box, `make_grid`, unless a grid is passed in) -- where the reference
-    had a full D2H copy + CPU tree build.  "grid" / "exhaustive" force one."""
+    had a full D2H copy + CPU tree build.  "grid" / "exhaustive" force one.  `out` [N,k] int32 / `scratch` (int32,
+    eg_knn_small_scratch_bytes): caller-owned buffers of the exhaustive search (a training loop reuses them)."""
     assert points.is_cuda and points.dtype == torch.float32 and points.dim() == 2 and points.shape[1] == 3
     assert 1 <= k <= 32
     pts = points.detach().contiguous()
     N = pts.shape[0]
     dev = pts.device
     if method == "exhaustive" or (method == "auto" and N <= KNN_EXHAUSTIVE_MAX):
-        idx = torch.empty(N, k, dtype=torch.int32, device=dev)
+        idx = torch.empty(N, k, dtype=torch.int32, device=dev) if out is None else out
+        assert idx.shape == (N, k) and idx.dtype == torch.int32 and idx.is_contiguous()
         d2 = torch.empty(N, k, device=dev) if want_dist else None
         nbytes = int(load().eg_knn_small_scratch_bytes(N, k))
-        scratch = torch.empty(max(nbytes, 8) // 4, dtype=torch.int32, device=dev)
+        if scratch is None or scratch.numel() * 4 < nbytes:
+            scratch = torch.empty(max(nbytes, 8) // 4, dtype=torch.int32, device=dev)
         call("eg_knn_small", ptr(pts), N, k, ptr(scratch), ptr(idx), ptr(d2) if d2 is not None else None, stream())
         return idx, (d2.sqrt() if d2 is not None else None)
     lo_h, cell, dims = grid if grid is not None else make_grid(pts)
@@ -82,7 +86,7 @@ def knn(points: Tensor, k: int, want_dist: bool = False, grid=None, method: str 
     counts = torch.zeros(ncell, dtype=torch.int32, device=dev)
     start = torch.empty(ncell + 1, dtype=torch.int32, device=dev)
     order = torch.empty(N, 4, device=dev)  # the points in cell order: x y z index
-    idx = torch.empty(N, k, dtype=torch.int32, device=dev)
+    idx = torch.empty(N, k, dtype=torch.int32, device=dev) if out is None else out
     d2 = torch.empty(N, k, device=dev) if want_dist else None
     origin = (C.c_float * 3)(*lo_h)
     cdims = (C.c_int32 * 3)(*dims)

@@ -36,8 +36,10 @@ def _anneal(cfg: Dict, key: str, step: int, max_steps: int) -> float:
 
 def train_epoch(tr: EdgeTrainer, views: Iterable[int], epoch: int, num_epochs: int, projection_cfg: Dict,
                 orientation_cfg: Dict, edge_threshold: float = 0.5,
-                generator: Optional[torch.Generator] = None) -> float:
-    """train_gaussians.py:17-141 for one epoch; returns the average projection loss."""
+                generator: Optional[torch.Generator] = None, read_back: bool = True) -> Optional[float]:
+    """train_gaussians.py:17-141 for one epoch; returns the average projection loss -- or, with read_back=False,
+    parks the epoch's loss sum on the device (EdgeTrainer.mark_epoch, no host sync) and returns the number of
+    iterations; the caller collects the sums of several epochs with one `pop_losses()`."""
     ratio = _anneal(projection_cfg, "bg_edge_pixel_ratio", epoch, num_epochs)
     tr.loss_scale = float(_anneal({"lambda_annealing": projection_cfg["lambda_annealing"],
                                    "lambda_start": projection_cfg["lambda_start"],
@@ -78,14 +80,24 @@ def train_epoch(tr: EdgeTrainer, views: Iterable[int], epoch: int, num_epochs: i
             if apply_ratio:
                 tr.regulariser_step("ratio", None, orientation_cfg["ratio_loss_scale_factor"], want_value=False)
     flush_steps()
+    if not read_back:
+        tr.mark_epoch()
+        return n
     return tr.pop_loss() / max(n, 1)
 
 
 def train(tr: EdgeTrainer, model_cfg: Dict, training_cfg: Dict, view_order: Callable[[int], Iterable[int]],
           edge_masks_u8: Optional[torch.Tensor] = None, on_epoch: Optional[Callable[[int, float, int], None]] = None,
-          generator: Optional[torch.Generator] = None, num_epochs: Optional[int] = None) -> List[float]:
+          generator: Optional[torch.Generator] = None, num_epochs: Optional[int] = None,
+          sync_every: int = 8) -> List[float]:
     """train_gaussians.py:144-222.  `model_cfg` / `training_cfg` are the reference's JSON sections;
-    `edge_masks_u8` [V,H,W] (gt >= threshold) is needed only for the not-projecting cull."""
+    `edge_masks_u8` [V,H,W] (gt >= threshold) is needed only for the not-projecting cull.
+
+    The host reads the device back (loss sums, sticky overflow flag, launch-shape hints: ONE small copy) only every
+    `sync_every` epochs, before every densify / cull event and at the end; in between the epochs are enqueued
+    back to back with their loss sums parked on the device, so the host prepares epoch e + 1 while the device still
+    runs epoch e.  `on_epoch(epoch, avg_loss, N)` is therefore called late -- in order, at the next read-back.
+    sync_every = 1 is the reference's cadence (one read-back per epoch)."""
     loss_cfg = training_cfg["loss"]
     proj_cfg, orient_cfg = loss_cfg["projection_losses"], loss_cfg["orientation_losses"]
     num_epochs = training_cfg["num_epochs"] if num_epochs is None else num_epochs
@@ -94,10 +106,30 @@ def train(tr: EdgeTrainer, model_cfg: Dict, training_cfg: Dict, view_order: Call
     thr = get("edge_detection_threshold", 0.5)
     if tr.capacity == 0:
         tr.ensure_capacity()
-    history = []
+    history: List[float] = []
+    parked: List = []  # (epoch, iterations) of the epochs whose loss sums are still on the device
+    ready: List = []  # [epoch, N] read back, on_epoch not yet called (it reports N AFTER the epoch's events)
+    events = set()
+    for flag, key in (("if_duplicate_high_pos_grad", "dup_high_pos_grads_at_epoch"),
+                      ("if_cull_gaussians_not_projecting", "cull_gaussians_not_projecting_at_epoch"),
+                      ("if_cull_low_opacity", "cull_opacity_at_epoch")):
+        if get(flag, True):
+            events.update(get(key, []))
+
+    def read_back():
+        sums, _rest = tr.pop_losses()
+        assert len(sums) == len(parked)
+        for (e, n), sm in zip(parked, sums):
+            history.append(sm / max(n, 1))
+            ready.append([e, tr.N])
+        ready[-1][1] = None  # the epoch that just ran: its events (below) may still change N
+        parked.clear()
+
     for epoch in range(num_epochs):
-        avg = train_epoch(tr, view_order(epoch), epoch, num_epochs, proj_cfg, orient_cfg, thr, generator)
-        history.append(avg)
+        n = train_epoch(tr, view_order(epoch), epoch, num_epochs, proj_cfg, orient_cfg, thr, generator, read_back=False)
+        parked.append((epoch, n))
+        if len(parked) >= max(1, sync_every) or epoch in events or epoch == num_epochs - 1 or len(tr._journal) > 4096:
+            read_back()
         changed = False
         if get("if_duplicate_high_pos_grad", True) and epoch in get("dup_high_pos_grads_at_epoch", []):
             kind = get("dup_threshold_type", "percentile")
@@ -129,5 +161,7 @@ def train(tr: EdgeTrainer, model_cfg: Dict, training_cfg: Dict, view_order: Call
                 tr.spatial_sort()        # new rows were appended / rows were dropped: restore the layout
             tr.ensure_capacity()         # N changed: re-size the isect buffers (one count-only sweep)
         if on_epoch:
-            on_epoch(epoch, avg, tr.N)
+            for e, n_e in ready:
+                on_epoch(e, history[e], tr.N if n_e is None else n_e)
+        ready.clear()
     return history

@@ -177,7 +177,11 @@ class EdgeTrainer:
         self.render, self.alphas, self.vpix = img(), img(), img()
         self.gtstop = torch.zeros(H, W, 3, device=d)  # {vpix * T_final, stop id, stop depth bits} for the fused backward
         self.last_ids = img(dtype=torch.int32)
-        self.loss_acc = torch.zeros(1, device=d)
+        # running projection-loss sum (what the step kernels add to) + the parked sums of the epochs marked since the
+        # last read-back (mark_epoch); one buffer: one device->host copy reads them all
+        self._loss_buf = torch.zeros(1 + 64, device=d)
+        self.loss_acc = self._loss_buf[:1]
+        self._n_marks = 0
 
     def _alloc_isect(self, capacity: int, seg_cap: int = 0):
         """capacity: upper bound on the tile intersections of one view (sizes the item workspace);
@@ -498,7 +502,7 @@ class EdgeTrainer:
         return self._batched_raw(list(views), list(wmaps), False, slot)
 
     # ------------------------------------------------------------------ overflow: journal, snapshot, replay
-    _SNAP_TENSORS = ("means", "log_scales", "quats", "logit_opacities", "adam_m", "adam_v", "absgrads")
+    _SNAP_TENSORS = ("means", "log_scales", "quats", "logit_opacities", "adam_m", "adam_v", "absgrads", "loss_acc")
 
     def _snapshot(self) -> None:
         self._snap = {k: getattr(self, k).clone() for k in self._SNAP_TENSORS}
@@ -548,14 +552,15 @@ class EdgeTrainer:
             self.total.zero_()
             for b in self._batches.values():
                 b["total"].zero_()
-            self.loss_acc.zero_()
-            self._restore()
+            self._restore()  # (the running loss sum included)
             for kind, view, wmap, epoch, ls in journal:
                 self.epoch, self.loss_scale = epoch, ls
                 if kind == "1":
                     self._step_raw(view, wmap)
                 elif kind == "r":
                     self._regulariser_raw(view, self.loss_acc[0], *wmap)
+                elif kind == "e":
+                    self._mark_raw(view)
                 else:
                     self._batched_raw(view, wmap, True)
             if not self.overflowed() and not self._rewalk_missed():
@@ -566,9 +571,28 @@ class EdgeTrainer:
     def flush(self) -> None:
         """Drain the stream, verify that no step since the last read-back overflowed (repairing it if one
         did) and forget the journal.  Every operation that changes the state outside train_step calls it."""
-        if self.overflowed() or self._rewalk_missed():
+        r = self._read_words()
+        if r["overflow"] or r["missed"]:
             self._recover_from_overflow()
         self._journal.clear()
+
+    # ------------------------------------------------------------------ epoch marks (no host sync)
+    def _mark_raw(self, k: int) -> None:
+        self._loss_buf[1 + k:2 + k].copy_(self.loss_acc)
+        self.loss_acc.zero_()
+
+    def mark_epoch(self) -> int:
+        """Device-side end of an epoch: park the running projection-loss sum in the next slot and zero the
+        accumulator -- no read-back.  `pop_losses()` later returns the parked sums in order.  The mark is journalled
+        like a step, so an overflow replay across several epochs reproduces every sum."""
+        k = self._n_marks
+        if 1 + k >= self._loss_buf.numel():
+            raise RuntimeError("mark_epoch: 64 epochs are parked; call pop_losses()")
+        self._mark_raw(k)
+        if self.replay_on_overflow and self._journal:
+            self._journal.append(("e", k, None, self.epoch, self.loss_scale))
+        self._n_marks = k + 1
+        return k
 
     def train_step_staged(self, view: int, wmap: Tensor, mark=None) -> None:
         """The same step as ``train_step`` but sequenced from Python, one C-ABI call per stage, with
@@ -664,13 +688,22 @@ class EdgeTrainer:
         the means, the one thing that needs the host) is refreshed at most once per epoch and N, inflated by 10 %:
         a mean that drifts out of it is clamped into a boundary cell, which keeps the search exact."""
         from . import regularizers as R
-        if self.N <= R.KNN_EXHAUSTIVE_MAX:  # exhaustive search over the whole chip: no grid, no host sync
-            self.nn_indices = R.reference_nn_indices(self.means, dir_loss_num_nn, enforce_method)
-            return self.nn_indices
-        key = (self.epoch, self.N)
-        if getattr(self, "_knn_grid_key", None) != key:
-            self._knn_grid, self._knn_grid_key = R.make_grid(self.means, margin=0.1), key
-        self.nn_indices = R.reference_nn_indices(self.means, dir_loss_num_nn, enforce_method, self._knn_grid)
+        n = 2 * dir_loss_num_nn + 1 if enforce_method == "enforce_half" else dir_loss_num_nn + 1
+        buf = self.__dict__.get("_knn_buf")
+        if buf is None or buf[0].shape != (self.N, n):  # the table (+ scratch of the exhaustive search) is reused
+            nbytes = int(_lib.load().eg_knn_small_scratch_bytes(self.N, n)) if self.N <= R.KNN_EXHAUSTIVE_MAX else 8
+            buf = (torch.empty(self.N, n, dtype=torch.int32, device=self.dev),
+                   torch.empty(max(nbytes, 8) // 4, dtype=torch.int32, device=self.dev))
+            self._knn_buf = buf
+        grid = None
+        if self.N > R.KNN_EXHAUSTIVE_MAX:
+            key = (self.epoch, self.N)
+            if getattr(self, "_knn_grid_key", None) != key:
+                self._knn_grid, self._knn_grid_key = R.make_grid(self.means, margin=0.1), key
+            grid = self._knn_grid
+        R.knn(self.means, n, grid=grid, out=buf[0], scratch=buf[1])
+        self.nn_table = buf[0]              # [N, n]: k_nearest_sklearn's table (self excluded)
+        self.nn_indices = buf[0][:, 1:]     # the reference then drops the nearest neighbour too (edge_gs.py:342)
         return self.nn_indices
 
     def regulariser_step(self, kind: str, avg_loss_sum=None, scale_factor: float = 0.01,
@@ -698,58 +731,78 @@ class EdgeTrainer:
         return float(loss) if want_value else loss
 
     def _regulariser_raw(self, kind, avg_loss_sum, scale_factor, dir_loss_num_nn, enforce_method):
-        from . import regularizers as R
-        N = self.N
-        gm, gq, gs, go = self.grad_views()
-        self.grads.zero_()
+        """kNN (direction) + ONE native enqueue (eg_regulariser_step: loss, lambda on the device, backward, Adam).
+        avg_loss_sum: a device scalar tensor or a host float.  Returns the loss value as a device scalar."""
+        if kind not in ("direction", "ratio"):
+            raise ValueError(f"unknown regulariser: {kind}")
+        K = top_k = 0
+        nn = None
         if kind == "direction":
             self.update_nearest_neighbors(dir_loss_num_nn, enforce_method)
-            loss, dm, dq = R.direction_loss(self.means, self.quats, self.log_scales, self.nn_indices,
-                                            dir_loss_num_nn if enforce_method == "enforce_half" else 0)
-            lam = avg_loss_sum * scale_factor / loss  # device scalar (or host float / device scalar)
-            gm.copy_(dm * lam)
-            gq.copy_(dq * lam)
-        elif kind == "ratio":
-            loss, ds = R.ratio_loss(self.log_scales)
-            lam = avg_loss_sum * scale_factor / loss
-            gs.copy_(ds * lam)
-        else:
-            raise ValueError(f"unknown regulariser: {kind}")
+            nn, K = self.nn_table, self.nn_table.shape[1] - 1
+            top_k = dir_loss_num_nn if enforce_method == "enforce_half" else 0
         self.group_steps = [self.group_steps[0] + 1, self.group_steps[1] + 1, self.group_steps[2] + 1,
                             self.group_steps[3]]
         self._set_hyper()
         self._hyper.group_steps[3] = -1  # the opacity optimizer does not step here (train_gaussians.py:116-119)
-        call("eg_adam_multi", ptr(self.means), ptr(self.log_scales), ptr(self.quats), ptr(self.logit_opacities),
-             ptr(gm), ptr(gs), ptr(gq), ptr(go), ptr(self.adam_m), ptr(self.adam_v), N, self._hyper, None, None,
-             stream())
-        return loss
+        work = self.__dict__.get("_reg_work")
+        if work is None:
+            work = self._reg_work = torch.zeros(2, device=self.dev)
+        dev_sum = isinstance(avg_loss_sum, Tensor)
+        call("eg_regulariser_step", 0 if kind == "direction" else 1, ptr(self.means), ptr(self.quats),
+             ptr(self.log_scales), ptr(self.logit_opacities), ptr(self.adam_m), ptr(self.adam_v), ptr(self.grads), self.N,
+             ptr(nn) if nn is not None else None, K + 1, 1, K, top_k, ptr(avg_loss_sum) if dev_sum else None,
+             0.0 if dev_sum else float(avg_loss_sum), float(scale_factor), ptr(work), self._hyper, stream())
+        return work[1]
 
     # ------------------------------------------------------------------ read-backs (these sync)
-    def pop_loss(self) -> float:
-        """Sum of the projection losses since the last call (the reference's avg_loss numerator,
-        train_gaussians.py:99) -- ONE device sync for many steps instead of two per step."""
-        v = float(self.loss_acc.item())
-        m_last, ovf, _items, tile_max = self._totals()
-        if ovf or self._rewalk_missed():  # sticky flags: SOME step since the last read-back must be repeated
+    def _read_words(self) -> Dict:
+        """ONE device->host copy (one sync) of every word the host looks at between runs of steps: the loss sums,
+        (M, sticky overflow flag, items, largest tile) and the re-walk control words (longest exact-stop list seen,
+        missed-re-walk flag) of the single-view buffers and of every batched set in use."""
+        o = 4 * (self.T + self.max_items + 2)
+        n = 1 + self._n_marks
+        parts = [self._loss_buf[:n].view(torch.int32), self.total, self.workspace[o:o + 8].view(torch.int32)]
+        for b in self._batches.values():
+            parts.append(b["total"].max(dim=0).values)
+            parts.append(b["workspace"][:, o:o + 8].contiguous().view(torch.int32).view(-1, 2).max(dim=0).values)
+        host = torch.cat(parts).cpu()
+        sums = host[:n].view(torch.float32).tolist()
+        words = host[n:].tolist()
+        tot, seen, missed = words[0:4], words[4], words[5]
+        batch_seen = []
+        for i in range(len(self._batches)):
+            w = words[6 + 6 * i:12 + 6 * i]
+            tot = [max(a, x) for a, x in zip(tot, w[:4])]
+            batch_seen.append(w[4])
+            missed = max(missed, w[5])
+        return {"acc": sums[0], "marks": sums[1:], "m_last": tot[0], "overflow": tot[1] != 0, "tile_max": tot[3],
+                "seen": seen, "batch_seen": batch_seen, "missed": missed != 0}
+
+    def _sync_state(self) -> Dict:
+        """The read-back between runs of steps: checks the sticky flags (replaying the journalled steps when one is
+        raised), forgets the journal, zeroes the loss sums and refreshes launch-shape hints and buffer sizes."""
+        r = self._read_words()
+        if r["overflow"] or r["missed"]:  # sticky flags: SOME step since the last read-back must be repeated
             self._recover_from_overflow()  # raises IsectOverflow when the steps cannot be replayed
-            v = float(self.loss_acc.item())
-            m_last, _, _items, tile_max = self._totals()
+            r = self._read_words()
         self._journal.clear()
         self.loss_acc.zero_()
+        self._n_marks = 0
         # the stream is drained anyway: refresh the launch-shape hints -- the longest exact-stop re-walk list since
         # the last read-back (control word 2 of the compositing workspace) ...
-        ctl2 = self.workspace[4 * (self.T + self.max_items + 2):4 * (self.T + self.max_items + 3)].view(torch.int32)
-        seen = int(ctl2.item())
-        ctl2.zero_()
-        if seen != self.rewalk_hint:
-            self.rewalk_hint = seen
+        o = 4 * (self.T + self.max_items + 2)
+        if r["seen"]:
+            self.workspace[o:o + 4].zero_()
+        if r["seen"] != self.rewalk_hint:
+            self.rewalk_hint = r["seen"]
             self._args_cache = {}
-        for b in self._batches.values():
-            o = 4 * (self.T + self.max_items + 2)
-            w2 = b["workspace"][:, o:o + 4].contiguous().view(torch.int32)
-            b["rewalk_hint"] = int(w2.max().item())
-            b["workspace"][:, o:o + 4].zero_()
+        for b, seen in zip(self._batches.values(), r["batch_seen"]):
+            b["rewalk_hint"] = seen
+            if seen:
+                b["workspace"][:, o:o + 4].zero_()
         # ... and the tile-sort launch hint from the last step's scan
+        m_last, tile_max = r["m_last"], r["tile_max"]
         if tile_max > getattr(self, "max_tile_seen", 0):
             self.max_tile_seen = tile_max
             self._args_cache = {}
@@ -764,7 +817,19 @@ class EdgeTrainer:
             cap = int(m_last * 1.5) + 4096
         if seg != self.seg_cap or cap != self.capacity:
             self._alloc_isect(cap, seg)
-        return v
+        return r
+
+    def pop_loss(self) -> float:
+        """Sum of the projection losses since the last read-back (the reference's avg_loss numerator,
+        train_gaussians.py:99) -- ONE device sync for many steps instead of two per step."""
+        r = self._sync_state()
+        return float(sum(r["marks"]) + r["acc"])
+
+    def pop_losses(self):
+        """(sums of the epochs parked by mark_epoch since the last read-back, in order; the sum of the steps after the
+        last mark) -- one device sync for many EPOCHS."""
+        r = self._sync_state()
+        return [float(x) for x in r["marks"]], float(r["acc"])
 
     def _totals(self):
         """(M, sticky overflow flag, items, largest tile) of the last step(s): single-view buffers and, when a

@@ -328,6 +328,17 @@ int eg_direction_loss(const float *means, const float *quats, const float *log_s
 int eg_ratio_loss(const float *log_scales, int32_t N, float *g_scales /*[N,3] written*/, float *sum_out,
                   eg_stream_t stream);
 
+/* One regulariser iteration of train_gaussians.py:108-131 as one native enqueue: loss ('direction' kind 0 /
+ * 'ratio' kind 1), lambda = loss_sum * scale_factor / loss formed on the device, backward, and the Adam step of the
+ * means / scales / quats optimizers (set hyper.group_steps[3] < 0: the opacity optimizer does not step there).
+ * grads: [11 N] scratch in the block layout of eg_train_step's gradient buffer.  nn: neighbour table [N, nn_stride];
+ * columns nn_offset .. nn_offset + K - 1 are used (the reference drops the nearest one, edge_gs.py:342).
+ * loss_sum: device scalar or NULL (then loss_sum_host).  work: [2] floats; work[1] = the loss value afterwards. */
+int eg_regulariser_step(int32_t kind, float *means, float *quats, float *log_scales, float *logit_opacities,
+                        float *adam_m, float *adam_v, float *grads, int32_t N, const int32_t *nn, int32_t nn_stride,
+                        int32_t nn_offset, int32_t K, int32_t top_k, const float *loss_sum, float loss_sum_host,
+                        float scale_factor, float *work /*[2]*/, eg_adam_hyper hyper, eg_stream_t stream);
+
 /* ---- the per-pixel loss weights of the 'bg_edge_ratio' strategy (edge_gs.py:298-314 in weight-map form) built on
  * the device: out[p] = [gt_p >= thr] / n_edge + [p among perm[0 .. n_sel)] / n_sel; perm = a random permutation
  * drawn by the caller (int64, distinct, taken modulo HW like the reference's unravel, :303-310). */
