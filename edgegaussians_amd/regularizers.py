@@ -55,8 +55,9 @@ def make_grid(points: Tensor, margin: float = 0.0):
 
 
 # up to this many points the exhaustive search (eg_knn_small: N^2 pairs over the whole chip, no grid, no host sync)
-# beats the grid search, whatever the distribution of the points
-KNN_EXHAUSTIVE_MAX = 32768
+# beats the grid search on trained-like clouds (curves + floaters) and matches it on uniform ones: 0.10 vs 0.27-0.40 ms
+# at 10 k points, 0.29 vs 0.30-0.51 ms at 20 k, 0.48 vs 0.27-0.53 ms at 32 k (tools/bench_regularizers.py)
+KNN_EXHAUSTIVE_MAX = 24576
 
 
 def knn(points: Tensor, k: int, want_dist: bool = False, grid=None, method: str = "auto", out: Tensor = None,

@@ -623,7 +623,7 @@ def test_large_tile_grids_take_the_fallback_binning_paths(env, W, H):
 @pytest.mark.parametrize("method", ["grid", "exhaustive"])
 @pytest.mark.parametrize("k,clustered", [(6, False), (6, True), (16, False), (21, True)])
 def test_knn_matches_sklearn(env, k, clustered, method):
-    """Both searches (uniform grid: eg_knn; exhaustive, the default up to 32 k points: eg_knn_small) against
+    """Both searches (uniform grid: eg_knn; exhaustive, the default up to 24 k points: eg_knn_small) against
     sklearn's KD-tree, which is what the reference calls (edge_gs.py:135-151)."""
     from sklearn.neighbors import NearestNeighbors
     from edgegaussians_amd import regularizers as R

@@ -36,6 +36,32 @@ def main(n=100_000):
     t0 = time.perf_counter()
     NearestNeighbors(n_neighbors=7, algorithm="auto", metric="euclidean").fit(x).kneighbors(x)
     out["sklearn_kdtree_cpu_ms"] = 1e3 * (time.perf_counter() - t0)
+    # the two searches around the switch-over (regularizers.KNN_EXHAUSTIVE_MAX), uniform points and a trained-like
+    # cloud (a quarter of the points on 12 line segments, the rest faint floaters through the volume), rows in
+    # Morton order like EdgeTrainer(spatial_order=True) keeps them
+    from edgegaussians_amd.trainer import EdgeTrainer  # noqa: F401  (Morton helper lives there)
+    rows = []
+    g = torch.Generator().manual_seed(0)
+    for m in (4000, 10000, 20000, 32768, 65536):
+        for kind in ("uniform", "trained-like"):
+            p = torch.rand(m, 3, generator=g)
+            if kind == "trained-like":
+                t = torch.rand(m, 1, generator=g)
+                seg = torch.randint(0, 12, (m,), generator=g)
+                a, b = torch.rand(12, 3, generator=g), torch.rand(12, 3, generator=g)
+                p[: m // 4] = (a[seg] * (1 - t) + b[seg] * t + 0.003 * torch.randn(m, 3, generator=g))[: m // 4]
+            p = p.cuda()
+            q16 = ((p - p.min(0).values) / (p.max(0).values - p.min(0).values + 1e-9) * 1023).long()
+            code = torch.zeros(m, dtype=torch.long, device=p.device)
+            for bit in range(10):
+                for ax in range(3):
+                    code |= ((q16[:, ax] >> bit) & 1) << (3 * bit + ax)
+            p = p[torch.argsort(code)].contiguous()
+            grid = R.make_grid(p)
+            rows.append({"n": m, "points": kind,
+                         "exhaustive_ms": timed(lambda: R.knn(p, 6, method="exhaustive"), 10),
+                         "grid_ms": timed(lambda: R.knn(p, 6, method="grid", grid=grid), 10)})
+    out["knn_k6_by_size"] = rows
     print(json.dumps(out))
 
 

@@ -19,6 +19,7 @@ done
 timeout 300 python bench.py --force-dp --no-cpu-baseline --no-traffic --no-extra 2>/dev/null | tail -1 > $O/bench_config2_force_dp.json
 timeout 300 python tools/bench_regularizers.py 2>/dev/null | tail -1 > $O/regularizers_timing.json
 timeout 300 python tools/train_abc_fixture.py 2>/dev/null | tail -5 > $O/train_abc_fixture.txt
+( echo "--- first run of the process (--cold) ---"; timeout 300 python tools/train_abc_fixture.py --cold 2>/dev/null | tail -2 | head -1 ) >> $O/train_abc_fixture.txt
 cd /tmp && export TMPDIR=/tmp
 for c in config1 config2; do
   rm -rf /tmp/ev_$c /tmp/evsq_$c
