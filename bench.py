@@ -235,7 +235,7 @@ def measure(name, args, device, rank, world, backend, spread=False, steps=None, 
         elif dp is None:
             tr.train_step_batched([(s * vps + i) % n_views for i in range(vps)], [whole] * vps)
         elif vps == 1:  # keep the replicas identical: the pre-warm goes through the all-reduce as well
-            dp.step(egdist.view_for(s, rank, world, n_views), whole)
+            dp.step(egdist.view_for(s, rank, world, n_views), whole, next_view=egdist.view_for(s + 1, rank, world, n_views))
         else:
             dp.step([egdist.view_for(s, rank, world, n_views, vps, i) for i in range(vps)], [whole] * vps)
     torch.cuda.synchronize()
@@ -264,7 +264,8 @@ def measure(name, args, device, rank, world, backend, spread=False, steps=None, 
                 tr.train_step(v, wmap_for(s, v))
             elif vps == 1:
                 v = egdist.view_for(s, rank, world, n_views)
-                dp.step(v, wmap_for(s, v))
+                # the rank knows its next view: the post-reduce Adam also projects + bins it (one launch less)
+                dp.step(v, wmap_for(s, v), next_view=egdist.view_for(s + 1, rank, world, n_views))
             else:  # C views per rank and step: batched launch sequences, first half's all-reduce hidden
                 vs = [egdist.view_for(s, rank, world, n_views, vps, i) for i in range(vps)]
                 dp.step(vs, [wmap_for(s * vps + i, v) for i, v in enumerate(vs)])

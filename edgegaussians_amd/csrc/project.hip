@@ -836,6 +836,56 @@ project_bwd_emit_kernel(float *__restrict__ means, float *__restrict__ quats, fl
                       out, s_mem);
 }
 
+// Data-parallel tail: the four Adam steps on the ALL-REDUCED gradients (what eg_adam_multi does, same arithmetic)
+// and -- with the updated parameters still in registers -- the projection, binning and tile scan of the view this
+// rank rasterises NEXT (the body of project_emit_kernel): the tail fusion of the single-GPU step for the
+// data-parallel leg, one launch and one read of the parameters instead of two.
+template <bool LDS_HIST>
+__global__ void __launch_bounds__(kPE)
+adam_emit_kernel(float *__restrict__ means, float *__restrict__ scales, float *__restrict__ quats,
+                 float *__restrict__ opacities, const float *__restrict__ g_means, const float *__restrict__ g_scales,
+                 const float *__restrict__ g_quats, const float *__restrict__ g_opacities, float *__restrict__ am,
+                 float *__restrict__ av, int N, AdamK hyper, const float *__restrict__ absgrad_inc,
+                 float *__restrict__ absgrads, const float *__restrict__ next_viewmat,
+                 const float *__restrict__ next_K, int width, int height, uint32_t flags, float4 *__restrict__ splat,
+                 int *__restrict__ cursor, int seg_cap, unsigned long long *__restrict__ keys, const SegOut out) {
+  extern __shared__ __attribute__((aligned(16))) int s_mem[];
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = g < N;
+  Raw raw = {};
+  if (live) {
+    raw = load_raw(means, quats, scales, opacities, g);
+    if (absgrads) absgrads[g] += absgrad_inc[g];
+    // moment layout: [means 3N | scales 3N | quats 4N | opacities N]
+    const size_t oM = 0, oS = 3 * (size_t)N, oQ = 6 * (size_t)N, oO = 10 * (size_t)N;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      float m = am[oM + 3 * g + k], v = av[oM + 3 * g + k];
+      adam1(raw.m[k], g_means[3 * g + k], m, v, 0, hyper);
+      means[3 * g + k] = raw.m[k]; am[oM + 3 * g + k] = m; av[oM + 3 * g + k] = v;
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      float m = am[oS + 3 * g + k], v = av[oS + 3 * g + k];
+      adam1(raw.s[k], g_scales[3 * g + k], m, v, 1, hyper);
+      scales[3 * g + k] = raw.s[k]; am[oS + 3 * g + k] = m; av[oS + 3 * g + k] = v;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float m = am[oQ + 4 * g + k], v = av[oQ + 4 * g + k];
+      adam1(raw.q[k], g_quats[4 * g + k], m, v, 2, hyper);
+      quats[4 * g + k] = raw.q[k]; am[oQ + 4 * g + k] = m; av[oQ + 4 * g + k] = v;
+    }
+    {
+      float m = am[oO + g], v = av[oO + g];
+      adam1(raw.o, g_opacities[g], m, v, 3, hyper);
+      opacities[g] = raw.o; am[oO + g] = m; av[oO + g] = v;
+    }
+  }
+  emit_body<LDS_HIST>(raw, live, g, load_cam(next_viewmat, next_K), width, height, flags, splat, cursor, seg_cap, keys,
+                      out, s_mem);
+}
+
 static int launch_project_fwd(const float *means, const float *quats, const float *scales, const float *opacities,
                               const float *viewmat, const float *K, int32_t N, int32_t width, int32_t height,
                               float near_plane, float far_plane, float eps2d, float radius_clip, uint32_t flags,
@@ -1013,6 +1063,37 @@ extern "C" int eg_adam_multi(float *means, float *scales, float *quats, float *o
                                                           g_quats, g_opacities, m, v, N, make_adamk(hyper),
                                                           absgrad_inc, absgrads);
   return check_launch("adam_multi");
+}
+
+extern "C" int eg_adam_emit(float *means, float *scales, float *quats, float *opacities, const float *g_means,
+                            const float *g_scales, const float *g_quats, const float *g_opacities, float *m, float *v,
+                            int32_t N, eg_adam_hyper hyper, const float *absgrad_inc, float *absgrads,
+                            const float *next_viewmat, const float *next_K, int32_t width, int32_t height,
+                            uint32_t flags, float *splat, int32_t *tile_cursor, int32_t seg_cap, uint64_t *keys,
+                            int32_t *item_first, int32_t max_items, int32_t *total, int32_t *ticket,
+                            eg_stream_t stream) {
+  EG_REQUIRE(N > 0 && hyper.step >= 1 && width > 0 && height > 0 && seg_cap > 0 && max_items > 0, "bad sizes / step");
+  EG_REQUIRE(means && scales && quats && opacities && g_means && g_scales && g_quats && g_opacities && m && v &&
+                 next_viewmat && next_K && splat && tile_cursor && keys && item_first && total && ticket,
+             "null pointer");
+  EG_REQUIRE(!absgrads || absgrad_inc, "absgrads needs absgrad_inc");
+  const int T = cdiv(width, kTile) * cdiv(height, kTile);
+  EG_REQUIRE((int64_t)T * seg_cap < (1ll << 31), "T * seg_cap must fit 31 bits");
+  SegOut out;
+  out.item_first = item_first; out.max_items = max_items;
+  out.total = total; out.ticket = ticket;
+  hipStream_t st = as_stream(stream);
+  if (2 * T <= 16384)
+    adam_emit_kernel<true><<<cdiv(N, kPE), kPE, sizeof(int) * 2 * T, st>>>(
+        means, scales, quats, opacities, g_means, g_scales, g_quats, g_opacities, m, v, N, make_adamk(hyper),
+        absgrad_inc, absgrads, next_viewmat, next_K, width, height, flags, (float4 *)splat, tile_cursor, seg_cap,
+        (unsigned long long *)keys, out);
+  else
+    adam_emit_kernel<false><<<cdiv(N, kPE), kPE, 0, st>>>(
+        means, scales, quats, opacities, g_means, g_scales, g_quats, g_opacities, m, v, N, make_adamk(hyper),
+        absgrad_inc, absgrads, next_viewmat, next_K, width, height, flags, (float4 *)splat, tile_cursor, seg_cap,
+        (unsigned long long *)keys, out);
+  return check_launch("adam_emit");
 }
 
 extern "C" int eg_absgrad_accum(const float *means2d_absgrad, int32_t N, float *absgrads, eg_stream_t stream) {

@@ -35,7 +35,7 @@ class GradWorker(Protocol):
     """What the driver needs from a per-rank worker (EdgeTrainer implements it on the GPU)."""
 
     def grad_step(self, view: int, wmap: torch.Tensor) -> torch.Tensor: ...
-    def apply_adam(self) -> None: ...
+    def apply_adam(self, next_view: Optional[int] = None) -> None: ...
 
 
 def init_from_env(backend: Optional[str] = None) -> tuple:
@@ -97,9 +97,12 @@ class DataParallelStep:
         return None
 
     # ------------------------------------------------------------------ one optimizer step
-    def step(self, view: Union[int, Sequence[int]], wmap) -> None:
+    def step(self, view: Union[int, Sequence[int]], wmap, next_view: Optional[int] = None) -> None:
         """`view`, `wmap`: this rank's view (+ weight map) of the step -- or lists of C views / maps, which run
-        as batched launch sequences with the first half's all-reduce hidden behind the second half."""
+        as batched launch sequences with the first half's all-reduce hidden behind the second half.
+        next_view (single-view form): the view this rank takes in the NEXT step, when the caller knows it -- the
+        post-reduce Adam then also projects + bins that view (EdgeTrainer.apply_adam(next_view): one launch instead
+        of two, the tail fusion of the single-GPU step)."""
         if isinstance(view, int):
             grads = self.worker.grad_step(view, wmap)
             e0 = self._mark()
@@ -107,7 +110,10 @@ class DataParallelStep:
             e1 = self._mark()
             if e0 is not None:
                 self._ev.append((e0, e1))
-            self.worker.apply_adam()
+            if next_view is None:
+                self.worker.apply_adam()
+            else:
+                self.worker.apply_adam(next_view=int(next_view))
             return
         views, wmaps = list(view), list(wmap)
         if len(views) == 1 or self.world <= 1:

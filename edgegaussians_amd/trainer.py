@@ -94,6 +94,7 @@ class EdgeTrainer:
         self.overflow_events = 0
         self.rewalk_misses = 0  # replays caused by a transmittance stop while the re-walk launch was being skipped
         self.rewalk_hint = -1  # re-walk list length seen at the last read-back (launch-shape hint; -1 = unknown)
+        self._projected: Optional[int] = None  # view already projected + binned by apply_adam(next_view=...)
         self._ws_tag = 0       # tags of the chained forward (eg_step_args.ws_tag): one fresh value per enqueued step
         self.chained_forward = bool(int(os.environ.get("EG_CHAINED", "1")))
         # noise of duplicate() comes from a dedicated generator seeded with (seed, event number): identical
@@ -156,6 +157,7 @@ class EdgeTrainer:
         self._alloc_per_gaussian()
 
     def _alloc_per_gaussian(self):
+        self._drop_projection()
         N, d = self.N, self.dev
         self.splat = torch.empty(N, 8, device=d)
         self.g2d = torch.empty(N, 8, device=d)  # written (not accumulated) by the footprint backward
@@ -186,6 +188,7 @@ class EdgeTrainer:
     def _alloc_isect(self, capacity: int, seg_cap: int = 0):
         """capacity: upper bound on the tile intersections of one view (sizes the item workspace);
         seg_cap > 0: segmented binning, the key / id arrays hold T fixed segments of seg_cap slots."""
+        self._drop_projection()
         self.capacity = int(capacity)
         self.seg_cap = int(seg_cap)
         n_keys = max(self.T * self.seg_cap, self.capacity)  # (the staged path always uses the classic layout)
@@ -334,6 +337,14 @@ class EdgeTrainer:
         self._ws_tag += n
         return t
 
+    def _drop_projection(self) -> None:
+        """Forget the view pre-projected by apply_adam(next_view=...).  Its binning has counted the tile cursors
+        up and no sort has taken them back down: zero them, so that the next projection starts clean."""
+        if getattr(self, "_projected", None) is not None and getattr(self, "tile_counts", None) is not None:
+            self.tile_counts.zero_()
+            self.ticket.zero_()
+        self._projected = None
+
     def _ctl_words(self):
         """[(max re-walk list length, missed-re-walk flag)] of every compositing workspace in use (one small D2H each)."""
         o = 4 * (self.T + self.max_items + 2)
@@ -385,6 +396,7 @@ class EdgeTrainer:
         self._steps_raw(views, wmaps)
 
     def _steps_raw(self, views, wmaps) -> None:
+        self._drop_projection()
         K = len(views)
         self._advance_all()   # step 0's counts; the native loop advances them by k
         self._set_hyper()
@@ -402,6 +414,7 @@ class EdgeTrainer:
         self.step += K
 
     def _step_raw(self, view: int, wmap: Tensor) -> None:
+        self._drop_projection()
         self._advance_all()
         self._set_hyper()
         call("eg_train_step", C.byref(self._args(view, wmap, True)), stream())
@@ -444,6 +457,7 @@ class EdgeTrainer:
         return b
 
     def _batched_raw(self, views, wmaps, fused_adam: bool, slot: int = 0) -> Tensor:
+        self._drop_projection()
         Cn = len(views)
         if not self.seg_cap:
             raise RuntimeError("train_step_batched needs the segmented binning layout (EdgeTrainer(segmented=True))")
@@ -510,6 +524,7 @@ class EdgeTrainer:
                                  self.epoch, self.loss_scale)
 
     def _restore(self) -> None:
+        self._drop_projection()
         for k in self._SNAP_TENSORS:
             getattr(self, k).copy_(self._snap[k])  # in place: the cached argument block keeps its pointers
         (self.adam_step, gs, self.step, self.absgrads_normalize_factor, self.epoch, self.loss_scale) = self._snap["scalars"]
@@ -660,7 +675,15 @@ class EdgeTrainer:
         blocks) for the data-parallel driver, which all-reduces them and then calls ``apply_adam``."""
         if self.capacity == 0:
             self.ensure_capacity()
-        call("eg_train_step", C.byref(self._args(view, wmap, False)), stream())
+        a = self._args(view, wmap, False)
+        # apply_adam(next_view=view) has already projected + binned this view with the parameters it produced
+        a.have_projection = 1 if (self._projected == view and self.seg_cap) else 0
+        if a.have_projection:
+            self._projected = None  # consumed: the step's sort returns the cursors to zero
+        else:
+            self._drop_projection()
+        call("eg_train_step", C.byref(a), stream())
+        a.have_projection = 0
         self.step += 1
         return self.grads
 
@@ -668,7 +691,10 @@ class EdgeTrainer:
         N, g = self.N, self.grads.view(-1)
         return (g[:3 * N].view(N, 3), g[3 * N:7 * N].view(N, 4), g[7 * N:10 * N].view(N, 3), g[10 * N:11 * N])
 
-    def apply_adam(self) -> None:
+    def apply_adam(self, next_view: Optional[int] = None) -> None:
+        """The four Adam steps on the (all-reduced) gradient buffer.  next_view: the view this rank rasterises next
+        -- Adam and that view's projection + binning then run as ONE launch (eg_adam_emit) and the following
+        `grad_step(next_view)` skips its projection."""
         self._advance_all()
         self._set_hyper()
         c = self._args_cache.get("adam_ptrs")
@@ -677,8 +703,17 @@ class EdgeTrainer:
             c = (ptr(self.means), ptr(self.log_scales), ptr(self.quats), ptr(self.logit_opacities),
                  g0, g0 + 4 * 7 * N, g0 + 4 * 3 * N, g0 + 4 * 10 * N, ptr(self.adam_m), ptr(self.adam_v), g0 + 4 * 11 * N)
             self._args_cache["adam_ptrs"] = c
-        call("eg_adam_multi", c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7], c[8], c[9], self.N, self._hyper,
-             c[10], ptr(self.absgrads), stream())  # += all-reduced absgrad block
+        self._drop_projection()
+        if next_view is not None and self.seg_cap and self.capacity:
+            fl = (_lib.FLAG_LOG_SCALES | _lib.FLAG_LOGIT_OPACITIES | _lib.FLAG_ANTIALIASED | _lib.FLAG_TIGHT_TILES)
+            call("eg_adam_emit", c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7], c[8], c[9], self.N, self._hyper,
+                 c[10], ptr(self.absgrads), self.viewmats.data_ptr() + 64 * next_view, self.Ks.data_ptr() + 36 * next_view,
+                 self.width, self.height, fl, ptr(self.splat), ptr(self.tile_counts), self.seg_cap, ptr(self.keys),
+                 ptr(self.item_offsets), self.max_items, ptr(self.total), ptr(self.ticket), stream())
+            self._projected = int(next_view)
+        else:
+            call("eg_adam_multi", c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7], c[8], c[9], self.N, self._hyper,
+                 c[10], ptr(self.absgrads), stream())  # += all-reduced absgrad block
         self.absgrads_normalize_factor += 1
 
     # ------------------------------------------------------------------ orientation regularisers (8f)
@@ -733,6 +768,7 @@ class EdgeTrainer:
     def _regulariser_raw(self, kind, avg_loss_sum, scale_factor, dir_loss_num_nn, enforce_method):
         """kNN (direction) + ONE native enqueue (eg_regulariser_step: loss, lambda on the device, backward, Adam).
         avg_loss_sum: a device scalar tensor or a host float.  Returns the loss value as a device scalar."""
+        self._drop_projection()
         if kind not in ("direction", "ratio"):
             raise ValueError(f"unknown regulariser: {kind}")
         K = top_k = 0
@@ -885,6 +921,7 @@ class EdgeTrainer:
     def spatial_sort(self) -> None:
         """Permute every per-Gaussian array (parameters, Adam moments, absgrads) into Morton order of
         the current means.  A pure relabelling: the step treats Gaussians independently."""
+        self._drop_projection()
         N = self.N
         if N == 0:
             return

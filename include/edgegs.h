@@ -263,6 +263,17 @@ int eg_adam_multi(float *means, float *scales, float *quats, float *opacities,
                                              all-reduced increment of the data-parallel leg)*/,
                   eg_stream_t stream);
 
+/* The same four Adam steps (identical arithmetic) fused with eg_project_emit of the view this rank rasterises NEXT:
+ * the tail of a data-parallel step (after the all-reduce of the gradients), one launch and one read of the
+ * parameters instead of two.  The step that follows passes eg_step_args.have_projection = 1.  flags as
+ * eg_project_emit; buffers as eg_project_emit (segmented layout). */
+int eg_adam_emit(float *means, float *scales, float *quats, float *opacities,
+                 const float *g_means, const float *g_scales, const float *g_quats, const float *g_opacities,
+                 float *m, float *v, int32_t N, eg_adam_hyper hyper, const float *absgrad_inc, float *absgrads,
+                 const float *next_viewmat, const float *next_K, int32_t width, int32_t height, uint32_t flags,
+                 float *splat, int32_t *tile_cursor, int32_t seg_cap, uint64_t *keys, int32_t *item_first,
+                 int32_t max_items, int32_t *total, int32_t *ticket, eg_stream_t stream);
+
 /* ---- fused G9 + absgrad + Adam: single-GPU training step tail (no gradient exchange needed). */
 int eg_project_bwd_adam(float *means, float *quats, float *scales, float *opacities,
                         const float *viewmat, const float *K, int32_t N, int32_t width, int32_t height,

@@ -496,9 +496,10 @@ def test_data_parallel_leg_on_gpu_single_rank(env):
     sched = LRSchedule(scales_start=0, quats_start=0, opacities_start=0)
     mk = lambda: EdgeTrainer(sc.means, sc.log_scales, sc.quats, sc.logit_opacities, sc.viewmats, sc.Ks, sc.gt,  # noqa: E731
                              sc.width, sc.height, schedule=sched)
-    a, b = mk(), mk()
+    a, b, c = mk(), mk(), mk()
     a.ensure_capacity()
     b.ensure_capacity()
+    c.ensure_capacity()
     sock = socket.socket()
     sock.bind(("127.0.0.1", 0))
     port = sock.getsockname()[1]
@@ -508,11 +509,17 @@ def test_data_parallel_leg_on_gpu_single_rank(env):
     try:
         dp = egdist.DataParallelStep(b)
         dp.world = 2  # force the collective even with one rank
-        for s, v in enumerate([0, 2, 1]):
+        dpc = egdist.DataParallelStep(c)  # ... and with the next view announced: Adam + its projection in one launch
+        dpc.world = 2
+        order = [0, 2, 1, 1, 0]
+        for s, v in enumerate(order):
             w = synth.weight_map("weighted" if s != 1 else "bg_edge_ratio", sc.gt[v],
                                  generator=torch.Generator().manual_seed(s)).cuda()
             a.train_step(v, w)
             dp.step(v, w)
+            # (step 2 announces a view that is NOT the one taken next: the pre-projection must then be ignored)
+            nxt = None if s + 1 >= len(order) else (order[s + 1] if s != 2 else 0)
+            dpc.step(v, w, next_view=nxt)
         torch.cuda.synchronize()
     finally:
         dist.destroy_process_group()
@@ -520,8 +527,13 @@ def test_data_parallel_leg_on_gpu_single_rank(env):
                        (a.logit_opacities, b.logit_opacities, "opac"), (a.absgrads, b.absgrads, "absgrads"),
                        (a.adam_m, b.adam_m, "m"), (a.adam_v, b.adam_v, "v")):
         assert_close(x, y, rtol=1e-6, name=name)
-    assert a.absgrads_normalize_factor == b.absgrads_normalize_factor == 4
-    assert abs(a.pop_loss() - b.pop_loss()) < 1e-6
+    for x, y, name in ((b.means, c.means, "means"), (b.log_scales, c.log_scales, "scales"), (b.quats, c.quats, "quats"),
+                       (b.logit_opacities, c.logit_opacities, "opac"), (b.absgrads, c.absgrads, "absgrads"),
+                       (b.adam_m, c.adam_m, "m"), (b.adam_v, c.adam_v, "v")):
+        assert_close(x, y, rtol=1e-6, name="announced next view: " + name)
+    assert a.absgrads_normalize_factor == b.absgrads_normalize_factor == c.absgrads_normalize_factor == 6
+    la, lb, lc = a.pop_loss(), b.pop_loss(), c.pop_loss()
+    assert abs(la - lb) < 1e-6 and abs(lb - lc) < 1e-6
 
 
 # ------------------------------------------------------------------ edge cases and full-size properties
