@@ -18,10 +18,12 @@ from ._lib import call, load, ptr, stream
 
 
 def make_grid(points: Tensor, margin: float = 0.0):
-    """Uniform search grid over the points' bounding box (one host sync): (origin, cell edge, dims).  With
-    `margin` > 0 the box is inflated by that fraction so that the grid can be REUSED while the points move: a
-    point that leaves the box is clamped into a boundary cell, which keeps the search exact (every cell still
-    lies at least as far from a query as its index distance says) and only costs speed."""
+    """Uniform search grid over the points' bounding box chosen on the HOST (one sync): (origin, cell edge, dims),
+    ~4 points per cell if they fill the box.  Only for callers that want to fix the grid themselves (`knn(...,
+    grid=...)`, the C entry eg_knn); `knn` by default lets the device choose (eg_knn_auto: no sync).  With
+    `margin` > 0 the box is inflated by that fraction so that the grid can be REUSED while the points move: a point
+    that leaves the box is clamped into a boundary cell, which keeps the search exact (every cell still lies at
+    least as far from a query as its index distance says) and only costs speed."""
     pts = points.detach()
     N = pts.shape[0]
     lo_h, hi_h = pts.min(dim=0).values.tolist(), pts.max(dim=0).values.tolist()
@@ -29,70 +31,63 @@ def make_grid(points: Tensor, margin: float = 0.0):
     lo_h = [l - margin * e for l, e in zip(lo_h, ext)]
     ext = [e * (1.0 + 2.0 * margin) for e in ext]
     vol = ext[0] * ext[1] * ext[2]
-    # ~8 points per cell if they fill the box: the 27 cells around a query then hold its K <= 32 neighbours and the
-    # first round settles it (a range look-up costs ~10 candidate evaluations: fewer, fuller cells win)
-    cell = max((vol * 8.0 / max(N, 1)) ** (1.0 / 3.0), max(ext) / 512.0)
-    lo_t = torch.tensor(lo_h, device=pts.device)
-
-    def dims_of(c):
-        return [max(1, min(512, int(math.ceil(e / c)))) for e in ext]
-
-    # trained Gaussians sit on curves, not in the volume: shrink the cells until an OCCUPIED cell holds ~8 points
-    # (a query thread walks every point of the 27 cells around it), within 2^24 cells of scratch
-    for _ in range(4):
-        d = dims_of(cell)
-        ids = ((pts - lo_t) / cell).floor().long().clamp_(min=0)
-        ids = (ids[:, 2].clamp_(max=d[2] - 1) * d[1] + ids[:, 1].clamp_(max=d[1] - 1)) * d[0] + ids[:, 0].clamp_(max=d[0] - 1)
-        occ = N / max(int(torch.unique(ids).numel()), 1)
-        if occ <= 16.0:
-            break
-        smaller = cell * max((8.0 / occ) ** 0.5, 0.25)
-        ds = dims_of(smaller)
-        if smaller < max(ext) / 512.0 or ds[0] * ds[1] * ds[2] > (1 << 24):
-            break
-        cell = smaller
-    return lo_h, float(cell), dims_of(cell)
+    cell = max((vol * 4.0 / max(N, 1)) ** (1.0 / 3.0), max(ext) / 256.0)
+    dims = [max(1, min(256, int(math.ceil(e / cell)))) for e in ext]
+    return lo_h, float(cell), dims
 
 
-# up to this many points the exhaustive search (eg_knn_small: N^2 pairs over the whole chip, no grid, no host sync)
-# beats the grid search on trained-like clouds (curves + floaters) and matches it on uniform ones: 0.10 vs 0.27-0.40 ms
-# at 10 k points, 0.29 vs 0.30-0.51 ms at 20 k, 0.48 vs 0.27-0.53 ms at 32 k (tools/bench_regularizers.py)
-KNN_EXHAUSTIVE_MAX = 24576
+# up to this many points the exhaustive search (eg_knn_small: one launch, N^2 pairs over the whole chip) beats the grid
+# search (six small launches): 35 us against 43-54 us at 4 k points; at 10 k it is 105 against 50-64
+# (tools/bench_regularizers.py)
+KNN_EXHAUSTIVE_MAX = 5000
+_knn_scratch = {}
+
+
+def _grid_buffers(N: int, ncell: int, dev):
+    """cell_of [N], counts [ncell] (zero between calls), start [ncell + 1], order [N,4], 64 bytes of grid scratch --
+    cached per (N, ncell, device): a training loop calls this every few steps with the same sizes."""
+    key = (N, ncell, str(dev))
+    b = _knn_scratch.get(key)
+    if b is None:
+        if len(_knn_scratch) > 8:
+            _knn_scratch.clear()
+        b = (torch.empty(N, dtype=torch.int32, device=dev), torch.zeros(ncell, dtype=torch.int32, device=dev),
+             torch.empty(ncell + 1, dtype=torch.int32, device=dev), torch.empty(N, 4, device=dev),
+             torch.zeros(16, dtype=torch.int32, device=dev))
+        _knn_scratch[key] = b
+    return b
 
 
 def knn(points: Tensor, k: int, want_dist: bool = False, grid=None, method: str = "auto", out: Tensor = None,
         scratch: Tensor = None) -> Tuple[Tensor, Tensor]:
-    """Indices [N,k] (int32, ascending distance, self excluded) and, optionally, distances [N,k].
-    method "auto": exhaustive search for N <= KNN_EXHAUSTIVE_MAX (no host sync at all), else the uniform-grid
-    search (one host sync for the bounding box, `make_grid`, unless a grid is passed in) -- where the reference
-    had a full D2H copy + CPU tree build.  "grid" / "exhaustive" force one.  `out` [N,k] int32 / `scratch` (int32,
-    eg_knn_small_scratch_bytes): caller-owned buffers of the exhaustive search (a training loop reuses them)."""
+    """Indices [N,k] (int32, ascending distance, self excluded) and, optionally, distances [N,k] -- exact, and
+    without a host sync: method "auto" = exhaustive search for N <= KNN_EXHAUSTIVE_MAX (eg_knn_small), else the
+    uniform-grid search on a grid the DEVICE chooses (eg_knn_auto: bounding box by a reduction kernel, cell count a
+    function of N) -- where the reference had a full D2H copy + CPU tree build.  "exhaustive" / "grid" force one;
+    `grid` = a host-chosen grid from `make_grid` (eg_knn).  `out` [N,k] int32: caller-owned result buffer."""
     assert points.is_cuda and points.dtype == torch.float32 and points.dim() == 2 and points.shape[1] == 3
     assert 1 <= k <= 32
     pts = points.detach().contiguous()
     N = pts.shape[0]
     dev = pts.device
-    if method == "exhaustive" or (method == "auto" and N <= KNN_EXHAUSTIVE_MAX):
-        idx = torch.empty(N, k, dtype=torch.int32, device=dev) if out is None else out
-        assert idx.shape == (N, k) and idx.dtype == torch.int32 and idx.is_contiguous()
-        d2 = torch.empty(N, k, device=dev) if want_dist else None
-        nbytes = int(load().eg_knn_small_scratch_bytes(N, k))
-        if scratch is None or scratch.numel() * 4 < nbytes:
-            scratch = torch.empty(max(nbytes, 8) // 4, dtype=torch.int32, device=dev)
-        call("eg_knn_small", ptr(pts), N, k, ptr(scratch), ptr(idx), ptr(d2) if d2 is not None else None, stream())
-        return idx, (d2.sqrt() if d2 is not None else None)
-    lo_h, cell, dims = grid if grid is not None else make_grid(pts)
-    ncell = dims[0] * dims[1] * dims[2]
-    cell_of = torch.empty(N, dtype=torch.int32, device=dev)
-    counts = torch.zeros(ncell, dtype=torch.int32, device=dev)
-    start = torch.empty(ncell + 1, dtype=torch.int32, device=dev)
-    order = torch.empty(N, 4, device=dev)  # the points in cell order: x y z index
     idx = torch.empty(N, k, dtype=torch.int32, device=dev) if out is None else out
+    assert idx.shape == (N, k) and idx.dtype == torch.int32 and idx.is_contiguous()
     d2 = torch.empty(N, k, device=dev) if want_dist else None
-    origin = (C.c_float * 3)(*lo_h)
-    cdims = (C.c_int32 * 3)(*dims)
-    call("eg_knn", ptr(pts), N, k, origin, float(cell), cdims, ptr(cell_of), ptr(counts), ptr(start), ptr(order),
-         ptr(idx), ptr(d2) if d2 is not None else None, stream())
+    d2p = ptr(d2) if d2 is not None else None
+    if method == "exhaustive" or (method == "auto" and grid is None and N <= KNN_EXHAUSTIVE_MAX):
+        call("eg_knn_small", ptr(pts), N, k, None, ptr(idx), d2p, stream())
+    elif grid is None:
+        D = int(load().eg_knn_auto_dims(N, k))
+        cell_of, counts, start, order, gs = _grid_buffers(N, D * D * D, dev)
+        call("eg_knn_auto", ptr(pts), N, k, ptr(cell_of), ptr(counts), ptr(start), ptr(order), ptr(gs), ptr(idx), d2p,
+             stream())
+    else:
+        lo_h, cell, dims = grid
+        cell_of, counts, start, order, _ = _grid_buffers(N, dims[0] * dims[1] * dims[2], dev)
+        origin = (C.c_float * 3)(*lo_h)
+        cdims = (C.c_int32 * 3)(*dims)
+        call("eg_knn", ptr(pts), N, k, origin, float(cell), cdims, ptr(cell_of), ptr(counts), ptr(start), ptr(order),
+             ptr(idx), d2p, stream())
     return idx, (d2.sqrt() if d2 is not None else None)
 
 

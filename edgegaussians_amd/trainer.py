@@ -719,26 +719,16 @@ class EdgeTrainer:
     # ------------------------------------------------------------------ orientation regularisers (8f)
     def update_nearest_neighbors(self, dir_loss_num_nn: int = 5, enforce_method: str = "enforce_full") -> Tensor:
         """`update_nearest_neighbors` (edge_gs.py:326-344) on device; keeps the reference's quirk of
-        skipping the nearest neighbour (see regularizers.reference_nn_indices).  The search grid (bounding box of
-        the means, the one thing that needs the host) is refreshed at most once per epoch and N, inflated by 10 %:
-        a mean that drifts out of it is clamped into a boundary cell, which keeps the search exact."""
+        skipping the nearest neighbour (see regularizers.reference_nn_indices).  No host sync: the search grid
+        (bounding box of the means) is chosen on the device."""
         from . import regularizers as R
         n = 2 * dir_loss_num_nn + 1 if enforce_method == "enforce_half" else dir_loss_num_nn + 1
         buf = self.__dict__.get("_knn_buf")
-        if buf is None or buf[0].shape != (self.N, n):  # the table (+ scratch of the exhaustive search) is reused
-            nbytes = int(_lib.load().eg_knn_small_scratch_bytes(self.N, n)) if self.N <= R.KNN_EXHAUSTIVE_MAX else 8
-            buf = (torch.empty(self.N, n, dtype=torch.int32, device=self.dev),
-                   torch.empty(max(nbytes, 8) // 4, dtype=torch.int32, device=self.dev))
-            self._knn_buf = buf
-        grid = None
-        if self.N > R.KNN_EXHAUSTIVE_MAX:
-            key = (self.epoch, self.N)
-            if getattr(self, "_knn_grid_key", None) != key:
-                self._knn_grid, self._knn_grid_key = R.make_grid(self.means, margin=0.1), key
-            grid = self._knn_grid
-        R.knn(self.means, n, grid=grid, out=buf[0], scratch=buf[1])
-        self.nn_table = buf[0]              # [N, n]: k_nearest_sklearn's table (self excluded)
-        self.nn_indices = buf[0][:, 1:]     # the reference then drops the nearest neighbour too (edge_gs.py:342)
+        if buf is None or buf.shape != (self.N, n):  # the table is reused from call to call
+            buf = self._knn_buf = torch.empty(self.N, n, dtype=torch.int32, device=self.dev)
+        R.knn(self.means, n, out=buf)  # exhaustive (small N) or device-chosen grid: no host sync either way
+        self.nn_table = buf              # [N, n]: k_nearest_sklearn's table (self excluded)
+        self.nn_indices = buf[:, 1:]     # the reference then drops the nearest neighbour too (edge_gs.py:342)
         return self.nn_indices
 
     def regulariser_step(self, kind: str, avg_loss_sum=None, scale_factor: float = 0.01,

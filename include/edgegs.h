@@ -309,14 +309,25 @@ int eg_project_visibility(const float *means, int32_t N, const float *cams /*[V,
 
 /* ---- nearest neighbours + orientation regularisers (train_gaussians.py:108-131).
  * eg_knn: exact K <= 32 nearest neighbours (self excluded, ascending distance, ties by index) of N 3D
- * points on a uniform grid: origin/cell/dims chosen by the caller (bounding box of the points, ~2
- * points per cell).  Scratch: cell_of[N], cell_counts[C] (zero on entry, returned to zero),
+ * points on a uniform grid: origin/cell/dims chosen by the caller (bounding box of the points, a few
+ * points per cell).  A wavefront answers a few cell-ordered queries one after the other: the rows of the query's
+ * block of cells are dealt to groups of lanes, a lane evaluates one candidate per round, the K-best list is spread
+ * over the lanes (insertion = one DPP shift, the same cost for every K).  Scratch: cell_of[N], cell_counts[C] (zero on entry, returned to zero),
  * cell_start[C+1], sorted[N,4] (the points in cell order: x y z index) with C = dims[0]*dims[1]*dims[2].  Replaces k_nearest_sklearn
  * (edge_gs.py:135-151). */
 int eg_knn(const float *points /*[N,3]*/, int32_t N, int32_t K, const float *origin_host /*[3]*/, float cell,
            const int32_t *dims_host /*[3]*/, int32_t *cell_of, int32_t *cell_counts, int32_t *cell_start,
            float *sorted /*[N,4]*/, int32_t *out_idx /*[N,K]*/, float *out_d2 /*[N,K]|NULL squared distances*/,
            eg_stream_t stream);
+
+/* eg_knn_auto: the grid search with the grid chosen on the DEVICE: bounding box by a reduction kernel, D x D x D
+ * cubic cells with D = eg_knn_auto_dims(N, K) (a function of the sizes only, so the caller can size the scratch without
+ * looking at the points) -- no host sync at all.  Scratch: cell_of[N], cell_counts[D^3] (zero on entry, returned to zero),
+ * cell_start[D^3 + 1], sorted[N,4], grid_scratch (64 bytes).  Same result as eg_knn / eg_knn_small. */
+int32_t eg_knn_auto_dims(int32_t N, int32_t K);
+int eg_knn_auto(const float *points /*[N,3]*/, int32_t N, int32_t K, int32_t *cell_of, int32_t *cell_counts,
+                int32_t *cell_start, float *sorted, void *grid_scratch, int32_t *out_idx /*[N,K]*/,
+                float *out_d2 /*[N,K] or NULL*/, eg_stream_t stream);
 
 /* eg_knn_small: the same result (exact K <= 32 neighbours, self excluded, ascending (distance, index)) by
  * exhaustive search, for N <= 131072: no grid, no host-side bounding box.  A lane holds a candidate, a wavefront owns a

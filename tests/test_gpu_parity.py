@@ -632,11 +632,19 @@ def test_large_tile_grids_take_the_fallback_binning_paths(env, W, H):
 
 
 # ------------------------------------------------------------------ 8(f): kNN + orientation regularisers
-@pytest.mark.parametrize("method", ["grid", "exhaustive"])
+def _knn(R, pts, k, method, **kw):
+    """method: "exhaustive" (eg_knn_small), "grid" (eg_knn_auto: grid chosen on the device), "hostgrid" (eg_knn)."""
+    if method == "hostgrid":
+        return R.knn(pts, k, method="grid", grid=R.make_grid(pts, margin=0.05), **kw)
+    return R.knn(pts, k, method=method, **kw)
+
+
+@pytest.mark.parametrize("method", ["grid", "hostgrid", "exhaustive"])
 @pytest.mark.parametrize("k,clustered", [(6, False), (6, True), (16, False), (21, True)])
 def test_knn_matches_sklearn(env, k, clustered, method):
-    """Both searches (uniform grid: eg_knn; exhaustive, the default up to 24 k points: eg_knn_small) against
-    sklearn's KD-tree, which is what the reference calls (edge_gs.py:135-151)."""
+    """The three entries (grid chosen on the device: eg_knn_auto, the default above 5 k points; caller's grid:
+    eg_knn; exhaustive: eg_knn_small) against sklearn's KD-tree, which is what the reference calls
+    (edge_gs.py:135-151)."""
     from sklearn.neighbors import NearestNeighbors
     from edgegaussians_amd import regularizers as R
     g = torch.Generator().manual_seed(11)
@@ -650,30 +658,36 @@ def test_knn_matches_sklearn(env, k, clustered, method):
         pts = torch.rand(n, 3, generator=g) * torch.tensor([1.0, 0.6, 0.3])
     if clustered:  # ... and faint floaters spread through the volume (three quarters of a trained ABC model)
         pts[n // 2:] = torch.rand(n - n // 2, 3, generator=g) * 1.3 - 0.15
-    idx, dist = R.knn(pts.cuda(), k, want_dist=True, method=method)
+    idx, dist = _knn(R, pts.cuda(), k, method, want_dist=True)
     d_ref, i_ref = NearestNeighbors(n_neighbors=k + 1, algorithm="auto", metric="euclidean").fit(pts.numpy()).kneighbors(pts.numpy())
     d_ref, i_ref = d_ref[:, 1:], i_ref[:, 1:]  # k_nearest_sklearn drops the point itself (edge_gs.py:151)
     assert np.allclose(to_np(dist), d_ref, rtol=1e-4, atol=1e-7)
     assert (to_np(idx) == i_ref).mean() > 0.999  # equal up to exact distance ties
     # the reference's neighbour set: ranks 2 .. k+1
-    nn = R.reference_nn_indices(pts.cuda(), k - 1, method=method)
+    nn = R.reference_nn_indices(pts.cuda(), k - 1, method=method.replace("hostgrid", "grid"))
     assert nn.shape == (n, k - 1) and (to_np(nn) == i_ref[:, 1:]).mean() > 0.999
 
 
 def test_knn_exhaustive_equals_grid_search(env):
-    """The two searches order candidates by the same (distance, index) key: identical tables, at sizes on either
-    side of the split-count steps of eg_knn_small (1 .. 64 candidate chunks) and with coincident points."""
+    """The searches order candidates by the same (distance, index) key: identical tables from the exhaustive
+    search, the device-chosen grid and a caller-chosen grid, from one point up to 10^5, with coincident points,
+    and with all points on a line / in one spot (degenerate bounding boxes)."""
     from edgegaussians_amd import regularizers as R
     g = torch.Generator().manual_seed(5)
-    for n, k in ((1, 3), (2, 1), (7, 6), (63, 8), (300, 6), (5000, 11), (40000, 6)):
+    for n, k in ((1, 3), (2, 1), (7, 6), (63, 8), (300, 6), (5000, 11), (40000, 6), (100000, 21), (3000, 4), (3001, 4)):
         pts = torch.rand(n, 3, generator=g)
         if n >= 300:
             pts[: n // 10] = pts[n // 10: 2 * (n // 10)]  # exact duplicates: distance ties resolved by index
+        if n == 3000:
+            pts[:, 1:] = 0.25  # all on one line
+        if n == 3001:
+            pts[:] = pts[0]    # all in one spot: every distance ties
         pts = pts.cuda()
         ia, da = R.knn(pts, k, want_dist=True, method="grid")
         ib, db = R.knn(pts, k, want_dist=True, method="exhaustive")
-        assert torch.equal(ia, ib), (n, k, int((ia != ib).sum()))
-        assert torch.allclose(da, db, rtol=1e-6, atol=0)
+        ic, dc = _knn(R, pts, k, "hostgrid", want_dist=True)
+        assert torch.equal(ia, ib) and torch.equal(ia, ic), (n, k, int((ia != ib).sum()), int((ia != ic).sum()))
+        assert torch.allclose(da, db, rtol=1e-6, atol=0) and torch.allclose(da, dc, rtol=1e-6, atol=0)
         assert int((ia >= 0).sum(1).min()) == min(k, n - 1)  # fewer than k other points: the tail stays -1
 
 

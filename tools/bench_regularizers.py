@@ -36,13 +36,14 @@ def main(n=100_000):
     t0 = time.perf_counter()
     NearestNeighbors(n_neighbors=7, algorithm="auto", metric="euclidean").fit(x).kneighbors(x)
     out["sklearn_kdtree_cpu_ms"] = 1e3 * (time.perf_counter() - t0)
-    # the two searches around the switch-over (regularizers.KNN_EXHAUSTIVE_MAX), uniform points and a trained-like
+    # the two searches around the switch-over (regularizers.KNN_EXHAUSTIVE_MAX) and at scale (grid chosen on the
+    # device, eg_knn_auto; K = 6 as ABC / DTU, K = 11 as Replica's dir_loss_num_nn = 10), uniform points and a trained-like
     # cloud (a quarter of the points on 12 line segments, the rest faint floaters through the volume), rows in
     # Morton order like EdgeTrainer(spatial_order=True) keeps them
     from edgegaussians_amd.trainer import EdgeTrainer  # noqa: F401  (Morton helper lives there)
     rows = []
     g = torch.Generator().manual_seed(0)
-    for m in (4000, 10000, 20000, 32768, 65536):
+    for m in (2000, 4000, 10000, 32768, 100000, 500000):
         for kind in ("uniform", "trained-like"):
             p = torch.rand(m, 3, generator=g)
             if kind == "trained-like":
@@ -57,10 +58,10 @@ def main(n=100_000):
                 for ax in range(3):
                     code |= ((q16[:, ax] >> bit) & 1) << (3 * bit + ax)
             p = p[torch.argsort(code)].contiguous()
-            grid = R.make_grid(p)
             rows.append({"n": m, "points": kind,
-                         "exhaustive_ms": timed(lambda: R.knn(p, 6, method="exhaustive"), 10),
-                         "grid_ms": timed(lambda: R.knn(p, 6, method="grid", grid=grid), 10)})
+                         "exhaustive_ms": timed(lambda: R.knn(p, 6, method="exhaustive"), 10) if m <= 65536 else None,
+                         "grid_ms": timed(lambda: R.knn(p, 6, method="grid"), 10),
+                         "grid_k11_ms": timed(lambda: R.knn(p, 11, method="grid"), 10)})
     out["knn_k6_by_size"] = rows
     print(json.dumps(out))
 
