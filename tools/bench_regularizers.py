@@ -18,13 +18,17 @@ def main(n=100_000):
     q, ls = sc.quats.cuda(), sc.log_scales.cuda()
 
     def timed(fn, reps):
+        """median of `reps` synchronised calls, ms (a first call after an allocation can take milliseconds)"""
+        fn()
         fn()
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
+        ts = []
         for _ in range(reps):
+            t0 = time.perf_counter()
             fn()
-        torch.cuda.synchronize()
-        return 1e3 * (time.perf_counter() - t0) / reps
+            torch.cuda.synchronize()
+            ts.append(1e3 * (time.perf_counter() - t0))
+        return sorted(ts)[len(ts) // 2]
 
     nn = R.reference_nn_indices(pts, 5)
     out = {"n": n,
