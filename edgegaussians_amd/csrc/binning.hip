@@ -318,6 +318,11 @@ tile_sort_kernel(unsigned long long *__restrict__ keys, const int *__restrict__ 
   for (int tile = blockIdx.x; tile < T; tile += gridDim.x) {
   __syncthreads();
   long long start, end;
+  // Segmented layout: the tile's keys sit at a FIXED address, so the first key of every thread is requested before
+  // the population is known (one round trip to memory instead of two: most tiles hold fewer keys than the workgroup
+  // has threads); a slot beyond the population holds a stale key of an earlier step and is dropped below
+  unsigned long long spec0 = ~0ull;
+  if (!LARGE && seg.cursor && tid < seg.seg_cap) spec0 = keys[(size_t)tile * seg.seg_cap + tid];
   if (seg.cursor) {
     if (!LARGE) {
       const int kept = min(seg.cursor[tile], seg.seg_cap);  // every thread reads it; reset after the barrier
@@ -358,7 +363,7 @@ tile_sort_kernel(unsigned long long *__restrict__ keys, const int *__restrict__ 
       const int i = tid + j * THREADS;
       kr[j] = kInf;
       if (j * THREADS < n && i < n) {
-        kr[j] = segk[i];
+        kr[j] = (!LARGE && j == 0 && seg.cursor) ? spec0 : segk[i];
         const unsigned d = (unsigned)(kr[j] >> 32);
         dmin = min(dmin, d);
         dmax = max(dmax, d);

@@ -775,7 +775,7 @@ project_emit_kernel(const float *__restrict__ means, const float *__restrict__ q
 // Tail fusion across the step boundary (single-view training, consecutive steps enqueued natively): the
 // projection backward + absgrad + Adam of view k and -- with the parameters still in registers -- the projection,
 // binning and tile scan of view k + 1.  One launch and one read of the parameters instead of two.
-template <bool LDS_HIST>
+template <bool LDS_HIST, bool HOIST>
 __global__ void __launch_bounds__(kPE)
 project_bwd_emit_kernel(float *__restrict__ means, float *__restrict__ quats, float *__restrict__ scales,
                         float *__restrict__ opacities, const float *__restrict__ viewmat, const float *__restrict__ K,
@@ -789,7 +789,34 @@ project_bwd_emit_kernel(float *__restrict__ means, float *__restrict__ quats, fl
   const bool live = g < N;
   Raw raw = {};
   if (live) {
+    // Every load of this thread is issued HERE, before anything waits: parameters, radius, the g2d record (the
+    // footprint backward writes one for every Gaussian, visible or not), the absgrad accumulator and the 22 Adam
+    // moments -- one round trip to memory instead of three (the compiler does not hoist loads over the
+    // `radius > 0` branch; ~100 k threads are 1.5 waves per SIMD: nothing else hides the latency)
+    // (HOIST: 144 instead of 104 VGPRs, i.e. 3 instead of 4 waves per SIMD -- with 200 k Gaussians, 3 waves per SIMD
+    // of work, the late loads of the plain order overlap better: 49 vs 58 us; the launcher picks by N)
     raw = load_raw(means, quats, scales, opacities, g);
+    const int radius = __float_as_int(splat[2 * g + 1].w);
+    float4 ga = make_float4(0.f, 0.f, 0.f, 0.f), gb = ga;
+    float ag = 0.f;
+    // moment layout: [means 3N | scales 3N | quats 4N | opacities N]
+    const size_t oM = 0, oS = 3 * (size_t)N, oQ = 6 * (size_t)N, oO = 10 * (size_t)N;
+    float mm[11], vv[11];
+    auto load_moments = [&]() {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        mm[k] = am[oM + 3 * g + k]; vv[k] = av[oM + 3 * g + k];
+        mm[3 + k] = am[oS + 3 * g + k]; vv[3 + k] = av[oS + 3 * g + k];
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { mm[6 + k] = am[oQ + 4 * g + k]; vv[6 + k] = av[oQ + 4 * g + k]; }
+      mm[10] = am[oO + g]; vv[10] = av[oO + g];
+    };
+    if (HOIST) {
+      ga = g2d[2 * g]; gb = g2d[2 * g + 1];
+      ag = absgrads ? absgrads[g] : 0.f;
+      load_moments();
+    }
     const Cam cam = load_cam(viewmat, K);
     Grads gr;
 #pragma unroll
@@ -797,39 +824,34 @@ project_bwd_emit_kernel(float *__restrict__ means, float *__restrict__ quats, fl
 #pragma unroll
     for (int k = 0; k < 4; ++k) gr.quat[k] = 0.f;
     gr.opac = 0.f;
-    const int radius = __float_as_int(splat[2 * g + 1].w);
     if (radius > 0) {
-      const float4 ga = g2d[2 * g], gb = g2d[2 * g + 1];
+      if (!HOIST) {
+        ga = g2d[2 * g]; gb = g2d[2 * g + 1];
+        ag = absgrads ? absgrads[g] : 0.f;
+      }
       Fwd f;
       forward_geom(cam, raw, width, height, -3.0e38f, 3.0e38f, eps2d, flags, f);
       backward_geom(cam, f, eps2d, flags, ga, gb, false, 0.f, 0.f, gr);
-      if (absgrads) absgrads[g] += sqrtf(ga.z * ga.z + ga.w * ga.w);
+      if (absgrads) absgrads[g] = ag + sqrtf(ga.z * ga.z + ga.w * ga.w);
     }
-    // moment layout: [means 3N | scales 3N | quats 4N | opacities N]
-    const size_t oM = 0, oS = 3 * (size_t)N, oQ = 6 * (size_t)N, oO = 10 * (size_t)N;
+    if (!HOIST) load_moments();
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-      float m = am[oM + 3 * g + k], v = av[oM + 3 * g + k];
-      adam1(raw.m[k], gr.mean[k], m, v, 0, hyper);
-      means[3 * g + k] = raw.m[k]; am[oM + 3 * g + k] = m; av[oM + 3 * g + k] = v;
+      adam1(raw.m[k], gr.mean[k], mm[k], vv[k], 0, hyper);
+      means[3 * g + k] = raw.m[k]; am[oM + 3 * g + k] = mm[k]; av[oM + 3 * g + k] = vv[k];
     }
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-      float m = am[oS + 3 * g + k], v = av[oS + 3 * g + k];
-      adam1(raw.s[k], gr.scale[k], m, v, 1, hyper);
-      scales[3 * g + k] = raw.s[k]; am[oS + 3 * g + k] = m; av[oS + 3 * g + k] = v;
+      adam1(raw.s[k], gr.scale[k], mm[3 + k], vv[3 + k], 1, hyper);
+      scales[3 * g + k] = raw.s[k]; am[oS + 3 * g + k] = mm[3 + k]; av[oS + 3 * g + k] = vv[3 + k];
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      float m = am[oQ + 4 * g + k], v = av[oQ + 4 * g + k];
-      adam1(raw.q[k], gr.quat[k], m, v, 2, hyper);
-      quats[4 * g + k] = raw.q[k]; am[oQ + 4 * g + k] = m; av[oQ + 4 * g + k] = v;
+      adam1(raw.q[k], gr.quat[k], mm[6 + k], vv[6 + k], 2, hyper);
+      quats[4 * g + k] = raw.q[k]; am[oQ + 4 * g + k] = mm[6 + k]; av[oQ + 4 * g + k] = vv[6 + k];
     }
-    {
-      float m = am[oO + g], v = av[oO + g];
-      adam1(raw.o, gr.opac, m, v, 3, hyper);
-      opacities[g] = raw.o; am[oO + g] = m; av[oO + g] = v;
-    }
+    adam1(raw.o, gr.opac, mm[10], vv[10], 3, hyper);
+    opacities[g] = raw.o; am[oO + g] = mm[10]; av[oO + g] = vv[10];
   }
   // the next view, with the updated parameters still in registers (this thread's splat row of view k is dead now)
   emit_body<LDS_HIST>(raw, live, g, load_cam(next_viewmat, next_K), width, height, flags, splat, cursor, seg_cap, keys,
@@ -1017,16 +1039,18 @@ int launch_project_bwd_emit(float *means, float *quats, float *scales, float *op
   SegOut out;
   out.item_first = item_first; out.max_items = max_items;
   out.total = total; out.ticket = ticket;
-  if (2 * T <= 16384)
-    project_bwd_emit_kernel<true><<<cdiv(N, kPE), kPE, sizeof(int) * 2 * T, st>>>(
-        means, quats, scales, opacities, viewmat, K, next_viewmat, next_K, N, width, height, eps2d, flags,
-        (float4 *)splat, (const float4 *)g2d, absgrads, m, v, make_adamk(hyper), tile_cursor, seg_cap,
-        (unsigned long long *)keys, out);
-  else
-    project_bwd_emit_kernel<false><<<cdiv(N, kPE), kPE, 0, st>>>(
-        means, quats, scales, opacities, viewmat, K, next_viewmat, next_K, N, width, height, eps2d, flags,
-        (float4 *)splat, (const float4 *)g2d, absgrads, m, v, make_adamk(hyper), tile_cursor, seg_cap,
-        (unsigned long long *)keys, out);
+  const bool hoist = N <= 160000;  // up to ~2.5 waves of these threads per SIMD
+#define EG_BWD_EMIT(LDS, HO, SMEM)                                                                                  \
+  project_bwd_emit_kernel<LDS, HO><<<cdiv(N, kPE), kPE, SMEM, st>>>(                                               \
+      means, quats, scales, opacities, viewmat, K, next_viewmat, next_K, N, width, height, eps2d, flags,           \
+      (float4 *)splat, (const float4 *)g2d, absgrads, m, v, make_adamk(hyper), tile_cursor, seg_cap,               \
+      (unsigned long long *)keys, out)
+  if (2 * T <= 16384) {
+    if (hoist) EG_BWD_EMIT(true, true, sizeof(int) * 2 * T); else EG_BWD_EMIT(true, false, sizeof(int) * 2 * T);
+  } else {
+    if (hoist) EG_BWD_EMIT(false, true, 0); else EG_BWD_EMIT(false, false, 0);
+  }
+#undef EG_BWD_EMIT
   return check_launch("project_bwd_emit");
 }
 }  // namespace eg
