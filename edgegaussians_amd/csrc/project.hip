@@ -704,7 +704,8 @@ __device__ __forceinline__ void emit_body(const Raw &raw, bool live, int g, cons
   // atomics (vmcnt) before the workgroup takes its ticket.
   __shared__ int s_last;
   __shared__ int s_tmp[kPE / 64];
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // (every cursor atomic of this workgroup is a RETURNING atomic whose value has been consumed above, i.e. it has
+  // been performed; the key / parameter stores still in flight need not be waited for: the scan reads cursors only)
   __syncthreads();
   if (threadIdx.x == 0) s_last = (atomicAdd(out.ticket, 1) == (int)gridDim.x - 1);
   __syncthreads();
