@@ -86,7 +86,7 @@ _SIGS = {
     "eg_project_hits": [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _vp, _vp],
     "eg_project_visibility": [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _vp, _vp],
     "eg_knn": [_vp, _i32, _i32, C.POINTER(_f), _f, C.POINTER(_i32), _vp, _vp, _vp, _vp, _vp, _vp, _vp],
-    "eg_knn_small": [_vp, _i32, _i32, _vp, _vp, _vp, _vp],
+    "eg_knn_small": [_vp, _i32, _i32, _vp, _vp, _vp],
     "eg_knn_auto": [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "eg_direction_loss": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp],
     "eg_ratio_loss": [_vp, _i32, _vp, _vp, _vp],
@@ -97,7 +97,7 @@ _SIGS = {
 }
 EXPORTS = sorted(list(_SIGS) + ["eg_last_error_string", "eg_version", "eg_device_count",
                                  "eg_composite_workspace_bytes", "eg_composite_workspace_ctl_bytes",
-                                 "eg_batched_workspace_stride", "eg_knn_small_scratch_bytes", "eg_knn_auto_dims", "eg_timing_begin", "eg_timing_end",
+                                 "eg_batched_workspace_stride", "eg_knn_auto_dims", "eg_timing_begin", "eg_timing_end",
                                  "eg_timing_stage_count", "eg_timing_stage_name"])
 
 _lib: Optional[C.CDLL] = None
@@ -130,8 +130,6 @@ def load(require_device: bool = True) -> C.CDLL:
         lib.eg_composite_workspace_ctl_bytes.argtypes = [_i64, _i64]
         lib.eg_batched_workspace_stride.restype = _i64
         lib.eg_batched_workspace_stride.argtypes = [_i64, _i64]
-        lib.eg_knn_small_scratch_bytes.restype = _i64
-        lib.eg_knn_small_scratch_bytes.argtypes = [_i32, _i32]
         lib.eg_knn_auto_dims.restype = _i32
         lib.eg_knn_auto_dims.argtypes = [_i32, _i32]
         _lib = lib

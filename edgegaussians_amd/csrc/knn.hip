@@ -561,14 +561,8 @@ extern "C" int eg_knn_auto(const float *points, int32_t N, int32_t K, int32_t *c
                          stream);
 }
 
-extern "C" int64_t eg_knn_small_scratch_bytes(int32_t N, int32_t K) {
-  (void)N; (void)K;
-  return 0;  // (the lists live in registers; kept in the ABI for callers that size a buffer)
-}
-
-extern "C" int eg_knn_small(const float *points, int32_t N, int32_t K, void *scratch, int32_t *out_idx,
-                            float *out_d2, eg_stream_t stream) {
-  (void)scratch;
+extern "C" int eg_knn_small(const float *points, int32_t N, int32_t K, int32_t *out_idx, float *out_d2,
+                            eg_stream_t stream) {
   EG_REQUIRE(N >= 0 && K >= 1 && K <= 32, "bad arguments");
   if (N == 0) return EG_OK;
   EG_REQUIRE(points && out_idx, "null pointer");

@@ -58,8 +58,8 @@ def _grid_buffers(N: int, ncell: int, dev):
     return b
 
 
-def knn(points: Tensor, k: int, want_dist: bool = False, grid=None, method: str = "auto", out: Tensor = None,
-        scratch: Tensor = None) -> Tuple[Tensor, Tensor]:
+def knn(points: Tensor, k: int, want_dist: bool = False, grid=None, method: str = "auto",
+        out: Tensor = None) -> Tuple[Tensor, Tensor]:
     """Indices [N,k] (int32, ascending distance, self excluded) and, optionally, distances [N,k] -- exact, and
     without a host sync: method "auto" = exhaustive search for N <= KNN_EXHAUSTIVE_MAX (eg_knn_small), else the
     uniform-grid search on a grid the DEVICE chooses (eg_knn_auto: bounding box by a reduction kernel, cell count a
@@ -75,7 +75,7 @@ def knn(points: Tensor, k: int, want_dist: bool = False, grid=None, method: str 
     d2 = torch.empty(N, k, device=dev) if want_dist else None
     d2p = ptr(d2) if d2 is not None else None
     if method == "exhaustive" or (method == "auto" and grid is None and N <= KNN_EXHAUSTIVE_MAX):
-        call("eg_knn_small", ptr(pts), N, k, None, ptr(idx), d2p, stream())
+        call("eg_knn_small", ptr(pts), N, k, ptr(idx), d2p, stream())
     elif grid is None:
         D = int(load().eg_knn_auto_dims(N, k))
         cell_of, counts, start, order, gs = _grid_buffers(N, D * D * D, dev)

@@ -330,13 +330,10 @@ int eg_knn_auto(const float *points /*[N,3]*/, int32_t N, int32_t K, int32_t *ce
                 float *out_d2 /*[N,K] or NULL*/, eg_stream_t stream);
 
 /* eg_knn_small: the same result (exact K <= 32 neighbours, self excluded, ascending (distance, index)) by
- * exhaustive search, for N <= 131072: no grid, no host-side bounding box.  A lane holds a candidate, a wavefront owns a
- * few queries whose K-best lists are spread over its lanes (one DPP shift per insertion).  Faster than the grid search
- * up to ~2-3 * 10^4 points and insensitive to their distribution (trained Gaussians: dense curves + isolated
- * floaters); fastest when the rows are in spatial order (the scan starts at the queries' own rows).
- * scratch: unused (eg_knn_small_scratch_bytes returns 0; kept for callers that size a buffer). */
-int64_t eg_knn_small_scratch_bytes(int32_t N, int32_t K);
-int eg_knn_small(const float *points /*[N,3]*/, int32_t N, int32_t K, void *scratch, int32_t *out_idx /*[N,K]*/,
+ * exhaustive search in ONE launch, for N <= 131072: no grid, no scratch.  A lane holds a candidate, a wavefront owns a
+ * few queries whose K-best lists are spread over its lanes (one DPP shift per insertion).  The fastest entry up to
+ * ~5 * 10^3 points; fastest when the rows are in spatial order (the scan starts at the queries' own rows). */
+int eg_knn_small(const float *points /*[N,3]*/, int32_t N, int32_t K, int32_t *out_idx /*[N,K]*/,
                  float *out_d2 /*[N,K] or NULL*/, eg_stream_t stream);
 /* compute_direction_loss (edge_gs.py:346-373): sum_out[0] += sum over the counted (i,k) of
  * |m_i . unit(mu_i - mu_nn(i,k))|; g_means += and g_quats = the gradient of that SUM.  top_k <= 0 or >= K:

@@ -1,0 +1,185 @@
+"""Host logic of the epoch driver (edgegaussians_amd/train_loop.py, the mirror of train_gaussians.py:17-222) on a
+recording stand-in for EdgeTrainer: the calendar, the strategy alternation, the regulariser cadence, the batching of
+iterations into native runs, and the read-back cadence (loss sums parked on the device, one read-back per
+`sync_every` epochs, before every densify / cull event and at the end) with `on_epoch` reporting each epoch's average
+loss and the Gaussian count AFTER that epoch's events.  No GPU, no native library."""
+import json
+import os
+
+import pytest
+
+from edgegaussians_amd import train_loop
+from edgegaussians_amd.trainer import LRSchedule
+
+
+class FakeTrainer:
+    """Loss of a step = 1 + 0.001 * (global step index); densify doubles N, culls remove 10 %."""
+
+    def __init__(self, n=100):
+        self.N, self.capacity, self.spatial_order = n, 1, True
+        self.step, self.epoch, self.loss_scale = 0, 0, 1.0
+        self.schedule = None
+        self._journal = []
+        self.acc, self.marks = 0.0, []
+        self.log = []          # ("steps", epoch, views, strategies) | ("reg", kind) | ("sync",) | ("dup",) ...
+        self.syncs = 0
+
+    # -- what train_epoch uses
+    def ensure_capacity(self):
+        self.log.append(("capacity", self.N))
+
+    def weight_map(self, view, strategy, ratio, generator, threshold):
+        return (strategy, round(ratio, 6))
+
+    def train_steps(self, views, wmaps):
+        for _ in views:
+            self.acc += 1.0 + 0.001 * self.step
+            self.step += 1
+        self._journal.extend(views)
+        self.log.append(("steps", self.epoch, list(views), [w[0] for w in wmaps], self.loss_scale))
+
+    def regulariser_step(self, kind, avg_loss_sum, scale_factor, *a, **k):
+        assert avg_loss_sum is None  # lambda comes from the device accumulator
+        self.log.append(("reg", kind, self.step, scale_factor))
+
+    def mark_epoch(self):
+        self.marks.append(self.acc)
+        self.acc = 0.0
+        return len(self.marks) - 1
+
+    def pop_losses(self):
+        self.syncs += 1
+        self.log.append(("sync", self.epoch))
+        m, rest = self.marks, self.acc
+        self.marks, self.acc, self._journal = [], 0.0, []
+        return m, rest
+
+    def pop_loss(self):
+        m, rest = self.pop_losses()
+        return sum(m) + rest
+
+    # -- events
+    def duplicate_high_pos_gradients(self, *a, **k):
+        assert not self.marks, "events run on a read-back state"
+        self.N *= 2
+        self.log.append(("dup", self.epoch))
+
+    def cull_opacity(self, v):
+        assert not self.marks
+        self.N -= self.N // 10
+        self.log.append(("cull_opacity", self.epoch))
+
+    def cull_not_projecting(self, masks, thr):
+        assert not self.marks
+        self.N -= self.N // 10
+        self.log.append(("cull_np", self.epoch))
+
+    def reset_absgrads(self):
+        self.log.append(("reset_absgrads", self.epoch))
+
+    def spatial_sort(self):
+        self.log.append(("sort", self.epoch))
+
+
+@pytest.fixture
+def cfg(golden_dir):
+    return json.load(open(os.path.join(golden_dir, "abc_train_config.json")))  # configs/ABC_DexiNed.json, parsed
+
+
+def _run(cfg, sync_every, epochs=60, views=7):
+    model_cfg, training_cfg = dict(cfg["model"]), json.loads(json.dumps(cfg["training"]))
+    model_cfg.update(dup_high_pos_grads_at_epoch=[10, 30], cull_opacity_at_epoch=[20],
+                     cull_gaussians_not_projecting_at_epoch=[30, 45])
+    ol, pl = training_cfg["loss"]["orientation_losses"], training_cfg["loss"]["projection_losses"]
+    ol["start_dir_loss_at_epoch"], ol["start_ratio_loss_at_epoch"] = 40, 40
+    pl["start_alternating_at_epoch"] = 5
+    tr = FakeTrainer()
+    seen = []
+    hist = train_loop.train(tr, model_cfg, training_cfg, lambda e: [(e + i) % views for i in range(views)],
+                            edge_masks_u8=object(), on_epoch=lambda e, l, n: seen.append((e, l, n)),
+                            num_epochs=epochs, sync_every=sync_every)
+    return tr, hist, seen
+
+
+@pytest.mark.parametrize("sync_every", [1, 4, 8, 1000])
+def test_history_and_on_epoch_do_not_depend_on_the_read_back_cadence(cfg, sync_every):
+    tr, hist, seen = _run(cfg, sync_every)
+    views, epochs = 7, 60
+    # average loss of epoch e: steps e*7 .. e*7+6 of the fake's loss law
+    for e in range(epochs):
+        want = sum(1.0 + 0.001 * (e * views + i) for i in range(views)) / views
+        assert abs(hist[e] - want) < 1e-12
+    assert [s[0] for s in seen] == list(range(epochs))            # in order, every epoch once
+    assert [s[1] for s in seen] == hist
+    # N reported for an epoch is the count AFTER that epoch's events (train_gaussians.py logs after them)
+    n, want_n = 100, []
+    for e in range(epochs):
+        if e in (10, 30):
+            n *= 2
+        if e in (30, 45):
+            n -= n // 10
+        if e == 20:
+            n -= n // 10
+        want_n.append(n)
+    assert [s[2] for s in seen] == want_n
+    # read-backs: at least one before every event epoch's events and one at the end; none in between beyond the cadence
+    sync_epochs = [x[1] for x in tr.log if x[0] == "sync"]
+    for e in (10, 20, 30, 45, epochs - 1):
+        assert e in sync_epochs
+    if sync_every >= 1000:
+        assert sync_epochs == [10, 20, 30, 45, epochs - 1]
+    if sync_every == 1:
+        assert sync_epochs == list(range(epochs))
+
+
+def test_calendar_strategies_and_regulariser_cadence(cfg):
+    tr, hist, seen = _run(cfg, 8)
+    steps = [x for x in tr.log if x[0] == "steps"]
+    # every iteration is enqueued exactly once, in the caller's view order
+    flat = [(x[1], v) for x in steps for v in x[2]]
+    assert flat == [(e, (e + i) % 7) for e in range(60) for i in range(7)]
+    # strategy: `loss_before_alternating` up to the start epoch, then less_freq on every `period`-th GLOBAL step
+    pl = cfg["training"]["loss"]["projection_losses"]
+    period = pl["sampling_whole_num_epochs_ratio"]
+    k = 0
+    for x in steps:
+        for s in x[3]:
+            e = x[1]
+            if e > 5:
+                assert s == (pl["less_freq_loss"] if k % period == 0 else pl["more_freq_loss"]), (e, k, s)
+            else:
+                assert s == pl["loss_before_alternating"]
+            k += 1
+    # regularisers: after epoch 40, direction then ratio after every 5th global step; the steps in between go out
+    # as ONE native run
+    regs = [x for x in tr.log if x[0] == "reg"]
+    assert regs and all(r[2] % 5 == 0 for r in regs)
+    first = min(r[2] for r in regs)
+    assert first >= 41 * 7 and first < 41 * 7 + 5
+    kinds = [r[1] for r in regs]
+    assert kinds[0::2] == ["direction"] * (len(kinds) // 2) and kinds[1::2] == ["ratio"] * (len(kinds) // 2)
+    late = [x for x in steps if x[1] > 41]
+    assert max(len(x[2]) for x in late) <= 5 and max(len(x[2]) for x in steps if x[1] < 40) == 7
+    # after an event: absgrads reset, rows re-sorted, capacity re-sized -- in that order, once per event epoch
+    for e in (10, 20, 30, 45):
+        tail = [x[0] for x in tr.log if len(x) > 1 and x[1] == e and x[0] in ("reset_absgrads", "sort")]
+        assert tail == ["reset_absgrads", "sort"]
+
+
+def test_unknown_dup_threshold_type_raises_like_the_reference(cfg):
+    model_cfg, training_cfg = dict(cfg["model"]), cfg["training"]
+    model_cfg.update(dup_high_pos_grads_at_epoch=[1], dup_threshold_type="percentile")
+    with pytest.raises(NotImplementedError):
+        train_loop.train(FakeTrainer(), model_cfg, training_cfg, lambda e: [0, 1], num_epochs=3)
+
+
+def test_lr_schedule_is_installed_from_the_config(cfg):
+    tr = FakeTrainer()
+    train_loop.train(tr, dict(cfg["model"]), cfg["training"], lambda e: [0], num_epochs=1)
+    assert isinstance(tr.schedule, LRSchedule)
+    want = cfg["training"]["optim"]
+    lr0, lr35 = tr.schedule.at(0), tr.schedule.at(35)
+    assert lr0["means"] == pytest.approx(want["means"]["start_lr"])
+    assert lr35["means"] == pytest.approx(want["means"]["start_lr"] * want["means"]["gamma"] ** 3)  # milestones 10 20 30
+    assert lr0["opacities"] == 0.0 and lr35["opacities"] == pytest.approx(want["opacities"]["start_lr"])  # from epoch 20
+    assert lr0["scales"] == 0.0 and lr35["scales"] == pytest.approx(want["scales"]["start_lr"])
