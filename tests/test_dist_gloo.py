@@ -30,6 +30,7 @@ class CpuOracleWorker:
         self.step = 0
         self.absgrads = torch.zeros(self.N)
         self.grads = torch.zeros(self.N * 12)
+        self.announced = []
 
     def grad_views(self):
         N, g = self.N, self.grads
@@ -48,7 +49,8 @@ class CpuOracleWorker:
             dst.copy_(src)
         return self.grads
 
-    def apply_adam(self):
+    def apply_adam(self, next_view=None):
+        self.announced.append(next_view)  # (EdgeTrainer projects that view in the same launch; nothing to do here)
         self.step += 1
         gs = self.grad_views()
         for i in range(4):
@@ -85,13 +87,14 @@ def _worker(rank, world, port, ret):
         for rr in range(world):
             vv = egdist.view_for(step, rr, world, 4)
             want += ref.grad_step(vv, wmaps[vv]).clone()
-        dp.step(view, wmaps[view])
+        dp.step(view, wmaps[view], next_view=egdist.view_for(step + 1, rank, world, 4) if step == 0 else None)
         ok &= bool(torch.allclose(wk.grads, want, rtol=1e-5, atol=1e-9))
         # replicas identical: max |p - p_rank0| == 0 bit for bit
         for t in wk.p + [wk.absgrads]:
             ref_t = t.clone()
             dist.broadcast(ref_t, src=0)
             ok &= bool(torch.equal(ref_t, t))
+    ok &= wk.announced == [egdist.view_for(1, rank, world, 4), None]
     ret[rank] = ok
     dist.destroy_process_group()
 
@@ -144,7 +147,9 @@ def _gpu_worker(rank, world, port, ret):
                 want += ref.grad_step(vv, wmaps[vv])
         mine = [egdist.view_for(step, rank, world, V, Cn, slot) for slot in range(Cn)]
         if Cn == 1:
-            dp.step(mine[0], wmaps[mine[0]])
+            # the rank announces its next view (Adam then projects it in the same launch); after step 1 the announced
+            # view is NOT what follows (a batched step does): the pre-projection must be dropped cleanly
+            dp.step(mine[0], wmaps[mine[0]], next_view=egdist.view_for(step + 1, rank, world, V))
         else:
             dp.step(mine, [wmaps[v] for v in mine])
         got = tr.grads.clone()
