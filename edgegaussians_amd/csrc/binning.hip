@@ -285,10 +285,16 @@ struct SegTable {
   int *cursor;
   int seg_cap;
   int *tile_start, *tile_end;  // [T]
-  const int *item_first;       // [T] (from the scan in eg_project_emit)
+  int *item_first;             // [T]: from the scan in eg_project_emit -- or, with `total`, WRITTEN here
   int *item_end;               // [T]
   int *item_tile;              // [max_items]
   int max_items;
+  // != nullptr: "prefix here" (the training step, T <= 2048).  The projection kernel then skips its serial tail
+  // (ticket, last workgroup, scan: ~3 us on the critical path of every step); every tile's workgroup instead sums
+  // the item counts of the tiles before it from the cursors -- which therefore stay untouched during this kernel:
+  // the compositing kernel returns them to zero -- and the last tile's workgroup leaves the totals
+  // [4]: M, sticky overflow flag, items, largest tile population.
+  int *total;
 };
 
 // THREADS = number of buckets; CAP = keys per buffer (two buffers).  n_lo < n handled here.
@@ -306,6 +312,7 @@ tile_sort_kernel(unsigned long long *__restrict__ keys, const int *__restrict__ 
     if (seg.cursor) {
       seg.cursor += bv * bt.tiles; seg.tile_start += bv * bt.tiles; seg.tile_end += bv * bt.tiles;
       seg.item_first += bv * bt.tiles; seg.item_end += bv * bt.tiles; seg.item_tile += bv * bt.items;
+      if (seg.total) seg.total += 4 * bv;
     }
   }
   unsigned long long *kout = s;      // [CAP] keys scattered by bucket (the fast path keeps its input in registers)
@@ -318,6 +325,34 @@ tile_sort_kernel(unsigned long long *__restrict__ keys, const int *__restrict__ 
   for (int tile = blockIdx.x; tile < T; tile += gridDim.x) {
   __syncthreads();
   long long start, end;
+  __shared__ int s_pre[3][THREADS / 64];
+  bool prefix_pending = false;  // (uniform) the tile prefix still has to be finished: see SegTable::total
+  int pop_here = 0;
+  // after a barrier: every thread sums the waves' partials; thread 0 writes the tile's table entries (and the
+  // totals of the view, if this is the last tile), the first threads the item -> tile map
+  auto finish_prefix = [&](int kept_) {
+    int isum = 0, msum = 0, cmax = 0;
+#pragma unroll
+    for (int w = 0; w < THREADS / 64; ++w) { isum += s_pre[0][w]; msum += s_pre[1][w]; cmax = max(cmax, s_pre[2][w]); }
+    const int first_ = min(isum, seg.max_items);
+    const int items_ = min(max(1, (kept_ + 127) >> 7), max(0, seg.max_items - first_));
+    if (tid == 0) {
+      seg.item_first[tile] = first_;
+      seg.tile_start[tile] = tile * seg.seg_cap;
+      seg.tile_end[tile] = tile * seg.seg_cap + kept_;
+      seg.item_end[tile] = first_ + items_;
+      if (tile == T - 1) {  // the last tile's prefix covers everything: the totals of the view
+        const int itot = isum + max(1, (kept_ + 127) >> 7);
+        cmax = max(cmax, pop_here);
+        seg.total[0] = msum + kept_;
+        if (cmax > seg.seg_cap || itot > seg.max_items) seg.total[1] = 1;  // sticky: only the host clears it
+        seg.total[2] = min(itot, seg.max_items);
+        seg.total[3] = cmax;
+      }
+    }
+    for (int i = tid; i < items_; i += THREADS) seg.item_tile[first_ + i] = tile;
+    prefix_pending = false;
+  };
   // Segmented layout: the tile's keys sit at a FIXED address, so the first key of every thread is requested before
   // the population is known (one round trip to memory instead of two: most tiles hold fewer keys than the workgroup
   // has threads); a slot beyond the population holds a stale key of an earlier step and is dropped below
@@ -325,16 +360,46 @@ tile_sort_kernel(unsigned long long *__restrict__ keys, const int *__restrict__ 
   if (!LARGE && seg.cursor && tid < seg.seg_cap) spec0 = keys[(size_t)tile * seg.seg_cap + tid];
   if (seg.cursor) {
     if (!LARGE) {
-      const int kept = min(seg.cursor[tile], seg.seg_cap);  // every thread reads it; reset after the barrier
-      const int first = seg.item_first[tile], items = min(max(1, (kept + 127) >> 7), max(0, seg.max_items - first));
-      __syncthreads();
-      if (tid == 0) {
-        seg.cursor[tile] = 0;  // ready for the next step
-        seg.tile_start[tile] = tile * seg.seg_cap;
-        seg.tile_end[tile] = tile * seg.seg_cap + kept;
-        seg.item_end[tile] = first + items;
+      int kept, first, items;
+      if (seg.total) {
+        // The populations of the tiles before this one are REQUESTED by all threads before anything is waited for
+        // (they travel with the tile's own cursor and first keys); per-wave partial sums go to LDS and the prefix
+        // is finished right after the FIRST barrier the sort takes anyway (finish_prefix below): no barrier of its own
+        int pv[kPrefixHereMaxTiles / THREADS];
+#pragma unroll
+        for (int j = 0; j < kPrefixHereMaxTiles / THREADS; ++j)
+          pv[j] = (tid + j * THREADS < tile) ? seg.cursor[tid + j * THREADS] : -1;
+        pop_here = seg.cursor[tile];
+        kept = min(pop_here, seg.seg_cap);
+        int isum = 0, msum = 0, cmax = 0;
+#pragma unroll
+        for (int j = 0; j < kPrefixHereMaxTiles / THREADS; ++j)
+          if (pv[j] >= 0) {
+            const int kk = min(pv[j], seg.seg_cap);
+            isum += max(1, (kk + 127) >> 7); msum += kk; cmax = max(cmax, pv[j]);
+          }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+          isum += __shfl_xor(isum, d, 64);
+          msum += __shfl_xor(msum, d, 64);
+          cmax = max(cmax, __shfl_xor(cmax, d, 64));
+        }
+        if ((tid & 63) == 0) { s_pre[0][tid >> 6] = isum; s_pre[1][tid >> 6] = msum; s_pre[2][tid >> 6] = cmax; }
+        prefix_pending = true;
+        first = items = 0;
+      } else {
+        kept = min(seg.cursor[tile], seg.seg_cap);  // every thread reads it; reset after the barrier
+        first = seg.item_first[tile];
+        items = min(max(1, (kept + 127) >> 7), max(0, seg.max_items - first));
+        __syncthreads();
+        if (tid == 0) {
+          seg.cursor[tile] = 0;  // ready for the next step
+          seg.tile_start[tile] = tile * seg.seg_cap;
+          seg.tile_end[tile] = tile * seg.seg_cap + kept;
+          seg.item_end[tile] = first + items;
+        }
+        for (int i = tid; i < items; i += THREADS) seg.item_tile[first + i] = tile;
       }
-      for (int i = tid; i < items; i += THREADS) seg.item_tile[first + i] = tile;
       start = (long long)tile * seg.seg_cap;
       end = start + kept;
     } else {  // launched after the small variant: the ranges are in place
@@ -347,8 +412,10 @@ tile_sort_kernel(unsigned long long *__restrict__ keys, const int *__restrict__ 
     if (end > capacity) end = capacity;
   }
   const int n = (int)(end - start);
-  if (n <= 0) continue;
-  if (LARGE ? (n <= small_cap) : (n > small_cap)) continue;  // the other variant owns this tile
+  if (n <= 0 || (LARGE ? (n <= small_cap) : (n > small_cap))) {  // empty, or the other variant owns this tile
+    if (prefix_pending) { __syncthreads(); finish_prefix(n); }
+    continue;
+  }
   unsigned long long *segk = keys + start;
   const unsigned long long kInf = ~0ull;
 
@@ -381,6 +448,7 @@ tile_sort_kernel(unsigned long long *__restrict__ keys, const int *__restrict__ 
     }
     if (lane == 0) { wave_tmp[wv] = dmin; wave_tmp[16 + wv] = dmax; }
     __syncthreads();
+    if (prefix_pending) finish_prefix(n);
 #pragma unroll
     for (int w = 0; w < NW; ++w) { dmin = min(dmin, wave_tmp[w]); dmax = max(dmax, wave_tmp[16 + w]); }
     const float scale = (float)THREADS / ((float)(dmax - dmin) + 1.f);
@@ -456,6 +524,7 @@ tile_sort_kernel(unsigned long long *__restrict__ keys, const int *__restrict__ 
 
   // ---- oversized segment (n > CAP): hybrid global/LDS bitonic network.  Virtual size P (power of two),
   // indices >= n behave as +inf and never move (the network only ever moves larger keys to higher indices).
+  if (prefix_pending) { __syncthreads(); finish_prefix(n); }
   constexpr int BCAP = CAP;
   long long P = BCAP;
   while (P < n) P <<= 1;
@@ -610,21 +679,23 @@ extern "C" int eg_sort_segments(uint64_t *keys, int32_t *tile_cursor, int32_t T,
   SegTable seg;
   seg.cursor = tile_cursor; seg.seg_cap = seg_cap;
   seg.tile_start = tile_start; seg.tile_end = tile_end;
-  seg.item_first = item_first; seg.item_end = item_end;
+  seg.item_first = const_cast<int32_t *>(item_first); seg.item_end = item_end;  // (read only: total == nullptr)
   seg.item_tile = item_tile; seg.max_items = max_items;
+  seg.total = nullptr;
   return launch_tile_sort(keys, nullptr, T, (int64_t)T * seg_cap, flatten_ids, nullptr, max_tile_hint, seg, stream);
 }
 
 namespace eg {
 int launch_sort_segments(uint64_t *keys, int32_t *tile_cursor, int32_t T, int32_t seg_cap, int32_t *flatten_ids,
-                         int32_t *tile_start, int32_t *tile_end, const int32_t *item_first, int32_t *item_end,
+                         int32_t *tile_start, int32_t *tile_end, int32_t *item_first, int32_t *item_end,
                          int32_t *item_tile, int32_t max_items, int32_t max_tile_hint, const Batch &bt, int C,
-                         hipStream_t st) {
+                         hipStream_t st, int32_t *total_prefix_here) {
   SegTable seg;
   seg.cursor = tile_cursor; seg.seg_cap = seg_cap;
   seg.tile_start = tile_start; seg.tile_end = tile_end;
   seg.item_first = item_first; seg.item_end = item_end;
   seg.item_tile = item_tile; seg.max_items = max_items;
+  seg.total = total_prefix_here;
   return launch_tile_sort(keys, nullptr, T, (int64_t)T * seg_cap, flatten_ids, nullptr, max_tile_hint, seg,
                           (eg_stream_t)st, bt, C);
 }

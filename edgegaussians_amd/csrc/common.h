@@ -29,6 +29,9 @@ void timing_mark(int mark, hipStream_t stream);
 // per-view work buffer of a batched step is a [C, ...] array; Batch holds the strides between the per-view
 // copies and the per-view inputs.  A default-constructed Batch (all strides zero, no pointers) is the
 // single-view launch: blockIdx.y is 0 and the kernels use their own view arguments.
+// largest tile grid for which the sort kernel forms the tile prefix itself (every tile's workgroup reads the
+// cursors of the tiles before it: O(T^2 / 2) loads in all)
+constexpr int kPrefixHereMaxTiles = 2048;
 constexpr int kMaxBatch = EG_MAX_BATCH;
 struct Batch {
   long long splat4 = 0;    // splat / g2d: float4 units (2 N)
@@ -46,22 +49,22 @@ int launch_project_emit(const float *means, const float *quats, const float *log
                         float *splat, int32_t *tile_cursor, int32_t seg_cap, uint64_t *keys, int32_t *item_first,
                         int32_t max_items, int32_t *total, int32_t *ticket, const Batch &bt, int C, hipStream_t st);
 int launch_sort_segments(uint64_t *keys, int32_t *tile_cursor, int32_t T, int32_t seg_cap, int32_t *flatten_ids,
-                         int32_t *tile_start, int32_t *tile_end, const int32_t *item_first, int32_t *item_end,
+                         int32_t *tile_start, int32_t *tile_end, int32_t *item_first, int32_t *item_end,
                          int32_t *item_tile, int32_t max_items, int32_t max_tile_hint, const Batch &bt, int C,
-                         hipStream_t st);
+                         hipStream_t st, int32_t *total_prefix_here = nullptr);
 int launch_composite_fwd_segments(const float *splat, const int32_t *tile_start, const int32_t *tile_end,
                                   const int32_t *item_first, const int32_t *item_end, const int32_t *item_tile,
                                   const int32_t *flatten_ids, int32_t width, int32_t height, float loss_scale,
                                   float *loss_out, const int32_t *total, int64_t max_items, void *workspace,
                                   float *gtstop, int32_t rewalk_hint, const Batch &bt, int C, hipStream_t st,
-                                  int32_t max_tile_hint, int32_t chain_tag);
+                                  int32_t max_tile_hint, int32_t chain_tag, int32_t *cursor_reset = nullptr);
 int composite_fwd_segments_hinted(const float *splat, const int32_t *tile_start, const int32_t *tile_end,
                                   const int32_t *item_first, const int32_t *item_end, const int32_t *item_tile,
                                   const int32_t *flatten_ids, int32_t width, int32_t height, float *render, float *alphas,
                                   int32_t *last_ids, const float *gt, const float *wmap, float loss_scale, float *vpix,
                                   float *loss_out, const int32_t *total, int64_t max_items, void *workspace,
                                   float *gtstop, int32_t rewalk_hint, int32_t max_tile_hint, int32_t chain_tag,
-                                  hipStream_t st);
+                                  hipStream_t st, int32_t *cursor_reset = nullptr);
 int launch_footprint_bwd(const float *splat, int32_t N, int32_t width, int32_t height, const float *gtstop, float *g2d,
                          const Batch &bt, int C, hipStream_t st);
 int launch_project_bwd_emit(float *means, float *quats, float *scales, float *opacities, const float *viewmat,

@@ -284,6 +284,9 @@ __device__ __forceinline__ int item_tile_coop(const int *__restrict__ item_offse
 // the item -> tile map.
 struct TileTable {
   const int *start, *end, *item_first, *item_end, *item_tile;
+  // != nullptr (the training step when the sort kernel forms the tile prefix itself, binning.hip): the binning
+  // cursors [T], which the first slice workgroup of every tile returns to zero for the next projection
+  int *cursor_reset;
 };
 
 // pixel of thread `tid` in the slice-parallel kernels: wave w owns the 8x8 quadrant (w & 1, w >> 1)
@@ -466,6 +469,7 @@ struct SliceWs {
 __device__ __forceinline__ TileTable view_of(TileTable tt, const Batch &bt, int v) {
   tt.start += v * bt.tiles; tt.end += v * bt.tiles; tt.item_first += v * bt.tiles; tt.item_end += v * bt.tiles;
   if (tt.item_tile) tt.item_tile += v * bt.items;
+  if (tt.cursor_reset) tt.cursor_reset += v * bt.tiles;
   return tt;
 }
 __device__ __forceinline__ SliceWs view_of(SliceWs ws, const Batch &bt, int v) {
@@ -591,6 +595,7 @@ composite_slice_fwd_kernel(const float4 *__restrict__ splat, const TileTable tt_
   const int start = tt.start[tile] + (b - i0) * kSlice;
   const int end = min(tt.end[tile], start + kSlice);
   const int idx = start + tid;
+  if (tt.cursor_reset && b == i0 && tid == 0) tt.cursor_reset[tile] = 0;
 
   float P = 1.f;
   int L = -1;
@@ -793,6 +798,7 @@ composite_chained_fwd_kernel(const float4 *__restrict__ splat, const TileTable t
   const int i0 = tt.item_first[tile], ns = tt.item_end[tile] - i0, s_me = b - i0;
   const int t_start = tt.start[tile], t_end = tt.end[tile];
   const int start = t_start + s_me * kSlice, end = min(t_end, start + kSlice);
+  if (tt.cursor_reset && s_me == 0 && tid == 0) tt.cursor_reset[tile] = 0;
   const bool has_loss = wmap != nullptr;
   const float w_p = (has_loss && inside) ? wmap[i * width + j] : 0.f;
   const float gt_p = (has_loss && inside) ? gt[i * width + j] : 0.f;
@@ -1618,7 +1624,7 @@ extern "C" int eg_composite_fwd(const float *splat, const float *colors, int32_t
   const int tw = cdiv(width, kTile), th = cdiv(height, kTile);
   hipStream_t s = as_stream(stream);
   if (!colors && item_offsets && total && workspace && max_items > 0) {
-    const TileTable tt = {offsets, offsets + 1, item_offsets, item_offsets + 1, nullptr};
+    const TileTable tt = {offsets, offsets + 1, item_offsets, item_offsets + 1, nullptr, nullptr};
     return launch_sliced_fwd((const float4 *)splat, tt, channels, flatten_ids, width, height, render, alphas, last_ids,
                              gt, wmap, loss_scale, vpix, loss_out, total, max_items, workspace, gtstop, rewalk_hint, s);
   }
@@ -1639,8 +1645,8 @@ int composite_fwd_segments_hinted(const float *splat, const int32_t *tile_start,
                                   int32_t *last_ids, const float *gt, const float *wmap, float loss_scale, float *vpix,
                                   float *loss_out, const int32_t *total, int64_t max_items, void *workspace,
                                   float *gtstop, int32_t rewalk_hint, int32_t max_tile_hint, int32_t chain_tag,
-                                  hipStream_t st) {
-  const TileTable tt = {tile_start, tile_end, item_first, item_end, item_tile};
+                                  hipStream_t st, int32_t *cursor_reset) {
+  const TileTable tt = {tile_start, tile_end, item_first, item_end, item_tile, cursor_reset};
   return launch_sliced_fwd((const float4 *)splat, tt, 1, flatten_ids, width, height, render, alphas, last_ids, gt, wmap,
                            loss_scale, vpix, loss_out, total, max_items, workspace, gtstop, rewalk_hint, st, Batch{}, 1,
                            max_tile_hint, chain_tag);
@@ -1661,7 +1667,7 @@ extern "C" int eg_composite_fwd_segments(const float *splat, const int32_t *tile
   EG_REQUIRE((render && alphas && last_ids) || gtstop, "render / alphas / last_ids are optional only with gtstop");
   EG_REQUIRE(!wmap || gt, "wmap needs gt");
   EG_REQUIRE(!gtstop || wmap, "gtstop needs the fused loss");
-  const TileTable tt = {tile_start, tile_end, item_first, item_end, item_tile};
+  const TileTable tt = {tile_start, tile_end, item_first, item_end, item_tile, nullptr};
   return launch_sliced_fwd((const float4 *)splat, tt, 1, flatten_ids, width, height, render, alphas, last_ids, gt, wmap,
                            loss_scale, vpix, loss_out, total, max_items, workspace, gtstop, rewalk_hint,
                            as_stream(stream));
@@ -1704,8 +1710,8 @@ int launch_composite_fwd_segments(const float *splat, const int32_t *tile_start,
                                   const int32_t *flatten_ids, int32_t width, int32_t height, float loss_scale,
                                   float *loss_out, const int32_t *total, int64_t max_items, void *workspace,
                                   float *gtstop, int32_t rewalk_hint, const Batch &bt, int C, hipStream_t st,
-                                  int32_t max_tile_hint, int32_t chain_tag) {
-  const TileTable tt = {tile_start, tile_end, item_first, item_end, item_tile};
+                                  int32_t max_tile_hint, int32_t chain_tag, int32_t *cursor_reset) {
+  const TileTable tt = {tile_start, tile_end, item_first, item_end, item_tile, cursor_reset};
   return launch_sliced_fwd((const float4 *)splat, tt, 1, flatten_ids, width, height, nullptr, nullptr, nullptr,
                            bt.gt[0], bt.wmap[0], loss_scale, nullptr, loss_out, total, max_items, workspace, gtstop,
                            rewalk_hint, st, bt, C, max_tile_hint, chain_tag);

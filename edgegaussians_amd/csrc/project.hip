@@ -702,6 +702,9 @@ __device__ __forceinline__ void emit_body(const Raw &raw, bool live, int g, cons
   // coherence point, not in an XCD-private L2 line) and are read here with device-scope atomic loads,
   // so no cache write-back / invalidate fence is needed: every wave only drains its own outstanding
   // atomics (vmcnt) before the workgroup takes its ticket.
+  // out.ticket == nullptr: the sort kernel forms the tile prefix and the totals itself (binning.hip, "prefix
+  // here"): this kernel ends with its last key store instead of ~3 us of barrier, ticket, cursor loads and scan
+  if (out.ticket == nullptr) return;
   __shared__ int s_last;
   __shared__ int s_tmp[kPE / 64];
   // (every cursor atomic of this workgroup is a RETURNING atomic whose value has been consumed above, i.e. it has
@@ -764,7 +767,8 @@ project_emit_kernel(const float *__restrict__ means, const float *__restrict__ q
   const int bv = blockIdx.y;
   SegOut out = out_;
   splat += bv * bt.splat4; cursor += bv * bt.tiles; keys += bv * bt.keys;
-  out.item_first += bv * bt.tiles; out.total += 4 * bv; out.ticket += bv;
+  out.item_first += bv * bt.tiles; out.total += 4 * bv;
+  if (out.ticket) out.ticket += bv;
   if (bt.viewmat[0]) { viewmat = bt.viewmat[bv]; K = bt.K[bv]; }
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
   const bool live = g < N;

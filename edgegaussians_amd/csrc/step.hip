@@ -129,16 +129,28 @@ extern "C" int eg_train_step(const eg_step_args *a, eg_stream_t stream) {
     // segmented binning: projection + binning (+ the item scan by its last workgroup) in one pass, then the
     // per-tile sort, which also writes the tile / item tables; there is no emit kernel, its stage stays empty
     // (the previous step's last kernel may already have projected + binned this view: have_projection)
-    rc = a->have_projection ? EG_OK
-                            : eg_project_emit(a->means, a->quats, a->log_scales, a->logit_opacities, a->viewmat, a->K,
-                                              a->N, a->width, a->height, flags, a->splat, a->tile_counts, a->seg_cap,
-                                              a->keys, a->item_offsets, (int32_t)a->max_items, a->total, a->ticket, stream);
-    if (rc) return rc;
+    // prefix_here (small tile grids): the projection kernels end without their serial tail (ticket, last workgroup,
+    // tile scan); the sort kernel's workgroups form the item prefix of their tile from the cursors themselves and the
+    // compositing kernel returns the cursors to zero (binning.hip, SegTable::total)
+    const bool prefix_here = T <= kPrefixHereMaxTiles;
+    EG_REQUIRE((int64_t)T * a->seg_cap < (1ll << 31), "T * seg_cap must fit 31 bits");
+    if (!a->have_projection) {
+      rc = prefix_here ? launch_project_emit(a->means, a->quats, a->log_scales, a->logit_opacities, a->viewmat, a->K, a->N,
+                                             a->width, a->height, flags, a->splat, a->tile_counts, a->seg_cap, a->keys,
+                                             a->item_offsets, (int32_t)a->max_items, a->total, nullptr, Batch{}, 1, st)
+                       : eg_project_emit(a->means, a->quats, a->log_scales, a->logit_opacities, a->viewmat, a->K, a->N,
+                                         a->width, a->height, flags, a->splat, a->tile_counts, a->seg_cap, a->keys,
+                                         a->item_offsets, (int32_t)a->max_items, a->total, a->ticket, stream);
+      if (rc) return rc;
+    }
     EG_MARK(kMarkProjectBin);
     EG_MARK(kMarkEmit);
-    rc = eg_sort_segments(a->keys, a->tile_counts, T, a->seg_cap, a->flatten_ids, a->offsets, a->tile_end,
-                          a->item_offsets, a->item_end, a->item_tile, (int32_t)a->max_items, a->max_tile_hint,
-                          stream);
+    rc = prefix_here ? launch_sort_segments(a->keys, a->tile_counts, T, a->seg_cap, a->flatten_ids, a->offsets,
+                                            a->tile_end, a->item_offsets, a->item_end, a->item_tile,
+                                            (int32_t)a->max_items, a->max_tile_hint, Batch{}, 1, st, a->total)
+                     : eg_sort_segments(a->keys, a->tile_counts, T, a->seg_cap, a->flatten_ids, a->offsets, a->tile_end,
+                                        a->item_offsets, a->item_end, a->item_tile, (int32_t)a->max_items,
+                                        a->max_tile_hint, stream);
     if (rc) return rc;
     EG_MARK(kMarkSort);
     EG_REQUIRE(a->splat && a->offsets && a->flatten_ids && a->total && a->workspace && a->max_items > 0 &&
@@ -147,7 +159,8 @@ extern "C" int eg_train_step(const eg_step_args *a, eg_stream_t stream) {
     rc = composite_fwd_segments_hinted(a->splat, a->offsets, a->tile_end, a->item_offsets, a->item_end, a->item_tile,
                                        a->flatten_ids, a->width, a->height, a->render, a->alphas, a->last_ids, a->gt,
                                        a->wmap, a->loss_scale, a->vpix, a->loss, a->total, a->max_items, a->workspace,
-                                       a->gtstop, a->rewalk_hint, a->max_tile_hint, a->ws_tag, st);
+                                       a->gtstop, a->rewalk_hint, a->max_tile_hint, a->ws_tag, st,
+                                       prefix_here ? a->tile_counts : nullptr);
     if (rc) return rc;
   } else {
   // tile_counts is zero on entry (caller zero-initialises it once): the projection counts it up and its
@@ -179,7 +192,8 @@ extern "C" int eg_train_step(const eg_step_args *a, eg_stream_t stream) {
     rc = launch_project_bwd_emit(a->means, a->quats, a->log_scales, a->logit_opacities, a->viewmat, a->K,
                                  a->next_viewmat, a->next_K, a->N, a->width, a->height, 0.3f, flags, a->splat, a->g2d,
                                  a->absgrads, a->adam_m, a->adam_v, *a->adam_host, a->tile_counts, a->seg_cap, a->keys,
-                                 a->item_offsets, (int32_t)a->max_items, a->total, a->ticket, st);
+                                 a->item_offsets, (int32_t)a->max_items, a->total,
+                                 T <= kPrefixHereMaxTiles ? nullptr : a->ticket, st);
   else if (a->adam_host)
     rc = eg_project_bwd_adam(a->means, a->quats, a->log_scales, a->logit_opacities, a->viewmat, a->K, a->N,
                              a->width, a->height, 0.3f, flags, a->splat, a->g2d, a->adam_m, a->adam_v, a->absgrads,
@@ -228,18 +242,21 @@ extern "C" int eg_train_step_batched(const eg_step_args *a, int32_t C, const flo
     bt.viewmat[v] = viewmats[v]; bt.K[v] = Ks[v]; bt.gt[v] = gts[v]; bt.wmap[v] = wmaps[v];
   }
   hipStream_t st = as_stream(stream);
+  // (see eg_train_step; with C views the prefix loads multiply: 8 views at 512 x 512 lost 7 us to them)
+  const bool prefix_here = (int64_t)T * C <= kPrefixHereMaxTiles;
   int rc = launch_project_emit(a->means, a->quats, a->log_scales, a->logit_opacities, bt.viewmat[0], bt.K[0], a->N,
                                a->width, a->height, flags, a->splat, a->tile_counts, a->seg_cap, a->keys,
-                               a->item_offsets, (int32_t)a->max_items, a->total, a->ticket, bt, C, st);
+                               a->item_offsets, (int32_t)a->max_items, a->total, prefix_here ? nullptr : a->ticket, bt,
+                               C, st);
   if (rc) return rc;
   rc = launch_sort_segments(a->keys, a->tile_counts, T, a->seg_cap, a->flatten_ids, a->offsets, a->tile_end,
                             a->item_offsets, a->item_end, a->item_tile, (int32_t)a->max_items, a->max_tile_hint, bt, C,
-                            st);
+                            st, prefix_here ? a->total : nullptr);
   if (rc) return rc;
   rc = launch_composite_fwd_segments(a->splat, a->offsets, a->tile_end, a->item_offsets, a->item_end, a->item_tile,
                                      a->flatten_ids, a->width, a->height, a->loss_scale, a->loss, a->total,
                                      a->max_items, a->workspace, a->gtstop, a->rewalk_hint, bt, C, st,
-                                     a->max_tile_hint, a->ws_tag);
+                                     a->max_tile_hint, a->ws_tag, prefix_here ? a->tile_counts : nullptr);
   if (rc) return rc;
   rc = launch_footprint_bwd(a->splat, a->N, a->width, a->height, a->gtstop, a->g2d, bt, C, st);
   if (rc) return rc;

@@ -543,6 +543,9 @@ class EdgeTrainer:
         clean."""
         if not (self.replay_on_overflow and self._journal and self._snap is not None):
             self.clear_overflow()
+            self.tile_counts.zero_()
+            for b in self._batches.values():
+                b["tile_counts"].zero_()
             self._grow_isect(2.0)  # leave usable buffers behind for a caller that catches and restarts
             raise IsectOverflow("tile-intersection buffers overflowed and the steps since the last read-back "
                                 "cannot be replayed (journal off or data-parallel leg): results are invalid; "
@@ -565,8 +568,10 @@ class EdgeTrainer:
                 self.overflow_events += 1
                 self._grow_isect(2.0)  # (drops the batched work buffers as well: re-allocated, flags clear)
             self.total.zero_()
+            self.tile_counts.zero_()  # (a step that ran out of items leaves the cursors of the unserved tiles behind)
             for b in self._batches.values():
                 b["total"].zero_()
+                b["tile_counts"].zero_()
             self._restore()  # (the running loss sum included)
             for kind, view, wmap, epoch, ls in journal:
                 self.epoch, self.loss_scale = epoch, ls
