@@ -419,6 +419,11 @@ typedef struct {
   int32_t ws_tag;
 } eg_step_args;
 
+/* (Segmented layout, tile grids of <= 2048 tiles: eg_train_step / eg_train_steps / eg_train_step_batched run the
+ * projection kernels without their ticket + scan tail -- `ticket` is then unused -- let every tile's sort workgroup
+ * form its item prefix from the cursors, and have the compositing kernel return the cursors to zero.  Same tables,
+ * same results; the stand-alone entries eg_project_emit / eg_sort_segments / eg_composite_fwd_segments keep the
+ * protocol described with them.) */
 int eg_train_step(const eg_step_args *args_host, eg_stream_t stream);
 
 /* ---- K consecutive steps by one native call: step k = eg_train_step on view views_host[k] (taken out of the
