@@ -140,6 +140,7 @@ constexpr float kThrMargin = 1e-3f;
 
 __device__ __forceinline__ void tile_box_tight(float x, float y, int radius, float a, float b, float c, float o,
                                                int tw, int th, int &x0, int &y0, int &x1, int &y1) {
+#pragma clang fp contract(off)  // (same decisions in every kernel this is inlined into: see forward_geom)
   tile_box(x, y, radius, tw, th, x0, y0, x1, y1);
   const float thr = __logf(255.f * o) + kThrMargin;
   const float det = a * c - b * b;
@@ -162,11 +163,13 @@ __device__ __forceinline__ void tile_box_tight(float x, float y, int radius, flo
 // it is a 1-D quadratic minimised in closed form (clamped to the edge).  Thin diagonal edge Gaussians
 // miss many of the tiles their AABB touches.  A small relative slack keeps the test conservative.
 __device__ __forceinline__ float sigma_at(float a, float b, float c, float dx, float dy) {
+#pragma clang fp contract(off)  // (same decisions in every kernel this is inlined into: see forward_geom)
   return 0.5f * (a * dx * dx + c * dy * dy) + b * dx * dy;
 }
 
 __device__ __forceinline__ bool ellipse_hits_rect(float x, float y, float a, float b, float c, float thr,
                                                   float rx0, float ry0, float rx1, float ry1) {
+#pragma clang fp contract(off)  // (same decisions in every kernel this is inlined into: see forward_geom)
   // offsets of the rectangle relative to the centre (dx = x - px as in the kernels; sign is irrelevant
   // for a centred quadratic, so use p - centre)
   const float u0 = rx0 - x, u1 = rx1 - x, v0 = ry0 - y, v1 = ry1 - y;

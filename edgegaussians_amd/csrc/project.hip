@@ -64,6 +64,13 @@ __device__ __forceinline__ Raw load_raw(const float *__restrict__ means, const f
 __device__ __forceinline__ bool forward_geom(const Cam &cam, const Raw &raw, int width, int height,
                                              float near_plane, float far_plane, float eps2d, uint32_t flags,
                                              Fwd &f) {
+  // No FMA contraction in here (nor in the tile tests of common.h): this function is inlined into four kernels
+  // (project_fwd, project_emit, the projection backward's recomputation, the tail-fused next-view projection), and
+  // the compiler's contraction choices differ from one inlining context to the next -- the packed records of the
+  // operator path and of the training step then differ in the last bit, and with them a float-borderline tile hit
+  // or alpha threshold here and there (1600 x 1200, 200 k Gaussians: one Gaussian's gradient off by 4e-4 of the
+  // maximum between the two paths).  Separate multiplies and adds are also what the C oracle (gcc, x86-64) does.
+#pragma clang fp contract(off)
   const float mx = raw.m[0], my = raw.m[1], mz = raw.m[2];
   f.x = cam.R[0] * mx + cam.R[1] * my + cam.R[2] * mz + cam.t[0];
   f.y = cam.R[3] * mx + cam.R[4] * my + cam.R[5] * mz + cam.t[1];
@@ -143,6 +150,7 @@ __device__ __forceinline__ bool forward_geom(const Cam &cam, const float *__rest
 }
 
 __device__ __forceinline__ int radius_of(const Fwd &f, int width, int height, float radius_clip) {
+#pragma clang fp contract(off)
   const float bh = 0.5f * (f.b00 + f.b11);
   const float v1 = bh + sqrtf(fmaxf(0.01f, bh * bh - f.det1));
   const float radius = ceilf(3.f * sqrtf(v1));

@@ -28,3 +28,45 @@ def test_fused_step_vs_c_oracle_full_size(name):
     n, W, H, view, strategy = SIZES[name]
     sc = synth.make_scene(n, 2, W, H, seed=0, anisotropy=5.0, spread_opacity=True)
     check_fused_step_vs_c_oracle(sc, view, strategy, name)
+
+
+@pytest.mark.parametrize("name", ["config1", "config3"])
+def test_operator_and_classic_layout_equal_the_fused_step_full_size(name):
+    """The three ways through the library at full size, on the same inputs: the fused step (segmented binning,
+    eg_train_step without Adam), the same step on the classic count / scan / emit layout, and the drop-in operator
+    (`rasterization` + torch autograd, what train_gaussians.py calls): loss and every gradient tensor agree to 1e-4
+    of the tensor's scale, the absgrad increment included."""
+    import torch
+    from edgegaussians_amd import EdgeTrainer, rasterization, synth
+    from tests.util import frac_bad, record, rel_err, strict_inputs
+    n, W, H, view, strategy = SIZES[name]
+    sc0 = synth.make_scene(n, 2, W, H, seed=0, anisotropy=5.0, spread_opacity=True)
+    sc, _fw, _border, w, _ = strict_inputs(sc0, view, strategy)
+    w = w.cuda()
+    N = sc.means.shape[0]
+    res, losses = {}, {}
+    for seg in (True, False):
+        tr = EdgeTrainer(sc.means, sc.log_scales, sc.quats, sc.logit_opacities, sc.viewmats, sc.Ks, sc.gt, W, H,
+                         segmented=seg)
+        tr.ensure_capacity()
+        tr.grad_step(view, w)
+        res[seg] = [t.clone() for t in tr.grad_views()] + [tr.grads.view(-1)[11 * N:].clone()]
+        losses[seg] = tr.pop_loss()
+        del tr
+    p = [t.clone().cuda().requires_grad_(True) for t in (sc.means, sc.quats, sc.log_scales, sc.logit_opacities)]
+    render, _alpha, info = rasterization(p[0], p[1], torch.exp(p[2]), torch.sigmoid(p[3]).squeeze(-1),
+                                         torch.ones(N, 3, device="cuda"), sc.viewmats[view:view + 1].cuda(),
+                                         sc.Ks[view:view + 1].cuda(), W, H, packed=False, absgrad=True,
+                                         rasterize_mode="antialiased")
+    loss = (w * (torch.clamp(render[0, ..., 0], 0, 1) - sc.gt[view].cuda()).abs()).sum()
+    loss.backward()
+    op = [p[0].grad, p[1].grad, p[2].grad, p[3].grad.view(-1), info["means2d"].absgrad[0].norm(dim=-1)]
+    assert abs(losses[False] - losses[True]) <= 1e-5 * abs(losses[True])
+    assert abs(float(loss.detach()) - losses[True]) <= 1e-5 * abs(losses[True])
+    worst = {}
+    for key, a, b, c in zip(("means", "quats", "scales", "opacities", "absgrad"), res[True], res[False], op):
+        scale = float(a.abs().max())
+        for other, t in (("classic", b), ("operator", c)):
+            assert frac_bad(t, a, 1e-4, 1e-4 * scale) == 0.0, (name, key, other, rel_err(t, a))
+            worst[f"{other}_{key}"] = rel_err(t, a)
+    record("three_paths_full_size", config=name, max_norm_rel_err=max(worst.values()), by_tensor=worst)
