@@ -1430,3 +1430,20 @@ def test_bench_line_contract(env):
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and "traffic" in rf and rf["achieved"] > 0
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == d["unit"] and cb["sample"]
+
+
+@pytest.mark.parametrize("W,H,n", [(1024, 512, 8000), (1040, 512, 8000), (2048, 16, 3000), (33, 17, 500), (721, 403, 6000)])
+def test_tile_grid_shapes_around_the_prefix_switch(env, W, H, n):
+    """Tile grids on either side of kPrefixHereMaxTiles (2048 tiles: the sort kernel forms the tile prefix and the
+    compositing kernel returns the cursors to zero; above it the projection kernel's last workgroup scans), strips one
+    tile high / wide, and sizes that are not multiples of 16: one fused step against the plain-C oracle, then a
+    native run of steps (tail fusion across the step boundary) that must leave every cursor at zero."""
+    _lib, synth, O = env
+    sc = synth.make_scene(n, 2, W, H, seed=5, anisotropy=5.0, spread_opacity=True, scale=0.01)
+    tr, _, _ = check_fused_step_vs_c_oracle(sc, 1, "weighted", f"grid_{W}x{H}")
+    wm = synth.weight_map("whole", sc.gt[0]).cuda()
+    tr.train_steps([0, 1, 0, 1, 1, 0], [wm] * 6)
+    loss = tr.pop_loss()
+    assert math.isfinite(loss) and loss > 0
+    assert int(tr.tile_counts.abs().sum()) == 0 and int(tr.ticket.abs().sum()) == 0
+    assert tr.overflow_events == 0
