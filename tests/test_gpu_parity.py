@@ -1242,15 +1242,16 @@ def test_train_loop_survives_a_capacity_crossing(env):
     assert float(torch.sigmoid(tr.logit_opacities).mean()) > 0.5
 
 
-@pytest.mark.parametrize("Cn", [1, 3, 8])
-def test_batched_views_equal_the_sum_of_single_view_steps(env, Cn):
+@pytest.mark.parametrize("Cn,w,h", [(1, 200, 136), (3, 200, 136), (8, 200, 136), (3, 640, 512)])
+def test_batched_views_equal_the_sum_of_single_view_steps(env, Cn, w, h):
     """C views in one launch sequence (gridDim.y = view).  Guarantee = the data-parallel one:
     summed gradient == sum of the per-view gradients at the same parameters (same kernels, so to rounding of the
     final sum), loss == sum of losses, absgrad increment == sum of increments; and the batched optimizer step ==
-    eg_adam_multi on that sum."""
+    eg_adam_multi on that sum.  (640 x 512 with 3 views: 3840 tiles in the launch, i.e. the tile scan stays in the
+    projection kernel; the small image: the sort kernel forms the prefix.)"""
     _lib, synth, O = env
     from edgegaussians_amd import EdgeTrainer, LRSchedule
-    sc = _scene(synth, n=4000, w=200, h=136, views=8)
+    sc = _scene(synth, n=4000, w=w, h=h, views=8)
     sched = LRSchedule(scales_start=0, quats_start=0, opacities_start=0)
     mk = lambda: EdgeTrainer(sc.means, sc.log_scales, sc.quats, sc.logit_opacities, sc.viewmats, sc.Ks, sc.gt,  # noqa: E731
                              sc.width, sc.height, schedule=sched)
