@@ -295,6 +295,7 @@ struct AdamK {
 };
 
 __device__ __forceinline__ void adam1(float &p, float g, float &m, float &v, int grp, const AdamK &h) {
+#pragma clang fp contract(off)  // (one rounding sequence in every kernel: see forward_geom)
   if (!h.active[grp]) return;
   m = m * h.b1 + g * h.omb1;
   v = v * h.b2 + (g * g) * h.omb2;
@@ -309,6 +310,7 @@ struct Grads {
 __device__ __forceinline__ void backward_geom(const Cam &cam, const Fwd &f, float eps2d, uint32_t flags,
                                               const float4 ga, const float4 gb, bool ext, float v_comp_ext,
                                               float v_depth_ext, Grads &o) {
+#pragma clang fp contract(off)  // (one rounding sequence in every kernel: see forward_geom)
   const float vx = ga.x, vy = ga.y;
   const float va = gb.x, vb = gb.y, vc = gb.z, vo_eff = gb.w;
   const bool aa = flags & EG_FLAG_ANTIALIASED;
