@@ -119,7 +119,7 @@ def measure_traffic(config, spread, steps=40):
             cmd = [exe, "--kernel-trace", "--pmc", counter, "-d", os.path.join(tmp, counter), "-o", "p", "--",
                    sys.executable, os.path.abspath(__file__), "--config", config, "--steps", str(steps), "--warmup", "5",
                    "--profile-only"] + (["--spread-opacity"] if spread else [])
-            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=420)
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=200)
             db = None
             for dp_, _, fs in os.walk(os.path.join(tmp, counter)):
                 for f in fs:
