@@ -1564,7 +1564,10 @@ static int launch_sliced_fwd(const float4 *splat, const TileTable tt, int channe
   // find an empty list costs 4.5 us, 64 cost 1.3 us); any grid is correct
   // rewalk_hint == EG_REWALK_SPECULATE: no launch at all; a pixel that does stop raises control word 3 instead
   const int skip = rewalk_hint == EG_REWALK_SPECULATE;
-  if (!skip && chain_tag > 0) {
+  // (rewalk_hint == 0 without speculation -- a caller without a journal, e.g. the data-parallel leg, that has seen no
+  // stop lately: the fused slice kernel + a 64-workgroup re-walk launch that finds an empty list is 3 us cheaper than
+  // the chained kernel's look-back, and still exact should a pixel stop after all)
+  if (!skip && chain_tag > 0 && rewalk_hint != 0) {
     // pixels do reach the stop: slice products, phase B and the exact stop in one kernel (decoupled look-back)
     if (channels == 1)
       composite_chained_fwd_kernel<1><<<dim3((unsigned)max_items, C), 256, 0, s>>>(
