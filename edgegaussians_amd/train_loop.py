@@ -128,7 +128,8 @@ def train(tr: EdgeTrainer, model_cfg: Dict, training_cfg: Dict, view_order: Call
     for epoch in range(num_epochs):
         n = train_epoch(tr, view_order(epoch), epoch, num_epochs, proj_cfg, orient_cfg, thr, generator, read_back=False)
         parked.append((epoch, n))
-        if len(parked) >= max(1, sync_every) or epoch in events or epoch == num_epochs - 1 or len(tr._journal) > 4096:
+        # (the trainer parks at most 64 epoch sums on the device between two read-backs)
+        if len(parked) >= max(1, min(sync_every, 60)) or epoch in events or epoch == num_epochs - 1 or len(tr._journal) > 4096:
             read_back()
         changed = False
         if get("if_duplicate_high_pos_grad", True) and epoch in get("dup_high_pos_grads_at_epoch", []):

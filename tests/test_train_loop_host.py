@@ -126,7 +126,7 @@ def test_history_and_on_epoch_do_not_depend_on_the_read_back_cadence(cfg, sync_e
     sync_epochs = [x[1] for x in tr.log if x[0] == "sync"]
     for e in (10, 20, 30, 45, epochs - 1):
         assert e in sync_epochs
-    if sync_every >= 1000:
+    if sync_every >= 1000:  # capped at 60 epochs per read-back (the device parks at most 64 sums)
         assert sync_epochs == [10, 20, 30, 45, epochs - 1]
     if sync_every == 1:
         assert sync_epochs == list(range(epochs))
