@@ -641,11 +641,11 @@ static int launch_tile_sort(uint64_t *keys, const int32_t *offsets, int32_t T, i
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLargeLds);
     g_sort_attr_set = true;
   }
-  // max_tile_hint: the largest tile population the caller has seen (0 = unknown).  If even 1.5x that
+  // max_tile_hint: the largest tile population the caller has seen (0 = unknown).  If even 1.25x that
   // fits the small variant, the launch of the large one (256 workgroups of 1024 threads and 136 KiB of
   // LDS that would all find nothing to do: ~3 us) is skipped and the small variant owns EVERY tile -- a
   // tile that outgrew the hint is then still sorted correctly, by the slower paths of the small variant.
-  const bool small_only = max_tile_hint > 0 && (int64_t)max_tile_hint * 3 / 2 <= kSmall;
+  const bool small_only = max_tile_hint > 0 && (int64_t)max_tile_hint * 5 / 4 <= kSmall;
   if (wide)
     tile_sort_kernel<512, kSmall, false><<<dim3(T, C), 512, kSmall * 8 + 2 * 512 * 4, as_stream(stream)>>>(
         (unsigned long long *)keys, offsets, T, (long long)capacity, small_only ? 0x7fffffff : kSmall, flatten_ids,

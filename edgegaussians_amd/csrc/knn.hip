@@ -26,60 +26,67 @@ __device__ __forceinline__ int3 cell_of_point(const Grid &g, float x, float y, f
   return c;
 }
 
-// The bounding box on the device (eg_knn_auto: no host-side look at the points).  Floats are compared as ordered
-// integers; mm: [6] = min xyz, max xyz in that encoding.
-__device__ __forceinline__ int ordered_of(float f) {
-  const int b = __float_as_int(f);
-  return b >= 0 ? b : b ^ 0x7fffffff;
+// The bounding box on the device (eg_knn_auto: no host-side look at the points), ONE launch: floats are compared as
+// order-preserving unsigned integers; the scratch words hold max(~u) for the minima and max(u) for the maxima, so that
+// an all-zero scratch is the identity (the caller zeroes it once; the last workgroup -- device-scope ticket -- turns
+// the box into the grid parameters and hands the words back zeroed).  mm: [6] extrema, [6] ticket.
+__device__ __forceinline__ unsigned ordered_u(float f) {
+  const unsigned b = (unsigned)__float_as_int(f);
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
 }
-__device__ __forceinline__ float float_of(int k) { return __int_as_float(k >= 0 ? k : k ^ 0x7fffffff); }
-
-__global__ void knn_bbox_init_kernel(int *__restrict__ mm) {
-  if (threadIdx.x < 6) mm[threadIdx.x] = threadIdx.x < 3 ? 0x7fffffff : (int)0x80000000;
+__device__ __forceinline__ float float_of_u(unsigned u) {
+  return __int_as_float((int)((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u));
 }
 
+// D x D x D cubic cells over the box (inflated by 0.1 %: the maxima must land inside the last cell)
 __global__ void __launch_bounds__(256)
-knn_bbox_kernel(const float *__restrict__ pts, int N, int *__restrict__ mm) {
-  int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, hi[3] = {(int)0x80000000, (int)0x80000000, (int)0x80000000};
+knn_bbox_kernel(const float *__restrict__ pts, int N, unsigned *__restrict__ mm, int D, Grid *__restrict__ out) {
+  unsigned lo[3] = {0u, 0u, 0u}, hi[3] = {0u, 0u, 0u};  // lo holds max(~u)
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x)
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-      const int v = ordered_of(pts[3 * i + k]);
-      lo[k] = min(lo[k], v);
-      hi[k] = max(hi[k], v);
+      const unsigned u = ordered_u(pts[3 * i + k]);
+      lo[k] = max(lo[k], ~u);
+      hi[k] = max(hi[k], u);
     }
   // wave -> workgroup -> six atomics per workgroup (same-address atomics serialise at ~60 ns each: one per WAVE of
   // a 1024-workgroup grid cost 280 us)
-  __shared__ int s_lo[4][3], s_hi[4][3];
+  __shared__ unsigned s_lo[4][3], s_hi[4][3];
+  __shared__ int s_last;
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
-      lo[k] = min(lo[k], __shfl_xor(lo[k], d, 64));
-      hi[k] = max(hi[k], __shfl_xor(hi[k], d, 64));
+      lo[k] = max(lo[k], (unsigned)__shfl_xor((int)lo[k], d, 64));
+      hi[k] = max(hi[k], (unsigned)__shfl_xor((int)hi[k], d, 64));
     }
     if ((threadIdx.x & 63) == 0) { s_lo[threadIdx.x >> 6][k] = lo[k]; s_hi[threadIdx.x >> 6][k] = hi[k]; }
   }
   __syncthreads();
   if (threadIdx.x < 3) {
     const int k = threadIdx.x;
-    atomicMin(&mm[k], min(min(s_lo[0][k], s_lo[1][k]), min(s_lo[2][k], s_lo[3][k])));
+    atomicMax(&mm[k], max(max(s_lo[0][k], s_lo[1][k]), max(s_lo[2][k], s_lo[3][k])));
     atomicMax(&mm[3 + k], max(max(s_hi[0][k], s_hi[1][k]), max(s_hi[2][k], s_hi[3][k])));
   }
-}
-
-// D x D x D cubic cells over the box (inflated by 0.1 %: the maxima must land inside the last cell)
-__global__ void knn_grid_params_kernel(const int *__restrict__ mm, int D, Grid *__restrict__ out) {
-  if (threadIdx.x != 0) return;
-  float lo[3], ext = 1e-6f;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the extrema are at the L2 before this workgroup's ticket is
+  __syncthreads();
+  if (threadIdx.x == 0) s_last = (atomicAdd((int *)&mm[6], 1) == (int)gridDim.x - 1);
+  __syncthreads();
+  if (!s_last || threadIdx.x != 0) return;
+  float lof[3], ext = 1e-6f;
   for (int k = 0; k < 3; ++k) {
-    lo[k] = float_of(mm[k]);
-    ext = fmaxf(ext, float_of(mm[3 + k]) - lo[k]);
+    const unsigned l = ~__hip_atomic_load(&mm[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned h = __hip_atomic_load(&mm[3 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    lof[k] = float_of_u(l);
+    ext = fmaxf(ext, float_of_u(h) - lof[k]);
+    mm[k] = 0u;
+    mm[3 + k] = 0u;
   }
+  mm[6] = 0u;
   Grid g;
   g.cell = ext * 1.002f / (float)D;
   g.inv_cell = 1.f / g.cell;
-  g.ox = lo[0] - 0.001f * ext; g.oy = lo[1] - 0.001f * ext; g.oz = lo[2] - 0.001f * ext;
+  g.ox = lof[0] - 0.001f * ext; g.oy = lof[1] - 0.001f * ext; g.oz = lof[2] - 0.001f * ext;
   g.nx = g.ny = g.nz = D;
   *out = g;
 }
@@ -359,6 +366,20 @@ knn_wave_kernel(const float *__restrict__ pts, int N, int K, int *__restrict__ o
 // -lambda / (N k); lambda is data-dependent in the reference, train_gaussians.py:113).
 // top_k in (0, K): the 'enforce_half' method (edge_gs.py:366-369) -- only the top_k best-aligned of the K
 // listed neighbours count (sort descending, mean of the first k); otherwise every neighbour counts.
+// sum of `acc` over a 256-thread workgroup, ONE atomic per workgroup (a same-address atomic per wavefront -- 1563 of
+// them at 100 k Gaussians -- serialises at the L2: 15 of the 29 us of the ratio-loss kernel)
+__device__ __forceinline__ void block_sum_add(float acc, float *__restrict__ sum_out) {
+  __shared__ float s_part[4];
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
+  if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float t = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
+    if (t != 0.f) unsafeAtomicAdd(sum_out, t);
+  }
+}
+
 constexpr int kMaxDirNN = 32;
 __global__ void __launch_bounds__(256)
 direction_loss_kernel(const float *__restrict__ means, const float *__restrict__ quats,
@@ -440,9 +461,7 @@ direction_loss_kernel(const float *__restrict__ means, const float *__restrict__
     g_quats[4 * i + 2] = (ny - d * y) * qinv;
     g_quats[4 * i + 3] = (nz - d * z) * qinv;
   }
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
-  if ((threadIdx.x & 63) == 0 && acc != 0.f) unsafeAtomicAdd(sum_out, acc);
+  block_sum_add(acc, sum_out);
 }
 
 // ratio loss (edge_gs.py:375-380): mean_i second-largest / largest scale.  Value (sum of ratios) and
@@ -467,9 +486,7 @@ ratio_loss_kernel(const float *__restrict__ log_scales, int N, float *__restrict
     g_scales[3 * i] = g[0]; g_scales[3 * i + 1] = g[1]; g_scales[3 * i + 2] = g[2];
   }
   float acc = r;
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
-  if ((threadIdx.x & 63) == 0 && acc != 0.f) unsafeAtomicAdd(sum_out, acc);
+  block_sum_add(acc, sum_out);
 }
 
 
@@ -543,18 +560,17 @@ extern "C" int32_t eg_knn_auto_dims(int32_t N, int32_t K) {
 
 extern "C" int eg_knn_auto(const float *points, int32_t N, int32_t K, int32_t *cell_of /*[N]*/,
                            int32_t *cell_counts /*[D^3] zero on entry and on exit*/, int32_t *cell_start /*[D^3+1]*/,
-                           float *sorted /*[N,4]*/, void *grid_scratch /*64 bytes*/, int32_t *out_idx,
+                           float *sorted /*[N,4]*/, void *grid_scratch /*64 bytes, zeroed once by the caller*/,
+                           int32_t *out_idx,
                            float *out_d2, eg_stream_t stream) {
   EG_REQUIRE(N >= 0 && K >= 1 && K <= 32, "bad arguments");
   if (N == 0) return EG_OK;
   EG_REQUIRE(points && cell_of && cell_counts && cell_start && sorted && grid_scratch && out_idx, "null pointer");
   const int D = eg_knn_auto_dims(N, K);
   hipStream_t st = as_stream(stream);
-  int *mm = (int *)grid_scratch;          // 6 ints
-  Grid *gp = (Grid *)(mm + 8);            // 8 words, 32-byte aligned when the scratch is
-  knn_bbox_init_kernel<<<1, 64, 0, st>>>(mm);
-  knn_bbox_kernel<<<min(cdiv(N, 2048), 128), 256, 0, st>>>(points, N, mm);
-  knn_grid_params_kernel<<<1, 64, 0, st>>>(mm, D, gp);
+  unsigned *mm = (unsigned *)grid_scratch;  // 6 extrema + ticket (all zero between calls)
+  Grid *gp = (Grid *)(mm + 8);              // 8 words, 32-byte aligned when the scratch is
+  knn_bbox_kernel<<<min(cdiv(N, 2048), 128), 256, 0, st>>>(points, N, mm, D, gp);
   Grid g = {};
   g.nx = g.ny = g.nz = D;  // (only the pointer's copy is read by the kernels)
   return knn_grid_search(points, N, K, g, gp, D * D * D, cell_of, cell_counts, cell_start, sorted, out_idx, out_d2,

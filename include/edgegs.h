@@ -323,7 +323,7 @@ int eg_knn(const float *points /*[N,3]*/, int32_t N, int32_t K, const float *ori
 /* eg_knn_auto: the grid search with the grid chosen on the DEVICE: bounding box by a reduction kernel, D x D x D
  * cubic cells with D = eg_knn_auto_dims(N, K) (a function of the sizes only, so the caller can size the scratch without
  * looking at the points) -- no host sync at all.  Scratch: cell_of[N], cell_counts[D^3] (zero on entry, returned to zero),
- * cell_start[D^3 + 1], sorted[N,4], grid_scratch (64 bytes).  Same result as eg_knn / eg_knn_small. */
+ * cell_start[D^3 + 1], sorted[N,4], grid_scratch (64 bytes, zero on entry, returned to zero).  Same result as eg_knn / eg_knn_small. */
 int32_t eg_knn_auto_dims(int32_t N, int32_t K);
 int eg_knn_auto(const float *points /*[N,3]*/, int32_t N, int32_t K, int32_t *cell_of, int32_t *cell_counts,
                 int32_t *cell_start, float *sorted, void *grid_scratch, int32_t *out_idx /*[N,K]*/,
