@@ -87,7 +87,7 @@ _SIGS = {
     "eg_project_visibility": [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _vp, _vp],
     "eg_knn": [_vp, _i32, _i32, C.POINTER(_f), _f, C.POINTER(_i32), _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "eg_knn_small": [_vp, _i32, _i32, _vp, _vp, _vp],
-    "eg_knn_auto": [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "eg_knn_auto": [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp],
     "eg_direction_loss": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp],
     "eg_ratio_loss": [_vp, _i32, _vp, _vp, _vp],
     "eg_regulariser_step": [_i32] + [_vp] * 7 + [_i32, _vp, _i32, _i32, _i32, _i32, _vp, _f, _f, _vp, AdamHyper, _vp],

@@ -205,7 +205,7 @@ template <int Q>
 __global__ void __launch_bounds__(256)
 knn_grid_wave_kernel(int N, int K, Grid g_, const Grid *__restrict__ gp, const int *__restrict__ cell_start,
                      const float4 *__restrict__ sorted, int *__restrict__ out_idx, float *__restrict__ out_d2,
-                     int r_brute) {
+                     int r_brute, float *kth /*[N] or NULL: see eg_knn_auto*/, float kth_slack) {
   const Grid g = gp ? *gp : g_;
   const int lane = threadIdx.x & 63;
   const int q0 = __builtin_amdgcn_readfirstlane((blockIdx.x * 4 + (threadIdx.x >> 6)) * Q);
@@ -215,7 +215,12 @@ knn_grid_wave_kernel(int N, int K, Grid g_, const Grid *__restrict__ gp, const i
     const int i = __float_as_int(me.w);
     const int3 c = cell_of_point(g, me.x, me.y, me.z);
     WaveList w;
-    wavelist_reset(w, 3.0e38f);
+    // temporal coherence: the K-th squared distance this point had in the caller's previous search (inflated) is the
+    // entry bound from the first candidate on -- ~K insertions instead of ~K ln(n / K).  Only a filter: should the
+    // point's neighbourhood have thinned out, fewer than K candidates pass, the K-th distance stays infinite, the
+    // block is not settled and the re-scan runs without the bound.
+    const float bound0 = kth ? kth[i] * kth_slack : 3.0e38f;
+    wavelist_reset(w, bound0 > 0.f ? bound0 : 3.0e38f);
     bool settled = false;
     for (int r = 1; !settled;) {
       if (r > r_brute && r < rmax) break;
@@ -278,6 +283,7 @@ knn_grid_wave_kernel(int N, int K, Grid g_, const Grid *__restrict__ gp, const i
     if (lane < K) {
       out_idx[(size_t)i * K + lane] = w.j;
       if (out_d2) out_d2[(size_t)i * K + lane] = w.d;
+      if (kth && lane == K - 1) kth[i] = w.j >= 0 ? w.d : 0.f;  // (0 = unknown: fewer than K other points)
     }
   }
 }
@@ -511,7 +517,8 @@ using namespace eg;
 // count -> scan -> scatter (points in cell order) -> wave-cooperative query; grid by value (host) or by pointer (device)
 static int knn_grid_search(const float *points, int32_t N, int32_t K, const Grid &g, const Grid *gp, int C,
                            int32_t *cell_of, int32_t *cell_counts, int32_t *cell_start, float *sorted,
-                           int32_t *out_idx, float *out_d2, eg_stream_t stream) {
+                           int32_t *out_idx, float *out_d2, eg_stream_t stream, float *kth = nullptr,
+                           float kth_slack = 0.f) {
   hipStream_t st = as_stream(stream);
   // a block of radius r costs (2r+1)^2 row look-ups, the exhaustive scan N / 64 rounds of ~15 instructions:
   // beyond this radius the scan is the cheaper way to settle an outlier
@@ -526,7 +533,7 @@ static int knn_grid_search(const float *points, int32_t N, int32_t K, const Grid
   knn_scan_kernel<<<scan_blocks, 256, 0, st>>>(cell_counts, C, cell_start, (unsigned long long *)sorted);
   knn_scatter_kernel<<<cdiv(N, 256), 256, 0, st>>>(points, cell_of, N, cell_start, cell_counts, (float4 *)sorted);
   knn_grid_wave_kernel<4><<<cdiv(N, 16), 256, 0, st>>>(N, K, g, gp, cell_start, (const float4 *)sorted, out_idx, out_d2,
-                                                       r_brute);
+                                                       r_brute, kth, kth_slack);
   return check_launch("knn");
 }
 
@@ -562,7 +569,7 @@ extern "C" int eg_knn_auto(const float *points, int32_t N, int32_t K, int32_t *c
                            int32_t *cell_counts /*[D^3] zero on entry and on exit*/, int32_t *cell_start /*[D^3+1]*/,
                            float *sorted /*[N,4]*/, void *grid_scratch /*64 bytes, zeroed once by the caller*/,
                            int32_t *out_idx,
-                           float *out_d2, eg_stream_t stream) {
+                           float *out_d2, float *kth, float kth_slack, eg_stream_t stream) {
   EG_REQUIRE(N >= 0 && K >= 1 && K <= 32, "bad arguments");
   if (N == 0) return EG_OK;
   EG_REQUIRE(points && cell_of && cell_counts && cell_start && sorted && grid_scratch && out_idx, "null pointer");
@@ -574,7 +581,7 @@ extern "C" int eg_knn_auto(const float *points, int32_t N, int32_t K, int32_t *c
   Grid g = {};
   g.nx = g.ny = g.nz = D;  // (only the pointer's copy is read by the kernels)
   return knn_grid_search(points, N, K, g, gp, D * D * D, cell_of, cell_counts, cell_start, sorted, out_idx, out_d2,
-                         stream);
+                         stream, kth, kth_slack);
 }
 
 extern "C" int eg_knn_small(const float *points, int32_t N, int32_t K, int32_t *out_idx, float *out_d2,

@@ -59,12 +59,16 @@ def _grid_buffers(N: int, ncell: int, dev):
 
 
 def knn(points: Tensor, k: int, want_dist: bool = False, grid=None, method: str = "auto",
-        out: Tensor = None) -> Tuple[Tensor, Tensor]:
+        out: Tensor = None, kth: Tensor = None, kth_slack: float = 1.2) -> Tuple[Tensor, Tensor]:
     """Indices [N,k] (int32, ascending distance, self excluded) and, optionally, distances [N,k] -- exact, and
     without a host sync: method "auto" = exhaustive search for N <= KNN_EXHAUSTIVE_MAX (eg_knn_small), else the
     uniform-grid search on a grid the DEVICE chooses (eg_knn_auto: bounding box by a reduction kernel, cell count a
     function of N) -- where the reference had a full D2H copy + CPU tree build.  "exhaustive" / "grid" force one;
-    `grid` = a host-chosen grid from `make_grid` (eg_knn).  `out` [N,k] int32: caller-owned result buffer."""
+    `grid` = a host-chosen grid from `make_grid` (eg_knn).  `out` [N,k] int32: caller-owned result buffer.
+    `kth` [N] float32 (device-grid search only): every point's K-th squared distance of the caller's PREVIOUS search
+    of the same, slowly moving points (zeros = unknown); read as the entry bound of the point's list (times
+    kth_slack), overwritten with this search's -- ~K insertions per query instead of ~K ln(n / K); the result does
+    not depend on it."""
     assert points.is_cuda and points.dtype == torch.float32 and points.dim() == 2 and points.shape[1] == 3
     assert 1 <= k <= 32
     pts = points.detach().contiguous()
@@ -79,8 +83,10 @@ def knn(points: Tensor, k: int, want_dist: bool = False, grid=None, method: str 
     elif grid is None:
         D = int(load().eg_knn_auto_dims(N, k))
         cell_of, counts, start, order, gs = _grid_buffers(N, D * D * D, dev)
+        if kth is not None:
+            assert kth.shape == (N,) and kth.dtype == torch.float32 and kth.is_cuda and kth.is_contiguous()
         call("eg_knn_auto", ptr(pts), N, k, ptr(cell_of), ptr(counts), ptr(start), ptr(order), ptr(gs), ptr(idx), d2p,
-             stream())
+             ptr(kth) if kth is not None else None, float(kth_slack), stream())
     else:
         lo_h, cell, dims = grid
         cell_of, counts, start, order, _ = _grid_buffers(N, dims[0] * dims[1] * dims[2], dev)

@@ -160,6 +160,7 @@ class EdgeTrainer:
         self._drop_projection()
         N, d = self.N, self.dev
         self.splat = torch.empty(N, 8, device=d)
+        self.__dict__.pop("_knn_buf", None)  # (neighbour table + per-row K-th distances: the rows have changed)
         self.g2d = torch.empty(N, 8, device=d)  # written (not accumulated) by the footprint backward
         self.tile_mask = torch.zeros(N, dtype=torch.int32, device=d)  # exact tile hits per Gaussian (bit mask)
         self.grads = torch.zeros(N, 12, device=d)  # [means3|quats4|scales3|opac1|absgrad-inc1] for all-reduce
@@ -731,7 +732,12 @@ class EdgeTrainer:
         buf = self.__dict__.get("_knn_buf")
         if buf is None or buf.shape != (self.N, n):  # the table is reused from call to call
             buf = self._knn_buf = torch.empty(self.N, n, dtype=torch.int32, device=self.dev)
-        R.knn(self.means, n, out=buf)  # exhaustive (small N) or device-chosen grid: no host sync either way
+            # every Gaussian's K-th squared distance of the previous search: the means move a little between two
+            # regulariser steps, so it is a tight entry bound for the next one (zeros = unknown; dropped whenever the
+            # rows change: N, spatial re-sort)
+            self._knn_kth = torch.zeros(self.N, device=self.dev)
+        # exhaustive (small N) or device-chosen grid: no host sync either way
+        R.knn(self.means, n, out=buf, kth=self._knn_kth if self.N > R.KNN_EXHAUSTIVE_MAX else None)
         self.nn_table = buf              # [N, n]: k_nearest_sklearn's table (self excluded)
         self.nn_indices = buf[:, 1:]     # the reference then drops the nearest neighbour too (edge_gs.py:342)
         return self.nn_indices

@@ -327,7 +327,12 @@ int eg_knn(const float *points /*[N,3]*/, int32_t N, int32_t K, const float *ori
 int32_t eg_knn_auto_dims(int32_t N, int32_t K);
 int eg_knn_auto(const float *points /*[N,3]*/, int32_t N, int32_t K, int32_t *cell_of, int32_t *cell_counts,
                 int32_t *cell_start, float *sorted, void *grid_scratch, int32_t *out_idx /*[N,K]*/,
-                float *out_d2 /*[N,K] or NULL*/, eg_stream_t stream);
+                float *out_d2 /*[N,K] or NULL*/,
+                float *kth /*[N] or NULL: temporal coherence for callers that search the SAME (slowly moving) points
+                             again and again -- on entry each point's K-th squared distance of the previous call
+                             (0 = unknown), used times kth_slack as the entry bound of its list; on exit this call's.
+                             Exactness does not depend on it: a bound that turns out too small costs a re-scan */,
+                float kth_slack /* e.g. 1.2 */, eg_stream_t stream);
 
 /* eg_knn_small: the same result (exact K <= 32 neighbours, self excluded, ascending (distance, index)) by
  * exhaustive search in ONE launch, for N <= 131072: no grid, no scratch.  A lane holds a candidate, a wavefront owns a

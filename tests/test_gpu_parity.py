@@ -1448,3 +1448,32 @@ def test_tile_grid_shapes_around_the_prefix_switch(env, W, H, n):
     assert math.isfinite(loss) and loss > 0
     assert int(tr.tile_counts.abs().sum()) == 0 and int(tr.ticket.abs().sum()) == 0
     assert tr.overflow_events == 0
+
+
+def test_knn_with_the_previous_searches_bound(env):
+    """eg_knn_auto's temporal-coherence input (every point's K-th squared distance of the previous search as the
+    entry bound of its list): the tables are the same with no bound, with the bound of an identical cloud, after the
+    points have moved a little, and with bounds that are far too small (the re-scan path) or garbage."""
+    from edgegaussians_amd import regularizers as R
+    g = torch.Generator().manual_seed(9)
+    n, k = 30000, 6
+    pts = torch.rand(n, 3, generator=g)
+    pts[: n // 4] = (pts[: n // 4] * 0.02 + 0.5)  # a dense clump inside a sparse cloud
+    pts = pts.cuda()
+    ref, dref = R.knn(pts, k, want_dist=True, method="grid")
+    kth = torch.zeros(n, device="cuda")
+    a, _ = R.knn(pts, k, method="grid", kth=kth)                      # unknown bounds (zeros) -> fills kth
+    assert torch.equal(a, ref)
+    assert torch.allclose(kth.sqrt(), dref[:, k - 1], rtol=1e-6)
+    b, _ = R.knn(pts, k, method="grid", kth=kth)                      # tight bounds
+    assert torch.equal(b, ref)
+    moved = (pts + 0.002 * torch.randn(n, 3, generator=g).cuda()).contiguous()
+    want, _ = R.knn(moved, k, method="grid")
+    c, _ = R.knn(moved, k, method="grid", kth=kth)                    # yesterday's bounds on moved points
+    assert torch.equal(c, want)
+    tiny = torch.full((n,), 1e-12, device="cuda")
+    d, _ = R.knn(pts, k, method="grid", kth=tiny)                     # every bound too small: re-scan without it
+    assert torch.equal(d, ref)
+    junk = torch.rand(n, generator=g).cuda() * 1e-3
+    e, _ = R.knn(pts, k, method="grid", kth=junk)
+    assert torch.equal(e, ref)
