@@ -394,6 +394,14 @@ direction_loss_kernel(const float *__restrict__ means, const float *__restrict__
                       float *__restrict__ sum_out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   float acc = 0.f;
+  // Gradients w.r.t. the means of the workgroup's OWN 256 rows are collected in LDS and flushed with three global
+  // atomics per row; with the rows in spatial order most neighbours of a row sit in the same workgroup, so the 18
+  // device-scope float atomics per Gaussian (15 scattered to neighbours, 3 to itself) drop to 3 + the neighbours
+  // that live in other workgroups
+  __shared__ float s_g[256 * 3];
+  const int b0 = blockIdx.x * 256;
+  s_g[threadIdx.x] = 0.f; s_g[256 + threadIdx.x] = 0.f; s_g[512 + threadIdx.x] = 0.f;
+  __syncthreads();
   if (i < N) {
     float w = quats[4 * i], x = quats[4 * i + 1], y = quats[4 * i + 2], z = quats[4 * i + 3];
     const float qinv = rsqrtf(w * w + x * x + y * y + z * z);
@@ -447,13 +455,20 @@ direction_loss_kernel(const float *__restrict__ means, const float *__restrict__
       const float vu = sg * dot;  // (sg m) . u
       const float gx = (sg * mx - vu * ux) * inv, gy = (sg * my - vu * uy) * inv, gz = (sg * mz - vu * uz) * inv;
       vpx += gx; vpy += gy; vpz += gz;
-      unsafeAtomicAdd(&g_means[3 * j], -gx);
-      unsafeAtomicAdd(&g_means[3 * j + 1], -gy);
-      unsafeAtomicAdd(&g_means[3 * j + 2], -gz);
+      const unsigned jl = (unsigned)(j - b0);
+      if (jl < 256u) {
+        atomicAdd(&s_g[3 * jl], -gx);
+        atomicAdd(&s_g[3 * jl + 1], -gy);
+        atomicAdd(&s_g[3 * jl + 2], -gz);
+      } else {
+        unsafeAtomicAdd(&g_means[3 * j], -gx);
+        unsafeAtomicAdd(&g_means[3 * j + 1], -gy);
+        unsafeAtomicAdd(&g_means[3 * j + 2], -gz);
+      }
     }
-    unsafeAtomicAdd(&g_means[3 * i], vpx);
-    unsafeAtomicAdd(&g_means[3 * i + 1], vpy);
-    unsafeAtomicAdd(&g_means[3 * i + 2], vpz);
+    atomicAdd(&s_g[3 * threadIdx.x], vpx);
+    atomicAdd(&s_g[3 * threadIdx.x + 1], vpy);
+    atomicAdd(&s_g[3 * threadIdx.x + 2], vpz);
     // rotation column c -> normalised quaternion -> raw quaternion
     float vR[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     vR[c] = vmx; vR[3 + c] = vmy; vR[6 + c] = vmz;
@@ -466,6 +481,13 @@ direction_loss_kernel(const float *__restrict__ means, const float *__restrict__
     g_quats[4 * i + 1] = (nx - d * x) * qinv;
     g_quats[4 * i + 2] = (ny - d * y) * qinv;
     g_quats[4 * i + 3] = (nz - d * z) * qinv;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {  // coalesced flush of the workgroup's 768 accumulators
+    const int e = k * 256 + threadIdx.x;
+    const float v = s_g[e];
+    if (v != 0.f && 3 * (size_t)b0 + e < 3 * (size_t)N) unsafeAtomicAdd(&g_means[3 * (size_t)b0 + e], v);
   }
   block_sum_add(acc, sum_out);
 }
