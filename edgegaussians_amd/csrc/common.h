@@ -67,6 +67,10 @@ int composite_fwd_segments_hinted(const float *splat, const int32_t *tile_start,
                                   hipStream_t st, int32_t *cursor_reset = nullptr);
 int launch_footprint_bwd(const float *splat, int32_t N, int32_t width, int32_t height, const float *gtstop, float *g2d,
                          const Batch &bt, int C, hipStream_t st);
+int launch_adam_regulariser(float *means, float *scales, float *quats, float *opacities, const float *g_means,
+                            const float *g_scales, const float *g_quats, float *m, float *v, int32_t N,
+                            const eg_adam_hyper &hyper, const float *sum, const float *loss_sum, float loss_sum_host,
+                            float factor, float w, int ratio, float *loss_out, hipStream_t st);
 int launch_project_bwd_emit(float *means, float *quats, float *scales, float *opacities, const float *viewmat,
                             const float *K, const float *next_viewmat, const float *next_K, int32_t N, int32_t width,
                             int32_t height, float eps2d, uint32_t flags, float *splat, const float *g2d, float *absgrads,

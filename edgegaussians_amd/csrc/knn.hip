@@ -518,20 +518,6 @@ ratio_loss_kernel(const float *__restrict__ log_scales, int N, float *__restrict
 }
 
 
-// The tail of a regulariser iteration (train_gaussians.py:108-131) on the device: loss value from the kernel's sum,
-// lambda = (running projection-loss sum) * factor / loss, gradients scaled in place.  Same float32 operation
-// order as the tensor expressions it replaces: loss = 1 + w * sum (direction, w = -1 / (N k)) or sum / N (ratio);
-// g = (raw * w) * lambda or (raw / N) * lambda.
-__global__ void __launch_bounds__(256)
-regulariser_scale_kernel(float *__restrict__ g, size_t n, const float *__restrict__ sum,
-                         const float *__restrict__ loss_sum_dev, float loss_sum_host, float factor, float w,
-                         float n_gauss, int ratio, float *__restrict__ loss_out) {
-  const float loss = ratio ? sum[0] / n_gauss : 1.0f + w * sum[0];
-  const float lam = (loss_sum_dev ? loss_sum_dev[0] * factor : loss_sum_host * factor) / loss;
-  const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-  if (i == 0 && loss_out) loss_out[0] = loss;
-  if (i < n) g[i] = (ratio ? g[i] / n_gauss : g[i] * w) * lam;
-}
 }  // namespace eg
 
 using namespace eg;
@@ -659,26 +645,27 @@ extern "C" int eg_regulariser_step(int32_t kind, float *means, float *quats, flo
   if (N == 0) return EG_OK;
   EG_REQUIRE(means && quats && log_scales && logit_opacities && adam_m && adam_v && grads && work, "null pointer");
   hipStream_t st = as_stream(stream);
-  float *gm = grads, *gq = grads + 3 * (size_t)N, *gs = grads + 7 * (size_t)N, *go = grads + 10 * (size_t)N;
-  if (hipMemsetAsync(grads, 0, sizeof(float) * 11 * (size_t)N, st) != hipSuccess ||
-      hipMemsetAsync(work, 0, sizeof(float) * 2, st) != hipSuccess)
-    return check_launch("regulariser_step memset");
+  float *gm = grads, *gq = grads + 3 * (size_t)N, *gs = grads + 7 * (size_t)N;
+  // the loss kernel leaves RAW gradients and the sum of the per-Gaussian terms; the Adam kernel forms the loss value
+  // and lambda from them and scales on the fly; the blocks a loss does not touch are never read (zero gradients)
+  if (hipMemsetAsync(work, 0, sizeof(float) * 2, st) != hipSuccess) return check_launch("regulariser_step memset");
+  int rc;
   if (kind == 0) {
     EG_REQUIRE(nn && K >= 1 && K <= kMaxDirNN && nn_offset >= 0 && nn_offset + K <= nn_stride, "bad neighbour table");
+    if (hipMemsetAsync(gm, 0, sizeof(float) * 3 * (size_t)N, st) != hipSuccess)  // (accumulated with atomics)
+      return check_launch("regulariser_step memset");
     direction_loss_kernel<<<cdiv(N, 256), 256, 0, st>>>(means, quats, log_scales, nn + nn_offset, nn_stride, N, K,
                                                         top_k, gm, gq, work);
+    rc = check_launch("regulariser_step");
+    if (rc) return rc;
     const int used = (top_k > 0 && top_k < K) ? top_k : K;
-    // means and quats are adjacent blocks: one scaling launch over both
-    regulariser_scale_kernel<<<cdiv(7 * (int64_t)N, 256), 256, 0, st>>>(
-        gm, 7 * (size_t)N, work, loss_sum, loss_sum_host, scale_factor, (float)(-1.0 / ((double)N * used)), (float)N, 0,
-        work + 1);
-  } else {
-    ratio_loss_kernel<<<cdiv(N, 256), 256, 0, st>>>(log_scales, N, gs, work);
-    regulariser_scale_kernel<<<cdiv(3 * (int64_t)N, 256), 256, 0, st>>>(gs, 3 * (size_t)N, work, loss_sum, loss_sum_host,
-                                                                      scale_factor, 0.f, (float)N, 1, work + 1);
+    return launch_adam_regulariser(means, log_scales, quats, logit_opacities, gm, nullptr, gq, adam_m, adam_v, N, hyper,
+                                   work, loss_sum, loss_sum_host, scale_factor, (float)(-1.0 / ((double)N * used)), 0,
+                                   work + 1, st);
   }
-  int rc = check_launch("regulariser_step");
+  ratio_loss_kernel<<<cdiv(N, 256), 256, 0, st>>>(log_scales, N, gs, work);
+  rc = check_launch("regulariser_step");
   if (rc) return rc;
-  return eg_adam_multi(means, log_scales, quats, logit_opacities, gm, gs, gq, go, adam_m, adam_v, N, hyper, nullptr,
-                       nullptr, stream);
+  return launch_adam_regulariser(means, log_scales, quats, logit_opacities, nullptr, gs, nullptr, adam_m, adam_v, N, hyper,
+                                 work, loss_sum, loss_sum_host, scale_factor, 0.f, 1, work + 1, st);
 }

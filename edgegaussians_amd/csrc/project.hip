@@ -541,12 +541,31 @@ project_bwd_batched_kernel(float *__restrict__ means, float *__restrict__ quats,
 }
 
 // stand-alone Adam over the 11 N parameters (used after an RCCL gradient all-reduce)
+// Gradients of a regulariser iteration (train_gaussians.py:108-131) scaled on the fly: the loss kernels of knn.hip leave
+// RAW gradients and the sum of the per-Gaussian terms; loss = 1 + w * sum (direction) or sum / N (ratio),
+// lambda = (running projection-loss sum) * factor / loss, g = (raw * w) * lambda or (raw / N) * lambda -- the float32
+// operation order of the tensor expressions this replaces.  A null gradient pointer is a zero gradient (the optimizers
+// whose parameter is outside the loss still step: torch 1.13's zero_grad() leaves zeros, not None).
+struct RegScale {
+  const float *sum;       // null: plain Adam (no scaling)
+  const float *loss_sum;  // device scalar or null -> loss_sum_host
+  float loss_sum_host, factor, w, n_gauss;
+  int ratio;
+  float *loss_out;
+};
+
 __global__ void __launch_bounds__(256)
 adam_multi_kernel(float *__restrict__ means, float *__restrict__ scales, float *__restrict__ quats,
                   float *__restrict__ opacities, const float *__restrict__ g_means,
                   const float *__restrict__ g_scales, const float *__restrict__ g_quats,
                   const float *__restrict__ g_opacities, float *__restrict__ am, float *__restrict__ av, int N,
-                  AdamK hyper, const float *__restrict__ absgrad_inc, float *__restrict__ absgrads) {
+                  AdamK hyper, const float *__restrict__ absgrad_inc, float *__restrict__ absgrads, RegScale rs) {
+  float lam = 1.f;
+  if (rs.sum) {
+    const float loss = rs.ratio ? rs.sum[0] / rs.n_gauss : 1.0f + rs.w * rs.sum[0];
+    lam = (rs.loss_sum ? rs.loss_sum[0] * rs.factor : rs.loss_sum_host * rs.factor) / loss;
+    if (rs.loss_out && blockIdx.x == 0 && threadIdx.x == 0) rs.loss_out[0] = loss;
+  }
   if (absgrads)
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < (size_t)N; i += (size_t)gridDim.x * blockDim.x)
       absgrads[i] += absgrad_inc[i];
@@ -558,7 +577,9 @@ adam_multi_kernel(float *__restrict__ means, float *__restrict__ scales, float *
     else if (i < 10 * (size_t)N) { p = quats; g = g_quats; grp = 2; j = i - 6 * (size_t)N; }
     else { p = opacities; g = g_opacities; grp = 3; j = i - 10 * (size_t)N; }
     float pv = p[j], m = am[i], v = av[i];
-    adam1(pv, g[j], m, v, grp, hyper);
+    float gv = g ? g[j] : 0.f;
+    if (rs.sum && g) gv = (rs.ratio ? gv / rs.n_gauss : gv * rs.w) * lam;
+    adam1(pv, gv, m, v, grp, hyper);
     p[j] = pv; am[i] = m; av[i] = v;
   }
 }
@@ -1100,9 +1121,25 @@ extern "C" int eg_adam_multi(float *means, float *scales, float *quats, float *o
   const int blocks = min(cdiv(11 * (int64_t)N, 256), 2048);
   adam_multi_kernel<<<blocks, 256, 0, as_stream(stream)>>>(means, scales, quats, opacities, g_means, g_scales,
                                                           g_quats, g_opacities, m, v, N, make_adamk(hyper),
-                                                          absgrad_inc, absgrads);
+                                                          absgrad_inc, absgrads, RegScale{});
   return check_launch("adam_multi");
 }
+
+namespace eg {
+// Adam of a regulariser iteration: gradients scaled by lambda on the fly (RegScale above), null pointer = zero gradient
+int launch_adam_regulariser(float *means, float *scales, float *quats, float *opacities, const float *g_means,
+                            const float *g_scales, const float *g_quats, float *m, float *v, int32_t N,
+                            const eg_adam_hyper &hyper, const float *sum, const float *loss_sum, float loss_sum_host,
+                            float factor, float w, int ratio, float *loss_out, hipStream_t st) {
+  RegScale rs;
+  rs.sum = sum; rs.loss_sum = loss_sum; rs.loss_sum_host = loss_sum_host; rs.factor = factor; rs.w = w;
+  rs.n_gauss = (float)N; rs.ratio = ratio; rs.loss_out = loss_out;
+  const int blocks = min(cdiv(11 * (int64_t)N, 256), 2048);
+  adam_multi_kernel<<<blocks, 256, 0, st>>>(means, scales, quats, opacities, g_means, g_scales, g_quats, nullptr, m, v, N,
+                                            make_adamk(hyper), nullptr, nullptr, rs);
+  return check_launch("adam_regulariser");
+}
+}  // namespace eg
 
 extern "C" int eg_adam_emit(float *means, float *scales, float *quats, float *opacities, const float *g_means,
                             const float *g_scales, const float *g_quats, const float *g_opacities, float *m, float *v,
