@@ -24,6 +24,7 @@ with several ranks sharing one GPU (GPU test, RCCL refuses that).
 """
 from __future__ import annotations
 
+import numbers
 import os
 from typing import List, Optional, Protocol, Sequence, Union
 
@@ -103,7 +104,8 @@ class DataParallelStep:
         next_view (single-view form): the view this rank takes in the NEXT step, when the caller knows it -- the
         post-reduce Adam then also projects + bins that view (EdgeTrainer.apply_adam(next_view): one launch instead
         of two, the tail fusion of the single-GPU step)."""
-        if isinstance(view, int):
+        if isinstance(view, numbers.Integral) or (isinstance(view, torch.Tensor) and view.dim() == 0):
+            view = int(view)
             grads = self.worker.grad_step(view, wmap)
             e0 = self._mark()
             self._all_reduce(grads)
@@ -125,7 +127,7 @@ class DataParallelStep:
                 self._ev.append((e0, e1))
             self.worker.apply_adam()
             return
-        h = len(views) // 2
+        h = (len(views) + 1) // 2  # odd C: the larger half first, its collective is the hidden one
         ga = self.worker.grad_step_batched(views[:h], wmaps[:h], slot=1)   # first half -> second buffer
         work = self._all_reduce(ga, async_op=True)                         # ... reduced on RCCL's stream while
         gb = self.worker.grad_step_batched(views[h:], wmaps[h:], slot=0)   # the second half is rasterised

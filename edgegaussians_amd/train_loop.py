@@ -89,7 +89,7 @@ def train_epoch(tr: EdgeTrainer, views: Iterable[int], epoch: int, num_epochs: i
 def train(tr: EdgeTrainer, model_cfg: Dict, training_cfg: Dict, view_order: Callable[[int], Iterable[int]],
           edge_masks_u8: Optional[torch.Tensor] = None, on_epoch: Optional[Callable[[int, float, int], None]] = None,
           generator: Optional[torch.Generator] = None, num_epochs: Optional[int] = None,
-          sync_every: int = 8) -> List[float]:
+          sync_every: Optional[int] = None) -> List[float]:
     """train_gaussians.py:144-222.  `model_cfg` / `training_cfg` are the reference's JSON sections;
     `edge_masks_u8` [V,H,W] (gt >= threshold) is needed only for the not-projecting cull.
 
@@ -97,7 +97,11 @@ def train(tr: EdgeTrainer, model_cfg: Dict, training_cfg: Dict, view_order: Call
     `sync_every` epochs, before every densify / cull event and at the end; in between the epochs are enqueued
     back to back with their loss sums parked on the device, so the host prepares epoch e + 1 while the device still
     runs epoch e.  `on_epoch(epoch, avg_loss, N)` is therefore called late -- in order, at the next read-back.
-    sync_every = 1 is the reference's cadence (one read-back per epoch)."""
+    sync_every = 1 is the reference's cadence (one read-back per epoch) and the default when `on_epoch` is given (a
+    callback that snapshots the trainer then sees the state at the end of ITS epoch); without a callback the default is
+    8.  A callback that only logs may pass a larger `sync_every` explicitly."""
+    if sync_every is None:
+        sync_every = 1 if on_epoch is not None else 8
     loss_cfg = training_cfg["loss"]
     proj_cfg, orient_cfg = loss_cfg["projection_losses"], loss_cfg["orientation_losses"]
     num_epochs = training_cfg["num_epochs"] if num_epochs is None else num_epochs
@@ -110,11 +114,19 @@ def train(tr: EdgeTrainer, model_cfg: Dict, training_cfg: Dict, view_order: Call
     parked: List = []  # (epoch, iterations) of the epochs whose loss sums are still on the device
     ready: List = []  # [epoch, N] read back, on_epoch not yet called (it reports N AFTER the epoch's events)
     events = set()
-    for flag, key in (("if_duplicate_high_pos_grad", "dup_high_pos_grads_at_epoch"),
-                      ("if_cull_gaussians_not_projecting", "cull_gaussians_not_projecting_at_epoch"),
-                      ("if_cull_low_opacity", "cull_opacity_at_epoch")):
-        if get(flag, True):
+    for flag, key, default in (("if_duplicate_high_pos_grad", "dup_high_pos_grads_at_epoch", True),
+                               ("if_cull_gaussians_not_projecting", "cull_gaussians_not_projecting_at_epoch", True),
+                               ("if_cull_low_opacity", "cull_opacity_at_epoch", True),
+                               ("if_cull_wayward", "cull_wayward_at_epoch", False)):  # (dataclass defaults, edge_gs.py:20-54)
+        if get(flag, default):
             events.update(get(key, []))
+    if get("if_reset_opacity", False):
+        # train_gaussians.py:210-211 calls model.reset_opacities(optimizers), which takes no argument (edge_gs.py:425):
+        # the reference dies with a TypeError at the first such epoch; every shipped config spells the key
+        # "if reset_opacity" (configs/*.json:37), which the dataclass never sees
+        raise NotImplementedError("if_reset_opacity=True: the reference raises TypeError at reset_opacity_at_epoch "
+                                  "(train_gaussians.py:211 passes an argument edge_gs.py:425 does not take)")
+    reset_value = get("reset_opacity_value", 0.08)  # the clamp of every cull (edge_gs.py:416-417,425-429)
 
     def read_back():
         sums, _rest = tr.pop_losses()
@@ -129,7 +141,8 @@ def train(tr: EdgeTrainer, model_cfg: Dict, training_cfg: Dict, view_order: Call
         n = train_epoch(tr, view_order(epoch), epoch, num_epochs, proj_cfg, orient_cfg, thr, generator, read_back=False)
         parked.append((epoch, n))
         # (the trainer parks at most 64 epoch sums on the device between two read-backs)
-        if len(parked) >= max(1, min(sync_every, 60)) or epoch in events or epoch == num_epochs - 1 or len(tr._journal) > 4096:
+        if (len(parked) >= max(1, min(sync_every, 60)) or epoch in events or epoch == num_epochs - 1
+                or len(tr._journal) > 4096 or tr.journal_bytes() > (1 << 29)):
             read_back()
         changed = False
         if get("if_duplicate_high_pos_grad", True) and epoch in get("dup_high_pos_grads_at_epoch", []):
@@ -145,19 +158,26 @@ def train(tr: EdgeTrainer, model_cfg: Dict, training_cfg: Dict, view_order: Call
         if get("if_cull_gaussians_not_projecting", True) and epoch in get("cull_gaussians_not_projecting_at_epoch", []):
             if edge_masks_u8 is None:
                 edge_masks_u8 = (tr.gt >= thr).to(torch.uint8)
-            tr.cull_not_projecting(edge_masks_u8, get("cull_gaussians_not_projecting_threshold", 0.35))
+            tr.cull_not_projecting(edge_masks_u8, get("cull_gaussians_not_projecting_threshold", 0.35),
+                                   reset_opacity_value=reset_value)
             changed = True
         if get("if_cull_low_opacity", True) and epoch in get("cull_opacity_at_epoch", []):
             if get("cull_opacity_type", "absolute") == "absolute":
-                tr.cull_opacity(get("cull_opacity_value", 0.05))
+                tr.cull_opacity(get("cull_opacity_value", 0.05), reset_opacity_value=reset_value)
             else:
                 q = torch.quantile(torch.sigmoid(tr.logit_opacities), get("cull_opacity_value", 0.05))
-                tr.cull(torch.sigmoid(tr.logit_opacities) < q)
+                tr.cull(torch.sigmoid(tr.logit_opacities) < q, reset_value)
             changed = True
-        # cull_wayward computes a mask and never applies it (edge_gs.py:498-542): a no-op, skipped
-        # "if reset_opacity" (with a space) never matches the dataclass field (configs/*.json:37): always False
-        if changed:
+        # cull_wayward computes a mask and never applies it (edge_gs.py:498-542) -- but its epochs still set
+        # reset_absgrads (train_gaussians.py:204-208,218-219; configs/Replica.json:15,20 turns it on at epochs 45
+        # and 300): the accumulator that decides the next duplication restarts there.  (update_nn is moot here: the
+        # neighbour table is rebuilt by every direction-regulariser step.)
+        wayward = get("if_cull_wayward", False) and epoch in get("cull_wayward_at_epoch", [])
+        if changed or wayward:
+            if tr._journal:
+                tr.flush()
             tr.reset_absgrads()          # train_gaussians.py:218-219
+        if changed:
             if tr.spatial_order:
                 tr.spatial_sort()        # new rows were appended / rows were dropped: restore the layout
             tr.ensure_capacity()         # N changed: re-size the isect buffers (one count-only sweep)

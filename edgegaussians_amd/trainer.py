@@ -247,6 +247,7 @@ class EdgeTrainer:
     # ------------------------------------------------------------------ capacity
     def count_intersections(self, view: int) -> int:
         """M for one view (count-only pass: projection + per-tile counts + scan).  Host sync."""
+        self._drop_projection()  # (overwrites splat and the cursors a pre-projected view would still need)
         call("eg_project_fwd", ptr(self.means), ptr(self.quats), ptr(self.log_scales), ptr(self.logit_opacities),
              ptr(self.viewmats[view]), ptr(self.Ks[view]), self.N, self.width, self.height, 0.01, 1e10, 0.3, 0.0,
              _lib.FLAG_LOG_SCALES | _lib.FLAG_LOGIT_OPACITIES | _lib.FLAG_ANTIALIASED | _lib.FLAG_TIGHT_TILES,
@@ -262,6 +263,7 @@ class EdgeTrainer:
     def ensure_capacity(self, slack: float = 1.3, views: Optional[List[int]] = None) -> int:
         """Sizes the isect buffers from a count-only sweep (called at start and after every
         densify / cull event, i.e. whenever N changes -- 22 times in a 400-epoch ABC run)."""
+        self._drop_projection()
         views = list(range(self.V)) if views is None else views
         m_max, tile_max = 0, 0
         for v in views:
@@ -588,6 +590,19 @@ class EdgeTrainer:
                 self.epoch, self.loss_scale = epoch_now, ls_now
                 return
         raise IsectOverflow("tile-intersection buffers still overflow after 8 doublings")
+
+    def journal_bytes(self) -> int:
+        """Bytes of the distinct weight maps the journal keeps alive (the per-step `bg_edge_ratio` draws are fresh
+        tensors: at 1600 x 1200 a window of 8 epochs holds ~0.7 GB of them); `train()` reads back early when this
+        grows past 512 MB."""
+        seen, total = set(), 0
+        for entry in self._journal:
+            w = entry[2]
+            for t in (w if isinstance(w, (list, tuple)) else (w,)):
+                if isinstance(t, Tensor) and t.data_ptr() not in seen:
+                    seen.add(t.data_ptr())
+                    total += t.numel() * t.element_size()
+        return total
 
     def flush(self) -> None:
         """Drain the stream, verify that no step since the last read-back overflowed (repairing it if one
@@ -987,9 +1002,11 @@ class EdgeTrainer:
         self._alloc_per_gaussian()
         return N - n_keep
 
-    def cull_opacity(self, value: float = 0.05) -> int:
+    def cull_opacity(self, value: float = 0.05, reset_opacity_value: float = 0.08) -> int:
         """cull_gaussians_opacity, 'absolute' (edge_gs.py:477-488; every shipped config)."""
-        return self.cull(torch.sigmoid(self.logit_opacities) < value)
+        if self._journal:
+            self.flush()  # the mask must come from the verified state (steps may still be rolled back and replayed)
+        return self.cull(torch.sigmoid(self.logit_opacities) < value, reset_opacity_value)
 
     def duplicate(self, dup_mask: Tensor, dup_factor: int = 3, noise_scale: float = 0.05,
                   noise: Optional[Tensor] = None) -> int:
@@ -1047,6 +1064,8 @@ class EdgeTrainer:
         config).  'percentile_top' (:559-568): the threshold is the int(1/value)-quantile boundary of the
         RAW mean absgrads ('lower' interpolation) -- and is then compared with the NORMALISED values, as the
         reference does."""
+        if self._journal:
+            self.flush()  # absgrads of steps that may still be replayed must not decide the mask
         g = self.absgrads / self.absgrads_normalize_factor
         gn = (g - g.min()) / (g.max() - g.min())
         if threshold_type == "absolute":
@@ -1064,15 +1083,18 @@ class EdgeTrainer:
         self.absgrads = torch.zeros(self.means.shape[0], device=self.dev)
         self.absgrads_normalize_factor = 1
 
-    def cull_not_projecting(self, edge_masks_u8: Tensor, min_projecting_fraction: float = 0.1) -> int:
+    def cull_not_projecting(self, edge_masks_u8: Tensor, min_projecting_fraction: float = 0.1,
+                            reset_opacity_value: float = 0.08) -> int:
         """cull_gaussians_not_projecting (edge_gs.py:578-601) as one N x V device kernel.
         edge_masks_u8: [V,H,W] uint8 (gt >= 0.5)."""
+        if self._journal:
+            self.flush()
         P = torch.bmm(self.Ks, self.viewmats[:, :3, :4]).contiguous()  # K @ viewmat[:3,:4]
         hits = torch.zeros(self.N, dtype=torch.int32, device=self.dev)
         call("eg_project_hits", ptr(self.means), self.N, ptr(P), self.V, ptr(edge_masks_u8.contiguous()),
              self.width, self.height, ptr(hits), stream())
         frac = hits.float() / float(self.V)
-        return self.cull(frac < min_projecting_fraction)
+        return self.cull(frac < min_projecting_fraction, reset_opacity_value)
 
     # ------------------------------------------------------------------ hand-off
     def export_as_ply(self, ply_path: str) -> None:
@@ -1101,6 +1123,8 @@ class EdgeTrainer:
     def state_dict(self) -> Dict[str, Tensor]:
         """Same keys / shapes -- and, whatever the internal row order, the same row order -- as the
         reference's checkpoint (edge_gs.py:625-633)."""
+        if self._journal:
+            self.flush()  # (speculated / overflowed steps are repaired before anything is exported)
         r = self._in_reference_order
         return {"gauss_params.means": r(self.means).clone(), "gauss_params.scales": r(self.log_scales).clone(),
                 "gauss_params.quats": r(self.quats).clone(),

@@ -371,7 +371,63 @@ def train_config():
     json.dump(out, open(os.path.join(OUT, "abc_train_config.json"), "w"), indent=1, sort_keys=True)
 
 
+def replica_calendar():
+    """The reference's own epoch driver (train_gaussians.py:144-222) run on configs/Replica.json with a RECORDING
+    stand-in for the model (its config is the reference's dataclass, filled the way dacite fills it) and a no-op
+    train_epoch: the trace is which model methods the reference calls after which epoch -- in particular that a
+    `cull_wayward` epoch (whose mask is never applied, edge_gs.py:498-542) still ends in `reset_absgrads`."""
+    _stub("torch.utils.tensorboard", SummaryWriter=lambda *a, **k: types.SimpleNamespace(add_scalar=lambda *a, **k: None))
+    _stub("edgegaussians.vis.vis_utils")
+    import importlib
+    tg = importlib.import_module("train_gaussians")
+    cfg = json.load(open(os.path.join(REF, "configs/Replica.json")))
+    mc = _from_dict(edge_gs.EdgeGaussianSplattingConfig, cfg["model"])
+    trace = []
+
+    class Rec:
+        config = mc
+        gauss_params = {"means": torch.zeros(5, 3)}
+        epoch = -1
+
+        def __getattr__(self, name):
+            def f(*a, **k):
+                trace.append([self.epoch, name])
+            return f
+
+    model = Rec()
+
+    def fake_epoch(model_, dl, opt, dev, sw, epoch, *a, **k):
+        model_.epoch = epoch
+        return 0.0
+
+    tg.train_epoch = fake_epoch
+    tg.train_utils.get_optimizers_schedulers = lambda **k: ({}, {})
+    tg.train_utils.save_model = lambda *a, **k: None
+    tg.tqdm = lambda **k: types.SimpleNamespace(__enter__=lambda s: s, __exit__=lambda s, *a: None)
+    import contextlib
+
+    class _Bar(contextlib.AbstractContextManager):
+        def set_postfix(self, *a, **k): pass
+        def update(self, *a, **k): pass
+        def __exit__(self, *a): return False
+    tg.tqdm = lambda **k: _Bar()
+    tr_cfg = cfg["training"]
+    tg.train(model, tr_cfg, None, "/tmp/_eg_log", "/tmp/_eg_out", "cpu")
+    used = ["if_duplicate_high_pos_grad", "dup_threshold_type", "dup_threshold_value", "dup_factor",
+            "dup_high_pos_grads_at_epoch", "if_cull_low_opacity", "cull_opacity_type", "cull_opacity_value",
+            "cull_opacity_at_epoch", "if_cull_gaussians_not_projecting", "cull_gaussians_not_projecting_at_epoch",
+            "cull_gaussians_not_projecting_threshold", "if_cull_wayward", "cull_wayward_at_epoch",
+            "init_dup_rand_noise_scale", "reset_opacity_value"]
+    out = {"model": {k: getattr(mc, k) for k in used}, "if_reset_opacity_as_parsed": bool(mc.if_reset_opacity),
+           "training": {"num_epochs": tr_cfg["num_epochs"], "optim": tr_cfg["optim"], "loss": tr_cfg["loss"]},
+           "calls_after_epoch": [t for t in trace if t[0] >= 0]}
+    json.dump(out, open(os.path.join(OUT, "replica_calendar.json"), "w"), indent=None, sort_keys=True)
+
+
 if __name__ == "__main__":
+    if "--only-calendar" in sys.argv:
+        replica_calendar()
+        raise SystemExit(0)
     views, keep = cameras_and_edges()
     if "--only-train" in sys.argv:
         train_fixture(views)
@@ -392,5 +448,6 @@ if __name__ == "__main__":
     m, cams = losses_and_masks(views, keep)
     densify_cull(m, cams)
     boundary_trace(views)
+    replica_calendar()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -64,15 +64,21 @@ class FakeTrainer:
         self.N *= 2
         self.log.append(("dup", self.epoch))
 
-    def cull_opacity(self, v):
+    def cull_opacity(self, v, reset_opacity_value=0.08):
         assert not self.marks
         self.N -= self.N // 10
-        self.log.append(("cull_opacity", self.epoch))
+        self.log.append(("cull_opacity", self.epoch, v, reset_opacity_value))
 
-    def cull_not_projecting(self, masks, thr):
+    def cull_not_projecting(self, masks, thr, reset_opacity_value=0.08):
         assert not self.marks
         self.N -= self.N // 10
-        self.log.append(("cull_np", self.epoch))
+        self.log.append(("cull_np", self.epoch, thr, reset_opacity_value))
+
+    def flush(self):
+        self._journal = []
+
+    def journal_bytes(self):
+        return 0
 
     def reset_absgrads(self):
         self.log.append(("reset_absgrads", self.epoch))
@@ -183,3 +189,39 @@ def test_lr_schedule_is_installed_from_the_config(cfg):
     assert lr35["means"] == pytest.approx(want["means"]["start_lr"] * want["means"]["gamma"] ** 3)  # milestones 10 20 30
     assert lr0["opacities"] == 0.0 and lr35["opacities"] == pytest.approx(want["opacities"]["start_lr"])  # from epoch 20
     assert lr0["scales"] == 0.0 and lr35["scales"] == pytest.approx(want["scales"]["start_lr"])
+
+
+def test_replica_calendar_matches_the_reference_driver(golden_dir):
+    """configs/Replica.json through the reference's own `train()` (recorded by tests/golden/make_golden.py
+    `replica_calendar`) against this driver: the same events after the same epochs -- including the absgrad reset of
+    the `cull_wayward` epochs 45 and 300, whose mask the reference computes and never applies (edge_gs.py:498-542,
+    train_gaussians.py:204-208,218-219) -- and the config's `reset_opacity_value` / cull value reach the culls."""
+    ref = json.load(open(os.path.join(golden_dir, "replica_calendar.json")))
+    name = {"duplicate_high_pos_gradients": "dup", "cull_gaussians_opacity": "cull_opacity",
+            "cull_gaussians_not_projecting": "cull_np", "reset_absgrads": "reset_absgrads"}
+    want = [(name[c], e) for e, c in ref["calls_after_epoch"] if c in name]
+    assert ("reset_absgrads", 45) in want and ("reset_absgrads", 300) in want  # the wayward epochs
+    tr = FakeTrainer()
+    model_cfg = dict(ref["model"], reset_opacity_value=0.11)
+    train_loop.train(tr, model_cfg, ref["training"], lambda e: [0, 1, 2], edge_masks_u8=object())
+    got = [(x[0], x[1]) for x in tr.log if x[0] in name.values()]
+    assert got == want
+    culls = [x for x in tr.log if x[0] == "cull_opacity"]
+    assert culls and all(x[2] == ref["model"]["cull_opacity_value"] and x[3] == 0.11 for x in culls)
+    # a wayward epoch changes no rows: no re-sort, no capacity sweep
+    assert not [x for x in tr.log if x[0] == "sort" and x[1] in (45, 300)]
+    assert ref["if_reset_opacity_as_parsed"] is False  # "if reset_opacity" (configs/*.json:37) never reaches the dataclass
+    with pytest.raises(NotImplementedError):
+        train_loop.train(FakeTrainer(), dict(model_cfg, if_reset_opacity=True), ref["training"], lambda e: [0], num_epochs=1)
+
+
+def test_on_epoch_defaults_to_the_reference_cadence(cfg):
+    """Without an explicit `sync_every` a callback is called after ITS epoch (one read-back per epoch, like the
+    reference's loop); without a callback the loop reads back every 8 epochs."""
+    tr = FakeTrainer()
+    train_loop.train(tr, dict(cfg["model"]), cfg["training"], lambda e: [0, 1], num_epochs=9,
+                     on_epoch=lambda e, l, n: None)
+    assert [x[1] for x in tr.log if x[0] == "sync"] == list(range(9))
+    tr = FakeTrainer()
+    train_loop.train(tr, dict(cfg["model"]), cfg["training"], lambda e: [0, 1], num_epochs=9)
+    assert [x[1] for x in tr.log if x[0] == "sync"] == [7, 8]
