@@ -83,14 +83,15 @@ def build_trainer(name, seed, device, spread_opacity=False):
     # initialisation, hands them over in random order
     tr = EdgeTrainer(sc.means, sc.log_scales, sc.quats, sc.logit_opacities, sc.viewmats, sc.Ks, sc.gt,
                      w, h, device=device, schedule=sched, spatial_order=not os.environ.get("EG_NO_SPATIAL_ORDER"))
-    g = torch.Generator().manual_seed(seed + 1)
     whole = synth.weight_map("whole", sc.gt[0]).to(device).contiguous()
-    ratio = [synth.weight_map("bg_edge_ratio", sc.gt[i], 1.0, g).to(device).contiguous() for i in range(v)]
+    # the `bg_edge_ratio` sample is DRAWN inside the loop, like the real one (train_loop.py: one eg_ratio_wmap_seeded
+    # launch on every 5th step), not precomputed
+    ratio = lambda view: tr.weight_map(view, "bg_edge_ratio", 1.0)  # noqa: E731
     return tr, sc, whole, ratio, ("real poses of scan 00004926 (intrinsics 800->512)" if real else "synthetic look-at poses")
 
 
 # kernel name (as rocprofv3 reports it) -> stage of eg_train_step
-STAGE_OF = {"project_emit_kernel": "project_bwd_adam+next_project_bin", "project_bwd_emit_kernel": "project_bwd_adam+next_project_bin",
+STAGE_OF = {"composite_wave_fwd_kernel": "composite_slice_fwd", "project_emit_kernel": "project_bwd_adam+next_project_bin", "project_bwd_emit_kernel": "project_bwd_adam+next_project_bin",
             "tile_emit_kernel": "tile_emit",
             "tile_sort_kernel": "tile_sort", "composite_slice_fwd_kernel": "composite_slice_fwd",
             "composite_chained_fwd_kernel": "composite_slice_fwd",  # (the pre-warm window runs before the first read-back)
@@ -118,7 +119,7 @@ def measure_traffic(config, spread, steps=40):
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             cmd = [exe, "--kernel-trace", "--pmc", counter, "-d", os.path.join(tmp, counter), "-o", "p", "--",
                    sys.executable, os.path.abspath(__file__), "--config", config, "--steps", str(steps), "--warmup", "5",
-                   "--profile-only"] + (["--spread-opacity"] if spread else [])
+                   "--profile-only"] + (["--spread-opacity"] if spread else ["--init-opacity"])
             r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=200)
             db = None
             for dp_, _, fs in os.walk(os.path.join(tmp, counter)):
@@ -155,6 +156,71 @@ def measure_traffic(config, spread, steps=40):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 2.0  # wave64 VALU instructions/s: 256 CUs x 4 SIMDs, 2 cycles each (MI355X_MICROARCH.md)
+
+
+def measure_issue(config, spread, steps=40):
+    """The issue-side ("second") roofline of every kernel of the step, measured NOW: one rocprofv3 --pmc pass with SQ
+    counters over `--profile-only`, kernel durations from the same pass's kernel trace.  VALU issue rate =
+    SQ_INSTS_VALU per launch / duration against the chip's wave64 VALU issue peak; where the wave cycles go =
+    SQ_ACTIVE_INST_ANY (issuing) / SQ_WAIT_ANY (parked in s_waitcnt or a barrier) / SQ_WAIT_INST_ANY (issue-stalled)
+    as shares of SQ_WAVE_CYCLES.  Returns ({kernel: {...}}, provenance) or (None, reason)."""
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    tmp = tempfile.mkdtemp(prefix="eg_sq_", dir="/tmp")
+    counters = ["SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU", "SQ_WAIT_ANY",
+                "SQ_WAIT_INST_ANY", "SQ_BUSY_CYCLES"]
+    try:
+        cmd = [exe, "--kernel-trace", "--pmc", *counters, "-d", tmp, "-o", "q", "--", sys.executable,
+               os.path.abspath(__file__), "--config", config, "--steps", str(steps), "--warmup", "5", "--profile-only"] + \
+              (["--spread-opacity"] if spread else ["--init-opacity"])
+        r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=300)
+        db = None
+        for dp_, _, fs in os.walk(tmp):
+            for f in fs:
+                if f.endswith("_results.db"):
+                    db = os.path.join(dp_, f)
+        if r.returncode != 0 or db is None:
+            return None, f"rocprofv3 SQ pass failed (rc {r.returncode}): {r.stderr[-200:]}"
+        cur = sqlite3.connect(db).cursor()
+        short = lambda k: k.split("(")[0].replace("void ", "").replace("eg::", "").split("<")[0]  # noqa: E731
+        agg = {}
+        for kname, cname, v in cur.execute("select kernel_name, counter_name, value from counters_collection"):
+            a = agg.setdefault(short(kname), {}).setdefault(cname, [0, 0.0])
+            a[0] += 1
+            a[1] += v
+        dur = {}
+        for name, s0, e0 in cur.execute("select name, start, end from kernels"):
+            a = dur.setdefault(short(name), [0, 0.0])
+            a[0] += 1
+            a[1] += (e0 - s0) / 1e3
+        out = {}
+        for k, c in agg.items():
+            if k not in STAGE_OF or k not in dur:
+                continue
+            m = {n: a[1] / a[0] for n, a in c.items()}
+            us = dur[k][1] / dur[k][0]  # (durations under counter collection: serialised launches, a few % long)
+            wc = max(m.get("SQ_WAVE_CYCLES", 0.0), 1.0)
+            out[k] = {"avg_launch_us_under_pmc": us, "valu_wave_instructions_per_launch": m.get("SQ_INSTS_VALU"),
+                      "valu_issue_frac_of_peak": m.get("SQ_INSTS_VALU", 0.0) / (us * 1e-6) / VALU_ISSUE_PEAK,
+                      "wave_cycles_issuing": m.get("SQ_ACTIVE_INST_ANY", 0.0) / wc,
+                      "wave_cycles_parked_waitcnt_or_barrier": m.get("SQ_WAIT_ANY", 0.0) / wc,
+                      "wave_cycles_issue_stalled": m.get("SQ_WAIT_INST_ANY", 0.0) / wc,
+                      "waves_per_launch": m.get("SQ_WAVES")}
+        return out, ("same run: rocprofv3 --kernel-trace --pmc SQ_* (one pass) over `bench.py --profile-only`; VALU issue peak "
+                     f"{VALU_ISSUE_PEAK / 1e9:.0f} G wave64 instructions/s (2 cycles each; a pure v_fma stream measures 0.71 of it, "
+                     "v_exp / v_rcp cost 3 slots: tools/microbench/issue_rates.hip)")
+    except Exception as e:  # noqa: BLE001 -- the bench line must still be printed
+        return None, f"issue-roofline measurement failed: {e!r}"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def cpu_baseline(sc, budget_s=15.0, which="c"):
     """The CPU restatement of the SAME step timed on this host on a bounded sample of the SAME
     workload: whole view-steps until ~budget_s of CPU time is spent (at least 3 for the C oracle).
@@ -182,7 +248,8 @@ def cpu_baseline(sc, budget_s=15.0, which="c"):
         return {"value": n * steps / el, "unit": "Gaussians*views/s", "cores": CO.num_threads(), "kind": "port",
                 "ms_per_step": 1e3 * el / steps,
                 "sample": f"{steps} view-steps of the same workload (N={n}, {sc.width}x{sc.height}), "
-                          f"oracle/eg_oracle.c (C + OpenMP) on {CO.num_threads()} threads"}
+                          f"oracle/eg_oracle.c (C + OpenMP) on {CO.num_threads()} threads -- the UNTUNED parity checker "
+                          "(a per-pixel sequential walk written for exactness): a stated baseline, not a speed-up denominator"}
     from oracle import ref_torch as O
     P = {"means": torch.nn.Parameter(sc.means.clone()), "scales": torch.nn.Parameter(sc.log_scales.clone()),
          "quats": torch.nn.Parameter(sc.quats.clone()), "opacities": torch.nn.Parameter(sc.logit_opacities.clone())}
@@ -228,7 +295,7 @@ def measure(name, args, device, rank, world, backend, spread=False, steps=None, 
     if dp is not None and world == 1:
         dp.world = 2  # issue the collective
     def wmap_for(step, view):
-        return ratio[view] if step % 5 == 0 else whole  # configs/ABC_DexiNed.json:85-92
+        return ratio(view) if step % 5 == 0 else whole  # configs/ABC_DexiNed.json:85-92
 
     chunk = max(1, args.chunk)
 
@@ -295,6 +362,20 @@ def measure(name, args, device, rank, world, backend, spread=False, steps=None, 
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     loss_sum = tr.pop_loss()  # raises IsectOverflow if ANY step since the last read-back dropped intersections
+    # two more windows of the same K steps (informational: `value` is the contract's window above)
+    windows = [1e3 * dt / steps]
+    for rep in range(0 if args.profile_only else 2):
+        barrier()
+        t1 = time.perf_counter()
+        run(steps, warmup + (1 + rep) * steps)
+        barrier()
+        d2 = time.perf_counter() - t1
+        if world > 1:
+            t = torch.tensor([d2], device=device if backend == "nccl" else "cpu", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            d2 = float(t.item())
+        windows.append(1e3 * d2 / steps)
+        tr.pop_loss()
     if tr.overflow_events or tr.rewalk_misses or tr.overflowed() or not math.isfinite(loss_sum):
         # (a replayed window would have been timed twice)
         raise SystemExit(f"invalid run: overflow events={tr.overflow_events} re-walk misses={tr.rewalk_misses} loss={loss_sum}")
@@ -310,13 +391,17 @@ def measure(name, args, device, rank, world, backend, spread=False, steps=None, 
                    "gaussian_row_order": "morton" if tr.spatial_order else "as given",
                    "binning": "segmented" if tr.segmented else "scan",
                    "steps_per_native_enqueue": chunk if (dp is None and vps == 1) else 1,
-                   "exact_stop_rewalk": ("not launched (no pixel reaches the transmittance stop; speculation covered by the "
-                                         "step journal)" if tr._rewalk_arg(dp is None) == -2 else f"launched, list length hint {tr.rewalk_hint}"),
+                   "forward_mode": ("speculative (no pixel reaches the transmittance stop; a stop would replay the window "
+                                    "from the step journal)" if tr._rewalk_arg(dp is None) == -2
+                                    else "chained (exact transmittance stop resolved inside the forward kernel)"),
                    "parallelism": ("single GPU" if world == 1 else
                                    f"{world} independent replicas, one scene per GPU, no collective (BASELINE config 5)" if args.replicas
                                    else f"dp{world} (views sharded, RCCL all-reduce of [N,12] grads)")},
         "mean_loss": loss_sum / (warmup + steps),
         "host_enqueue_ms_per_step": 1e3 * t_enq / steps,
+        "prewarm_steps": pre_steps,  # untimed, before --warmup: same enqueue path, until a 200-step chunk's time settles
+        "ms_per_step_windows": windows,  # the contract's window first, then two repeats of the same K steps
+        "ms_per_step_min": min(windows), "ms_per_step_median": sorted(windows)[len(windows) // 2],
     }
     if dp is not None:
         # exposed all-reduce time on the compute stream (events around the collective), over a short extra window:
@@ -432,8 +517,12 @@ def main():
     ap.add_argument("--cpu-oracle", default="c", choices=["c", "torch"],
                     help="which CPU restatement to time as cpu_baseline (default: the C + OpenMP oracle)")
     ap.add_argument("--spread-opacity", action="store_true",
-                    help="opacities U(0.05,0.9) instead of the reference's init 0.08: a 'trained-like' scene in "
-                         "which many pixels hit the transmittance stop")
+                    help="opacities U(0.05,0.9): a 'trained-like' scene in which many pixels hit the transmittance stop. "
+                         "The DEFAULT for configs 2-4 (BASELINE: 'after densify' / trained scenes); config 1 defaults to "
+                         "the reference's initial opacity 0.08")
+    ap.add_argument("--init-opacity", action="store_true",
+                    help="every opacity at the reference's initial value 0.08 (edge_gs.py:93): no transmittance stops, "
+                         "tight tile boxes drop M ~2.5x -- the first ~7 %% of a real ABC run")
     ap.add_argument("--force-dp", action="store_true",
                     help="run the data-parallel code path (grad_step -> all-reduce -> eg_adam_multi) even with one "
                          "rank: measures the path's overhead without the communication")
@@ -474,6 +563,9 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=0, world_size=1)
 
+    if args.spread_opacity and args.init_opacity:
+        raise SystemExit("--spread-opacity and --init-opacity exclude each other")
+    args.spread_opacity = not args.init_opacity and (args.spread_opacity or args.config != "config1")
     if args.path == "operator":
         r = measure_operator(args.config, args, device, min(args.steps, 300), min(args.warmup, 50))
         print(json.dumps({"metric": "train-step Gaussians*views/sec", "n_gpus": 1, "higher_is_better": True, "scaling": "weak",
@@ -495,13 +587,20 @@ def main():
         out["roofline"]["traffic_source"] = src
         if stages:
             out["traffic_bytes_per_step_by_stage"] = stages
+        issue, isrc = measure_issue(args.config, args.spread_opacity)
+        # the issue-side roofline next to the HBM one: with a ~100 MB working set inside the 256 MB Infinity Cache the
+        # HBM fraction is structurally small; what bounds these kernels is VALU issue and dependent latency
+        out["roofline"]["secondary"] = {"bound": "valu_issue", "peak_G_wave_instr_per_s": VALU_ISSUE_PEAK / 1e9,
+                                        "kernels": issue, "source": isrc}
     if single and rank == 0 and not args.no_extra:
         # north_star's stated target is config 1 (~30 k Gaussians, the scan's 50 views @512x512): measured in this
         # same run, next to a trained-like variant of the headline (opacities U(0.05, 0.9): transmittance stops)
         extra = {}
-        for key, name, spread, vps in (("config1", "config1", False, 1), (f"{args.config}_trained_like", args.config, True, 1),
+        other = "init_opacity" if args.spread_opacity else "trained_like"
+        for key, name, spread, vps in (("config1", "config1", False, 1),
+                                       (f"{args.config}_{other}", args.config, not args.spread_opacity, 1),
                                        ("config1_4_views_per_step", "config1", False, 4),
-                                       (f"{args.config}_4_views_per_step", args.config, False, 4)):
+                                       (f"{args.config}_4_views_per_step", args.config, args.spread_opacity, 4)):
             if name == args.config and spread == args.spread_opacity and vps == args.views_per_step:
                 continue
             r = measure(name, args, device, rank, world, backend, spread=spread, vps=vps,

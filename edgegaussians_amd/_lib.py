@@ -27,6 +27,7 @@ FLAG_ANTIALIASED = 4
 FLAG_TIGHT_TILES = 8
 FLAG_ABSGRAD_WRITE = 16
 REWALK_SPECULATE = -2  # EG_REWALK_SPECULATE
+MAX_WS_TAG = 0x7ffffe    # EG_MAX_WS_TAG
 
 
 class AdamHyper(C.Structure):
@@ -52,6 +53,7 @@ class StepArgs(C.Structure):
         ("v_means", _vp), ("v_quats", _vp), ("v_scales", _vp), ("v_opacities", _vp),
         ("adam_host", C.POINTER(AdamHyper)),
         ("next_viewmat", _vp), ("next_K", _vp), ("have_projection", _i32), ("ws_tag", _i32),
+        ("item_rec", _vp),
     ]
 
 
@@ -142,9 +144,8 @@ def load(require_device: bool = True) -> C.CDLL:
 def composite_workspace(max_items: int, n_tiles: int, device) -> torch.Tensor:
     """Scratch of the slice-parallel forward for (max_items, n_tiles), control words zeroed (include/edgegs.h)."""
     lib = load()
-    ws = torch.empty(lib.eg_composite_workspace_bytes(max_items, n_tiles), dtype=torch.uint8, device=device)
-    ws[:lib.eg_composite_workspace_ctl_bytes(max_items, n_tiles)].zero_()
-    return ws
+    # (all of it zeroed: the hand-over granules of the wave-autonomous forward carry a tag, and tag 0 means "never written")
+    return torch.zeros(lib.eg_composite_workspace_bytes(max_items, n_tiles), dtype=torch.uint8, device=device)
 
 
 def call(name: str, *args) -> None:

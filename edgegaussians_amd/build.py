@@ -18,7 +18,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libedgegs.so")
 OBJ = os.path.join(HERE, "csrc", "_obj")
-SOURCES = ["project.hip", "binning.hip", "composite.hip", "densify.hip", "knn.hip", "step.hip"]
+SOURCES = ["project.hip", "binning.hip", "composite.hip", "composite_wave.hip", "densify.hip", "knn.hip", "step.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
          "-Wall", "-Wno-unused-function"]
 
@@ -34,7 +34,7 @@ def _stale() -> bool:
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in SOURCES + ["common.h"]]
+    deps = [os.path.join(CSRC, f) for f in SOURCES + ["common.h", "composite.h"]]
     deps.append(os.path.join(HERE, "..", "include", "edgegs.h"))
     return any(os.path.getmtime(d) > t for d in deps)
 

@@ -18,6 +18,8 @@
 // ties broken by Gaussian id, which is exactly what a stable sort of index-ordered emissions gives.
 // Segments larger than the LDS capacity fall back to a hybrid global/LDS bitonic sort by the
 // same workgroup (slow path, correct for any size).
+#include <cstdlib>
+
 #include "common.h"
 
 namespace eg {
@@ -295,6 +297,14 @@ struct SegTable {
   // the compositing kernel returns them to zero -- and the last tile's workgroup leaves the totals
   // [4]: M, sticky overflow flag, items, largest tile population.
   int *total;
+  // with `total`: number the items HEAVIEST TILE FIRST (rank by population, ties by tile index) instead of in tile
+  // order.  The compositing kernels take one workgroup per item in item order: the many-slice tiles, whose slices hand
+  // their products over to one another, are then dispatched first and their hand-over chains run under the rest of the
+  // launch instead of forming its tail; the tail is made of single-slice and empty tiles, which hand nothing over.
+  int rank_order;
+  // optional output for the wave-autonomous forward (composite_wave.hip): one 16-byte record per item
+  // {tile, slice | slices << 16, first key of the slice, end of the TILE's keys}
+  int4 *item_rec;
 };
 
 // THREADS = number of buckets; CAP = keys per buffer (two buffers).  n_lo < n handled here.
@@ -313,6 +323,7 @@ tile_sort_kernel(unsigned long long *__restrict__ keys, const int *__restrict__ 
       seg.cursor += bv * bt.tiles; seg.tile_start += bv * bt.tiles; seg.tile_end += bv * bt.tiles;
       seg.item_first += bv * bt.tiles; seg.item_end += bv * bt.tiles; seg.item_tile += bv * bt.items;
       if (seg.total) seg.total += 4 * bv;
+      if (seg.item_rec) seg.item_rec += bv * bt.items;
     }
   }
   unsigned long long *kout = s;      // [CAP] keys scattered by bucket (the fast path keeps its input in registers)
@@ -325,15 +336,17 @@ tile_sort_kernel(unsigned long long *__restrict__ keys, const int *__restrict__ 
   for (int tile = blockIdx.x; tile < T; tile += gridDim.x) {
   __syncthreads();
   long long start, end;
-  __shared__ int s_pre[3][THREADS / 64];
+  __shared__ int s_pre[4][THREADS / 64];
   bool prefix_pending = false;  // (uniform) the tile prefix still has to be finished: see SegTable::total
   int pop_here = 0;
   // after a barrier: every thread sums the waves' partials; thread 0 writes the tile's table entries (and the
   // totals of the view, if this is the last tile), the first threads the item -> tile map
   auto finish_prefix = [&](int kept_) {
-    int isum = 0, msum = 0, cmax = 0;
+    int isum = 0, msum = 0, cmax = 0, itot = 0;
 #pragma unroll
-    for (int w = 0; w < THREADS / 64; ++w) { isum += s_pre[0][w]; msum += s_pre[1][w]; cmax = max(cmax, s_pre[2][w]); }
+    for (int w = 0; w < THREADS / 64; ++w) {
+      isum += s_pre[0][w]; msum += s_pre[1][w]; cmax = max(cmax, s_pre[2][w]); itot += s_pre[3][w];
+    }
     const int first_ = min(isum, seg.max_items);
     const int items_ = min(max(1, (kept_ + 127) >> 7), max(0, seg.max_items - first_));
     if (tid == 0) {
@@ -341,16 +354,19 @@ tile_sort_kernel(unsigned long long *__restrict__ keys, const int *__restrict__ 
       seg.tile_start[tile] = tile * seg.seg_cap;
       seg.tile_end[tile] = tile * seg.seg_cap + kept_;
       seg.item_end[tile] = first_ + items_;
-      if (tile == T - 1) {  // the last tile's prefix covers everything: the totals of the view
-        const int itot = isum + max(1, (kept_ + 127) >> 7);
-        cmax = max(cmax, pop_here);
-        seg.total[0] = msum + kept_;
+      if (tile == T - 1) {  // (every workgroup has summed ALL tiles: this one leaves the totals of the view)
+        seg.total[0] = msum;
         if (cmax > seg.seg_cap || itot > seg.max_items) seg.total[1] = 1;  // sticky: only the host clears it
         seg.total[2] = min(itot, seg.max_items);
         seg.total[3] = cmax;
       }
     }
-    for (int i = tid; i < items_; i += THREADS) seg.item_tile[first_ + i] = tile;
+    for (int i = tid; i < items_; i += THREADS) {
+      seg.item_tile[first_ + i] = tile;
+      if (seg.item_rec) {
+        seg.item_rec[first_ + i] = make_int4(tile, i | (items_ << 16), tile * seg.seg_cap + i * 128, tile * seg.seg_cap + kept_);
+      }
+    }
     prefix_pending = false;
   };
   // Segmented layout: the tile's keys sit at a FIXED address, so the first key of every thread is requested before
@@ -365,26 +381,33 @@ tile_sort_kernel(unsigned long long *__restrict__ keys, const int *__restrict__ 
         // The populations of the tiles before this one are REQUESTED by all threads before anything is waited for
         // (they travel with the tile's own cursor and first keys); per-wave partial sums go to LDS and the prefix
         // is finished right after the FIRST barrier the sort takes anyway (finish_prefix below): no barrier of its own
+        // (ALL populations, not only those of the tiles in front: the item numbering may follow the populations' rank)
         int pv[kPrefixHereMaxTiles / THREADS];
 #pragma unroll
         for (int j = 0; j < kPrefixHereMaxTiles / THREADS; ++j)
-          pv[j] = (tid + j * THREADS < tile) ? seg.cursor[tid + j * THREADS] : -1;
+          pv[j] = (tid + j * THREADS < T) ? seg.cursor[tid + j * THREADS] : -1;
         pop_here = seg.cursor[tile];
         kept = min(pop_here, seg.seg_cap);
-        int isum = 0, msum = 0, cmax = 0;
+        int isum = 0, msum = 0, cmax = 0, itot = 0;
 #pragma unroll
         for (int j = 0; j < kPrefixHereMaxTiles / THREADS; ++j)
           if (pv[j] >= 0) {
-            const int kk = min(pv[j], seg.seg_cap);
-            isum += max(1, (kk + 127) >> 7); msum += kk; cmax = max(cmax, pv[j]);
+            const int tj = tid + j * THREADS;
+            const int kk = min(pv[j], seg.seg_cap), it = max(1, (kk + 127) >> 7);
+            const bool before = seg.rank_order ? (pv[j] > pop_here || (pv[j] == pop_here && tj < tile)) : tj < tile;
+            isum += before ? it : 0;
+            itot += it; msum += kk; cmax = max(cmax, pv[j]);
           }
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) {
           isum += __shfl_xor(isum, d, 64);
           msum += __shfl_xor(msum, d, 64);
+          itot += __shfl_xor(itot, d, 64);
           cmax = max(cmax, __shfl_xor(cmax, d, 64));
         }
-        if ((tid & 63) == 0) { s_pre[0][tid >> 6] = isum; s_pre[1][tid >> 6] = msum; s_pre[2][tid >> 6] = cmax; }
+        if ((tid & 63) == 0) {
+          s_pre[0][tid >> 6] = isum; s_pre[1][tid >> 6] = msum; s_pre[2][tid >> 6] = cmax; s_pre[3][tid >> 6] = itot;
+        }
         prefix_pending = true;
         first = items = 0;
       } else {
@@ -398,7 +421,12 @@ tile_sort_kernel(unsigned long long *__restrict__ keys, const int *__restrict__ 
           seg.tile_end[tile] = tile * seg.seg_cap + kept;
           seg.item_end[tile] = first + items;
         }
-        for (int i = tid; i < items; i += THREADS) seg.item_tile[first + i] = tile;
+        for (int i = tid; i < items; i += THREADS) {
+          seg.item_tile[first + i] = tile;
+          if (seg.item_rec) {
+            seg.item_rec[first + i] = make_int4(tile, i | (items << 16), tile * seg.seg_cap + i * 128, tile * seg.seg_cap + kept);
+          }
+        }
       }
       start = (long long)tile * seg.seg_cap;
       end = start + kept;
@@ -498,7 +526,8 @@ tile_sort_kernel(unsigned long long *__restrict__ keys, const int *__restrict__ 
         int rank = 0;
         for (int q = b0; q < b1; ++q) rank += (kout[q] < k) ? 1 : 0;
         const long long o = start + b0 + rank;
-        flatten_ids[o] = (int)(unsigned)(k & 0xffffffffull);
+        const int gid = (int)(unsigned)(k & 0xffffffffull);
+        flatten_ids[o] = gid;
         if (isect_ids) isect_ids[o] = ((long long)tile << 32) | (long long)(k >> 32);
       }
       continue;
@@ -516,7 +545,8 @@ tile_sort_kernel(unsigned long long *__restrict__ keys, const int *__restrict__ 
     bitonic_lds<THREADS>(kin, P, 2, P, tid);
     for (int i = tid; i < n; i += THREADS) {
       const unsigned long long key = kin[i];
-      flatten_ids[start + i] = (int)(unsigned)(key & 0xffffffffull);
+      const int gid = (int)(unsigned)(key & 0xffffffffull);
+      flatten_ids[start + i] = gid;
       if (isect_ids) isect_ids[start + i] = ((long long)tile << 32) | (long long)(key >> 32);
     }
     continue;
@@ -571,7 +601,8 @@ tile_sort_kernel(unsigned long long *__restrict__ keys, const int *__restrict__ 
   }
   for (int i = tid; i < n; i += THREADS) {
     const unsigned long long key = segk[i];
-    flatten_ids[start + i] = (int)(unsigned)(key & 0xffffffffull);
+    const int gid = (int)(unsigned)(key & 0xffffffffull);
+    flatten_ids[start + i] = gid;
     if (isect_ids) isect_ids[start + i] = ((long long)tile << 32) | (long long)(key >> 32);
   }
   }  // tile loop
@@ -682,6 +713,8 @@ extern "C" int eg_sort_segments(uint64_t *keys, int32_t *tile_cursor, int32_t T,
   seg.item_first = const_cast<int32_t *>(item_first); seg.item_end = item_end;  // (read only: total == nullptr)
   seg.item_tile = item_tile; seg.max_items = max_items;
   seg.total = nullptr;
+  seg.rank_order = 0;
+  seg.item_rec = nullptr;
   return launch_tile_sort(keys, nullptr, T, (int64_t)T * seg_cap, flatten_ids, nullptr, max_tile_hint, seg, stream);
 }
 
@@ -689,13 +722,16 @@ namespace eg {
 int launch_sort_segments(uint64_t *keys, int32_t *tile_cursor, int32_t T, int32_t seg_cap, int32_t *flatten_ids,
                          int32_t *tile_start, int32_t *tile_end, int32_t *item_first, int32_t *item_end,
                          int32_t *item_tile, int32_t max_items, int32_t max_tile_hint, const Batch &bt, int C,
-                         hipStream_t st, int32_t *total_prefix_here) {
+                         hipStream_t st, int32_t *total_prefix_here, int32_t *item_rec) {
   SegTable seg;
   seg.cursor = tile_cursor; seg.seg_cap = seg_cap;
   seg.tile_start = tile_start; seg.tile_end = tile_end;
   seg.item_first = item_first; seg.item_end = item_end;
   seg.item_tile = item_tile; seg.max_items = max_items;
   seg.total = total_prefix_here;
+  static const int rank_order = getenv("EG_TILE_ORDER") ? atoi(getenv("EG_TILE_ORDER")) : 1;
+  seg.rank_order = rank_order;
+  seg.item_rec = (int4 *)item_rec;
   return launch_tile_sort(keys, nullptr, T, (int64_t)T * seg_cap, flatten_ids, nullptr, max_tile_hint, seg,
                           (eg_stream_t)st, bt, C);
 }

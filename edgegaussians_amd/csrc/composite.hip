@@ -41,6 +41,7 @@
 #include <cstdlib>
 
 #include "common.h"
+#include "composite.h"
 
 namespace eg {
 
@@ -248,10 +249,6 @@ composite_bwd_unit_kernel(const float4 *__restrict__ splat, const int *__restric
   }
 }
 
-// ---------------------------------------------------------------------------------------------
-// item helpers
-constexpr int kSlice = 128;  // Gaussians per item (half the LDS of 256 => 8 workgroups/CU, 2x the items)
-
 // largest t with item_offsets[t] <= b (item_offsets[T] = n_items > b): the tile owning item b
 __device__ __forceinline__ int item_tile(const int *__restrict__ item_offsets, int T, int b) {
   int lo = 0, hi = T;
@@ -278,26 +275,6 @@ __device__ __forceinline__ int item_tile_coop(const int *__restrict__ item_offse
     s_tmp[4] = base + tid;  // the one tile whose (non-empty) item range holds b
   __syncthreads();
   return s_tmp[4];
-}
-
-// Where a tile's sorted ids and its items (128-Gaussian slices) live.  Classic layout: start = offsets,
-// end = offsets + 1, item_first = item_offsets, item_end = item_offsets + 1, item_tile = nullptr (the
-// owner of an item is found by search).  Segmented layout (eg_sort_segments): four explicit arrays and
-// the item -> tile map.
-struct TileTable {
-  const int *start, *end, *item_first, *item_end, *item_tile;
-  // != nullptr (the training step when the sort kernel forms the tile prefix itself, binning.hip): the binning
-  // cursors [T], which the first slice workgroup of every tile returns to zero for the next projection
-  int *cursor_reset;
-};
-
-// pixel of thread `tid` in the slice-parallel kernels: wave w owns the 8x8 quadrant (w & 1, w >> 1)
-// of the tile, lane l the pixel (l & 7, l >> 3) inside it (a compact 8x8 block culls far better
-// against thin ellipses than a 4x16 strip)
-__device__ __forceinline__ void quad_pixel(int tid, int &di, int &dj) {
-  const int w = tid >> 6, l = tid & 63;
-  di = ((w >> 1) << 3) + (l >> 3);
-  dj = ((w & 1) << 3) + (l & 7);
 }
 
 // Per-quadrant compacted lists of one slice in LDS, stored as PAIRS of Gaussians so that the walks
@@ -382,55 +359,6 @@ __device__ __forceinline__ PairEval eval_pair(const float4 X, const float4 Cq, c
   return r;
 }
 
-// per-pixel epilogue shared by the slice (combine) and re-walk kernels: outputs, fused clamp + weighted L1
-// (edge_gs.py:279,288-324) and the packed record the footprint backward reads.  Returns the loss term.
-// Per-pixel record the fused forward leaves for the footprint backward (12 bytes, one dwordx3 load):
-// v * T_final, and -- only for pixels whose front-to-back walk ended on the transmittance rule -- the
-// id and the depth bits of the last contributing Gaussian, so that a candidate decides "at or before
-// the stop" from the record alone (a per-visit gather of the stop Gaussian's depth cost 12 us/step
-// on a trained-like scene).
-struct StopRec {
-  float gT;
-  int stop_id;          // -1: the walk did not stop
-  unsigned stop_depth;  // depth float bits of Gaussian stop_id
-};
-static_assert(sizeof(StopRec) == 12, "gtstop is [H,W,3] 32-bit words");
-
-template <int CH>
-__device__ __forceinline__ float finalize_pixel(int p, float T, int last, bool stopped, const int *__restrict__ flat,
-                                                float *__restrict__ render, float *__restrict__ alphas,
-                                                int *__restrict__ last_ids, bool has_loss, float gt_p, float w,
-                                                float loss_scale, float *__restrict__ vpix,
-                                                StopRec *__restrict__ gtstop, const float4 *__restrict__ splat) {
-  const float pix = 1.f - T;  // unit colours, no background: sum_i alpha_i T_i == 1 - T_final
-  // the images are optional in the fused training step, whose backward reads only the gtstop record
-  if (alphas) alphas[p] = pix;
-  if (last_ids) last_ids[p] = last;
-  if (render) {
-#pragma unroll
-    for (int k = 0; k < CH; ++k) render[(size_t)p * CH + k] = pix;
-  }
-  float l = 0.f, v = 1.f;  // without the fused loss the record carries T_final itself (upstream gradient 1)
-  if (has_loss) {  // gt_p, w: this pixel's target and weight, loaded by the caller ahead of its own work
-    const float c0 = fminf(fmaxf(pix, 0.f), 1.f);
-    const float d = c0 - gt_p;
-    l = w * fabsf(d);
-    const float sgn = (d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f);
-    v = loss_scale * w * sgn;  // pix is in [0,1): the clamp always passes the gradient
-    if (vpix) vpix[p] = v;
-  }
-  if (gtstop) {
-    // v * T_final, and -- only for pixels whose walk stopped on the transmittance rule -- the id of
-    // the last contributing Gaussian
-    StopRec r;
-    r.gT = (T < 1.f) ? v * T : 0.f;
-    r.stop_id = stopped ? flat[last] : -1;
-    r.stop_depth = stopped ? (unsigned)__float_as_int(splat[2 * r.stop_id + 1].z) : 0u;
-    gtstop[p] = r;
-  }
-  return l;
-}
-
 __device__ __forceinline__ void block_loss_add(float l, float *sRed, float *__restrict__ loss_out) {
   const int tid = threadIdx.x;
 #pragma unroll
@@ -441,48 +369,6 @@ __device__ __forceinline__ void block_loss_add(float l, float *sRed, float *__re
     const float s = sRed[0] + sRed[1] + sRed[2] + sRed[3];
     if (s != 0.f) unsafeAtomicAdd(loss_out, s);
   }
-}
-
-// per-pixel hand-off from the combine to the re-walk kernel: the slice in which the stop falls and the state
-// before it
-struct StopInfo {
-  int slice;     // tile-local slice index, -1 = this pixel is final
-  float T;       // transmittance before that slice
-  int last;      // last contributor before that slice
-};
-
-// Scratch of the slice-parallel forward.  The control words must be ZERO before the first use; every launch
-// sequence hands them back zeroed (tile tickets by the combining workgroup, item flags and the list counter by
-// the re-walk kernel), so a workspace is zeroed once, when it is allocated.
-struct SliceWs {
-  int *tile_ticket;     // [T]   slices of the tile that have finished
-  int *item_flags;      // [max_items] 1 = the item is on the re-walk list
-  int *ctl;             // [4]   {list length, exit ticket of the re-walk kernel, longest list since the caller looked, missed re-walk}
-  int *exit_grp;        // [64 x 16] first level of the re-walk kernel's exit ticket, one cache line per group
-  int *ready;           // [max_items] chained forward: the caller's tag once the item's record is published
-  float *sliceP;        // [max_items][256] transmittance product of the slice (written only by tiles with > 1 slice)
-  int *sliceL;          // [max_items][256] its last contributor (global index into the sorted ids, -1 none)
-  StopInfo *stopinfo;   // [T][256]
-  int2 *rewalk;         // [max_items] (item, tile)
-  unsigned char *sliceQ;  // [max_items][128] quadrant verdicts
-};
-
-// the per-view copies of a batched step (blockIdx.y = view; strides are zero for a single view)
-__device__ __forceinline__ TileTable view_of(TileTable tt, const Batch &bt, int v) {
-  tt.start += v * bt.tiles; tt.end += v * bt.tiles; tt.item_first += v * bt.tiles; tt.item_end += v * bt.tiles;
-  if (tt.item_tile) tt.item_tile += v * bt.items;
-  if (tt.cursor_reset) tt.cursor_reset += v * bt.tiles;
-  return tt;
-}
-__device__ __forceinline__ SliceWs view_of(SliceWs ws, const Batch &bt, int v) {
-  const long long o = v * bt.ws_bytes;
-  ws.tile_ticket = (int *)((char *)ws.tile_ticket + o); ws.item_flags = (int *)((char *)ws.item_flags + o);
-  ws.ctl = (int *)((char *)ws.ctl + o); ws.exit_grp = (int *)((char *)ws.exit_grp + o);
-  ws.ready = (int *)((char *)ws.ready + o);
-  ws.sliceP = (float *)((char *)ws.sliceP + o);
-  ws.sliceL = (int *)((char *)ws.sliceL + o); ws.stopinfo = (StopInfo *)((char *)ws.stopinfo + o);
-  ws.rewalk = (int2 *)((char *)ws.rewalk + o); ws.sliceQ = (unsigned char *)ws.sliceQ + o;
-  return ws;
 }
 
 // Phase B for one tile (256 threads = its 256 pixels): T = product of the slice products in depth order, the
@@ -1324,10 +1210,21 @@ __device__ __forceinline__ void footprint_walk(const float4 s0, const float4 s1,
 
 __global__ void __launch_bounds__(256)
 footprint_bwd_kernel(const float4 *__restrict__ splat, int N, int width, int height,
-                     const StopRec *__restrict__ gtstop, float *__restrict__ g2d, const Batch bt) {
+                     const StopRec *__restrict__ gtstop, float *__restrict__ g2d, const Batch bt,
+                     float *__restrict__ loss_part, float *__restrict__ loss_out) {
   __shared__ float red[4][64 * 8];
   splat += blockIdx.y * bt.splat4; gtstop += blockIdx.y * bt.pixels; g2d += blockIdx.y * bt.splat4 * 4;  // view
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (loss_part && blockIdx.x == 0 && wv == 0) {
+    // the wave-autonomous forward left this view's loss terms in 64 partial sums: fold them into the caller's
+    // accumulator and hand the partials back zeroed
+    float *lp = (float *)((char *)loss_part + blockIdx.y * bt.ws_bytes);
+    float v = lp[lane];
+    if (v != 0.f) lp[lane] = 0.f;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    if (lane == 0 && v != 0.f) unsafeAtomicAdd(loss_out, v);
+  }
   const int wave = blockIdx.x * 4 + wv;
   const int gbase = wave * 8;
   if (gbase >= N) return;  // whole waves leave; there is no workgroup barrier below
@@ -1520,13 +1417,9 @@ composite_bwd_colors_kernel(const float4 *__restrict__ splat, const float *__res
 
 using namespace eg;
 
-// workspace layout: control words first (they must be zero before the first use, see SliceWs):
-//   tile_ticket i32[T] | item_flags i32[max_items] | ctl i32[4] | exit_grp i32[64 x 16] | ready i32[max_items]
-// then  sliceP f32[max_items][256] | sliceL i32[max_items][256] | stopinfo {i32,f32,i32}[T][256]
-//       | rewalk int2[max_items] | sliceQ u8[max_items][128]
 extern "C" int64_t eg_composite_workspace_ctl_bytes(int64_t max_items, int64_t n_tiles) {
   if (max_items < 0 || n_tiles < 0) return 0;
-  return (n_tiles + 2 * max_items + 4 + 64 * 16) * (int64_t)sizeof(int32_t);
+  return ctl_bytes_aligned(max_items, n_tiles);
 }
 
 extern "C" int64_t eg_composite_workspace_bytes(int64_t max_items, int64_t n_tiles) {
@@ -1534,21 +1427,6 @@ extern "C" int64_t eg_composite_workspace_bytes(int64_t max_items, int64_t n_til
   return eg_composite_workspace_ctl_bytes(max_items, n_tiles) +
          max_items * kTilePix * (int64_t)(sizeof(float) + sizeof(int32_t)) +
          n_tiles * kTilePix * (int64_t)sizeof(StopInfo) + max_items * (int64_t)sizeof(int2) + max_items * (int64_t)kSlice;
-}
-
-static SliceWs carve_workspace(void *workspace, int64_t max_items, int n_tiles) {
-  SliceWs ws;
-  ws.tile_ticket = (int *)workspace;
-  ws.item_flags = ws.tile_ticket + n_tiles;
-  ws.ctl = ws.item_flags + max_items;
-  ws.exit_grp = ws.ctl + 4;
-  ws.ready = ws.exit_grp + 64 * 16;
-  ws.sliceP = (float *)(ws.ready + max_items);
-  ws.sliceL = (int *)(ws.sliceP + (size_t)max_items * kTilePix);
-  ws.stopinfo = (StopInfo *)(ws.sliceL + (size_t)max_items * kTilePix);
-  ws.rewalk = (int2 *)(ws.stopinfo + (size_t)n_tiles * kTilePix);
-  ws.sliceQ = (unsigned char *)(ws.rewalk + max_items);
-  return ws;
 }
 
 // unit colours: slice-parallel forward (slice products + combine by the tile's last workgroup -> exact-stop re-walk)
@@ -1569,6 +1447,13 @@ static int launch_sliced_fwd(const float4 *splat, const TileTable tt, int channe
   // rewalk_hint == EG_REWALK_SPECULATE: no launch at all; a pixel that does stop raises control word 3 instead
   const int skip = rewalk_hint == EG_REWALK_SPECULATE;
   static const int dbg = getenv("EG_DBG_FWD") ? atoi(getenv("EG_DBG_FWD")) : 0;  // timing ablations only (wrong results)
+  static const bool old_fwd = getenv("EG_FWD_OLD") && atoi(getenv("EG_FWD_OLD")) != 0;  // A/B against round 2's kernels
+  // The training step (no images wanted, fused loss, segmented tables): the wave-autonomous forward of
+  // composite_wave.hip -- speculative while no pixel reaches the transmittance stop, chained (exact stop inside) otherwise
+  if (!old_fwd && channels == 1 && !render && !alphas && !last_ids && !vpix && gtstop && wmap && tt.item_rec &&
+      chain_tag > 0)
+    return launch_wave_fwd(splat, tt, flatten_ids, width, height, gt, wmap, loss_scale, total, max_items, workspace, gtstop,
+                           !skip, (unsigned)chain_tag, max_tile_hint, s, bt, C);
   // (rewalk_hint == 0 without speculation -- a caller without a journal, e.g. the data-parallel leg, that has seen no
   // stop lately: the fused slice kernel + a 64-workgroup re-walk launch that finds an empty list is 3 us cheaper than
   // the chained kernel's look-back, and still exact should a pixel stop after all)
@@ -1632,7 +1517,7 @@ extern "C" int eg_composite_fwd(const float *splat, const float *colors, int32_t
   const int tw = cdiv(width, kTile), th = cdiv(height, kTile);
   hipStream_t s = as_stream(stream);
   if (!colors && item_offsets && total && workspace && max_items > 0) {
-    const TileTable tt = {offsets, offsets + 1, item_offsets, item_offsets + 1, nullptr, nullptr};
+    const TileTable tt = {offsets, offsets + 1, item_offsets, item_offsets + 1, nullptr, nullptr, nullptr};
     return launch_sliced_fwd((const float4 *)splat, tt, channels, flatten_ids, width, height, render, alphas, last_ids,
                              gt, wmap, loss_scale, vpix, loss_out, total, max_items, workspace, gtstop, rewalk_hint, s);
   }
@@ -1653,8 +1538,8 @@ int composite_fwd_segments_hinted(const float *splat, const int32_t *tile_start,
                                   int32_t *last_ids, const float *gt, const float *wmap, float loss_scale, float *vpix,
                                   float *loss_out, const int32_t *total, int64_t max_items, void *workspace,
                                   float *gtstop, int32_t rewalk_hint, int32_t max_tile_hint, int32_t chain_tag,
-                                  hipStream_t st, int32_t *cursor_reset) {
-  const TileTable tt = {tile_start, tile_end, item_first, item_end, item_tile, cursor_reset};
+                                  hipStream_t st, int32_t *cursor_reset, const int32_t *item_rec) {
+  const TileTable tt = {tile_start, tile_end, item_first, item_end, item_tile, cursor_reset, (const int4 *)item_rec};
   return launch_sliced_fwd((const float4 *)splat, tt, 1, flatten_ids, width, height, render, alphas, last_ids, gt, wmap,
                            loss_scale, vpix, loss_out, total, max_items, workspace, gtstop, rewalk_hint, st, Batch{}, 1,
                            max_tile_hint, chain_tag);
@@ -1674,8 +1559,9 @@ extern "C" int eg_composite_fwd_segments(const float *splat, const int32_t *tile
              "null pointer");
   EG_REQUIRE((render && alphas && last_ids) || gtstop, "render / alphas / last_ids are optional only with gtstop");
   EG_REQUIRE(!wmap || gt, "wmap needs gt");
-  EG_REQUIRE(!gtstop || wmap, "gtstop needs the fused loss");
-  const TileTable tt = {tile_start, tile_end, item_first, item_end, item_tile, nullptr};
+  // (gtstop without the fused loss: the record carries T_final itself, upstream gradient 1 -- the drop-in operator's
+  // backward scales it by what autograd hands it)
+  const TileTable tt = {tile_start, tile_end, item_first, item_end, item_tile, nullptr, nullptr};
   return launch_sliced_fwd((const float4 *)splat, tt, 1, flatten_ids, width, height, render, alphas, last_ids, gt, wmap,
                            loss_scale, vpix, loss_out, total, max_items, workspace, gtstop, rewalk_hint,
                            as_stream(stream));
@@ -1706,7 +1592,7 @@ extern "C" int eg_composite_bwd_footprint(const float *splat, int32_t N, int32_t
   EG_REQUIRE(splat && gtstop && g2d, "null pointer");
   hipStream_t st = as_stream(stream);
   footprint_bwd_kernel<<<cdiv((int64_t)N, 32), 256, 0, st>>>((const float4 *)splat, N, width, height,
-                                                            (const StopRec *)gtstop, g2d, Batch{});
+                                                            (const StopRec *)gtstop, g2d, Batch{}, nullptr, nullptr);
   timing_mark(kMarkFootprint, st);
   return check_launch("composite_bwd_footprint");
 }
@@ -1718,16 +1604,19 @@ int launch_composite_fwd_segments(const float *splat, const int32_t *tile_start,
                                   const int32_t *flatten_ids, int32_t width, int32_t height, float loss_scale,
                                   float *loss_out, const int32_t *total, int64_t max_items, void *workspace,
                                   float *gtstop, int32_t rewalk_hint, const Batch &bt, int C, hipStream_t st,
-                                  int32_t max_tile_hint, int32_t chain_tag, int32_t *cursor_reset) {
-  const TileTable tt = {tile_start, tile_end, item_first, item_end, item_tile, cursor_reset};
+                                  int32_t max_tile_hint, int32_t chain_tag, int32_t *cursor_reset,
+                                  const int32_t *item_rec) {
+  const TileTable tt = {tile_start, tile_end, item_first, item_end, item_tile, cursor_reset, (const int4 *)item_rec};
   return launch_sliced_fwd((const float4 *)splat, tt, 1, flatten_ids, width, height, nullptr, nullptr, nullptr,
                            bt.gt[0], bt.wmap[0], loss_scale, nullptr, loss_out, total, max_items, workspace, gtstop,
                            rewalk_hint, st, bt, C, max_tile_hint, chain_tag);
 }
 int launch_footprint_bwd(const float *splat, int32_t N, int32_t width, int32_t height, const float *gtstop, float *g2d,
-                         const Batch &bt, int C, hipStream_t st) {
+                         const Batch &bt, int C, hipStream_t st, void *workspace, int64_t max_items, float *loss_out) {
+  float *loss_part = nullptr;
+  if (workspace && loss_out) loss_part = carve_workspace(workspace, max_items, cdiv(width, kTile) * cdiv(height, kTile)).loss_part;
   footprint_bwd_kernel<<<dim3(cdiv((int64_t)N, 32), C), 256, 0, st>>>((const float4 *)splat, N, width, height,
-                                                                     (const StopRec *)gtstop, g2d, bt);
+                                                                     (const StopRec *)gtstop, g2d, bt, loss_part, loss_out);
   timing_mark(kMarkFootprint, st);
   return check_launch("composite_bwd_footprint");
 }

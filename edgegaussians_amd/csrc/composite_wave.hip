@@ -1,0 +1,487 @@
+// G7 forward of the training step, wave-autonomous form (round 3).
+//
+// Replaces gsplat 1.0.0 rasterize_to_pixels_fwd as reached from edgegaussians/models/edge_gs.py:250-268 with the
+// clamp (edge_gs.py:279) and the projection loss (edge_gs.py:288-324, weight-map form) fused into the epilogue --
+// the same semantics as composite.hip's slice / chained kernels (restated in oracle/ref_torch.py:230-319), which stay
+// the path of the general C ABI (render / alphas / last_ids outputs, arbitrary colours, re-walk list).
+//
+// What round 2's kernels cost (config 2, 27.9 us; ablations and per-wave phase timings in profiles/r03_fwd_*): the walk
+// 11 us, the hand-over 3 us, and 9 us of STAGING -- the dependent loads at the head of every short-lived workgroup,
+// four exact ellipse-vs-quadrant tests per Gaussian run by two of the four waves while the other two wait, two
+// workgroup barriers around the list compaction, two more around the ticket.  A wave of the first wave-autonomous
+// version lived ~25 k cycles (~40 k with exact stops) of which it issued ~3 k: nine or ten DEPENDENT memory round
+// trips of ~2 k cycles each (item -> tile tables -> ids -> records -> publish -> drain -> flag / ticket -> poll ->
+// read back -> stop Gaussian's id -> its depth), and at 1.6 launch "rounds" of 8192 wave slots the kernel lasted two
+// wave lifetimes.  This version removes round trips and fits the reference's sizes into ONE round:
+//
+//   wave (slice = `span` consecutive 128-Gaussian items of a tile's depth-sorted list, quadrant = 8x8 pixels of the tile;
+//         span = 2 when the launch would not fit one round of wave slots otherwise: the workgroups of the odd items
+//         leave at once)
+//     head    : ONE 16-byte item record left by the sort kernel {tile, item | items << 16, first key, end of the tile}
+//     stage   : every lane fetches up to FOUR of the slice's Gaussians (all loads in flight together) and tests them against
+//               ITS quadrant only (the exact ellipse-vs-rectangle test, one per Gaussian and wave instead of four per
+//               Gaussian on half the waves); ballot + popcount compacts the hits into the wave's OWN list in LDS, in
+//               slice order
+//     walk    : 64 pixels x listed Gaussians, four list entries per iteration, broadcast LDS reads.  The entry holds
+//               the conic premultiplied by -log2(e) and log2(opacity), so that alpha = exp2(quadratic form): 14 VALU
+//               operations per (pixel, Gaussian) instead of 18, three b128 LDS reads per PAIR of entries instead of four
+//     hand-over (tiles with more than one slice), per quadrant, no workgroup involved, no flag, no ticket, no drain:
+//               a slice that has slices behind it publishes one DATA-TAGGED 8-byte granule per pixel
+//               {product, tag << 9 | slice-local index of its last contributor} with a single device-scope store and,
+//               in speculative mode, is done.  A reader polls the granules themselves (the tag is the call's; 16 in
+//               flight): in speculative mode only the tile's LAST slice looks back, multiplies the products in depth
+//               order and finalises the 64 pixels (a product that crosses 1e-4 raises the sticky miss word and the
+//               caller replays the step in chained mode); in chained mode EVERY slice looks back over the slices in
+//               front (lower block indices: dispatched earlier, never waiting on this one) and resolves a stop that
+//               falls inside it on the spot, from the list still in this wave's LDS.
+//
+// There is not a single workgroup barrier in the kernel: the four waves of a workgroup share nothing but the launch
+// slot.  Per-pixel loss terms are summed per wave and added to one of 64 partial sums (4 x tiles same-address atomics
+// would serialise at ~12 ns each); the footprint backward folds the partials into the caller's accumulator.
+#include <cstdlib>
+
+#include "common.h"
+#include "composite.h"
+
+namespace eg {
+
+// one wave's compacted list: PAIRS of Gaussians side by side (three broadcast ds_read_b128 fetch two entries)
+struct WaveList {
+  float4 X[kWaveSlice / 2 + 2];        // x0 x1 y0 y1
+  float4 C[kWaveSlice / 2 + 2];        // A0 A1 B0 B1     A = -log2(e) a / 2, B = -log2(e) b   (conic [[a, b], [b, c]])
+  float4 D[kWaveSlice / 2 + 2];        // C0 C1 lo0 lo1   C = -log2(e) c / 2, lo = log2(opacity)
+  unsigned char idx[kWaveSlice + 16];  // slice-local index of every entry
+};
+static_assert(sizeof(WaveList) % 16 == 0, "float4 alignment of the per-wave lists");
+
+constexpr float kNegLog2e = -1.44269504088896341f;
+constexpr int kNoContributor = 511;  // 9-bit "this slice did not contribute to the pixel"
+
+// does Gaussian (s0 = x y a b, s1 = c o depth radius) reach the pixel centres [qx + 0.5, qx + 7.5] x [qy + 0.5, qy + 7.5]
+// with alpha >= 1/255?  AABB reject and the exact ellipse-vs-rectangle test of common.h (ellipse_hits_rect: the minimum
+// of the convex quadratic over the rectangle lies at the centre or on one of the four edges) -- the same arithmetic,
+// written WITHOUT branches: the lanes of a wave hold unrelated Gaussians, every early exit is a divergent branch
+__device__ __forceinline__ bool quad_hit(const float4 s0, const float4 s1, float qx, float qy) {
+#pragma clang fp contract(off)
+  const float x = s0.x, y = s0.y, a = s0.z, b = s0.w, c = s1.x;
+  const float thr = __logf(255.f * s1.y) + kThrMargin;
+  const float det = a * c - b * b;
+  const bool valid = (thr > 0.f) & (det > 0.f);
+  const float k2 = 2.f * thr * __builtin_amdgcn_rcpf(det);  // hardware rcp / sqrt: the inflation covers 1 ulp
+  const float ex = __builtin_amdgcn_sqrtf(k2 * c) * 1.001f + 0.01f;
+  const float ey = __builtin_amdgcn_sqrtf(k2 * a) * 1.001f + 0.01f;
+  const float rx0 = qx + 0.5f, ry0 = qy + 0.5f, rx1 = qx + 7.5f, ry1 = qy + 7.5f;
+  const bool aabb = (x - ex <= rx1) & (x + ex >= rx0) & (y - ey <= ry1) & (y + ey >= ry0);
+  const float u0 = rx0 - x, u1 = rx1 - x, v0 = ry0 - y, v1 = ry1 - y;
+  const bool centre_in = (u0 <= 0.f) & (u1 >= 0.f) & (v0 <= 0.f) & (v1 >= 0.f);
+  const float nba = -b * __builtin_amdgcn_rcpf(a), nbc = -b * __builtin_amdgcn_rcpf(c);
+  const float us0 = fminf(fmaxf(nba * v0, u0), u1), us1 = fminf(fmaxf(nba * v1, u0), u1);
+  const float vs0 = fminf(fmaxf(nbc * u0, v0), v1), vs1 = fminf(fmaxf(nbc * u1, v0), v1);
+  const float best = fminf(fminf(sigma_at(a, b, c, us0, v0), sigma_at(a, b, c, us1, v1)),
+                           fminf(sigma_at(a, b, c, u0, vs0), sigma_at(a, b, c, u1, vs1)));
+  return valid & aabb & (centre_in | (best <= thr * 1.001f + 1e-3f));
+}
+
+__device__ __forceinline__ void put_entry(WaveList &wl, int pos, const float4 s0, const float4 s1, int slice_idx) {
+  const int pr = pos >> 1, sl = pos & 1;
+  float *X = (float *)&wl.X[pr], *Cc = (float *)&wl.C[pr], *D = (float *)&wl.D[pr];
+  X[sl] = s0.x; X[2 + sl] = s0.y;
+  Cc[sl] = (0.5f * kNegLog2e) * s0.z; Cc[2 + sl] = kNegLog2e * s0.w;
+  D[sl] = (0.5f * kNegLog2e) * s1.x; D[2 + sl] = __builtin_amdgcn_logf(s1.y);  // v_log_f32 = log2
+  wl.idx[pos] = (unsigned char)slice_idx;
+}
+
+__device__ __forceinline__ void wave_lds_fence() {
+  // LDS operations of one wave complete in order; this only keeps the compiler from moving them across
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Gaussians [start, end) of the sorted ids (at most kWaveSlice) -> this wave's list of those that reach its quadrant,
+// in slice order, padded with three rejecting sentinels (the walk reads four entries at a time).  Returns the length.
+template <int R>
+__device__ __forceinline__ int stage_rounds(WaveList &wl, const float4 *__restrict__ splat, const int *__restrict__ flat,
+                                            int start, int end, float qx, float qy, int lane) {
+  const int n = end - start;  // >= 1, <= 64 R
+  int g[R];
+  float4 r0[R], r1[R];
+  // Unconditional loads (a lane beyond the slice re-reads its last Gaussian): with a branch around each load the
+  // compiler waits for one gather before it issues the next -- four dependent round trips instead of two
+#pragma unroll
+  for (int r = 0; r < R; ++r) g[r] = flat[start + min(lane + 64 * r, n - 1)];
+#pragma unroll
+  for (int r = 0; r < R; ++r) { r0[r] = splat[2 * g[r]]; r1[r] = splat[2 * g[r] + 1]; }
+  bool hit[R];
+  unsigned long long bal[R];
+  int base[R + 1];
+  base[0] = 0;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    hit[r] = (lane + 64 * r < n) & quad_hit(r0[r], r1[r], qx, qy);
+    bal[r] = __ballot(hit[r]);
+    base[r + 1] = base[r] + __popcll(bal[r]);
+  }
+  const int n_mine = base[R];
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  wave_lds_fence();  // (a list that is being re-staged: the previous walk's reads come first)
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+    if (hit[r]) put_entry(wl, base[r] + __popcll(bal[r] & lt), r0[r], r1[r], lane + 64 * r);
+  if (lane < 3) {  // sentinels: log2(opacity) = -1e30 => alpha = 0
+    const int e = n_mine + lane, pr = e >> 1, sl = e & 1;
+    ((float *)&wl.X[pr])[sl] = 0.f; ((float *)&wl.X[pr])[2 + sl] = 0.f;
+    ((float *)&wl.C[pr])[sl] = 0.f; ((float *)&wl.C[pr])[2 + sl] = 0.f;
+    ((float *)&wl.D[pr])[sl] = 0.f; ((float *)&wl.D[pr])[2 + sl] = -1e30f;
+  }
+  wave_lds_fence();
+  return n_mine;
+}
+
+__device__ __forceinline__ int stage_wave(WaveList &wl, const float4 *__restrict__ splat, const int *__restrict__ flat,
+                                          int start, int end, float qx, float qy, int lane) {
+  const int n = end - start;  // (wave-uniform)
+  if (n <= 64) return stage_rounds<1>(wl, splat, flat, start, end, qx, qy, lane);
+  if (n <= 128) return stage_rounds<2>(wl, splat, flat, start, end, qx, qy, lane);
+  return stage_rounds<kWaveSlice / 64>(wl, splat, flat, start, end, qx, qy, lane);
+}
+
+// alpha of one list entry at pixel (px, py), and whether it counts.  s = log2(o) - log2(e) sigma is evaluated in one
+// fixed sequence everywhere (phase A and the exact-stop walk must agree bit for bit):
+//   sigma >= 0  <=>  s <= log2(o);   alpha = min(0.999, exp2(s));   alpha >= 1/255
+struct EntryEval {
+  float a;
+  bool k;
+};
+__device__ __forceinline__ EntryEval eval_entry(float x, float y, float A, float B, float Cq, float lo, float px, float py) {
+  const float dx = x - px, dy = y - py;
+  const float t = __builtin_fmaf(A, dx, B * dy);
+  const float u = __builtin_fmaf(Cq * dy, dy, lo);
+  const float s = __builtin_fmaf(dx, t, u);
+  const float e = __builtin_amdgcn_exp2f(s);
+  EntryEval r;
+  r.a = fminf(kAlphaMax, e);
+  r.k = (s <= lo) & (e >= kAlphaMin);  // '&': no short-circuit branch
+  return r;
+}
+
+// phase A: product of (1 - alpha) over the list in depth order, and (TRACK) the list position of the last contributor
+template <bool TRACK>
+__device__ __forceinline__ void walk_list(const WaveList &wl, int n_mine, float px, float py, float &P, int &Lpos) {
+  for (int t = 0; t < n_mine; t += 4) {
+    const int p = t >> 1;
+    const float4 X0 = wl.X[p], X1 = wl.X[p + 1], C0 = wl.C[p], C1 = wl.C[p + 1], D0 = wl.D[p], D1 = wl.D[p + 1];
+    const EntryEval e0 = eval_entry(X0.x, X0.z, C0.x, C0.z, D0.x, D0.z, px, py);
+    const EntryEval e1 = eval_entry(X0.y, X0.w, C0.y, C0.w, D0.y, D0.w, px, py);
+    const EntryEval e2 = eval_entry(X1.x, X1.z, C1.x, C1.z, D1.x, D1.z, px, py);
+    const EntryEval e3 = eval_entry(X1.y, X1.w, C1.y, C1.w, D1.y, D1.w, px, py);
+    P *= e0.k ? 1.f - e0.a : 1.f;  // depth order kept: ((P m0) m1) m2 ...
+    P *= e1.k ? 1.f - e1.a : 1.f;
+    P *= e2.k ? 1.f - e2.a : 1.f;
+    P *= e3.k ? 1.f - e3.a : 1.f;
+    if (TRACK) {
+      Lpos = e0.k ? t : Lpos;
+      Lpos = e1.k ? t + 1 : Lpos;
+      Lpos = e2.k ? t + 2 : Lpos;
+      Lpos = e3.k ? t + 3 : Lpos;
+    }
+  }
+}
+
+// Sequential walk with the stop rule (gsplat: stop BEFORE compositing the Gaussian that would take T to <= 1e-4):
+// lanes with `live` look for their stop from transmittance T.  Returns the list position of the last contributor
+// composited here (-1: none); the wave leaves as soon as none of its lanes is looking.
+__device__ __forceinline__ int exact_walk_wave(const WaveList &wl, int n_mine, float px, float py, bool &live, float &T,
+                                               bool &found) {
+  int lastpos = -1;
+  for (int t = 0; t < n_mine && __ballot(live) != 0ull; t += 2) {
+    const int p = t >> 1;
+    const float4 X0 = wl.X[p], C0 = wl.C[p], D0 = wl.D[p];
+    const EntryEval e0 = eval_entry(X0.x, X0.z, C0.x, C0.z, D0.x, D0.z, px, py);
+    const EntryEval e1 = eval_entry(X0.y, X0.w, C0.y, C0.w, D0.y, D0.w, px, py);
+    {
+      const float nT = T * (1.f - e0.a);
+      const bool hit = live & e0.k, stop = hit & (nT <= kTStop), upd = hit & !stop;
+      T = upd ? nT : T;
+      lastpos = upd ? t : lastpos;
+      found = found | stop;
+      live = live & !stop;
+    }
+    {
+      const float nT = T * (1.f - e1.a);
+      const bool hit = live & e1.k, stop = hit & (nT <= kTStop), upd = hit & !stop;
+      T = upd ? nT : T;
+      lastpos = upd ? t + 1 : lastpos;
+      found = found | stop;
+      live = live & !stop;
+    }
+  }
+  return lastpos;
+}
+
+// the training step's per-pixel epilogue: fused clamp + weighted L1 + upstream gradient, and the 12-byte record the
+// footprint backward reads (finalize_pixel<1> of composite.h without the optional images)
+__device__ __forceinline__ float finalize_train(int p, float T, int last, bool stopped, const int *__restrict__ flat,
+                                                float gt_p, float w, float loss_scale, StopRec *__restrict__ gtstop,
+                                                const float4 *__restrict__ splat) {
+  return finalize_pixel<1>(p, T, last, stopped, flat, nullptr, nullptr, nullptr, true, gt_p, w, loss_scale, nullptr, gtstop,
+                           splat);
+}
+
+__device__ __forceinline__ int gridDim_tiles(int tw, int height) { return tw * ((height + kTile - 1) / kTile); }
+
+// one pixel's granule of a slice: {product, tag << 9 | index of the last contributor}
+__device__ __forceinline__ unsigned long long load_granule(const unsigned long long *g) {
+  return __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Look back over slices [j_begin, j_end) of the tile (in front of the calling wave's): multiply their products onto T in
+// depth order, sixteen granules in flight per lane; a granule that does not carry this call's tag yet is asked for
+// again (the slices in front have lower block indices: they were dispatched earlier and wait on nobody behind them).
+// `before` becomes true for a pixel once the product crosses the transmittance threshold (its walk stopped in front).
+template <bool CHAINED>
+__device__ __forceinline__ void look_back(const unsigned long long *gran, int i0, int span, int j_begin, int j_end,
+                                          unsigned tag, bool inside, float &T, bool &before) {
+  for (int j16 = j_begin; j16 < j_end; j16 += 16) {
+    if (CHAINED && __ballot(!before && inside) == 0ull) break;  // every pixel of the quadrant stopped further in front
+    const int nb = min(16, j_end - j16);
+    unsigned long long G[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u)
+      G[u] = load_granule(&gran[(size_t)(i0 + (j16 + (u < nb ? u : 0)) * span) * kTilePix + threadIdx.x]);
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      if (u < nb) {
+        while ((unsigned)(G[u] >> 41) != tag) {  // (rare once the first poll has come back)
+          __builtin_amdgcn_s_sleep(1);
+          G[u] = load_granule(&gran[(size_t)(i0 + (j16 + u) * span) * kTilePix + threadIdx.x]);
+        }
+        const float nT = T * __int_as_float((int)(unsigned)G[u]);  // a slice without a contributor holds exactly 1
+        before = before | (nT <= kTStop);
+        T = before ? T : nT;
+      }
+    }
+  }
+}
+
+// TIMED (EG_FWD_PROF=1, debugging only): shader-clock ticks per phase of every wave of the LAST launch, one 8-word
+// record per wave in prof[(item * 4 + quadrant) * 8 ...] (plain stores: atomics on shared words would serialise and
+// be measured themselves); word 7 = 1 marks a wave that ran (read by eg_debug_fwd_profile)
+template <bool CHAINED, bool TIMED>
+__global__ void __launch_bounds__(256)
+composite_wave_fwd_kernel(const float4 *__restrict__ splat, const TileTable tt_, const int *__restrict__ total,
+                          const int *__restrict__ flat, int width, int height, int tw, const SliceWs ws_, unsigned tag,
+                          int span, const float *__restrict__ gt, const float *__restrict__ wmap, float loss_scale,
+                          StopRec *__restrict__ gtstop, const Batch bt, unsigned long long *__restrict__ prof) {
+  __shared__ WaveList lists[4];
+  long long t_prev = TIMED ? (long long)__builtin_readcyclecounter() : 0;
+  unsigned long long *my_prof = TIMED ? prof + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 : nullptr;
+#define EG_TICK(k)                                                                                        \
+  do {                                                                                                    \
+    if (TIMED) {                                                                                          \
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                         \
+      const long long now_ = (long long)__builtin_readcyclecounter();                                     \
+      if ((threadIdx.x & 63) == 0) my_prof[k] = (unsigned long long)(now_ - t_prev);                      \
+      t_prev = now_;                                                                                      \
+    }                                                                                                     \
+  } while (0)
+  const int bv = blockIdx.y;  // view of a batched step
+  const TileTable tt = view_of(tt_, bt, bv);
+  const SliceWs ws = view_of(ws_, bt, bv);
+  total += 4 * bv; flat += bv * bt.keys; splat += bv * bt.splat4; gtstop += bv * bt.pixels;
+  if (bt.gt[0]) { gt = bt.gt[bv]; wmap = bt.wmap[bv]; }
+  const int b = blockIdx.x;
+  if (b >= total[2]) return;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (TIMED && lane < 8) my_prof[lane] = lane == 7 ? 1ull : 0ull;
+  WaveList &wl = lists[wv];
+  // where this item lives: ONE 16-byte record left by the sort kernel.  A wave's slice is `span` consecutive items
+  // (span * 128 <= kWaveSlice Gaussians); the workgroups of the items in between have nothing to do
+  const int4 ir = tt.item_rec[b];
+  const int s128 = ir.y & 0xffff;
+  if (s128 % span) return;
+  const int tile = ir.x, s_me = s128 / span, ns = ((ir.y >> 16) + span - 1) / span, slice = span * kSlice;
+  const int start = ir.z, t_end = ir.w, end = min(t_end, start + slice);
+  const int i0 = b - s128, t_start = start - s128 * kSlice;  // (slice s of the tile publishes under item i0 + s * span)
+  const int ty = tile / tw, tx = tile - ty * tw;
+  // wave wv owns the 8x8 quadrant (wv & 1, wv >> 1) of the tile, lane l the pixel (l & 7, l >> 3) inside it
+  const int qj = tx * kTile + ((wv & 1) << 3), qi = ty * kTile + ((wv >> 1) << 3);
+  const int i = qi + (lane >> 3), j = qj + (lane & 7);
+  const bool inside = (i < height) && (j < width);
+  const float px = (float)j + 0.5f, py = (float)i + 0.5f;
+  if (tt.cursor_reset && s_me == 0 && threadIdx.x == 0) tt.cursor_reset[tile] = 0;
+  // who finalises pixels here: in speculative mode only the tile's last slice, in chained mode any slice may
+  const bool finisher = CHAINED || s_me == ns - 1;
+  // the pixel's target and loss weight do not depend on the slices: in flight under everything else
+  const int p = i * width + j;
+  const float w_p = (finisher && inside) ? wmap[p] : 0.f;
+  const float gt_p = (finisher && inside) ? gt[p] : 0.f;
+  EG_TICK(0);  // head: the item record (+ the pixel's gt / weight)
+
+  unsigned long long *gran = (unsigned long long *)ws.sliceP;  // [max_items][256] (sliceP and sliceL are contiguous)
+  float T = 1.f, l = 0.f;
+  bool before = false;  // the pixel stopped in a slice in front of this one
+  int looked = 0;       // slices [0, looked) are already folded into T
+
+  // ---- chained mode, DEAD SLICES.  In a trained scene a pixel's walk stops after a few dozen contributors: in a tile
+  // that holds thousands of Gaussians most slices lie behind EVERY pixel's stop and their staging and walk -- most of
+  // the launch's arithmetic -- are for nothing.  Whether a slice is dead is known only once the slices in front have
+  // finished, and waiting for them costs a live slice a whole wave lifetime; so the decision to wait is taken from the
+  // PREVIOUS call's outcome (scenes move slowly between steps): every (tile, quadrant) remembers the first slice that was
+  // dead.  A wave at or behind that slice first looks back over the slices in front of it only; if every pixel of its
+  // quadrant has indeed stopped there it publishes a neutral granule and leaves, otherwise it carries on as usual
+  // (late, nothing else).  The hint never changes a result.  Key = tag << 8 | (255 - slice), kept by atomicMax: a later
+  // call overrides an earlier one, within a call the smallest slice wins; two arrays alternate with the tag's parity.
+  int *hint_prev = ws.dead_hint + ((tag + 1u) & 1u) * 4 * gridDim_tiles(tw, height), *hint_cur = nullptr;
+  if (CHAINED) {
+    hint_cur = ws.dead_hint + (tag & 1u) * 4 * gridDim_tiles(tw, height) + tile * 4 + wv;
+    const int key = hint_prev[tile * 4 + wv];
+    const int h = ((unsigned)key >> 8) == ((tag - 1u) & kGranuleTagMask) ? 255 - (key & 255) : 0x7fffffff;
+    if (s_me >= h && s_me > 0 && h > 0) {
+      look_back<true>(gran, i0, span, 0, h, tag, inside, T, before);
+      looked = h;
+      if (__ballot(!before && inside) == 0ull) {  // dead, as last time
+        if (s_me < ns - 1) {
+          const unsigned long long rec = (unsigned long long)(unsigned)__float_as_int(1.f) |
+                                         ((unsigned long long)((tag << 9) | (unsigned)kNoContributor) << 32);
+          __hip_atomic_store(&gran[(size_t)b * kTilePix + threadIdx.x], rec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (lane == 0) atomicMax(hint_cur, (int)((tag << 8) | (unsigned)(255 - min(h, 255))));
+        return;
+      }
+    }
+  }
+
+  // ---- phase A: this slice's product (and last contributor) over this wave's quadrant
+  float P = 1.f;
+  int Lpos = -1, n_mine = 0;
+  if (end > start) {  // (an empty tile's single item has nothing to walk)
+    n_mine = stage_wave(wl, splat, flat, start, end, (float)qj, (float)qi, lane);
+    EG_TICK(1);  // staging: ids -> records -> quadrant tests -> list
+    walk_list<CHAINED>(wl, n_mine, px, py, P, Lpos);
+    if (TIMED) { float keep = P; asm volatile("" : "+v"(keep)); P = keep; }
+    EG_TICK(2);  // walk
+  }
+  const int Lidx = (CHAINED && Lpos >= 0) ? (int)wl.idx[Lpos] : kNoContributor;
+
+  // ---- publish for the slices behind this one: one data-tagged granule per pixel, a single store, nothing to wait for
+  if (s_me < ns - 1) {
+    const unsigned long long rec = (unsigned long long)(unsigned)__float_as_int(P) |
+                                   ((unsigned long long)((tag << 9) | (unsigned)Lidx) << 32);
+    __hip_atomic_store(&gran[(size_t)b * kTilePix + threadIdx.x], rec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (b = i0 + s_me * span)
+  }
+  EG_TICK(3);  // publish
+  if (!finisher) return;  // (speculative mode: whole wave)
+
+  // ---- look back over the slices in front (those a gated wave has not folded in yet)
+  look_back<CHAINED>(gran, i0, span, looked, s_me, tag, inside, T, before);
+  if (CHAINED && s_me > 0 && __ballot(!before && inside) == 0ull && lane == 0)  // this slice was dead: remember for next time
+    atomicMax(hint_cur, (int)((tag << 8) | (unsigned)(255 - min(s_me, 255))));
+  EG_TICK(4);  // look-back
+
+  if (!CHAINED) {
+    // ---- speculative mode (the tile's last slice): nothing is expected to stop
+    const float nT = T * P;
+    const bool stop_seen = before | (nT <= kTStop);
+    T = before ? T : nT;
+    if (__ballot(stop_seen && inside) != 0ull) {
+      // the caller speculated that no pixel would stop: tell it (sticky word 3 of the control block); it restores its
+      // state and runs the step again in chained mode
+      if (lane == 0) atomicExch(&ws.ctl[3], 1);
+    }
+    if (inside) l = finalize_train(p, T, 0, false, flat, gt_p, w_p, loss_scale, gtstop, splat);
+  } else {
+    // ---- chained mode: does the stop fall in this slice?
+    int last = -1;  // sorted index of the last contributor in front of a stop; -1: not known (yet)
+    bool cross = false;
+    if (!before && Lidx != kNoContributor) {
+      const float nT = T * P;
+      if (nT <= kTStop) cross = true; else T = nT;
+    }
+    cross = cross && inside;
+    bool found = false;
+    if (__ballot(cross) != 0ull) {
+      if (lane == 0 && ws.ctl[2] == 0) atomicMax(&ws.ctl[2], 1);  // "pixels do stop": the caller's launch-mode hint
+      // exact stop from the list still in LDS, sequentially in depth order from T; should float rounding move the
+      // crossing past the slice end, the same lanes carry on through the following slices (staged afresh)
+      bool live = cross;
+      const int lp = exact_walk_wave(wl, n_mine, px, py, live, T, found);
+      if (lp >= 0) last = start + (int)wl.idx[lp];
+      for (int s2 = s_me + 1; s2 < ns; ++s2) {
+        if (__ballot(cross && !found) == 0ull) break;
+        const int st2 = t_start + s2 * slice, en2 = min(t_end, st2 + slice);
+        const int n2 = stage_wave(wl, splat, flat, st2, en2, (float)qj, (float)qi, lane);
+        live = cross && !found;
+        const int lp2 = exact_walk_wave(wl, n2, px, py, live, T, found);
+        if (lp2 >= 0) last = st2 + (int)wl.idx[lp2];
+      }
+      if (cross && found && last < 0) {
+        // the stop is the first contributor of its slice: the last contributor sits in a slice in front (whose granule
+        // this lane has seen tagged already)
+        for (int js = s_me - 1; js >= 0; --js) {
+          const unsigned w1 = (unsigned)(load_granule(&gran[(size_t)(i0 + js * span) * kTilePix + threadIdx.x]) >> 32);
+          if ((int)(w1 & 511u) != kNoContributor) { last = t_start + js * slice + (int)(w1 & 511u); break; }
+        }
+      }
+    }
+    if (s_me + 1 < ns && __ballot(inside && !(before || (cross && found))) == 0ull && lane == 0)
+      atomicMax(hint_cur, (int)((tag << 8) | (unsigned)(255 - min(s_me + 1, 255))));  // the slices behind are dead
+    EG_TICK(5);  // exact stop
+    // finalise the pixels that stop here (whichever way the exact walk ended) and -- in the last slice -- the pixels
+    // that never stop
+    if (cross || (inside && !before && s_me == ns - 1))
+      l = finalize_train(p, T, max(last, 0), cross && found && last >= 0, flat, gt_p, w_p, loss_scale, gtstop, splat);
+  }
+  // loss terms of this wave's pixels -> one of 64 partial sums
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) l += __shfl_xor(l, d, 64);
+  if (lane == 0 && l != 0.f) unsafeAtomicAdd(&ws.loss_part[(tile * 4 + wv) & 63], l);
+  EG_TICK(6);  // epilogue
+#undef EG_TICK
+}
+
+static unsigned long long *g_prof = nullptr;
+static int64_t g_prof_items = 0;
+
+int launch_wave_fwd(const float4 *splat, const TileTable tt, const int32_t *flatten_ids, int width, int height,
+                    const float *gt, const float *wmap, float loss_scale, const int32_t *total, int64_t max_items,
+                    void *workspace, float *gtstop, int chained, unsigned tag, int max_tile_hint, hipStream_t s,
+                    const Batch &bt, int C) {
+  const int tw = cdiv(width, kTile), th = cdiv(height, kTile);
+  const SliceWs ws = carve_workspace(workspace, max_items, tw * th);
+  static const bool timed = getenv("EG_FWD_PROF") && atoi(getenv("EG_FWD_PROF")) != 0;
+  if (timed && (!g_prof || g_prof_items < max_items)) {
+    if (g_prof) (void)hipFree(g_prof);
+    g_prof_items = max_items;
+    (void)hipMalloc((void **)&g_prof, (size_t)max_items * 32 * sizeof(unsigned long long));
+  }
+  if (timed) (void)hipMemsetAsync(g_prof, 0, (size_t)max_items * 32 * sizeof(unsigned long long), s);
+  tag &= kGranuleTagMask;
+  // span: 128- or 256-Gaussian slices.  A wave lives ~25-45 k cycles whatever it does (a chain of dependent memory
+  // round trips) and the chip holds 8192 of them: a launch of more than one round lasts two wave lifetimes.  With
+  // max_items * C item workgroups of 4 waves the upper bound on the launch is known; pairs of items halve it.
+  static const int span_env = getenv("EG_WAVE_SPAN") ? atoi(getenv("EG_WAVE_SPAN")) : 0;
+  const int span = span_env == 1 || span_env == 2 ? span_env : ((int64_t)max_items * C * 4 > 6144 ? 2 : 1);
+  (void)max_tile_hint;
+  const dim3 grid((unsigned)max_items, C);
+#define EG_LAUNCH(CH_, TI_)                                                                                         \
+  composite_wave_fwd_kernel<CH_, TI_><<<grid, 256, 0, s>>>(splat, tt, total, flatten_ids, width, height, tw, ws, tag, \
+                                                          span, gt, wmap, loss_scale, (StopRec *)gtstop, bt, g_prof)
+  if (chained) { if (timed) EG_LAUNCH(true, true); else EG_LAUNCH(true, false); }
+  else         { if (timed) EG_LAUNCH(false, true); else EG_LAUNCH(false, false); }
+#undef EG_LAUNCH
+  timing_mark(kMarkSlice, s);
+  timing_mark(kMarkRewalk, s);
+  return check_launch("composite_fwd(wave)");
+}
+
+}  // namespace eg
+
+// debugging aid (EG_FWD_PROF=1): the per-wave phase records of the last forward launch ([items][4 quadrants][8] words,
+// see the kernel); returns the number of 8-word records copied (<= max_records) or a negative code.  Synchronises.
+extern "C" int64_t eg_debug_fwd_profile(uint64_t *out, int64_t max_records) {
+  if (!eg::g_prof || !out) return EG_ERR_ARG;
+  const int64_t n = eg::g_prof_items * 4 < max_records ? eg::g_prof_items * 4 : max_records;
+  if (hipMemcpy(out, eg::g_prof, (size_t)n * 8 * sizeof(uint64_t), hipMemcpyDeviceToHost) != hipSuccess) return EG_ERR_LAUNCH;
+  return n;
+}

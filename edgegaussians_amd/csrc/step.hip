@@ -145,12 +145,9 @@ extern "C" int eg_train_step(const eg_step_args *a, eg_stream_t stream) {
     }
     EG_MARK(kMarkProjectBin);
     EG_MARK(kMarkEmit);
-    rc = prefix_here ? launch_sort_segments(a->keys, a->tile_counts, T, a->seg_cap, a->flatten_ids, a->offsets,
-                                            a->tile_end, a->item_offsets, a->item_end, a->item_tile,
-                                            (int32_t)a->max_items, a->max_tile_hint, Batch{}, 1, st, a->total)
-                     : eg_sort_segments(a->keys, a->tile_counts, T, a->seg_cap, a->flatten_ids, a->offsets, a->tile_end,
-                                        a->item_offsets, a->item_end, a->item_tile, (int32_t)a->max_items,
-                                        a->max_tile_hint, stream);
+    rc = launch_sort_segments(a->keys, a->tile_counts, T, a->seg_cap, a->flatten_ids, a->offsets, a->tile_end,
+                              a->item_offsets, a->item_end, a->item_tile, (int32_t)a->max_items, a->max_tile_hint, Batch{}, 1,
+                              st, prefix_here ? a->total : nullptr, a->item_rec);
     if (rc) return rc;
     EG_MARK(kMarkSort);
     EG_REQUIRE(a->splat && a->offsets && a->flatten_ids && a->total && a->workspace && a->max_items > 0 &&
@@ -160,7 +157,7 @@ extern "C" int eg_train_step(const eg_step_args *a, eg_stream_t stream) {
                                        a->flatten_ids, a->width, a->height, a->render, a->alphas, a->last_ids, a->gt,
                                        a->wmap, a->loss_scale, a->vpix, a->loss, a->total, a->max_items, a->workspace,
                                        a->gtstop, a->rewalk_hint, a->max_tile_hint, a->ws_tag, st,
-                                       prefix_here ? a->tile_counts : nullptr);
+                                       prefix_here ? a->tile_counts : nullptr, a->item_rec);
     if (rc) return rc;
   } else {
   // tile_counts is zero on entry (caller zero-initialises it once): the projection counts it up and its
@@ -184,7 +181,9 @@ extern "C" int eg_train_step(const eg_step_args *a, eg_stream_t stream) {
   }
   // (slice / re-walk marks are recorded inside eg_composite_fwd)
   // backward: footprint compositing VJP, then projection VJP + absgrad (+ Adam)
-  rc = eg_composite_bwd_footprint(a->splat, a->N, a->width, a->height, a->gtstop, a->g2d, stream);
+  EG_REQUIRE(a->splat && a->gtstop && a->g2d, "null pointer");
+  rc = launch_footprint_bwd(a->splat, a->N, a->width, a->height, a->gtstop, a->g2d, Batch{}, 1, st,
+                            a->seg_cap > 0 ? a->workspace : nullptr, a->max_items, a->loss);
   if (rc) return rc;
   // (the footprint mark is recorded inside eg_composite_bwd_footprint)
   if (a->adam_host && a->next_viewmat && a->next_K && a->seg_cap > 0)
@@ -251,14 +250,15 @@ extern "C" int eg_train_step_batched(const eg_step_args *a, int32_t C, const flo
   if (rc) return rc;
   rc = launch_sort_segments(a->keys, a->tile_counts, T, a->seg_cap, a->flatten_ids, a->offsets, a->tile_end,
                             a->item_offsets, a->item_end, a->item_tile, (int32_t)a->max_items, a->max_tile_hint, bt, C,
-                            st, prefix_here ? a->total : nullptr);
+                            st, prefix_here ? a->total : nullptr, a->item_rec);
   if (rc) return rc;
   rc = launch_composite_fwd_segments(a->splat, a->offsets, a->tile_end, a->item_offsets, a->item_end, a->item_tile,
                                      a->flatten_ids, a->width, a->height, a->loss_scale, a->loss, a->total,
                                      a->max_items, a->workspace, a->gtstop, a->rewalk_hint, bt, C, st,
-                                     a->max_tile_hint, a->ws_tag, prefix_here ? a->tile_counts : nullptr);
+                                     a->max_tile_hint, a->ws_tag, prefix_here ? a->tile_counts : nullptr, a->item_rec);
   if (rc) return rc;
-  rc = launch_footprint_bwd(a->splat, a->N, a->width, a->height, a->gtstop, a->g2d, bt, C, st);
+  rc = launch_footprint_bwd(a->splat, a->N, a->width, a->height, a->gtstop, a->g2d, bt, C, st, a->workspace, a->max_items,
+                            a->loss);
   if (rc) return rc;
   return launch_project_bwd_batched(a->means, a->quats, a->log_scales, a->logit_opacities, a->N, a->width, a->height,
                                     0.3f, a->adam_host ? flags : (flags | EG_FLAG_ABSGRAD_WRITE), a->splat, a->g2d,
@@ -285,7 +285,7 @@ extern "C" int eg_train_steps(const eg_step_args *a, int32_t K, const int32_t *v
     s.K = Ks + 9 * (size_t)views_host[k];
     s.gt = gts + hw * (size_t)views_host[k];
     s.wmap = wmaps_host[k];
-    if (a->ws_tag > 0) s.ws_tag = (int32_t)(((int64_t)a->ws_tag + k - 1) % 0x7ffffff0) + 1;  // a fresh tag per step
+    if (a->ws_tag > 0) s.ws_tag = a->ws_tag + k;  // a fresh tag per step (the caller keeps ws_tag + K - 1 <= EG_MAX_WS_TAG)
     // inside the run the parameters change only through these steps: step k's last kernel projects view k + 1
     s.have_projection = (k > 0 && a->adam_host && a->seg_cap > 0) ? 1 : a->have_projection;
     s.next_viewmat = s.next_K = nullptr;

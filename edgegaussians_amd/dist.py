@@ -65,8 +65,36 @@ class DataParallelStep:
         self.worker = worker
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.time_comm = time_comm
         self._ev: List = []
+        # EdgeTrainer keeps the journal: (grad_step, all-reduce, apply_adam) triples are journalled like its own steps,
+        # its read-backs merge the sticky overflow / missed-stop words over the ranks (max) so that ALL ranks replay the
+        # same steps, and the loss sums it reports are sums over the ranks
+        self._journals = hasattr(worker, "attach_dp")
+        if self._journals:
+            worker.attach_dp(self)
+
+    def reduce_words(self, ints, floats):
+        """(element-wise max of `ints`, element-wise sum of `floats`) over the ranks, as Python lists."""
+        if self.world <= 1 or not dist.is_initialized():
+            return list(ints), list(floats)
+        dev = "cuda" if dist.get_backend(self.group) == "nccl" else "cpu"
+        out_i, out_f = list(ints), list(floats)
+        if ints:
+            t = torch.tensor(ints, dtype=torch.int64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+            out_i = [int(x) for x in t.tolist()]
+        if floats:
+            t = torch.tensor(floats, dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            out_f = [float(x) for x in t.tolist()]
+        return out_i, out_f
+
+    def all_reduce_(self, t: torch.Tensor) -> torch.Tensor:
+        """In-place sum over the ranks (what EdgeTrainer uses for the regulariser's running loss sum)."""
+        self._all_reduce(t)
+        return t
 
     # ------------------------------------------------------------------ the collective
     def _all_reduce(self, t: torch.Tensor, async_op: bool = False):
@@ -106,7 +134,18 @@ class DataParallelStep:
         of two, the tail fusion of the single-GPU step)."""
         if isinstance(view, numbers.Integral) or (isinstance(view, torch.Tensor) and view.dim() == 0):
             view = int(view)
-            grads = self.worker.grad_step(view, wmap)
+        else:
+            view, wmap = list(view), list(wmap)
+        if self._journals:
+            w = self.worker
+            w._journal_push(("d", view, (wmap, next_view), w.epoch, w.loss_scale))
+        self._step_raw(view, wmap, next_view)
+
+    def _step_raw(self, view, wmap, next_view=None) -> None:
+        """One (grad_step, all-reduce, apply_adam) triple -- also what a collective replay runs."""
+        j = {"journalled": True} if self._journals and self.worker.replay_on_overflow else {}
+        if isinstance(view, int):
+            grads = self.worker.grad_step(view, wmap, **j)
             e0 = self._mark()
             self._all_reduce(grads)
             e1 = self._mark()
@@ -119,7 +158,7 @@ class DataParallelStep:
             return
         views, wmaps = list(view), list(wmap)
         if len(views) == 1 or self.world <= 1:
-            grads = self.worker.grad_step_batched(views, wmaps)
+            grads = self.worker.grad_step_batched(views, wmaps, **j)
             e0 = self._mark()
             self._all_reduce(grads)
             e1 = self._mark()
@@ -128,9 +167,9 @@ class DataParallelStep:
             self.worker.apply_adam()
             return
         h = (len(views) + 1) // 2  # odd C: the larger half first, its collective is the hidden one
-        ga = self.worker.grad_step_batched(views[:h], wmaps[:h], slot=1)   # first half -> second buffer
-        work = self._all_reduce(ga, async_op=True)                         # ... reduced on RCCL's stream while
-        gb = self.worker.grad_step_batched(views[h:], wmaps[h:], slot=0)   # the second half is rasterised
+        ga = self.worker.grad_step_batched(views[:h], wmaps[:h], slot=1, **j)   # first half -> second buffer
+        work = self._all_reduce(ga, async_op=True)                              # ... reduced on RCCL's stream while
+        gb = self.worker.grad_step_batched(views[h:], wmaps[h:], slot=0, **j)   # the second half is rasterised
         e0 = self._mark()
         self._all_reduce(gb)
         if work is not None:

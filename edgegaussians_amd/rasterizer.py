@@ -27,6 +27,8 @@ from . import _lib
 from ._lib import call, ptr, stream
 
 TILE = 16
+import os as _os
+_FAST_ENABLED = bool(int(_os.environ.get("EG_OPERATOR_FAST", "1")))
 
 
 def _check(t: Tensor, shape, name: str, dtype=torch.float32):
@@ -189,6 +191,215 @@ class _Compositing(torch.autograd.Function):
                 None, None, None, None, None, None, None, None, None, None)
 
 
+# ------------------------------------------------------------------------------------------------------------------
+# Fast path for the reference's exact call pattern (edge_gs.py:247-279): one camera, colours == 1 without grad.
+# ONE autograd node over the kernels of the training step (segmented binning with tight tile boxes -> per-tile sort ->
+# slice-parallel compositing with the {T_final, stop} record -> footprint backward -> fused projection backward) on
+# work buffers cached per (N, width, height, device), one host read-back at the END of the forward (M, the sticky
+# overflow flag, the unit-colour verdict) where the general path -- like gsplat -- reads M in the middle, and an `info`
+# whose gsplat-layout binning tensors are computed only if somebody asks for them.
+import weakref
+
+
+class _FastBuffers:
+    """Cached work buffers of the fast path for one (N, width, height, device)."""
+
+    def __init__(self, N, width, height, dev):
+        self.N, self.width, self.height, self.dev = N, width, height, dev
+        self.tw, self.th = math.ceil(width / TILE), math.ceil(height / TILE)
+        self.T = self.tw * self.th
+        i32 = dict(dtype=torch.int32, device=dev)
+        self.tile_counts = torch.zeros(self.T, **i32)
+        self.tile_start = torch.zeros(self.T, **i32)
+        self.tile_end = torch.zeros(self.T, **i32)
+        self.item_first = torch.zeros(self.T + 1, **i32)
+        self.item_end = torch.zeros(self.T, **i32)
+        self.total = torch.zeros(4, **i32)
+        self.ticket = torch.zeros(1, **i32)
+        self.seg_cap = self.max_items = 0
+        self.max_tile = 0
+
+    def size(self, m: int, tile_max: int) -> None:
+        """(Re)allocate the intersection buffers for M = m, largest tile population tile_max (with head-room)."""
+        seg = (int(tile_max * 1.5) // 128 + 2) * 128
+        cap = int(m * 1.3) + 4096
+        if seg <= self.seg_cap and cap // 128 + self.T <= self.max_items:
+            return
+        self.seg_cap = max(seg, self.seg_cap)
+        self.max_items = max(cap // 128 + self.T, self.max_items)
+        self.max_tile = max(tile_max, self.max_tile)
+        i32 = dict(dtype=torch.int32, device=self.dev)
+        self.keys = torch.empty(self.T * self.seg_cap, dtype=torch.int64, device=self.dev)
+        self.flatten_ids = torch.empty(self.T * self.seg_cap, **i32)
+        self.item_tile = torch.zeros(self.max_items, **i32)
+        self.workspace = _lib.composite_workspace(self.max_items, self.T, self.dev)
+        self.total.zero_()
+        self.tile_counts.zero_()
+        self.ticket.zero_()
+
+
+_FAST: Dict = {}
+
+
+def _fast_buffers(N, width, height, dev) -> _FastBuffers:
+    key = (N, width, height, str(dev))
+    fb = _FAST.get(key)
+    if fb is None:
+        if len(_FAST) > 8:
+            _FAST.clear()
+        fb = _FAST[key] = _FastBuffers(N, width, height, dev)
+    return fb
+
+
+class _UnitRasterization(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means, quats, scales, opacities, viewmat, K, width, height, flags, unit_flag, holder):
+        N, dev = means.shape[0], means.device
+        fb = _fast_buffers(N, width, height, dev)
+        means_c, quats_c, scales_c, opac_c = means.contiguous(), quats.contiguous(), scales.contiguous(), opacities.contiguous()
+        vm, Kc = viewmat.contiguous(), K.contiguous()
+        fl = flags | _lib.FLAG_TIGHT_TILES
+        st = stream()
+        if fb.seg_cap == 0:  # first call for this shape: a count-only sweep sizes the buffers (one extra sync, once)
+            splat0 = torch.empty(N, 8, device=dev)
+            call("eg_project_fwd", ptr(means_c), ptr(quats_c), ptr(scales_c), ptr(opac_c), ptr(vm), ptr(Kc), N, width, height,
+                 0.01, 1e10, 0.3, 0.0, fl, ptr(splat0), None, None, None, None, None, None, ptr(fb.tile_counts), None, st)
+            offs = torch.empty(fb.T + 1, dtype=torch.int32, device=dev)
+            call("eg_tile_offsets", ptr(fb.tile_counts), fb.T, 1 << 40, ptr(offs), ptr(fb.item_first), ptr(fb.total), st)
+            tot = fb.total.tolist()
+            fb.tile_counts.zero_()
+            fb.size(int(tot[0]), int(tot[3]))
+        while True:
+            splat = torch.empty(N, 8, device=dev)
+            alphas = torch.empty(1, height, width, 1, device=dev)
+            last_ids = torch.empty(1, height, width, dtype=torch.int32, device=dev)
+            gtstop = torch.empty(height, width, 3, device=dev)
+            call("eg_project_emit", ptr(means_c), ptr(quats_c), ptr(scales_c), ptr(opac_c), ptr(vm), ptr(Kc), N, width, height,
+                 fl, ptr(splat), ptr(fb.tile_counts), fb.seg_cap, ptr(fb.keys), ptr(fb.item_first), fb.max_items,
+                 ptr(fb.total), ptr(fb.ticket), st)
+            call("eg_sort_segments", ptr(fb.keys), ptr(fb.tile_counts), fb.T, fb.seg_cap, ptr(fb.flatten_ids),
+                 ptr(fb.tile_start), ptr(fb.tile_end), ptr(fb.item_first), ptr(fb.item_end), ptr(fb.item_tile), fb.max_items,
+                 fb.max_tile, st)
+            call("eg_composite_fwd_segments", ptr(splat), ptr(fb.tile_start), ptr(fb.tile_end), ptr(fb.item_first),
+                 ptr(fb.item_end), ptr(fb.item_tile), ptr(fb.flatten_ids), width, height, ptr(alphas), ptr(alphas),
+                 ptr(last_ids), None, None, 1.0, None, None, ptr(fb.total), fb.max_items, ptr(fb.workspace), ptr(gtstop),
+                 -1, st)
+            # the ONE host read-back of the call, after everything has been enqueued: M, sticky overflow flag, items,
+            # largest tile -- and the verdict on the colours
+            vals = torch.cat([fb.total, unit_flag.to(torch.int32).reshape(1)]).tolist()
+            m, overflow, _items, tile_max, unit = (int(v) for v in vals)
+            holder["unit"] = bool(unit)
+            if not overflow:
+                break
+            fb.size(2 * max(m, 1), 2 * max(tile_max, 1))  # the scene outgrew the cached buffers: grow, run again
+        fb.max_tile = max(fb.max_tile, tile_max)
+        if m * 1.15 > (fb.max_items - fb.T) * 128 or tile_max * 1.15 > fb.seg_cap:
+            fb.size(m, tile_max)  # grow ahead of the drift (the next call finds room)
+        means2d = splat[:, 0:2].clone().view(1, N, 2)
+        ctx.save_for_backward(means_c, quats_c, scales_c, opac_c, vm, Kc, splat, gtstop)
+        ctx.cfg = (width, height, flags)
+        ctx.holder = holder
+        holder["splat"], holder["last_ids"] = splat, last_ids
+        ctx.mark_non_differentiable(last_ids)
+        return alphas, means2d, last_ids
+
+    @staticmethod
+    def backward(ctx, v_alphas, v_means2d, _v_last):
+        means, quats, scales, opac, vm, Kc, splat, gtstop = ctx.saved_tensors
+        width, height, flags = ctx.cfg
+        N, dev = means.shape[0], means.device
+        # the upstream gradient scales the record {T_final, stop id, stop depth} the forward left per pixel
+        # (unit colours: every colour channel IS the accumulated alpha, the caller's `render` is an expanded view of it, so
+        # autograd has already summed dL/drender over the channels into v_alphas)
+        v = v_alphas[0, ..., 0] if v_alphas is not None else None
+        g2d = torch.empty(N, 8, device=dev)
+        if v is None:
+            g2d.zero_()
+        else:
+            rec = gtstop.clone()
+            rec[..., 0] *= v
+            call("eg_composite_bwd_footprint", ptr(splat), N, width, height, ptr(rec), ptr(g2d), stream())
+        m2d = ctx.holder.get("means2d")
+        m2d = m2d() if m2d is not None else None
+        if m2d is not None and ctx.holder.get("absgrad"):
+            m2d.absgrad = g2d[:, 2:4].clone().view(1, N, 2)  # what the caller reads (edge_gs.py:612)
+        if v_means2d is not None:  # (somebody differentiated through info["means2d"])
+            g2d[:, 0:2] += v_means2d[0]
+        v_means = torch.empty(N, 3, device=dev)
+        v_quats = torch.empty(N, 4, device=dev)
+        v_scales = torch.empty(N, 3, device=dev)
+        v_opac = torch.empty(N, device=dev)
+        call("eg_project_bwd", ptr(means), ptr(quats), ptr(scales), ptr(opac), ptr(vm), ptr(Kc), N, width, height, 0.3, flags,
+             ptr(splat), ptr(g2d), None, None, ptr(v_means), ptr(v_quats), ptr(v_scales), ptr(v_opac), None, stream())
+        return v_means, v_quats, v_scales, v_opac, None, None, None, None, None, None, None
+
+
+class _LazyInfo(dict):
+    """gsplat's `info`: the cheap entries are there, the gsplat-layout binning tensors (tiles_per_gauss, isect_ids,
+    flatten_ids, isect_offsets) and the per-Gaussian arrays are computed from the call's packed records when read."""
+
+    _LAZY = ("radii", "depths", "conics", "opacities", "tiles_per_gauss", "isect_ids", "flatten_ids", "isect_offsets")
+
+    def __init__(self, eager, make):
+        super().__init__(eager)
+        self._make = make
+
+    def __missing__(self, key):
+        if key not in self._LAZY:
+            raise KeyError(key)
+        self.update(self._make(key))
+        return dict.__getitem__(self, key)
+
+    def __contains__(self, key):
+        return dict.__contains__(self, key) or key in self._LAZY
+
+    def get(self, key, default=None):
+        try:
+            return self[key]
+        except KeyError:
+            return default
+
+    def keys(self):
+        return list(dict.keys(self)) + [k for k in self._LAZY if not dict.__contains__(self, k)]
+
+
+def _fast_rasterization(means, quats, scales, opacities, colors, viewmats, Ks, width, height, absgrad, antialiased):
+    """Returns (render, alphas, info) or None when the colours turn out not to be all ones."""
+    N = means.shape[0]
+    tw, th = math.ceil(width / TILE), math.ceil(height / TILE)
+    flags = _lib.FLAG_ANTIALIASED if antialiased else 0
+    holder: Dict = {"absgrad": bool(absgrad)}
+    unit_flag = (colors == 1).all()
+    alphas, means2d, last_ids = _UnitRasterization.apply(
+        means, quats, scales, opacities, viewmats[0], Ks[0], width, height, flags, unit_flag, holder)
+    if not holder["unit"]:
+        return None
+    render = alphas.expand(1, height, width, colors.shape[-1])  # colours == 1: every channel is the accumulated alpha
+    holder["means2d"] = weakref.ref(means2d)
+    splat = holder.pop("splat")
+
+    def make(key):
+        if key in ("radii", "depths", "conics", "opacities"):
+            return {"radii": splat[:, 7].contiguous().view(torch.int32).view(1, N), "depths": splat[None, :, 6],
+                    "conics": torch.cat([splat[:, 2:4], splat[:, 4:5]], dim=-1)[None], "opacities": splat[None, :, 5]}
+        # gsplat's binning (3-sigma boxes, global (tile, depth) order) on this call's projection
+        with torch.no_grad():
+            radii = splat[:, 7].contiguous().view(torch.int32)
+            m2 = splat[:, 0:2].contiguous()
+            counts = torch.zeros(tw * th, dtype=torch.int32, device=means.device)
+            tpg = torch.empty(N, dtype=torch.int32, device=means.device)
+            call("eg_tile_count", ptr(m2), ptr(radii), N, width, height, ptr(tpg), ptr(counts), stream())
+            offsets, flat, ids, M, _io, _tot, _ni = isect_tiles_and_sort(m2, radii, splat[:, 6].contiguous(), counts, width,
+                                                                        height)
+        return {"tiles_per_gauss": tpg[None], "isect_ids": ids, "flatten_ids": flat,
+                "isect_offsets": offsets[:-1].reshape(1, th, tw)}
+
+    info = _LazyInfo({"camera_ids": None, "gaussian_ids": None, "means2d": means2d, "tile_width": tw, "tile_height": th,
+                      "width": width, "height": height, "tile_size": TILE, "n_cameras": 1, "last_ids": last_ids}, make)
+    return render, alphas, info
+
+
+
 def isect_tiles_and_sort(means2d: Tensor, radii: Tensor, depths: Tensor, counts: Tensor, width: int,
                          height: int, want_isect_ids: bool = True, max_tile_hint: Optional[int] = None,
                          extra_flag: Optional[Tensor] = None
@@ -258,6 +469,13 @@ def rasterization(
         raise NotImplementedError("colors must have 1 or 3 channels")
     width, height = int(width), int(height)
     antialiased = rasterize_mode == "antialiased"
+
+    if (Cn == 1 and colors.dim() == 2 and not colors.requires_grad and float(eps2d) == 0.3 and float(near_plane) == 0.01
+            and float(far_plane) == 1e10 and float(radius_clip) == 0.0 and N > 0 and _FAST_ENABLED):
+        # the reference's own call (edge_gs.py:247-268): colours torch.ones(N, 3) without grad, one camera
+        out = _fast_rasterization(means, quats, scales, opacities, colors, viewmats, Ks, width, height, absgrad, antialiased)
+        if out is not None:
+            return out
 
     radii, means2d, depths, conics, comps, tpg, counts, _splat = _Projection.apply(
         means, quats, scales, opacities.detach(), viewmats, Ks, width, height, float(eps2d),

@@ -36,10 +36,27 @@ def _anneal(cfg: Dict, key: str, step: int, max_steps: int) -> float:
 
 def train_epoch(tr: EdgeTrainer, views: Iterable[int], epoch: int, num_epochs: int, projection_cfg: Dict,
                 orientation_cfg: Dict, edge_threshold: float = 0.5,
-                generator: Optional[torch.Generator] = None, read_back: bool = True) -> Optional[float]:
+                generator: Optional[torch.Generator] = None, read_back: bool = True,
+                views_per_step: int = 1, dp=None) -> Optional[float]:
     """train_gaussians.py:17-141 for one epoch; returns the average projection loss -- or, with read_back=False,
     parks the epoch's loss sum on the device (EdgeTrainer.mark_epoch, no host sync) and returns the number of
-    iterations; the caller collects the sums of several epochs with one `pop_losses()`."""
+    iterations; the caller collects the sums of several epochs with one `pop_losses()`.
+
+    views_per_step = C > 1 (a THROUGHPUT mode, SURVEY 8e/8f: the reference steps after every view): the epoch's views
+    are taken C at a time and every batch is ONE optimizer step on the sum of its views' gradients (a last, short batch
+    is filled up from the front of the epoch's order) -- on one GPU as a batched launch sequence
+    (`EdgeTrainer.train_step_batched`), or with `dp` (a `dist.DataParallelStep` over `tr`, world size P dividing C)
+    sharded over the ranks: rank r rasterises views r C/P .. (r + 1) C/P - 1 of every batch, one all-reduce of the fused
+    [N,12] gradient buffer, the identical Adam on every rank.  Both forms follow the same trajectory up to the rounding
+    of the gradient sum; strategies, weight-map draws and the regulariser cadence count VIEWS exactly as with C = 1."""
+    C = int(views_per_step)
+    world = dp.world if dp is not None else 1
+    rank = dp.rank if dp is not None else 0
+    if C < 1 or C % world:
+        raise ValueError(f"views_per_step={C} must be a positive multiple of the world size {world}")
+    if C > 1 or dp is not None:
+        return _train_epoch_batched(tr, list(views), epoch, num_epochs, projection_cfg, orientation_cfg, edge_threshold,
+                                    generator, read_back, C, dp, world, rank)
     ratio = _anneal(projection_cfg, "bg_edge_pixel_ratio", epoch, num_epochs)
     tr.loss_scale = float(_anneal({"lambda_annealing": projection_cfg["lambda_annealing"],
                                    "lambda_start": projection_cfg["lambda_start"],
@@ -86,10 +103,63 @@ def train_epoch(tr: EdgeTrainer, views: Iterable[int], epoch: int, num_epochs: i
     return tr.pop_loss() / max(n, 1)
 
 
+def _train_epoch_batched(tr, views, epoch, num_epochs, projection_cfg, orientation_cfg, edge_threshold, generator,
+                         read_back, C, dp, world, rank):
+    ratio = _anneal(projection_cfg, "bg_edge_pixel_ratio", epoch, num_epochs)
+    tr.loss_scale = float(_anneal({"lambda_annealing": projection_cfg["lambda_annealing"],
+                                   "lambda_start": projection_cfg["lambda_start"],
+                                   "lambda_end": projection_cfg["lambda_end"]}, "lambda", epoch, num_epochs))
+    tr.epoch = epoch
+    alternate = epoch > projection_cfg["start_alternating_at_epoch"]
+    strategy = projection_cfg["loss_before_alternating"]
+    apply_dir = epoch > orientation_cfg["start_dir_loss_at_epoch"]
+    apply_ratio = epoch > orientation_cfg["start_ratio_loss_at_epoch"]
+    period = projection_cfg["sampling_whole_num_epochs_ratio"]
+    if len(views) % C:
+        views = views + views[:C - len(views) % C]
+    per_rank = C // world
+    n, step_no = 0, tr.step if dp is None else getattr(tr, "_dp_views_seen", tr.step)
+    for b0 in range(0, len(views), C):
+        batch = views[b0:b0 + C]
+        mine_v, mine_w = [], []
+        for k, idx in enumerate(batch):
+            if alternate:
+                strategy = projection_cfg["less_freq_loss"] if (step_no + k) % period == 0 else projection_cfg["more_freq_loss"]
+            if k // per_rank == rank:
+                mine_v.append(int(idx))
+                mine_w.append(tr.weight_map(idx, strategy, ratio, generator, edge_threshold))
+            elif strategy == "bg_edge_ratio" and generator is None:
+                tr.skip_weight_map_draw()  # (another rank's view: keep the draw sequence in step)
+            elif strategy == "bg_edge_ratio":
+                tr.weight_map(idx, strategy, ratio, generator, edge_threshold)  # (a host generator must be advanced by drawing)
+        if dp is None:
+            tr.train_step_batched(mine_v, mine_w)
+        elif per_rank == 1:
+            dp.step(mine_v[0], mine_w[0])
+        else:
+            dp.step(mine_v, mine_w)
+        n += C
+        crossed = (step_no + C) // 5 > step_no // 5  # (a multiple of five views was passed: train_gaussians.py:108)
+        step_no += C
+        if (apply_dir or apply_ratio) and crossed:
+            if apply_dir:
+                tr.regulariser_step("direction", None, orientation_cfg["dir_loss_scale_factor"],
+                                    orientation_cfg["dir_loss_num_nn"],
+                                    orientation_cfg.get("dir_loss_enforce_method", "enforce_full"), want_value=False)
+            if apply_ratio:
+                tr.regulariser_step("ratio", None, orientation_cfg["ratio_loss_scale_factor"], want_value=False)
+    if dp is not None:
+        tr._dp_views_seen = step_no  # (tr.step counts this rank's views only)
+    if not read_back:
+        tr.mark_epoch()
+        return n
+    return tr.pop_loss() / max(n, 1)
+
+
 def train(tr: EdgeTrainer, model_cfg: Dict, training_cfg: Dict, view_order: Callable[[int], Iterable[int]],
           edge_masks_u8: Optional[torch.Tensor] = None, on_epoch: Optional[Callable[[int, float, int], None]] = None,
           generator: Optional[torch.Generator] = None, num_epochs: Optional[int] = None,
-          sync_every: Optional[int] = None) -> List[float]:
+          sync_every: Optional[int] = None, views_per_step: int = 1, dp=None) -> List[float]:
     """train_gaussians.py:144-222.  `model_cfg` / `training_cfg` are the reference's JSON sections;
     `edge_masks_u8` [V,H,W] (gt >= threshold) is needed only for the not-projecting cull.
 
@@ -99,7 +169,13 @@ def train(tr: EdgeTrainer, model_cfg: Dict, training_cfg: Dict, view_order: Call
     runs epoch e.  `on_epoch(epoch, avg_loss, N)` is therefore called late -- in order, at the next read-back.
     sync_every = 1 is the reference's cadence (one read-back per epoch) and the default when `on_epoch` is given (a
     callback that snapshots the trainer then sees the state at the end of ITS epoch); without a callback the default is
-    8.  A callback that only logs may pass a larger `sync_every` explicitly."""
+    8.  A callback that only logs may pass a larger `sync_every` explicitly.
+
+    views_per_step / dp: see `train_epoch` -- C views per optimizer step, on one GPU or sharded over the ranks of a
+    `dist.DataParallelStep`.  Under `dp` every rank runs this same loop: the read-backs are collective (sticky overflow /
+    missed-stop flags by max, so that all ranks replay the same steps; loss sums by sum, so that every rank returns the
+    same history), densify / cull decisions come from the all-reduced absgrads and the seeded noise, and the replicas
+    stay bit-identical."""
     if sync_every is None:
         sync_every = 1 if on_epoch is not None else 8
     loss_cfg = training_cfg["loss"]
@@ -138,7 +214,8 @@ def train(tr: EdgeTrainer, model_cfg: Dict, training_cfg: Dict, view_order: Call
         parked.clear()
 
     for epoch in range(num_epochs):
-        n = train_epoch(tr, view_order(epoch), epoch, num_epochs, proj_cfg, orient_cfg, thr, generator, read_back=False)
+        n = train_epoch(tr, view_order(epoch), epoch, num_epochs, proj_cfg, orient_cfg, thr, generator, read_back=False,
+                        views_per_step=views_per_step, dp=dp)
         parked.append((epoch, n))
         # (the trainer parks at most 64 epoch sums on the device between two read-backs)
         if (len(parked) >= max(1, min(sync_every, 60)) or epoch in events or epoch == num_epochs - 1

@@ -95,6 +95,7 @@ class EdgeTrainer:
         self.rewalk_misses = 0  # replays caused by a transmittance stop while the re-walk launch was being skipped
         self.rewalk_hint = -1  # re-walk list length seen at the last read-back (launch-shape hint; -1 = unknown)
         self._projected: Optional[int] = None  # view already projected + binned by apply_adam(next_view=...)
+        self._dp = None  # the DataParallelStep driving this trainer (dist.py), if any: read-backs and replays are collective
         self._ws_tag = 0       # tags of the chained forward (eg_step_args.ws_tag): one fresh value per enqueued step
         self.chained_forward = bool(int(os.environ.get("EG_CHAINED", "1")))
         # noise of duplicate() comes from a dedicated generator seeded with (seed, event number): identical
@@ -200,6 +201,8 @@ class EdgeTrainer:
             self.tile_end = torch.zeros(self.T, dtype=torch.int32, device=self.dev)
             self.item_end = torch.zeros(self.T, dtype=torch.int32, device=self.dev)
             self.item_tile = torch.zeros(self.max_items, dtype=torch.int32, device=self.dev)
+            # the sort kernel's per-item records for the wave-autonomous forward (composite_wave.hip)
+            self.item_rec = torch.zeros(self.max_items, 4, dtype=torch.int32, device=self.dev)
         self.workspace = _lib.composite_workspace(self.max_items, self.T, self.dev)
         self._args_cache = {}
         self._batches = {}
@@ -243,6 +246,11 @@ class EdgeTrainer:
                  hw, ptr(w), stream())
             return w
         raise ValueError(f"Unknown projection loss strategy: {strategy}")
+
+    def skip_weight_map_draw(self) -> None:
+        """Advance the key of the device-side `bg_edge_ratio` draws without drawing: a data-parallel rank keeps its
+        draw sequence in step with the single-process run (and with the other ranks) for the views it does not own."""
+        self._wmap_draws = getattr(self, "_wmap_draws", 0) + 1
 
     # ------------------------------------------------------------------ capacity
     def count_intersections(self, view: int) -> int:
@@ -297,6 +305,7 @@ class EdgeTrainer:
             a.seg_cap = self.seg_cap
             if self.seg_cap:
                 a.tile_end, a.item_end, a.item_tile = ptr(self.tile_end), ptr(self.item_end), ptr(self.item_tile)
+                a.item_rec = ptr(self.item_rec)
             a.tile_counts, a.offsets, a.total = ptr(self.tile_counts), ptr(self.offsets), ptr(self.total)
             a.item_offsets, a.workspace, a.max_items = ptr(self.item_offsets), ptr(self.workspace), self.max_items
             a.tile_mask, a.ticket = ptr(self.tile_mask), ptr(self.ticket)
@@ -325,6 +334,11 @@ class EdgeTrainer:
             a.adam_host = self._args_cache["null_hyper"]
         return a
 
+    def attach_dp(self, dp) -> None:
+        """Called by dist.DataParallelStep: from now on every read-back merges the sticky flags (max) and the loss sums
+        (sum) over the ranks, and the journalled data-parallel steps are replayed by ALL ranks together."""
+        self._dp = dp
+
     def _rewalk_arg(self, journalled: bool) -> int:
         """The re-walk launch hint of the next enqueue.  While no pixel has reached the transmittance stop (the
         whole phase before opacities train up, edge_gs.py:93 starts them at 0.08) the launch is skipped
@@ -335,8 +349,16 @@ class EdgeTrainer:
         return self.rewalk_hint
 
     def _next_tag(self, n: int) -> int:
-        """First of n fresh tags (consecutive, in 1 .. 2^31 - 17, never 0)."""
-        t = self._ws_tag % 0x7ffffff0 + 1
+        """First of n fresh, consecutive tags in 1 .. EG_MAX_WS_TAG (23 bits: the forward's hand-over granules carry
+        them).  When the range is used up (every 8 million steps) the workspaces are zeroed and the tags start over, so
+        that a slot last written 2^23 steps ago can never be mistaken for this call's."""
+        if self._ws_tag + n > _lib.MAX_WS_TAG:
+            if self._journal:
+                self.flush()  # (the sticky words of the control block are about to go: look at them first)
+            for ws in [self.workspace] + [b["workspace"] for b in self._batches.values()]:
+                ws.zero_()
+            self._ws_tag = 0
+        t = self._ws_tag + 1
         self._ws_tag += n
         return t
 
@@ -430,8 +452,7 @@ class EdgeTrainer:
         lib = _lib.load()
         stride = int(lib.eg_batched_workspace_stride(self.max_items, T))
         ctl = int(lib.eg_composite_workspace_ctl_bytes(self.max_items, T))
-        ws = torch.empty(Cn, stride, dtype=torch.uint8, device=d)
-        ws[:, :ctl].zero_()
+        ws = torch.zeros(Cn, stride, dtype=torch.uint8, device=d)  # (all of it: granule tag 0 = never written)
         i32 = dict(dtype=torch.int32, device=d)
         b = dict(C=Cn, splat=torch.empty(Cn, N, 8, device=d), g2d=torch.empty(Cn, N, 8, device=d),
                  tile_counts=torch.zeros(Cn, T, **i32), offsets=torch.zeros(Cn, T, **i32),
@@ -441,6 +462,7 @@ class EdgeTrainer:
                  flatten_ids=torch.empty(Cn, T * self.seg_cap, **i32), total=torch.zeros(Cn, 4, **i32),
                  ticket=torch.zeros(Cn, **i32), gtstop=torch.zeros(Cn, self.height, self.width, 3, device=d),
                  workspace=ws, ws_stride=stride, rewalk_hint=-1)
+        b["item_rec"] = torch.zeros(Cn, self.max_items, 4, **i32)
         a = StepArgs()
         a.means, a.quats = ptr(self.means), ptr(self.quats)
         a.log_scales, a.logit_opacities = ptr(self.log_scales), ptr(self.logit_opacities)
@@ -452,6 +474,7 @@ class EdgeTrainer:
         a.tile_end, a.item_end, a.item_tile = ptr(b["tile_end"]), ptr(b["item_end"]), ptr(b["item_tile"])
         a.item_offsets, a.workspace, a.ticket = ptr(b["item_offsets"]), ptr(ws), ptr(b["ticket"])
         a.keys, a.flatten_ids, a.loss = ptr(b["keys"]), ptr(b["flatten_ids"]), ptr(self.loss_acc)
+        a.item_rec = ptr(b["item_rec"])
         b["args"] = a
         b["ptrs"] = [(C.c_void_p * Cn)() for _ in range(4)]
         b["hyper_ptr"] = C.pointer(self._hyper)
@@ -459,7 +482,7 @@ class EdgeTrainer:
         self._batches[Cn] = b
         return b
 
-    def _batched_raw(self, views, wmaps, fused_adam: bool, slot: int = 0) -> Tensor:
+    def _batched_raw(self, views, wmaps, fused_adam: bool, slot: int = 0, journalled: Optional[bool] = None) -> Tensor:
         self._drop_projection()
         Cn = len(views)
         if not self.seg_cap:
@@ -483,7 +506,8 @@ class EdgeTrainer:
         a.loss_scale = self.loss_scale
         a.max_tile_hint = getattr(self, "max_tile_seen", 0)
         a.ws_tag = self._next_tag(1) if self.chained_forward else 0
-        a.rewalk_hint = (_lib.REWALK_SPECULATE if (fused_adam and self.replay_on_overflow and b["rewalk_hint"] == 0
+        journalled = fused_adam if journalled is None else journalled
+        a.rewalk_hint = (_lib.REWALK_SPECULATE if (journalled and self.replay_on_overflow and b["rewalk_hint"] == 0
                                                    and self.rewalk_hint in (0, -1)) else b["rewalk_hint"])
         if fused_adam:
             self._advance_all()
@@ -510,13 +534,13 @@ class EdgeTrainer:
             self._journal.append(("b", views, wmaps, self.epoch, self.loss_scale))
         self._batched_raw(views, wmaps, True)
 
-    def grad_step_batched(self, views: List[int], wmaps: List[Tensor], slot: int = 0) -> Tensor:
+    def grad_step_batched(self, views: List[int], wmaps: List[Tensor], slot: int = 0, journalled: bool = False) -> Tensor:
         """Forward + loss + backward of C views, gradients SUMMED into ``self.grads`` (layout of grad_step), or
         into a second buffer of the same layout (slot = 1: the data-parallel driver reduces one half step while
         the other is computed)."""
         if self.capacity == 0:
             self.ensure_capacity()
-        return self._batched_raw(list(views), list(wmaps), False, slot)
+        return self._batched_raw(list(views), list(wmaps), False, slot, journalled)
 
     # ------------------------------------------------------------------ overflow: journal, snapshot, replay
     _SNAP_TENSORS = ("means", "log_scales", "quats", "logit_opacities", "adam_m", "adam_v", "absgrads", "loss_acc")
@@ -556,7 +580,10 @@ class EdgeTrainer:
         journal = list(self._journal)
         epoch_now, ls_now = self.epoch, self.loss_scale
         for _ in range(8):
-            if self._rewalk_missed():
+            missed, over = self._rewalk_missed(), self.overflowed()
+            if self._dp is not None and self._dp.world > 1:  # every rank repairs what ANY rank tripped over
+                (missed, over), _ = self._dp.reduce_words([int(missed), int(over)], [])
+            if missed:
                 self.rewalk_hint = -1  # stops exist: launch the re-walk from now on (the next read-back sizes it)
                 for b in self._batches.values():
                     b["rewalk_hint"] = -1
@@ -567,7 +594,7 @@ class EdgeTrainer:
                 for b in self._batches.values():
                     b["workspace"][:, o:o + 4].zero_()
                 self.rewalk_misses += 1
-            if self.overflowed():
+            if over:
                 self.overflow_events += 1
                 self._grow_isect(2.0)  # (drops the batched work buffers as well: re-allocated, flags clear)
             self.total.zero_()
@@ -584,22 +611,40 @@ class EdgeTrainer:
                     self._regulariser_raw(view, self.loss_acc[0], *wmap)
                 elif kind == "e":
                     self._mark_raw(view)
+                elif kind == "d":  # a data-parallel step: every rank replays it, the collective included
+                    self._dp._step_raw(view, wmap[0], wmap[1])
                 else:
                     self._batched_raw(view, wmap, True)
-            if not self.overflowed() and not self._rewalk_missed():
+            again = self.overflowed() or self._rewalk_missed()
+            if self._dp is not None and self._dp.world > 1:
+                again = bool(self._dp.reduce_words([int(again)], [])[0][0])
+            if not again:
                 self.epoch, self.loss_scale = epoch_now, ls_now
                 return
         raise IsectOverflow("tile-intersection buffers still overflow after 8 doublings")
+
+    def _journal_push(self, entry) -> None:
+        """(kind, a, b, epoch, loss_scale): snapshot the state in front of the first journalled step of a window."""
+        if self.replay_on_overflow:
+            if not self._journal:
+                self._snapshot()
+            self._journal.append(entry)
 
     def journal_bytes(self) -> int:
         """Bytes of the distinct weight maps the journal keeps alive (the per-step `bg_edge_ratio` draws are fresh
         tensors: at 1600 x 1200 a window of 8 epochs holds ~0.7 GB of them); `train()` reads back early when this
         grows past 512 MB."""
         seen, total = set(), 0
+        def tensors(x):
+            if isinstance(x, Tensor):
+                yield x
+            elif isinstance(x, (list, tuple)):
+                for y in x:
+                    yield from tensors(y)
+
         for entry in self._journal:
-            w = entry[2]
-            for t in (w if isinstance(w, (list, tuple)) else (w,)):
-                if isinstance(t, Tensor) and t.data_ptr() not in seen:
+            for t in tensors(entry[2]):
+                if t.data_ptr() not in seen:
                     seen.add(t.data_ptr())
                     total += t.numel() * t.element_size()
         return total
@@ -690,13 +735,17 @@ class EdgeTrainer:
             raise RuntimeError(lib.eg_last_error_string().decode())
         return {lib.eg_timing_stage_name(i).decode(): float(buf[i]) for i in range(k)}
 
-    def grad_step(self, view: int, wmap: Tensor) -> Tensor:
+    def grad_step(self, view: int, wmap: Tensor, journalled: bool = False) -> Tensor:
         """Forward + loss + backward only: leaves dL/d{means,quats,log_scales,logit_opacities} in
         ``self.grads`` ([means 3N | quats 4N | scales 3N | opac N | absgrad increment N] flat
-        blocks) for the data-parallel driver, which all-reduces them and then calls ``apply_adam``."""
+        blocks) for the data-parallel driver, which all-reduces them and then calls ``apply_adam``.
+        journalled: the caller keeps a journal of its steps (DataParallelStep does), so the forward may speculate that no
+        pixel reaches the transmittance stop, like train_step."""
         if self.capacity == 0:
             self.ensure_capacity()
         a = self._args(view, wmap, False)
+        if journalled:
+            a.rewalk_hint = self._rewalk_arg(True)
         # apply_adam(next_view=view) has already projected + binned this view with the parameters it produced
         a.have_projection = 1 if (self._projected == view and self.seg_cap) else 0
         if a.have_projection:
@@ -801,6 +850,10 @@ class EdgeTrainer:
         if work is None:
             work = self._reg_work = torch.zeros(2, device=self.dev)
         dev_sum = isinstance(avg_loss_sum, Tensor)
+        if dev_sum and self._dp is not None and self._dp.world > 1:
+            # data parallel: the epoch's running loss sum is the sum over the ranks' views (every replica forms the
+            # same lambda, train_gaussians.py:113,125); a copy is reduced, the local accumulator keeps its own share
+            avg_loss_sum = self._dp.all_reduce_(avg_loss_sum.detach().clone().reshape(1))
         call("eg_regulariser_step", 0 if kind == "direction" else 1, ptr(self.means), ptr(self.quats),
              ptr(self.log_scales), ptr(self.logit_opacities), ptr(self.adam_m), ptr(self.adam_v), ptr(self.grads), self.N,
              ptr(nn) if nn is not None else None, K + 1, 1, K, top_k, ptr(avg_loss_sum) if dev_sum else None,
@@ -828,6 +881,13 @@ class EdgeTrainer:
             tot = [max(a, x) for a, x in zip(tot, w[:4])]
             batch_seen.append(w[4])
             missed = max(missed, w[5])
+        if self._dp is not None and self._dp.world > 1:
+            # every rank must take the same decisions (replay or not, buffer sizes, launch modes): flags and shape hints
+            # by max, the loss sums by sum -- two small collectives per read-back
+            ints = [tot[0], tot[1], tot[3], seen, missed] + list(batch_seen)
+            ints, sums = self._dp.reduce_words(ints, sums)
+            tot = [ints[0], ints[1], tot[2], ints[2]]
+            seen, missed, batch_seen = ints[3], ints[4], list(ints[5:])
         return {"acc": sums[0], "marks": sums[1:], "m_last": tot[0], "overflow": tot[1] != 0, "tile_max": tot[3],
                 "seen": seen, "batch_seen": batch_seen, "missed": missed != 0}
 

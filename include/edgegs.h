@@ -422,7 +422,14 @@ typedef struct {
    * tags of all earlier calls on the same workspace since that workspace was zeroed (count up from 1;
    * eg_train_steps uses ws_tag .. ws_tag + K - 1).  0: the slice / combine / re-walk sequence. */
   int32_t ws_tag;
+  /* optional (segmented layout): the sort kernel then also leaves one 16-byte record per item -- item_rec [max_items, 4]
+   * = {tile, slice | slices << 16, first key of the slice, end of the tile's keys} -- and the step (no images wanted,
+   * ws_tag > 0) runs the wave-autonomous forward, whose hand-over granules carry ws_tag: 1 <= ws_tag <= EG_MAX_WS_TAG,
+   * different from the tag of every earlier call on this workspace since the workspace was last zeroed (the WHOLE
+   * workspace must be zero before its first use).  Batched step: [C, max_items, 4]. */
+  int32_t *item_rec;
 } eg_step_args;
+#define EG_MAX_WS_TAG 0x7ffffe
 
 /* (Segmented layout, tile grids of <= 2048 tiles: eg_train_step / eg_train_steps / eg_train_step_batched run the
  * projection kernels without their ticket + scan tail -- `ticket` is then unused -- let every tile's sort workgroup

@@ -91,6 +91,17 @@ def borderline_pixels(fw: Dict[str, np.ndarray], rel_alpha: float = 1e-4, rel_T:
     return mask
 
 
+def stopped_pixels(fw: Dict[str, np.ndarray]) -> np.ndarray:
+    """bool [H,W]: pixels whose front-to-back walk ended on the transmittance rule (next T <= 1e-4)."""
+    width, height = fw["_size"]
+    flat = np.ascontiguousarray(np.concatenate([fw["flatten_ids"], np.zeros(1, np.int32)]))
+    out = np.zeros((height, width), np.uint8)
+    load().ego_composite_stopped(_opt(fw["means2d"]), _opt(fw["conics"]), _opt(fw["opacities"]), width, height,
+                                 _opt(np.ascontiguousarray(fw["isect_offsets"].reshape(-1))), _opt(flat),
+                                 C.c_int64(fw["M"]), _opt(out))
+    return out > 0
+
+
 def project_borderline(means, quats, scales, viewmat, K, width, height, near_plane=0.01, eps2d=0.3,
                        rel: float = 2e-5) -> np.ndarray:
     """uint8 [N]: Gaussians whose integer decisions (radius ceil, culls, tile box) hinge on float rounding."""

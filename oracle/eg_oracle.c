@@ -218,6 +218,38 @@ void ego_composite_fwd(const float *means2d, const float *conics, const float *c
   }
 }
 
+/* which pixels' walks ended on the transmittance rule (the `break` of ego_composite_fwd above, same arithmetic):
+ * the fused HIP forward records the id of the last contributor only for those, so the parity tests need the set */
+void ego_composite_stopped(const float *means2d, const float *conics, const float *opac, int width, int height,
+                           const int32_t *offsets, const int32_t *flatten_ids, int64_t M, uint8_t *stopped) {
+  const int tw = (width + TILE - 1) / TILE, th = (height + TILE - 1) / TILE, T = tw * th;
+#pragma omp parallel for schedule(dynamic, 1)
+  for (int t = 0; t < T; ++t) {
+    const int64_t start = offsets[t], end = (t == T - 1) ? M : offsets[t + 1];
+    const int ty = t / tw, tx = t % tw;
+    for (int di = 0; di < TILE; ++di)
+      for (int dj = 0; dj < TILE; ++dj) {
+        const int i = ty * TILE + di, j = tx * TILE + dj;
+        if (i >= height || j >= width) continue;
+        const float px = (float)j + 0.5f, py = (float)i + 0.5f;
+        float Tt = 1.f;
+        uint8_t st = 0;
+        for (int64_t idx = start; idx < end; ++idx) {
+          const int g = flatten_ids[idx];
+          const float dx = means2d[2 * g] - px, dy = means2d[2 * g + 1] - py;
+          const float a = conics[3 * g], b = conics[3 * g + 1], c = conics[3 * g + 2];
+          const float sigma = 0.5f * (a * dx * dx + c * dy * dy) + b * dx * dy;
+          const float alpha = fminf(ALPHA_MAX, opac[g] * expf(-sigma));
+          if (sigma < 0.f || alpha < ALPHA_MIN) continue;
+          const float next_T = Tt * (1.f - alpha);
+          if (next_T <= T_STOP) { st = 1; break; }
+          Tt = next_T;
+        }
+        stopped[(size_t)i * width + j] = st;
+      }
+  }
+}
+
 /* ---------------------------------------------------------------- G8: compositing backward ------- */
 static inline void atomic_addf(float *p, float v) {
 #pragma omp atomic

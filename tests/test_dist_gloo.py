@@ -182,3 +182,111 @@ def test_data_parallel_driver_over_the_hip_path_two_ranks_one_gpu():
     ret = mgr.dict()
     mp.spawn(_gpu_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
     assert dict(ret) == {0: True, 1: True}
+
+
+# ------------------------------------------------------------------ train() under data parallelism (two ranks, one GPU)
+def _dp_train_cfg():
+    optim = {"means": {"start_lr": 2e-3, "milestones": [], "gamma": 1.0}, "scales": {"start_lr": 1e-4, "start_at_epoch": 0},
+             "quats": {"start_lr": 1e-3, "start_at_epoch": 0}, "opacities": {"start_lr": 0.2, "start_at_epoch": 0}}
+    training_cfg = {"num_epochs": 4, "optim": optim, "loss": {
+        "orientation_losses": {"start_dir_loss_at_epoch": 1, "start_ratio_loss_at_epoch": 1, "dir_loss_num_nn": 5,
+                               "dir_loss_scale_factor": 0.01, "ratio_loss_scale_factor": 0.01},
+        "projection_losses": {"lambda_annealing": "constant", "lambda_start": 1, "lambda_end": 1,
+                              "loss_before_alternating": "whole", "less_freq_loss": "bg_edge_ratio",
+                              "more_freq_loss": "whole", "start_alternating_at_epoch": 0,
+                              "bg_edge_pixel_ratio_annealing": "constant", "bg_edge_pixel_ratio_start": 1,
+                              "bg_edge_pixel_ratio_end": 1, "sampling_whole_num_epochs_ratio": 3}}}
+    model_cfg = {"if_duplicate_high_pos_grad": True, "dup_high_pos_grads_at_epoch": [1], "dup_threshold_type": "absolute",
+                 "dup_threshold_value": 0.3, "dup_factor": 2, "init_dup_rand_noise_scale": 0.01,
+                 "if_cull_low_opacity": False, "if_cull_gaussians_not_projecting": False}
+    return model_cfg, training_cfg
+
+
+def _dp_train_worker(rank, world, port, ret):
+    """`train()` under DataParallelStep, two ranks sharing cuda:0 (gloo): across a duplication event, regulariser steps
+    and a capacity crossing (buffers sized without slack while the opacities run up: some rank's step overflows, the
+    collective read-back makes BOTH ranks grow and replay).  Replicas bit-identical; history equal to the
+    single-process run that takes the same two views per optimizer step as one batched launch sequence."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK="0")
+    from edgegaussians_amd import EdgeTrainer, train
+    torch.cuda.set_device(0)
+    r, _, w = egdist.init_from_env("gloo")
+    assert (r, w) == (rank, world)
+    V = 6
+    sc = synth.make_scene(2500, V, 160, 112, seed=4, spread_opacity=False, scale=0.02)
+    model_cfg, training_cfg = _dp_train_cfg()
+
+    def mk():
+        t = EdgeTrainer(sc.means, sc.log_scales, sc.quats, sc.logit_opacities, sc.viewmats, sc.Ks, sc.gt,
+                        sc.width, sc.height, seed=7)
+        t.ensure_capacity(slack=1.0)
+        t._alloc_isect(t.m_max_seen + 64, (t.max_tile_seen // 128 + 1) * 128)  # no slack: the opacity ramp overflows it
+        t.gt.fill_(1.0)  # a target that wants everything opaque
+        return t
+
+    order = lambda e: [(e + k) % V for k in range(V)]  # noqa: E731
+    tr = mk()
+    dp = egdist.DataParallelStep(tr)
+    n_seen = []
+    hist = train(tr, model_cfg, training_cfg, order, views_per_step=2, dp=dp, on_epoch=lambda e, l, n: n_seen.append(n),
+                 sync_every=2)
+    ok = len(hist) == 4 and all(map(lambda x: x == x and abs(x) < 1e9, hist))
+    ok &= tr.overflow_events >= 1 and not tr.overflowed()         # the capacity crossing happened and was repaired
+    ok &= tr.N > 2500 and n_seen[-1] == tr.N                       # the duplication event happened
+    for t in (tr.means, tr.log_scales, tr.quats, tr.logit_opacities, tr.absgrads, tr.adam_m, tr.adam_v):
+        h = t.detach().cpu()
+        h0 = h.clone()
+        if h0.shape[0] != 0:
+            sz = torch.tensor([h0.shape[0]])
+            dist.broadcast(sz, src=0)
+            ok &= int(sz) == h.shape[0]
+            if int(sz) == h.shape[0]:
+                dist.broadcast(h0, src=0)
+                ok &= bool(torch.equal(h0, h))                     # replicas bit-identical
+    hh = torch.tensor(hist, dtype=torch.float64)
+    h0 = hh.clone()
+    dist.broadcast(h0, src=0)
+    ok &= bool(torch.equal(h0, hh))                                # every rank reports the same history
+    if rank == 0:
+        ref = mk()
+        hist_ref = train(ref, model_cfg, training_cfg, order, views_per_step=2)
+        ok &= ref.N == tr.N
+        ok &= all(abs(a - b) <= 2e-3 * abs(b) for a, b in zip(hist, hist_ref))
+        ret["hist"] = (list(hist), list(hist_ref), tr.overflow_events, ref.overflow_events, tr.rewalk_misses)
+    ret[rank] = bool(ok)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_data_parallel_training_survives_events_and_a_capacity_crossing():
+    assert torch.cuda.is_available()
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_dp_train_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert ret.get(0) is True and ret.get(1) is True, dict(ret)
+
+
+def test_reduce_words_over_gloo():
+    """The two small collectives of a data-parallel read-back: flags by max, loss sums by sum."""
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_reduce_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert dict(ret) == {0: True, 1: True}
+
+
+def _reduce_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    egdist.init_from_env("gloo")
+
+    class W:  # (no journal: a bare GradWorker)
+        pass
+    dp = egdist.DataParallelStep(W())
+    ints, floats = dp.reduce_words([rank, 1 - rank, 7], [0.5 + rank, 2.0])
+    ret[rank] = ints == [1, 1, 7] and floats == [2.0, 4.0] and dp.reduce_words([], []) == ([], [])
+    dist.destroy_process_group()

@@ -1,5 +1,6 @@
-"""Fused step against the plain-C oracle at the sizes BASELINE.json names (configs 1, 3, 4; config 2 and
-config 5's per-GPU workload are the same shape and are covered by test_gpu_parity.py's config-2 tests).
+"""Fused step against the plain-C oracle at the sizes BASELINE.json names: configs 1, 3, 4 on synthetic look-at
+poses, and the headline -- config 2 (config 5's per-GPU workload is the same shape) -- on the scan's 50 REAL poses, the
+scene bench.py times, in both opacity regimes.
 
 One view per size: gradients of `eg_train_step` (Adam off) against the C oracle's forward + backward on the
 same parameters, then one whole fused step (Adam on) against `ego_train_step`.  Floats 1e-4 on EVERY element:
@@ -7,6 +8,8 @@ the Gaussians whose integer decisions are float-borderline are taken out of the 
 pixels get zero loss weight on both sides (tests/util.py: check_fused_step_vs_c_oracle); both sets are
 counted and reported (gpurun_out/parity_report.jsonl -> profiles/).
 """
+import os
+
 import pytest
 
 from tests.util import check_fused_step_vs_c_oracle
@@ -28,6 +31,83 @@ def test_fused_step_vs_c_oracle_full_size(name):
     n, W, H, view, strategy = SIZES[name]
     sc = synth.make_scene(n, 2, W, H, seed=0, anisotropy=5.0, spread_opacity=True)
     check_fused_step_vs_c_oracle(sc, view, strategy, name)
+
+
+REAL_POSES = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cameras_00004926.npz")
+
+
+@pytest.mark.parametrize("spread,view,strategy,speculate", [(True, 7, "whole", False), (True, 31, "bg_edge_ratio", False),
+                                                             (False, 7, "whole", True), (False, 18, "weighted", False)])
+def test_fused_step_vs_c_oracle_config2_real_poses(spread, view, strategy, speculate):
+    """The headline workload itself (bench.py: 100 k Gaussians @512x512 on the real poses of scan 00004926): gradients
+    and one whole Adam step against the C oracle at 1e-4 on every element -- trained-like opacities U(0.05, 0.9) (the
+    chained forward resolves thousands of transmittance stops) and the initial opacity 0.08 (no pixel stops; with
+    `speculate` the whole step runs the forward in its speculative mode, as the trainer does in that phase)."""
+    from edgegaussians_amd import _lib, synth
+    _lib.load()
+    sc = synth.make_scene(100_000, 50, 512, 512, seed=0, anisotropy=5.0, spread_opacity=spread, cameras_npz=REAL_POSES)
+    tr, _sc, _w = check_fused_step_vs_c_oracle(sc, view, strategy, f"config2_real_poses_{'spread' if spread else 'init'}_v{view}",
+                                               speculate=speculate)
+    assert tr.max_tile_seen > 1000  # the real poses put the object in the central tiles (largest tile ~2.5 k)
+
+
+def test_batched_step_vs_c_oracle_config2_real_poses():
+    """SURVEY 8f rank 2 pinned to the oracle directly (round 2 compared the batched step with the single-view HIP
+    path only): C = 3 views of the headline scene in one launch sequence against the sum of the C oracle's per-view
+    gradients and one Adam step on it."""
+    from edgegaussians_amd import _lib, synth
+    from tests.util import check_batched_step_vs_c_oracle
+    _lib.load()
+    sc = synth.make_scene(100_000, 50, 512, 512, seed=0, anisotropy=5.0, spread_opacity=True, cameras_npz=REAL_POSES)
+    check_batched_step_vs_c_oracle(sc, [3, 22, 41], ["whole", "weighted", "bg_edge_ratio"], "config2_real_poses_C3")
+
+
+@pytest.mark.parametrize("n,W,H,real", [(100_000, 512, 512, True), (20_000, 330, 200, False)])
+def test_chained_forward_stop_records_vs_c_oracle(n, W, H, real):
+    """The chained forward (exact transmittance stop inside the kernel) pinned to the oracle directly: the per-pixel
+    record it leaves for the backward -- v T_final, and for every pixel whose walk stopped the id of its last
+    contributor -- against the C oracle's sequential walk: the SET of stopped pixels and their last contributors
+    exact outside the float-borderline pixels, T_final to 1e-5."""
+    import numpy as np
+    import torch
+    from edgegaussians_amd import EdgeTrainer, _lib, synth
+    from oracle import c_oracle as CO
+    from tests.util import record, strict_inputs
+    _lib.load()
+    # (the small case: Gaussians three times the usual size on a 330 x 200 image with partial border tiles -- 30 % of the
+    # pixels stop, the largest tile holds 3.9 k Gaussians = 31 slices)
+    sc0 = synth.make_scene(n, 50 if real else 2, W, H, seed=1, anisotropy=5.0, spread_opacity=True,
+                           cameras_npz=REAL_POSES if real else None, scale=0.004 if real else 0.012)
+    view = 12 if real else 1
+    sc, fw, border, _w, _removed = strict_inputs(sc0, view, "whole")
+    tr = EdgeTrainer(sc.means, sc.log_scales, sc.quats, sc.logit_opacities, sc.viewmats, sc.Ks, sc.gt, W, H)
+    tr.ensure_capacity(views=[view])
+    assert tr.chained_forward
+    # weights 1 everywhere and a target below every rendered value would make v = +1; simpler: a constant weight and
+    # gt = -1 (render - gt > 0 on every pixel), so that the record's first word is exactly T_final
+    tr.gt[view].fill_(-1.0)
+    w = torch.ones(H, W, device="cuda")
+    tr.grad_step(view, w)
+    torch.cuda.synchronize()
+    rec = tr.gtstop.cpu()
+    T_hip = rec[..., 0].numpy()
+    stop_id = rec[..., 1].contiguous().view(torch.int32).numpy()
+    stopped_o = CO.stopped_pixels(fw)
+    ok = ~border.numpy()
+    T_o = 1.0 - fw["alphas"].astype(np.float64)
+    covered = fw["alphas"] > 0
+    # T_final (the record holds 0 where nothing contributed: T == 1)
+    assert np.abs(np.where(covered, T_hip, 1.0) - T_o)[ok].max() <= 1e-5 * 1.0
+    # the set of stopped pixels, and who stopped them
+    assert np.array_equal((stop_id >= 0)[ok], stopped_o[ok])
+    last_gauss_o = fw["flatten_ids"][np.minimum(fw["last_ids"], max(fw["M"] - 1, 0))]
+    both = ok & stopped_o
+    assert both.sum() > (2000 if real else 200), "the scene must make the exact stop matter"
+    assert np.array_equal(stop_id[both], last_gauss_o[both])
+    record("chained_forward_stop_records_vs_c_oracle", gaussians=int(sc.means.shape[0]), width=W, height=H,
+           real_poses=bool(real), stopped_pixels=int(stopped_o.sum()), compared_stopped_pixels=int(both.sum()),
+           borderline_pixels=int(border.sum()), stop_set_mismatches=0, last_contributor_mismatches=0,
+           T_final_max_abs_err=float(np.abs(np.where(covered, T_hip, 1.0) - T_o)[ok].max()))
 
 
 @pytest.mark.parametrize("name", ["config1", "config3"])

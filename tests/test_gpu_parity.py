@@ -421,7 +421,9 @@ def test_grad_step_equals_autograd_path(env, segmented):
     tk.grad_step(1, w)
     assert_close(tk.render, render[0, ..., 0].detach(), rtol=1e-5, name="kept render")
     assert_close(tk.alphas, alpha[0, ..., 0].detach(), rtol=1e-5, name="kept alpha")
-    assert torch.equal(tk.grad_views()[0], gm), "same gradients with and without images"
+    # (with images the forward runs the workgroup-per-item kernels of the general API, without them the wave-autonomous
+    # kernel: the same arithmetic in a different association, alphas agree to rounding)
+    assert_close(tk.grad_views()[0], gm, rtol=1e-5, name="same gradients with and without images")
 
 
 def _grad_step_vs_torch_oracle(env, sc, view, label, strategy="whole"):
@@ -570,8 +572,9 @@ def test_empty_and_degenerate_scenes(env):
 
 
 def test_full_size_properties_config2(env):
-    """BASELINE config 2 (100 k Gaussians, 512x512) is too large for the dense oracle: check the
-    size-independent properties of the path instead."""
+    """BASELINE config 2 (100 k Gaussians, 512x512): the size-independent properties of the path, and the fused step
+    against the drop-in operator.  (The headline scene itself -- real poses, both opacity regimes -- is compared with
+    the C oracle in tests/test_gpu_fullsize.py::test_fused_step_vs_c_oracle_config2_real_poses.)"""
     _lib, synth, O = env
     from edgegaussians_amd import EdgeTrainer, rasterization
     W, H = 512, 512
@@ -1024,10 +1027,11 @@ def test_binning_layouts_agree_and_segment_overflow_is_flagged(env):
     la, lb = ta.pop_loss(), tb.pop_loss()
     assert abs(la - lb) <= 1e-6 * abs(la)
     for k, v in ta.state_dict().items():
-        # (the two layouts project with different kernels: same formulas, the compiler's FMA contraction may differ by
-        # an ulp, which Adam's epsilon amplifies for the elements whose gradient is ~1e-8: gradients are compared at
-        # 1e-6 below, the three-step states at the propagated 1e-4)
-        assert_close(tb.state_dict()[k], v, rtol=1e-4, name=k)
+        # (the two layouts project with different kernels and, since round 3, composite with different ones -- the
+        # classic layout keeps the workgroup-per-item forward, the segmented layout runs the wave-autonomous one: same
+        # formulas, roundings differ by an ulp, which Adam's epsilon amplifies for the elements whose gradient is ~1e-8:
+        # gradients are compared at 1e-5 above, the three-step states at the propagated 1e-4 with that handful admitted)
+        assert_close(tb.state_dict()[k], v, rtol=1e-4, max_bad=2e-3, name=k)
 
     assert int(tb.tile_counts.abs().sum()) == 0, "the segment cursors must be back at zero"
     # overflow: segments far too small for the busiest tiles -> excess dropped, STICKY flag raised, cursors clean
@@ -1477,3 +1481,54 @@ def test_knn_with_the_previous_searches_bound(env):
     junk = torch.rand(n, generator=g).cuda() * 1e-3
     e, _ = R.knn(pts, k, method="grid", kth=junk)
     assert torch.equal(e, ref)
+
+
+def test_operator_fast_path_equals_the_general_operator(env):
+    """The drop-in's fast path for the reference's own call (one camera, colours == 1 without grad: edge_gs.py:247-268)
+    -- one autograd node over the training step's kernels, cached buffers, one read-back at the end, lazy `info` --
+    against the general two-node operator on the same inputs: images, every gradient, `.absgrad`, and the gsplat-layout
+    `info` tensors it only computes when asked.  Non-unit colours must fall through to the general path."""
+    _lib, synth, O = env
+    from edgegaussians_amd import rasterizer as R
+    sc = _scene(synth, n=5000, w=200, h=136, views=2)
+    N, W, H = sc.means.shape[0], sc.width, sc.height
+    w = synth.weight_map("weighted", sc.gt[1]).cuda()
+
+    def run(fast, colors):
+        R._FAST_ENABLED = fast
+        try:
+            p = [t.clone().cuda().requires_grad_(True) for t in (sc.means, sc.quats, sc.log_scales, sc.logit_opacities)]
+            render, alpha, info = R.rasterization(p[0], p[1], torch.exp(p[2]), torch.sigmoid(p[3]).squeeze(-1), colors,
+                                                  sc.viewmats[1:2].cuda(), sc.Ks[1:2].cuda(), W, H, packed=False,
+                                                  absgrad=True, rasterize_mode="antialiased")
+            info["means2d"].retain_grad()  # edge_gs.py:271
+            loss = (w * (torch.clamp(render[0, ..., 0], 0, 1) - sc.gt[1].cuda()).abs()).sum()
+            loss.backward()
+            return render.detach(), alpha.detach(), info, [t.grad for t in p], float(loss)
+        finally:
+            R._FAST_ENABLED = True
+
+    ones = torch.ones(N, 3, device="cuda")
+    rf, af, inf_f, gf, lf = run(True, ones)
+    rg, ag, inf_g, gg, lg = run(False, ones)
+    assert isinstance(inf_f, R._LazyInfo) and not isinstance(inf_g, R._LazyInfo)
+    assert rf.shape == rg.shape == (1, H, W, 3) and af.shape == ag.shape == (1, H, W, 1)
+    assert_close(rf, rg, rtol=1e-6, name="render") and None
+    assert_close(af, ag, rtol=1e-6, name="alphas")
+    assert abs(lf - lg) <= 1e-6 * abs(lg)
+    for a, b, name in zip(gf, gg, ("means", "quats", "scales", "opacities")):
+        assert_close(a, b, rtol=1e-5, name=f"grad {name}")
+    assert_close(inf_f["means2d"].absgrad, inf_g["means2d"].absgrad, rtol=1e-5, name="absgrad")
+    assert inf_f["means2d"].requires_grad and not inf_f["means2d"].is_leaf and inf_f["means2d"].shape == (1, N, 2)
+    assert torch.equal(inf_f["radii"], inf_g["radii"]) and inf_f["radii"].dtype == torch.int32   # edge_gs.py:275
+    assert torch.equal(inf_f["last_ids"], inf_g["last_ids"])
+    for k in ("tiles_per_gauss", "isect_ids", "flatten_ids", "isect_offsets"):
+        assert k in inf_f and torch.equal(inf_f[k].reshape(-1), inf_g[k].reshape(-1)), k
+    assert_close(inf_f["depths"], inf_g["depths"], rtol=1e-6, name="depths")
+    assert_close(inf_f["conics"], inf_g["conics"], rtol=1e-6, name="conics")
+    assert_close(inf_f["opacities"], inf_g["opacities"].detach(), rtol=1e-6, name="opacities")
+    # colours that are not all ones: the verdict comes back with the call's one read-back and the general path takes over
+    cols = torch.rand(N, 3, device="cuda")
+    rc, _, inf_c, _, _ = run(True, cols)
+    rc2, _, _, _, _ = run(False, cols)
+    assert not isinstance(inf_c, R._LazyInfo) and torch.equal(rc, rc2)

@@ -38,6 +38,15 @@ class FakeTrainer:
         self._journal.extend(views)
         self.log.append(("steps", self.epoch, list(views), [w[0] for w in wmaps], self.loss_scale))
 
+    def train_step_batched(self, views, wmaps):
+        self.acc += sum(1.0 + 0.001 * (self.step + i) for i in range(len(views)))
+        self.step += len(views)
+        self._journal.append(tuple(views))
+        self.log.append(("batch", self.epoch, list(views), [w[0] for w in wmaps], self.loss_scale))
+
+    def skip_weight_map_draw(self):
+        self.log.append(("skip_draw", self.epoch))
+
     def regulariser_step(self, kind, avg_loss_sum, scale_factor, *a, **k):
         assert avg_loss_sum is None  # lambda comes from the device accumulator
         self.log.append(("reg", kind, self.step, scale_factor))
@@ -225,3 +234,58 @@ def test_on_epoch_defaults_to_the_reference_cadence(cfg):
     tr = FakeTrainer()
     train_loop.train(tr, dict(cfg["model"]), cfg["training"], lambda e: [0, 1], num_epochs=9)
     assert [x[1] for x in tr.log if x[0] == "sync"] == [7, 8]
+
+
+class FakeDP:
+    """A rank of a 2-way DataParallelStep over a FakeTrainer: records what the rank was asked to rasterise."""
+
+    def __init__(self, tr, rank, world=2):
+        self.worker, self.rank, self.world = tr, rank, world
+
+    def step(self, view, wmap, next_view=None):
+        views = [view] if isinstance(view, int) else list(view)
+        wm = [wmap] if isinstance(view, int) else list(wmap)
+        self.worker.log.append(("dp", self.worker.epoch, views, [w[0] for w in wm]))
+        self.worker._journal.append(tuple(views))
+
+
+def test_views_per_step_batches_and_shards_like_the_single_process_run(cfg):
+    """C = 2 views per optimizer step: the single-process run issues batched steps over consecutive pairs of the epoch's
+    order (a short last batch is filled from the front); under a 2-way data-parallel driver rank r rasterises view r of
+    every pair with the SAME strategy the single process gives that view, skips the `bg_edge_ratio` draws of the
+    other rank's views (the draw sequence stays in step), and the regulariser fires whenever a multiple of five VIEWS
+    has been passed."""
+    model_cfg, training_cfg = dict(cfg["model"]), json.loads(json.dumps(cfg["training"]))
+    model_cfg.update(if_duplicate_high_pos_grad=False, if_cull_low_opacity=False, if_cull_gaussians_not_projecting=False)
+    ol, pl = training_cfg["loss"]["orientation_losses"], training_cfg["loss"]["projection_losses"]
+    ol["start_dir_loss_at_epoch"], ol["start_ratio_loss_at_epoch"] = 1, 99
+    pl["start_alternating_at_epoch"] = -1
+    order = lambda e: [(3 * e + i) % 7 for i in range(7)]  # noqa: E731  (7 views: the last pair is filled up)
+    single = FakeTrainer()
+    train_loop.train(single, model_cfg, training_cfg, order, num_epochs=3, views_per_step=2)
+    batches = [x for x in single.log if x[0] == "batch"]
+    assert [len(b[2]) for b in batches] == [2] * 12 and sum(len(b[2]) for b in batches) == 24
+    assert batches[3][2] == [order(0)[6], order(0)[0]]  # the short batch wraps to the front of the epoch's order
+    period = pl["sampling_whole_num_epochs_ratio"]
+    flat = [s for b in batches for s in b[3]]
+    assert flat == [pl["less_freq_loss"] if k % period == 0 else pl["more_freq_loss"] for k in range(24)]
+    regs = [x for x in single.log if x[0] == "reg"]
+    # direction regulariser from epoch 2 on (epoch > 1): views 16..24 pass the multiples 20 (after the batch 18-19 -> 20)
+    assert [r[2] for r in regs] == [20] and all(r[1] == "direction" for r in regs)
+    ranks = []
+    for r in range(2):
+        tr = FakeTrainer()
+        train_loop.train(tr, model_cfg, training_cfg, order, num_epochs=3, views_per_step=2, dp=FakeDP(tr, r))
+        ranks.append(tr)
+        mine = [x for x in tr.log if x[0] == "dp"]
+        assert [m[2] for m in mine] == [[b[2][r]] for b in batches]
+        assert [m[3] for m in mine] == [[b[3][r]] for b in batches]
+        # the other rank's bg_edge_ratio views: draws skipped, one per such view
+        others = sum(1 for b in batches if b[3][1 - r] == "bg_edge_ratio")
+        assert sum(1 for x in tr.log if x[0] == "skip_draw") == others
+        # the regulariser fires on every rank after the same optimizer step as in the single-process run
+        pos = lambda log, key: [sum(1 for y in log[:i] if y[0] == key) for i, x in enumerate(log) if x[0] == "reg"]  # noqa: E731
+        assert pos(tr.log, "dp") == pos(single.log, "batch") == [10]
+    with pytest.raises(ValueError):
+        train_loop.train(FakeTrainer(), model_cfg, training_cfg, order, num_epochs=1, views_per_step=3,
+                         dp=FakeDP(FakeTrainer(), 0))

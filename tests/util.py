@@ -145,9 +145,11 @@ def oracle_raw_grads(sc, fw, w, view):
                   "means2d": want["means2d"], "absgrad2": want["absgrad"]}
 
 
-def check_fused_step_vs_c_oracle(sc, view, strategy, label, trainer_kwargs=None, whole_step=True):
+def check_fused_step_vs_c_oracle(sc, view, strategy, label, trainer_kwargs=None, whole_step=True, speculate=False):
     """eg_train_step (Adam off, then Adam on) against the C oracle on one view: every float at 1e-4, integer
     bookkeeping exact; borderline Gaussians removed, borderline pixels zero-weighted, both counted + reported.
+    speculate: the whole step runs the forward in its SPECULATIVE mode (no exact-stop handling: what the trainer
+    does while no pixel reaches the transmittance stop) and must not have needed a replay.
     Returns the trainer for further checks."""
     from edgegaussians_amd import EdgeTrainer, LRSchedule
     from oracle import c_oracle as CO
@@ -181,8 +183,14 @@ def check_fused_step_vs_c_oracle(sc, view, strategy, label, trainer_kwargs=None,
     # ---- one whole fused step (forward + loss + backward + absgrad + Adam) against ego_train_step
     ct = CO.CpuTrainer(sc.means.numpy(), sc.log_scales.numpy(), sc.quats.numpy(), sc.logit_opacities.numpy(), sched.at(0))
     lc, M = ct.train_step(sc.viewmats[view].numpy(), sc.Ks[view].numpy(), W, H, sc.gt[view].numpy(), w.numpy())
+    if speculate:
+        tr.rewalk_hint = 0  # "no pixel stopped lately": the journalled step speculates on it
+        tr._args_cache = {}
+        from edgegaussians_amd import _lib
+        assert tr._rewalk_arg(True) == _lib.REWALK_SPECULATE
     tr.train_step(view, w.cuda().contiguous())
     lg = tr.pop_loss()
+    assert not speculate or tr.rewalk_misses == 0, "the speculative forward saw a stop: pick a scene without stops"
     assert abs(lg - lc) <= 1e-4 * abs(lc) and M == fw["M"] and not tr.overflowed()
     assert_close(tr.absgrads, ct.absgrads, rtol=1e-4, name=f"{label} absgrads")
     # first Adam step: delta = -lr g / (|g| + eps).  Adam's epsilon makes the step ill-conditioned where
@@ -214,3 +222,60 @@ def check_fused_step_vs_c_oracle(sc, view, strategy, label, trainer_kwargs=None,
            absgrads_max_rel_err=rel_err(tr.absgrads, ct.absgrads), adam_delta_err_over_tolerance_vs_c_oracle=derr,
            adam_delta_err_over_tolerance_vs_float64_adam=aerr, largest_propagated_tolerance_in_lr=worst_bound)
     return tr, sc, w
+
+
+def check_batched_step_vs_c_oracle(sc, views, strategies, label):
+    """eg_train_step_batched (C views per launch sequence, ONE optimizer step) against the C oracle: the batched
+    gradient buffer = sum over the views of the oracle's per-view gradients (1e-4 on every element), the loss = sum of
+    the oracle's losses, and the whole batched step = Adam's first step (float64) on that sum with the propagated
+    tolerance of check_fused_step_vs_c_oracle.  Borderline Gaussians of ANY of the views leave the scene, each view's
+    borderline pixels get zero weight in that view."""
+    from edgegaussians_amd import EdgeTrainer, LRSchedule, synth
+    n0 = sc.means.shape[0]
+    sc, removed = clean_scene(sc, list(views))
+    N, W, H = sc.means.shape[0], sc.width, sc.height
+    assert removed <= max(3, 0.03 * n0)
+    wm, loss_o, ref, n_border = [], 0.0, None, 0
+    for k, (v, strat) in enumerate(zip(views, strategies)):
+        fw = oracle_forward(sc, v)
+        border = borderline_pixel_mask(fw, sc.gt[v])
+        n_border += int(border.sum())
+        w = masked_weights(synth.weight_map(strat, sc.gt[v], 1.0, torch.Generator().manual_seed(3 + k)), border)
+        lo, r = oracle_raw_grads(sc, fw, w, v)
+        loss_o += lo
+        ref = r if ref is None else {key: ref[key] + r[key] for key in ref}
+        wm.append(w.cuda().contiguous())
+    sched = LRSchedule(scales_start=0, quats_start=0, opacities_start=0)
+    tr = EdgeTrainer(sc.means, sc.log_scales, sc.quats, sc.logit_opacities, sc.viewmats, sc.Ks, sc.gt, W, H, schedule=sched)
+    tr.ensure_capacity(views=list(views))
+    tr.grad_step_batched(list(views), wm)
+    gm, gq, gs, go = [t.clone().cpu() for t in tr.grad_views()]
+    got = {"means": gm, "quats": gq, "scales": gs, "opac": go, "absgrad": tr.grads.view(-1)[11 * N:].clone().cpu()}
+    loss_g = tr.pop_loss()
+    assert not tr.overflowed() and abs(loss_g - loss_o) <= 1e-4 * abs(loss_o), (loss_g, loss_o)
+    keys = ("means", "quats", "scales", "opac", "absgrad")
+    errs = {k: rel_err(got[k], ref[k]) for k in keys}
+    for k in keys:
+        assert_close(got[k], ref[k], rtol=1e-4, name=f"{label} batched grad {k}")
+    # the whole batched step: one Adam step on the summed gradient
+    tr.train_step_batched(list(views), wm)
+    lg = tr.pop_loss()
+    assert abs(lg - loss_o) <= 1e-4 * abs(loss_o) and not tr.overflowed() and tr.overflow_events == 0
+    assert_close(tr.absgrads, ref["absgrad"], rtol=1e-4, name=f"{label} batched absgrads")
+    lrs = sched.at(0)
+    aerr = {}
+    for key, mine, init, lr in (("means", tr.means, sc.means, lrs["means"]), ("scales", tr.log_scales, sc.log_scales, lrs["scales"]),
+                                ("quats", tr.quats, sc.quats, lrs["quats"]),
+                                ("opac", tr.logit_opacities, sc.logit_opacities.view(-1), lrs["opacities"])):
+        g = torch.from_numpy(np.abs(np.asarray(ref[key], dtype=np.float64)).reshape(-1))
+        ulp = float(init.abs().max()) * 6e-8
+        bound = lr * (1e-4 + 1e-8 * (1e-4 * float(g.max())) / (g + 1e-8) ** 2) + ulp
+        have = mine.cpu().reshape(-1).double() - init.reshape(-1).double()
+        gg = torch.from_numpy(np.asarray(ref[key], dtype=np.float64).reshape(-1))
+        want_delta = -(lr / (1.0 - 0.9)) * (0.1 * gg) / (torch.sqrt(0.001 * gg * gg) / np.sqrt(1.0 - 0.999) + 1e-8)
+        aerr[key] = float(((have - want_delta).abs() / (2 * bound)).max())
+        assert aerr[key] <= 1.0, f"{label} batched delta {key} vs float64 Adam on the oracle's sum: {aerr[key]} x tolerance"
+    record("batched_step_vs_c_oracle", size=label, views=len(views), gaussians=N, removed_borderline_gaussians=removed,
+           borderline_pixels=n_border, loss_rel_err=abs(loss_g - loss_o) / abs(loss_o), grad_max_rel_err=errs,
+           adam_delta_err_over_tolerance=aerr)
+    return tr

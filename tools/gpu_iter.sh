@@ -9,7 +9,7 @@ if [ "${TESTS:-1}" = "1" ]; then
   timeout 1400 python -m pytest tests -m gpu -q --tb=short ${XFLAG:--x} $DESEL 2>&1 | grep -v "$F" | tail -${TAIL:-40} > $O/pytest_$TAG.log
 fi
 for c in ${CONFIGS:-config1 config2}; do
-  timeout 300 python bench.py --config $c --no-cpu-baseline --no-traffic --no-extra 2>$O/bench_${c}_$TAG.err | tail -1 > $O/bench_${c}_$TAG.json
+  timeout 300 python bench.py --config $c --init-opacity --no-cpu-baseline --no-traffic --no-extra 2>$O/bench_${c}_$TAG.err | tail -1 > $O/bench_${c}_$TAG.json
 done
 [ "${SPREAD:-1}" = "1" ] && timeout 300 python bench.py --config config2 --spread-opacity --no-cpu-baseline --no-traffic --no-extra 2>/dev/null | tail -1 > $O/bench_config2s_$TAG.json
 for c in ${BATCHED:-config1 config2}; do for v in 2 4 8; do timeout 300 python bench.py --config $c --views-per-step $v --steps 300 --warmup 30 --no-cpu-baseline --no-traffic --no-extra 2>$O/bench_${c}_b${v}_$TAG.err | tail -1 > $O/bench_${c}_b${v}_$TAG.json; done; done
