@@ -57,7 +57,12 @@ def test_argument_validation_without_launching(lib):
     assert h.eg_tile_offsets(None, 0, 0, None, None, None, None) == -1
     assert b"eg_tile_offsets" in h.eg_last_error_string()
     ctl = h.eg_composite_workspace_ctl_bytes(10, 4)
-    assert ctl == (4 + 2 * 10 + 4 + 64 * 16) * 4  # per-tile tickets, item flags + tags, 4 control words, 64 exit-ticket lines
+    # per-tile tickets, item flags + tags, 4 control words, 64 exit-ticket lines; then the words of the wave-autonomous
+    # forward (per-quadrant tickets and tags, 64 partial loss sums, the dead-slice hints), rounded up to 16 bytes: the
+    # hand-over granules behind them are single 8-byte words
+    words = (4 + 2 * 10 + 4 + 64 * 16) + (4 * 4 + 4 * 10 + 64 + 8 * 4)
+    assert ctl == (words + 3) // 4 * 16 and ctl % 16 == 0
+    assert h.eg_composite_workspace_ctl_bytes(10, 117) % 16 == 0  # (an odd tile count once mis-aligned the granules)
     assert h.eg_composite_workspace_bytes(10, 4) == ctl + 10 * 256 * 8 + 4 * 256 * 12 + 10 * 8 + 10 * 128
     assert h.eg_timing_stage_count() == 7 and h.eg_timing_stage_name(5) == b"footprint_bwd"
 
