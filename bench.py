@@ -91,7 +91,7 @@ def build_trainer(name, seed, device, spread_opacity=False):
 
 
 # kernel name (as rocprofv3 reports it) -> stage of eg_train_step
-STAGE_OF = {"composite_wave_fwd_kernel": "composite_slice_fwd", "project_emit_kernel": "project_bwd_adam+next_project_bin", "project_bwd_emit_kernel": "project_bwd_adam+next_project_bin",
+STAGE_OF = {"composite_wave_fwd_kernel": "composite_slice_fwd", "composite_wave2_fwd_kernel": "composite_slice_fwd", "project_emit_kernel": "project_bwd_adam+next_project_bin", "project_bwd_emit_kernel": "project_bwd_adam+next_project_bin",
             "tile_emit_kernel": "tile_emit",
             "tile_sort_kernel": "tile_sort", "composite_slice_fwd_kernel": "composite_slice_fwd",
             "composite_chained_fwd_kernel": "composite_slice_fwd",  # (the pre-warm window runs before the first read-back)

@@ -1175,10 +1175,23 @@ __device__ __forceinline__ void footprint_walk(const float4 s0, const float4 s1,
     if (qj < 0) { qj += pw; --qi; }
     if (qj >= pw) { qj -= pw; ++qi; }
   };
-  const StopRec none = {0.f, -1, 0u};  // gT == 0: the visit is skipped
+  // (`none` built from literals, the load under a plain `if`: with a constant aggregate the compiler selected between
+  // two ADDRESSES -- the record and the constant's -- and issued a flat load, with a pc-relative address computation, in
+  // every visit)
+  auto make_none = []() -> StopRec {
+    StopRec r;
+    r.gT = 0.f; r.stop_id = -1; r.stop_depth = 0u;  // gT == 0: the visit is skipped
+    return r;
+  };
+  const StopRec none = make_none();
   auto fetch = [&](int i, int c, int &j) -> StopRec {
     j = (int)ceilf(xoff + shear * (s0.y - ((float)i + 0.5f))) + c;
-    return (j >= jlo && j <= jhi) ? gtstop[__mul24(i, width) + j] : none;
+    StopRec r = make_none();
+    if (j >= jlo && j <= jhi) {
+      const StopRec t = gtstop[__mul24(i, width) + j];
+      r.gT = t.gT; r.stop_id = t.stop_id; r.stop_depth = t.stop_depth;
+    }
+    return r;
   };
   int di, dc;
   divmod(2 * n, di, dc);

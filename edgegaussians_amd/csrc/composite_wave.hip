@@ -46,13 +46,25 @@
 namespace eg {
 
 // one wave's compacted list: PAIRS of Gaussians side by side (three broadcast ds_read_b128 fetch two entries)
-struct WaveList {
-  float4 X[kWaveSlice / 2 + 2];        // x0 x1 y0 y1
-  float4 C[kWaveSlice / 2 + 2];        // A0 A1 B0 B1     A = -log2(e) a / 2, B = -log2(e) b   (conic [[a, b], [b, c]])
-  float4 D[kWaveSlice / 2 + 2];        // C0 C1 lo0 lo1   C = -log2(e) c / 2, lo = log2(opacity)
-  unsigned char idx[kWaveSlice + 16];  // slice-local index of every entry
+template <int CAP>
+struct WaveListT {
+  float4 X[CAP / 2 + 2];        // x0 x1 y0 y1
+  float4 C[CAP / 2 + 2];        // A0 A1 B0 B1     A = -log2(e) a / 2, B = -log2(e) b   (conic [[a, b], [b, c]])
+  float4 D[CAP / 2 + 2];        // C0 C1 lo0 lo1   C = -log2(e) c / 2, lo = log2(opacity)
+  unsigned char idx[CAP + 16];  // slice-local index of every entry
 };
-static_assert(sizeof(WaveList) % 16 == 0, "float4 alignment of the per-wave lists");
+
+// The workgroup's copy of its slice: every thread gathers ONE half record (the four quadrant waves used to gather the
+// whole slice each: 4x the traffic, 61 MB per launch against 14 MB algorithmic), one barrier, then every wave tests
+// all of them against its quadrant out of LDS.  It stays in place: a pixel that stops behind entry k of a list records
+// that Gaussian's id and depth bits for the backward from here (round 2's epilogue: two dependent global loads).
+template <int CAP>
+struct WgStage {
+  float4 A[CAP];  // x y a b
+  float4 B[CAP];  // c o depth radius
+  int gid[CAP];
+};
+static_assert(sizeof(WaveListT<128>) % 16 == 0 && sizeof(WaveListT<256>) % 16 == 0, "float4 alignment of the lists");
 
 constexpr float kNegLog2e = -1.44269504088896341f;
 constexpr int kNoContributor = 511;  // 9-bit "this slice did not contribute to the pixel"
@@ -82,6 +94,7 @@ __device__ __forceinline__ bool quad_hit(const float4 s0, const float4 s1, float
   return valid & aabb & (centre_in | (best <= thr * 1.001f + 1e-3f));
 }
 
+template <class WaveList>
 __device__ __forceinline__ void put_entry(WaveList &wl, int pos, const float4 s0, const float4 s1, int slice_idx) {
   const int pr = pos >> 1, sl = pos & 1;
   float *X = (float *)&wl.X[pr], *Cc = (float *)&wl.C[pr], *D = (float *)&wl.D[pr];
@@ -100,7 +113,7 @@ __device__ __forceinline__ void wave_lds_fence() {
 
 // Gaussians [start, end) of the sorted ids (at most kWaveSlice) -> this wave's list of those that reach its quadrant,
 // in slice order, padded with three rejecting sentinels (the walk reads four entries at a time).  Returns the length.
-template <int R>
+template <int R, class WaveList>
 __device__ __forceinline__ int stage_rounds(WaveList &wl, const float4 *__restrict__ splat, const int *__restrict__ flat,
                                             int start, int end, float qx, float qy, int lane) {
   const int n = end - start;  // >= 1, <= 64 R
@@ -138,12 +151,48 @@ __device__ __forceinline__ int stage_rounds(WaveList &wl, const float4 *__restri
   return n_mine;
 }
 
+// the same from the workgroup's LDS copy of the slice (n Gaussians)
+template <int R, class WaveList, class Stage>
+__device__ __forceinline__ int stage_from_lds(WaveList &wl, const Stage &st, int n, float qx, float qy, int lane) {
+  float4 r0[R], r1[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int k = min(lane + 64 * r, n - 1);
+    r0[r] = st.A[k];
+    r1[r] = st.B[k];
+  }
+  bool hit[R];
+  unsigned long long bal[R];
+  int base[R + 1];
+  base[0] = 0;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    hit[r] = (lane + 64 * r < n) & quad_hit(r0[r], r1[r], qx, qy);
+    bal[r] = __ballot(hit[r]);
+    base[r + 1] = base[r] + __popcll(bal[r]);
+  }
+  const int n_mine = base[R];
+  const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+    if (hit[r]) put_entry(wl, base[r] + __popcll(bal[r] & lt), r0[r], r1[r], lane + 64 * r);
+  if (lane < 3) {  // sentinels: log2(opacity) = -1e30 => alpha = 0
+    const int e = n_mine + lane, pr = e >> 1, sl = e & 1;
+    ((float *)&wl.X[pr])[sl] = 0.f; ((float *)&wl.X[pr])[2 + sl] = 0.f;
+    ((float *)&wl.C[pr])[sl] = 0.f; ((float *)&wl.C[pr])[2 + sl] = 0.f;
+    ((float *)&wl.D[pr])[sl] = 0.f; ((float *)&wl.D[pr])[2 + sl] = -1e30f;
+  }
+  wave_lds_fence();
+  return n_mine;
+}
+
+template <int SPAN, class WaveList>
 __device__ __forceinline__ int stage_wave(WaveList &wl, const float4 *__restrict__ splat, const int *__restrict__ flat,
                                           int start, int end, float qx, float qy, int lane) {
   const int n = end - start;  // (wave-uniform)
   if (n <= 64) return stage_rounds<1>(wl, splat, flat, start, end, qx, qy, lane);
-  if (n <= 128) return stage_rounds<2>(wl, splat, flat, start, end, qx, qy, lane);
-  return stage_rounds<kWaveSlice / 64>(wl, splat, flat, start, end, qx, qy, lane);
+  if (SPAN == 1 || n <= 128) return stage_rounds<2>(wl, splat, flat, start, end, qx, qy, lane);
+  return stage_rounds<2 * SPAN>(wl, splat, flat, start, end, qx, qy, lane);
 }
 
 // alpha of one list entry at pixel (px, py), and whether it counts.  s = log2(o) - log2(e) sigma is evaluated in one
@@ -166,7 +215,7 @@ __device__ __forceinline__ EntryEval eval_entry(float x, float y, float A, float
 }
 
 // phase A: product of (1 - alpha) over the list in depth order, and (TRACK) the list position of the last contributor
-template <bool TRACK>
+template <bool TRACK, class WaveList>
 __device__ __forceinline__ void walk_list(const WaveList &wl, int n_mine, float px, float py, float &P, int &Lpos) {
   for (int t = 0; t < n_mine; t += 4) {
     const int p = t >> 1;
@@ -188,9 +237,78 @@ __device__ __forceinline__ void walk_list(const WaveList &wl, int n_mine, float 
   }
 }
 
+// Phase A with CHECKPOINTS (chained mode): the product and the last contributor after every quarter of the list
+// capacity.  A pixel whose stop falls in this slice then starts its exact walk behind the last quarter its
+// transmittance survives -- at ITS OWN list position (per-lane LDS addresses): the wave walks a quarter of the list,
+// where a walk in lockstep from the front spans it all (the 64 pixels of a quadrant cross at different positions).
+template <class WaveList>
+__device__ __forceinline__ void walk_list_ck(const WaveList &wl, int n_mine, float px, float py, float &P, int &Lpos,
+                                             float (&ck)[4], unsigned &ckL) {
+  constexpr int kSeg = (int)(sizeof(wl.idx) - 16) / 4;
+  ckL = 0xffffffffu;
+#pragma unroll
+  for (int seg = 0; seg < 4; ++seg) {
+    const int t1 = min(n_mine, kSeg * (seg + 1));
+    for (int t = kSeg * seg; t < t1; t += 4) {
+      const int p = t >> 1;
+      const float4 X0 = wl.X[p], X1 = wl.X[p + 1], C0 = wl.C[p], C1 = wl.C[p + 1], D0 = wl.D[p], D1 = wl.D[p + 1];
+      const EntryEval e0 = eval_entry(X0.x, X0.z, C0.x, C0.z, D0.x, D0.z, px, py);
+      const EntryEval e1 = eval_entry(X0.y, X0.w, C0.y, C0.w, D0.y, D0.w, px, py);
+      const EntryEval e2 = eval_entry(X1.x, X1.z, C1.x, C1.z, D1.x, D1.z, px, py);
+      const EntryEval e3 = eval_entry(X1.y, X1.w, C1.y, C1.w, D1.y, D1.w, px, py);
+      P *= e0.k ? 1.f - e0.a : 1.f;
+      P *= e1.k ? 1.f - e1.a : 1.f;
+      P *= e2.k ? 1.f - e2.a : 1.f;
+      P *= e3.k ? 1.f - e3.a : 1.f;
+      Lpos = e0.k ? t : Lpos;
+      Lpos = e1.k ? t + 1 : Lpos;
+      Lpos = e2.k ? t + 2 : Lpos;
+      Lpos = e3.k ? t + 3 : Lpos;
+    }
+    ck[seg] = P;
+    ckL = (ckL & ~(0xffu << (8 * seg))) | (((unsigned)Lpos & 0xffu) << (8 * seg));  // (-1 -> 0xff: none yet)
+  }
+}
+
+// the exact stop, every lane from its own (even) list position pos: returns the position of the last contributor it
+// composited (-1: none); a lane that runs off the list without stopping carries on in the following slice
+template <class WaveList>
+__device__ __forceinline__ int exact_walk_lane(const WaveList &wl, int n_mine, int pos, float px, float py, bool &live,
+                                               float &T, bool &found) {
+  constexpr int kPairs = (int)(sizeof(wl.X) / sizeof(float4));
+  int lastpos = -1;
+  live = live & (pos < n_mine);
+  while (__ballot(live) != 0ull) {
+    const int p = min(pos >> 1, kPairs - 1);
+    const float4 X0 = wl.X[p], C0 = wl.C[p], D0 = wl.D[p];
+    const EntryEval e0 = eval_entry(X0.x, X0.z, C0.x, C0.z, D0.x, D0.z, px, py);
+    const EntryEval e1 = eval_entry(X0.y, X0.w, C0.y, C0.w, D0.y, D0.w, px, py);
+    {
+      const float nT = T * (1.f - e0.a);
+      const bool hit = live & e0.k, stop = hit & (nT <= kTStop), upd = hit & !stop;
+      T = upd ? nT : T;
+      lastpos = upd ? pos : lastpos;
+      found = found | stop;
+      live = live & !stop;
+    }
+    {
+      const float nT = T * (1.f - e1.a);
+      const bool hit = live & e1.k, stop = hit & (nT <= kTStop), upd = hit & !stop;
+      T = upd ? nT : T;
+      lastpos = upd ? pos + 1 : lastpos;
+      found = found | stop;
+      live = live & !stop;
+    }
+    pos += 2;
+    live = live & (pos < n_mine);
+  }
+  return lastpos;
+}
+
 // Sequential walk with the stop rule (gsplat: stop BEFORE compositing the Gaussian that would take T to <= 1e-4):
 // lanes with `live` look for their stop from transmittance T.  Returns the list position of the last contributor
 // composited here (-1: none); the wave leaves as soon as none of its lanes is looking.
+template <class WaveList>
 __device__ __forceinline__ int exact_walk_wave(const WaveList &wl, int n_mine, float px, float py, bool &live, float &T,
                                                bool &found) {
   int lastpos = -1;
@@ -239,18 +357,19 @@ __device__ __forceinline__ unsigned long long load_granule(const unsigned long l
 // depth order, sixteen granules in flight per lane; a granule that does not carry this call's tag yet is asked for
 // again (the slices in front have lower block indices: they were dispatched earlier and wait on nobody behind them).
 // `before` becomes true for a pixel once the product crosses the transmittance threshold (its walk stopped in front).
+constexpr int kLook = 8;
 template <bool CHAINED>
 __device__ __forceinline__ void look_back(const unsigned long long *gran, int i0, int span, int j_begin, int j_end,
                                           unsigned tag, bool inside, float &T, bool &before) {
-  for (int j16 = j_begin; j16 < j_end; j16 += 16) {
+  for (int j16 = j_begin; j16 < j_end; j16 += kLook) {
     if (CHAINED && __ballot(!before && inside) == 0ull) break;  // every pixel of the quadrant stopped further in front
-    const int nb = min(16, j_end - j16);
-    unsigned long long G[16];
+    const int nb = min(kLook, j_end - j16);
+    unsigned long long G[kLook];
 #pragma unroll
-    for (int u = 0; u < 16; ++u)
+    for (int u = 0; u < kLook; ++u)
       G[u] = load_granule(&gran[(size_t)(i0 + (j16 + (u < nb ? u : 0)) * span) * kTilePix + threadIdx.x]);
 #pragma unroll
-    for (int u = 0; u < 16; ++u) {
+    for (int u = 0; u < kLook; ++u) {
       if (u < nb) {
         while ((unsigned)(G[u] >> 41) != tag) {  // (rare once the first poll has come back)
           __builtin_amdgcn_s_sleep(1);
@@ -267,13 +386,16 @@ __device__ __forceinline__ void look_back(const unsigned long long *gran, int i0
 // TIMED (EG_FWD_PROF=1, debugging only): shader-clock ticks per phase of every wave of the LAST launch, one 8-word
 // record per wave in prof[(item * 4 + quadrant) * 8 ...] (plain stores: atomics on shared words would serialise and
 // be measured themselves); word 7 = 1 marks a wave that ran (read by eg_debug_fwd_profile)
-template <bool CHAINED, bool TIMED>
-__global__ void __launch_bounds__(256)
-composite_wave_fwd_kernel(const float4 *__restrict__ splat, const TileTable tt_, const int *__restrict__ total,
-                          const int *__restrict__ flat, int width, int height, int tw, const SliceWs ws_, unsigned tag,
-                          int span, const float *__restrict__ gt, const float *__restrict__ wmap, float loss_scale,
-                          StopRec *__restrict__ gtstop, const Batch bt, unsigned long long *__restrict__ prof) {
-  __shared__ WaveList lists[4];
+template <bool CHAINED, bool TIMED, int SPAN>
+__device__ __forceinline__ void wave_fwd_body(const float4 *__restrict__ splat, const TileTable tt_,
+                                              const int *__restrict__ total, const int *__restrict__ flat, int width,
+                                              int height, int tw, const SliceWs ws_, unsigned tag,
+                                              const float *__restrict__ gt, const float *__restrict__ wmap,
+                                              float loss_scale, StopRec *__restrict__ gtstop, const Batch bt,
+                                              unsigned long long *__restrict__ prof,
+                                              WaveListT<SPAN * kSlice> *lists, WgStage<SPAN * kSlice> &stg, int dbg) {
+  typedef WaveListT<SPAN * kSlice> WaveList;
+  constexpr int span = SPAN;
   long long t_prev = TIMED ? (long long)__builtin_readcyclecounter() : 0;
   unsigned long long *my_prof = TIMED ? prof + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 : nullptr;
 #define EG_TICK(k)                                                                                        \
@@ -316,7 +438,21 @@ composite_wave_fwd_kernel(const float4 *__restrict__ splat, const TileTable tt_,
   const int p = i * width + j;
   const float w_p = (finisher && inside) ? wmap[p] : 0.f;
   const float gt_p = (finisher && inside) ? gt[p] : 0.f;
-  EG_TICK(0);  // head: the item record (+ the pixel's gt / weight)
+  // the workgroup's copy of the slice: one half record per thread and round
+  if (end > start) {
+    const int n = end - start;
+#pragma unroll
+    for (int r = 0; r < SPAN; ++r) {
+      const int t = threadIdx.x + 256 * r, k = t >> 1;
+      if (k < n) {
+        const int g = flat[start + k];
+        const float4 rec = splat[2 * g + (t & 1)];
+        if (t & 1) stg.B[k] = rec; else { stg.A[k] = rec; stg.gid[k] = g; }
+      }
+    }
+  }
+  __syncthreads();  // (the only one: every wave of the workgroup is still here)
+  EG_TICK(0);  // head: the item record, the slice's records (+ the pixel's gt / weight)
 
   unsigned long long *gran = (unsigned long long *)ws.sliceP;  // [max_items][256] (sliceP and sliceL are contiguous)
   float T = 1.f, l = 0.f;
@@ -337,7 +473,7 @@ composite_wave_fwd_kernel(const float4 *__restrict__ splat, const TileTable tt_,
     hint_cur = ws.dead_hint + (tag & 1u) * 4 * gridDim_tiles(tw, height) + tile * 4 + wv;
     const int key = hint_prev[tile * 4 + wv];
     const int h = ((unsigned)key >> 8) == ((tag - 1u) & kGranuleTagMask) ? 255 - (key & 255) : 0x7fffffff;
-    if (s_me >= h && s_me > 0 && h > 0) {
+    if (s_me >= h && s_me > 0 && h > 0 && !(dbg & 4)) {
       look_back<true>(gran, i0, span, 0, h, tag, inside, T, before);
       looked = h;
       if (__ballot(!before && inside) == 0ull) {  // dead, as last time
@@ -353,12 +489,19 @@ composite_wave_fwd_kernel(const float4 *__restrict__ splat, const TileTable tt_,
   }
 
   // ---- phase A: this slice's product (and last contributor) over this wave's quadrant
-  float P = 1.f;
+  constexpr bool CK = CHAINED && SPAN == 1;  // (checkpoints for the exact stop: see walk_list_ck)
+  float P = 1.f, ck[4] = {1.f, 1.f, 1.f, 1.f};
+  unsigned ckL = 0xffffffffu;
   int Lpos = -1, n_mine = 0;
   if (end > start) {  // (an empty tile's single item has nothing to walk)
-    n_mine = stage_wave(wl, splat, flat, start, end, (float)qj, (float)qi, lane);
-    EG_TICK(1);  // staging: ids -> records -> quadrant tests -> list
-    walk_list<CHAINED>(wl, n_mine, px, py, P, Lpos);
+    const int n = end - start;
+    if (dbg & 1) n_mine = stage_wave<SPAN>(wl, splat, flat, start, end, (float)qj, (float)qi, lane);
+    else if (n <= 64) n_mine = stage_from_lds<1>(wl, stg, n, (float)qj, (float)qi, lane);
+    else if (SPAN == 1 || n <= 128) n_mine = stage_from_lds<2>(wl, stg, n, (float)qj, (float)qi, lane);
+    else n_mine = stage_from_lds<2 * SPAN>(wl, stg, n, (float)qj, (float)qi, lane);
+    EG_TICK(1);  // staging: quadrant tests -> list
+    if (CK) walk_list_ck(wl, n_mine, px, py, P, Lpos, ck, ckL);
+    else walk_list<CHAINED>(wl, n_mine, px, py, P, Lpos);
     if (TIMED) { float keep = P; asm volatile("" : "+v"(keep)); P = keep; }
     EG_TICK(2);  // walk
   }
@@ -392,7 +535,9 @@ composite_wave_fwd_kernel(const float4 *__restrict__ splat, const TileTable tt_,
     if (inside) l = finalize_train(p, T, 0, false, flat, gt_p, w_p, loss_scale, gtstop, splat);
   } else {
     // ---- chained mode: does the stop fall in this slice?
-    int last = -1;  // sorted index of the last contributor in front of a stop; -1: not known (yet)
+    int last = -1;           // sorted index of the last contributor in front of a stop (only when it sits in a slice in front)
+    int stop_id = -1;        // ... its Gaussian id and depth bits (read from the list in LDS)
+    unsigned stop_dep = 0u;
     bool cross = false;
     if (!before && Lidx != kNoContributor) {
       const float nT = T * P;
@@ -405,17 +550,41 @@ composite_wave_fwd_kernel(const float4 *__restrict__ splat, const TileTable tt_,
       // exact stop from the list still in LDS, sequentially in depth order from T; should float rounding move the
       // crossing past the slice end, the same lanes carry on through the following slices (staged afresh)
       bool live = cross;
-      const int lp = exact_walk_wave(wl, n_mine, px, py, live, T, found);
-      if (lp >= 0) last = start + (int)wl.idx[lp];
+      int lp;
+      if (CK && !(dbg & 2)) {
+        // start behind the last quarter of the list the pixel's transmittance survives
+        constexpr int kSeg = SPAN * kSlice / 4;
+        int pos0 = 0, lp0 = 0xff;
+        float Ts = T;
+        bool adv = true;
+#pragma unroll
+        for (int seg = 0; seg < 3; ++seg) {  // (static indices only: a dynamic one would put ck[] into scratch memory)
+          const float nT = T * ck[seg];
+          adv = adv & (nT > kTStop);
+          Ts = adv ? nT : Ts;
+          pos0 = adv ? kSeg * (seg + 1) : pos0;
+          lp0 = adv ? (int)((ckL >> (8 * seg)) & 0xffu) : lp0;
+        }
+        T = cross ? Ts : T;  // (the other lanes of the wave hold a finished transmittance)
+        lp = exact_walk_lane(wl, n_mine, pos0, px, py, live, T, found);
+        if (lp < 0 && lp0 != 0xff) lp = lp0;
+      } else {
+        lp = exact_walk_wave(wl, n_mine, px, py, live, T, found);
+      }
+      if (lp >= 0) {  // (the workgroup's copy of this slice is still in LDS)
+        const int k = (int)wl.idx[lp];
+        stop_id = stg.gid[k];
+        stop_dep = (unsigned)__float_as_int(stg.B[k].z);
+      }
       for (int s2 = s_me + 1; s2 < ns; ++s2) {
         if (__ballot(cross && !found) == 0ull) break;
         const int st2 = t_start + s2 * slice, en2 = min(t_end, st2 + slice);
-        const int n2 = stage_wave(wl, splat, flat, st2, en2, (float)qj, (float)qi, lane);
+        const int n2 = stage_wave<SPAN>(wl, splat, flat, st2, en2, (float)qj, (float)qi, lane);
         live = cross && !found;
         const int lp2 = exact_walk_wave(wl, n2, px, py, live, T, found);
-        if (lp2 >= 0) last = st2 + (int)wl.idx[lp2];
+        if (lp2 >= 0) { last = st2 + (int)wl.idx[lp2]; stop_id = -1; }  // (a slice staged by this wave alone: via memory below)
       }
-      if (cross && found && last < 0) {
+      if (cross && found && stop_id < 0 && last < 0) {
         // the stop is the first contributor of its slice: the last contributor sits in a slice in front (whose granule
         // this lane has seen tagged already)
         for (int js = s_me - 1; js >= 0; --js) {
@@ -429,8 +598,20 @@ composite_wave_fwd_kernel(const float4 *__restrict__ splat, const TileTable tt_,
     EG_TICK(5);  // exact stop
     // finalise the pixels that stop here (whichever way the exact walk ended) and -- in the last slice -- the pixels
     // that never stop
-    if (cross || (inside && !before && s_me == ns - 1))
-      l = finalize_train(p, T, max(last, 0), cross && found && last >= 0, flat, gt_p, w_p, loss_scale, gtstop, splat);
+    if (cross || (inside && !before && s_me == ns - 1)) {
+      if (cross && found && stop_id < 0 && last >= 0) {  // (rare: the last contributor sits in a slice in front)
+        stop_id = flat[last];
+        stop_dep = (unsigned)__float_as_int(splat[2 * stop_id + 1].z);
+      }
+      const float pix = 1.f - T, c0 = fminf(fmaxf(pix, 0.f), 1.f), d = c0 - gt_p;
+      const float v = loss_scale * w_p * ((d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f));
+      StopRec r;  // (finalize_pixel<1> of composite.h with the stop Gaussian already in registers)
+      r.gT = (T < 1.f) ? v * T : 0.f;
+      r.stop_id = (cross && found) ? stop_id : -1;
+      r.stop_depth = (cross && found && stop_id >= 0) ? stop_dep : 0u;
+      gtstop[p] = r;
+      l = w_p * fabsf(d);
+    }
   }
   // loss terms of this wave's pixels -> one of 64 partial sums
 #pragma unroll
@@ -438,6 +619,31 @@ composite_wave_fwd_kernel(const float4 *__restrict__ splat, const TileTable tt_,
   if (lane == 0 && l != 0.f) unsafeAtomicAdd(&ws.loss_part[(tile * 4 + wv) & 63], l);
   EG_TICK(6);  // epilogue
 #undef EG_TICK
+}
+
+// (span 1: eight waves per SIMD -- 64 VGPRs -- are worth more than the few registers the compiler would like on top)
+template <bool CHAINED, bool TIMED>
+__global__ void __launch_bounds__(256, 8)
+composite_wave_fwd_kernel(const float4 *__restrict__ splat, const TileTable tt, const int *__restrict__ total,
+                          const int *__restrict__ flat, int width, int height, int tw, const SliceWs ws, unsigned tag,
+                          const float *__restrict__ gt, const float *__restrict__ wmap, float loss_scale,
+                          StopRec *__restrict__ gtstop, const Batch bt, unsigned long long *__restrict__ prof, int dbg) {
+  __shared__ WaveListT<kSlice> lists[4];
+  __shared__ WgStage<kSlice> stg;
+  wave_fwd_body<CHAINED, TIMED, 1>(splat, tt, total, flat, width, height, tw, ws, tag, gt, wmap, loss_scale, gtstop, bt, prof,
+                                   lists, stg, dbg);
+}
+
+template <bool CHAINED, bool TIMED>
+__global__ void __launch_bounds__(256)
+composite_wave2_fwd_kernel(const float4 *__restrict__ splat, const TileTable tt, const int *__restrict__ total,
+                           const int *__restrict__ flat, int width, int height, int tw, const SliceWs ws, unsigned tag,
+                           const float *__restrict__ gt, const float *__restrict__ wmap, float loss_scale,
+                           StopRec *__restrict__ gtstop, const Batch bt, unsigned long long *__restrict__ prof, int dbg) {
+  __shared__ WaveListT<2 * kSlice> lists[4];
+  __shared__ WgStage<2 * kSlice> stg;
+  wave_fwd_body<CHAINED, TIMED, 2>(splat, tt, total, flat, width, height, tw, ws, tag, gt, wmap, loss_scale, gtstop, bt, prof,
+                                   lists, stg, dbg);
 }
 
 static unsigned long long *g_prof = nullptr;
@@ -457,18 +663,26 @@ int launch_wave_fwd(const float4 *splat, const TileTable tt, const int32_t *flat
   }
   if (timed) (void)hipMemsetAsync(g_prof, 0, (size_t)max_items * 32 * sizeof(unsigned long long), s);
   tag &= kGranuleTagMask;
-  // span: 128- or 256-Gaussian slices.  A wave lives ~25-45 k cycles whatever it does (a chain of dependent memory
-  // round trips) and the chip holds 8192 of them: a launch of more than one round lasts two wave lifetimes.  With
-  // max_items * C item workgroups of 4 waves the upper bound on the launch is known; pairs of items halve it.
-  static const int span_env = getenv("EG_WAVE_SPAN") ? atoi(getenv("EG_WAVE_SPAN")) : 0;
-  const int span = span_env == 1 || span_env == 2 ? span_env : ((int64_t)max_items * C * 4 > 6144 ? 2 : 1);
+  // span: a wave's slice is one 128-Gaussian item (span 1) or two (span 2, EG_WAVE_SPAN=2: an experiment that lost
+  // everywhere it was tried -- twice the LDS per wave takes a quarter of the wave slots away and the kernel lasts as
+  // long as its heaviest waves, which become twice as heavy; config 2 trained-like 46.7 -> 56.2 us)
+  static const int span = (getenv("EG_WAVE_SPAN") && atoi(getenv("EG_WAVE_SPAN")) == 2) ? 2 : 1;
+  // debugging switches (EG_WAVE_DBG bits): 1 stage from memory per wave instead of the workgroup's LDS copy, 2 exact stop
+  // in lockstep from the front instead of per lane from the checkpoints, 4 no dead-slice gating
+  static const int dbg = getenv("EG_WAVE_DBG") ? atoi(getenv("EG_WAVE_DBG")) : 0;
   (void)max_tile_hint;
   const dim3 grid((unsigned)max_items, C);
-#define EG_LAUNCH(CH_, TI_)                                                                                         \
-  composite_wave_fwd_kernel<CH_, TI_><<<grid, 256, 0, s>>>(splat, tt, total, flatten_ids, width, height, tw, ws, tag, \
-                                                          span, gt, wmap, loss_scale, (StopRec *)gtstop, bt, g_prof)
-  if (chained) { if (timed) EG_LAUNCH(true, true); else EG_LAUNCH(true, false); }
-  else         { if (timed) EG_LAUNCH(false, true); else EG_LAUNCH(false, false); }
+#define EG_LAUNCH(KN_, CH_, TI_)                                                                                    \
+  KN_<CH_, TI_><<<grid, 256, 0, s>>>(splat, tt, total, flatten_ids, width, height, tw, ws, tag, gt, wmap, loss_scale, \
+                                     (StopRec *)gtstop, bt, g_prof, dbg)
+#define EG_LAUNCH2(CH_, TI_)                                                 \
+  do {                                                                       \
+    if (span == 2) EG_LAUNCH(composite_wave2_fwd_kernel, CH_, TI_);          \
+    else EG_LAUNCH(composite_wave_fwd_kernel, CH_, TI_);                     \
+  } while (0)
+  if (chained) { if (timed) EG_LAUNCH2(true, true); else EG_LAUNCH2(true, false); }
+  else         { if (timed) EG_LAUNCH2(false, true); else EG_LAUNCH2(false, false); }
+#undef EG_LAUNCH2
 #undef EG_LAUNCH
   timing_mark(kMarkSlice, s);
   timing_mark(kMarkRewalk, s);

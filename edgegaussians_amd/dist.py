@@ -91,6 +91,19 @@ class DataParallelStep:
             out_f = [float(x) for x in t.tolist()]
         return out_i, out_f
 
+    def broadcast_(self, t: torch.Tensor, src: int = 0) -> torch.Tensor:
+        """In place from rank `src` (staged through the host in the several-ranks-on-one-GPU test mode)."""
+        if self.world <= 1 or not dist.is_initialized():
+            return t
+        if t.is_cuda and dist.get_backend(self.group) == "gloo":
+            host = t.cpu()
+            dist.broadcast(host, src=src, group=self.group)
+            if self.rank != src:
+                t.copy_(host)
+            return t
+        dist.broadcast(t, src=src, group=self.group)
+        return t
+
     def all_reduce_(self, t: torch.Tensor) -> torch.Tensor:
         """In-place sum over the ranks (what EdgeTrainer uses for the regulariser's running loss sum)."""
         self._all_reduce(t)

@@ -296,15 +296,17 @@ class _UnitRasterization(torch.autograd.Function):
         if m * 1.15 > (fb.max_items - fb.T) * 128 or tile_max * 1.15 > fb.seg_cap:
             fb.size(m, tile_max)  # grow ahead of the drift (the next call finds room)
         means2d = splat[:, 0:2].clone().view(1, N, 2)
+        # the last contributor of every pixel as a Gaussian id (the cached sorted ids are overwritten by the next call;
+        # gsplat's `last_ids` -- an index into ITS intersection list -- is derived from this on demand)
+        holder["last_gid"] = torch.index_select(fb.flatten_ids, 0, last_ids.view(-1)).view(height, width)
         ctx.save_for_backward(means_c, quats_c, scales_c, opac_c, vm, Kc, splat, gtstop)
         ctx.cfg = (width, height, flags)
         ctx.holder = holder
-        holder["splat"], holder["last_ids"] = splat, last_ids
-        ctx.mark_non_differentiable(last_ids)
-        return alphas, means2d, last_ids
+        holder["splat"] = splat
+        return alphas, means2d
 
     @staticmethod
-    def backward(ctx, v_alphas, v_means2d, _v_last):
+    def backward(ctx, v_alphas, v_means2d):
         means, quats, scales, opac, vm, Kc, splat, gtstop = ctx.saved_tensors
         width, height, flags = ctx.cfg
         N, dev = means.shape[0], means.device
@@ -338,7 +340,8 @@ class _LazyInfo(dict):
     """gsplat's `info`: the cheap entries are there, the gsplat-layout binning tensors (tiles_per_gauss, isect_ids,
     flatten_ids, isect_offsets) and the per-Gaussian arrays are computed from the call's packed records when read."""
 
-    _LAZY = ("radii", "depths", "conics", "opacities", "tiles_per_gauss", "isect_ids", "flatten_ids", "isect_offsets")
+    _LAZY = ("radii", "depths", "conics", "opacities", "tiles_per_gauss", "isect_ids", "flatten_ids", "isect_offsets",
+             "last_ids")
 
     def __init__(self, eager, make):
         super().__init__(eager)
@@ -370,13 +373,13 @@ def _fast_rasterization(means, quats, scales, opacities, colors, viewmats, Ks, w
     flags = _lib.FLAG_ANTIALIASED if antialiased else 0
     holder: Dict = {"absgrad": bool(absgrad)}
     unit_flag = (colors == 1).all()
-    alphas, means2d, last_ids = _UnitRasterization.apply(
+    alphas, means2d = _UnitRasterization.apply(
         means, quats, scales, opacities, viewmats[0], Ks[0], width, height, flags, unit_flag, holder)
     if not holder["unit"]:
         return None
     render = alphas.expand(1, height, width, colors.shape[-1])  # colours == 1: every channel is the accumulated alpha
     holder["means2d"] = weakref.ref(means2d)
-    splat = holder.pop("splat")
+    splat, last_gid, alpha_img = holder.pop("splat"), holder.pop("last_gid"), alphas.detach()
 
     def make(key):
         if key in ("radii", "depths", "conics", "opacities"):
@@ -391,11 +394,21 @@ def _fast_rasterization(means, quats, scales, opacities, colors, viewmats, Ks, w
             call("eg_tile_count", ptr(m2), ptr(radii), N, width, height, ptr(tpg), ptr(counts), stream())
             offsets, flat, ids, M, _io, _tot, _ni = isect_tiles_and_sort(m2, radii, splat[:, 6].contiguous(), counts, width,
                                                                         height)
+            # gsplat's last_ids: the position of the pixel's last contributor in ITS list = the entry (tile of the pixel,
+            # that Gaussian); pixels nothing contributed to hold 0
+            dev = means.device
+            tile_of_entry = torch.bucketize(torch.arange(M, device=dev), offsets[1:].long(), right=True)
+            skey, perm = torch.sort(tile_of_entry * N + flat.long())
+            ys, xs = torch.arange(height, device=dev) // TILE, torch.arange(width, device=dev) // TILE
+            q = (ys[:, None] * tw + xs[None, :]) * N + last_gid.long()
+            pos = torch.searchsorted(skey, q.reshape(-1)).clamp_(max=max(M - 1, 0))
+            hit = (skey[pos] == q.reshape(-1)) & (alpha_img.reshape(-1) > 0) if M > 0 else torch.zeros_like(pos, dtype=torch.bool)
+            last = torch.where(hit, perm[pos] if M > 0 else pos, torch.zeros_like(pos)).to(torch.int32).view(1, height, width)
         return {"tiles_per_gauss": tpg[None], "isect_ids": ids, "flatten_ids": flat,
-                "isect_offsets": offsets[:-1].reshape(1, th, tw)}
+                "isect_offsets": offsets[:-1].reshape(1, th, tw), "last_ids": last}
 
     info = _LazyInfo({"camera_ids": None, "gaussian_ids": None, "means2d": means2d, "tile_width": tw, "tile_height": th,
-                      "width": width, "height": height, "tile_size": TILE, "n_cameras": 1, "last_ids": last_ids}, make)
+                      "width": width, "height": height, "tile_size": TILE, "n_cameras": 1}, make)
     return render, alphas, info
 
 

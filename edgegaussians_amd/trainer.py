@@ -858,6 +858,13 @@ class EdgeTrainer:
              ptr(self.log_scales), ptr(self.logit_opacities), ptr(self.adam_m), ptr(self.adam_v), ptr(self.grads), self.N,
              ptr(nn) if nn is not None else None, K + 1, 1, K, top_k, ptr(avg_loss_sum) if dev_sum else None,
              0.0 if dev_sum else float(avg_loss_sum), float(scale_factor), ptr(work), self._hyper, stream())
+        if self._dp is not None and self._dp.world > 1:
+            # the regulariser kernels sum neighbour gradients with float atomics: every rank computes the SAME step up to
+            # the order of those additions, i.e. up to an ulp -- and replicas must stay bit-identical (densify / cull
+            # decisions, the sharded views' gradients).  Rank 0's result is the result: 128 bytes per Gaussian, every
+            # fifth view, on the same stream
+            for t in (self.means, self.log_scales, self.quats, self.adam_m, self.adam_v):
+                self._dp.broadcast_(t)
         return work[1]
 
     # ------------------------------------------------------------------ read-backs (these sync)

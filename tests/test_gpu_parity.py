@@ -1048,7 +1048,7 @@ def test_binning_layouts_agree_and_segment_overflow_is_flagged(env):
     assert tb.overflow_events >= 1 and not tb.overflowed() and tb.seg_cap > 128
     assert abs(la - lb) <= 1e-6 * abs(la)
     for k, v in ta.state_dict().items():
-        assert_close(tb.state_dict()[k], v, rtol=1e-4, name=f"after replay: {k}")
+        assert_close(tb.state_dict()[k], v, rtol=1e-4, max_bad=2e-3, name=f"after replay: {k}")  # (as above)
 
 
 def test_segmented_layout_with_a_giant_tile(env):
