@@ -12,6 +12,7 @@ accumulation) keep a looser, documented tolerance, because after the first Adam 
 implementations no longer hold bit-identical parameters.
 """
 import math
+import os
 
 import numpy as np
 import pytest
@@ -1435,6 +1436,30 @@ def test_bench_line_contract(env):
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and "traffic" in rf and rf["achieved"] > 0
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == d["unit"] and cb["sample"]
+    assert "untuned" in cb["sample"].lower()  # (a stated baseline, not a speed-up denominator)
+    # round 3: what happened before and around the timed window is on the line
+    assert d["prewarm_steps"] >= 400 and len(d["ms_per_step_windows"]) == 3
+    assert d["ms_per_step_windows"][0] == d["ms_per_step"]  # `value` is the contract's window, the repeats are extra
+    assert d["ms_per_step_min"] == min(d["ms_per_step_windows"]) and d["ms_per_step_median"] in d["ms_per_step_windows"]
+    assert d["config"]["forward_mode"].startswith(("speculative", "chained")) and "opacity" in d["config"]["workload"]
+
+
+def test_bench_issue_roofline_pass(env):
+    """`roofline.secondary` (the issue-side roofline, from a same-run rocprofv3 SQ-counter pass over bench.py itself):
+    every kernel of the step with its VALU wave-instructions per launch, its fraction of the chip's issue peak and
+    the split of its wave cycles."""
+    import shutil
+    import bench
+    if not (shutil.which("rocprofv3") or os.path.exists("/opt/rocm/bin/rocprofv3")):
+        pytest.skip("rocprofv3 not installed")
+    kernels, src = bench.measure_issue("config1", False, steps=10)
+    assert kernels is not None, src
+    assert "composite_wave_fwd_kernel" in kernels and "footprint_bwd_kernel" in kernels and "tile_sort_kernel" in kernels
+    for k, r in kernels.items():
+        assert r["valu_wave_instructions_per_launch"] > 0 and 0 < r["valu_issue_frac_of_peak"] < 1, (k, r)
+        shares = r["wave_cycles_issuing"] + r["wave_cycles_parked_waitcnt_or_barrier"] + r["wave_cycles_issue_stalled"]
+        assert 0.9 < shares < 1.1, (k, r)
+    assert bench.VALU_ISSUE_PEAK == 256 * 4 * 2.4e9 / 2.0
 
 
 @pytest.mark.parametrize("W,H,n", [(1024, 512, 8000), (1040, 512, 8000), (2048, 16, 3000), (33, 17, 500), (721, 403, 6000)])

@@ -3,7 +3,7 @@
 round-tagged names and derives the issue-side ("second") roofline of every kernel from the SQ counter pass:
 
     VALU issue rate = SQ_INSTS_VALU per launch / kernel duration, against the chip's wave64 VALU issue peak
-                      (256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction = 614 G wave-instructions/s)
+                      (256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction = 1229 G wave-instructions/s; round 2 priced 4 cycles)
     where the wave cycles go: SQ_ACTIVE_INST_ANY / SQ_WAIT_ANY / SQ_WAIT_INST_ANY as shares of SQ_WAVE_CYCLES
 
 usage: collect_profiles.py [r02]"""
@@ -16,8 +16,8 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EV = os.path.join(ROOT, "gpurun_out", "ev")
 OUT = os.path.join(ROOT, "profiles")
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r02"
-VALU_PEAK = 256 * 4 * 2.4e9 / 4.0
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r03"
+VALU_PEAK = 256 * 4 * 2.4e9 / 2.0  # (2 cycles per wave64 instruction: MI355X_MICROARCH.md, tools/microbench/issue_rates.hip)
 
 
 def kernel_avgs(path):
@@ -38,9 +38,13 @@ def main():
     copies = {"pytest_gpu.log": "pytest_gpu.log", "parity_report.jsonl": "parity_report.jsonl",
               "bench_default.json": "bench_default_config2.json", "bench_config1.json": "bench_config1.json",
               "bench_config3.json": "bench_config3.json", "bench_config4.json": "bench_config4.json",
+              "bench_config2_init_opacity.json": "bench_config2_init_opacity.json",
+              "bench_config3_init_opacity.json": "bench_config3_init_opacity.json",
+              "bench_config4_init_opacity.json": "bench_config4_init_opacity.json",
+              "issue_rates.txt": "microbench_issue_rates.txt", "operator_profile_config2.txt": "operator_profile_config2.txt", "fwd_wave_phases_config2.txt": "fwd_wave_phases_config2.txt",
               "bench_config2_force_dp.json": "bench_config2_force_dp.json", "regularizers_timing.json": "regularizers_timing.json",
               "train_abc_fixture.txt": "train_abc_fixture.txt"}
-    for c in ("config1", "config2"):
+    for c in ("config1", "config2", "config2i"):
         copies[f"kernel_stats_{c}.txt"] = f"kernel_stats_{c}.txt"
         copies[f"timeline_gaps_{c}.txt"] = f"timeline_gaps_{c}.txt"
         copies[f"sq_counters_{c}.txt"] = f"pmc_sq_counters_{c}.txt"
@@ -48,7 +52,7 @@ def main():
         p = os.path.join(EV, src)
         if os.path.exists(p):
             shutil.copy(p, os.path.join(OUT, f"{TAG}_{dst}"))
-    for c in ("config1", "config2"):
+    for c in ("config1", "config2", "config2i"):
         ks, sq = os.path.join(EV, f"kernel_stats_{c}.txt"), os.path.join(EV, f"sq_counters_{c}.txt")
         if not (os.path.exists(ks) and os.path.exists(sq)):
             continue

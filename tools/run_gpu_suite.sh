@@ -1,5 +1,5 @@
 #!/bin/bash
-# Full evidence run on the GPU box (round 2): parity tests + report, bench lines (headline with same-run PMC traffic,
+# Full evidence run on the GPU box (round 3): parity tests + report, bench lines (headline with same-run PMC traffic,
 # config1, trained-like, batched views, operator path, config3/4), rocprofv3 kernel stats + launch gaps, SQ counters.
 #   gpurun --timeout 3000 -- 'bash tools/run_gpu_suite.sh'
 # Everything lands in gpurun_out/ev/; copy what should be judged into profiles/ (tools/collect_profiles.py).
@@ -13,20 +13,27 @@ timeout 1500 python -m pytest tests -m gpu -q --tb=short 2>&1 | grep -v "$F" | t
 cp $R/gpurun_out/parity_report.jsonl $O/parity_report.jsonl 2>/dev/null
 ( time timeout 900 python bench.py ) 2>$O/bench_default.err | tail -1 > $O/bench_default.json
 timeout 600 python bench.py --config config1 --no-extra 2>/dev/null | tail -1 > $O/bench_config1.json
+timeout 600 python bench.py --config config2 --init-opacity --no-cpu-baseline --no-extra 2>/dev/null | tail -1 > $O/bench_config2_init_opacity.json
 for c in config3 config4; do
   timeout 600 python bench.py --config $c --no-cpu-baseline --no-traffic --no-extra 2>/dev/null | tail -1 > $O/bench_${c}.json
+  timeout 600 python bench.py --config $c --init-opacity --no-cpu-baseline --no-traffic --no-extra 2>/dev/null | tail -1 > $O/bench_${c}_init_opacity.json
 done
+tools/microbench/issue_rates > $O/issue_rates.txt 2>&1
+EG_FWD_PROF=1 python tools/fwd_prof.py config2 --spread 2>/dev/null | grep -v "^RCCL\|^HIP\|amdgpu.ids" > $O/fwd_wave_phases_config2.txt
+EG_FWD_PROF=1 python tools/fwd_prof.py config2 2>/dev/null | grep -v "^RCCL\|^HIP\|amdgpu.ids" >> $O/fwd_wave_phases_config2.txt
 timeout 300 python bench.py --force-dp --no-cpu-baseline --no-traffic --no-extra 2>/dev/null | tail -1 > $O/bench_config2_force_dp.json
 timeout 300 python tools/bench_regularizers.py 2>/dev/null | tail -1 > $O/regularizers_timing.json
+timeout 300 python tools/operator_profile.py config2 2>/dev/null | grep -v "^RCCL\|^HIP\|amdgpu.ids" > $O/operator_profile_config2.txt
 timeout 300 python tools/train_abc_fixture.py 2>/dev/null | tail -5 > $O/train_abc_fixture.txt
 ( echo "--- first run of the process (--cold) ---"; timeout 300 python tools/train_abc_fixture.py --cold 2>/dev/null | tail -2 | head -1 ) >> $O/train_abc_fixture.txt
 cd /tmp && export TMPDIR=/tmp
-for c in config1 config2; do
+for c in config1 config2 config2i; do
   rm -rf /tmp/ev_$c /tmp/evsq_$c
-  timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/ev_$c -o r -- python $R/bench.py --config $c --steps 300 --warmup 20 --profile-only > /dev/null 2>$O/prof_$c.err
+  a="--config $c"; [ $c = config2i ] && a="--config config2 --init-opacity"
+  timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/ev_$c -o r -- python $R/bench.py $a --steps 300 --warmup 20 --profile-only > /dev/null 2>$O/prof_$c.err
   python $R/tools/rocpd_summary.py /tmp/ev_$c/r_results.db $O/kernel_stats_$c.txt > /dev/null
   python $R/tools/timeline_gaps.py /tmp/ev_$c/r_results.db > $O/timeline_gaps_$c.txt
-  timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY -d /tmp/evsq_$c -o q -- python $R/bench.py --config $c --steps 40 --warmup 5 --profile-only > /dev/null 2>$O/sq_$c.err
+  timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY -d /tmp/evsq_$c -o q -- python $R/bench.py $a --steps 40 --warmup 5 --profile-only > /dev/null 2>$O/sq_$c.err
   python $R/tools/pmc_sq_summary.py $O/sq_counters_$c.txt /tmp/evsq_$c/q_results.db > /dev/null
 done
 cd $R
