@@ -453,7 +453,7 @@ composite_slice_fwd_kernel(const float4 *__restrict__ splat, const TileTable tt_
                            float *__restrict__ render, float *__restrict__ alphas, int *__restrict__ last_ids,
                            const float *__restrict__ gt, const float *__restrict__ wmap, float loss_scale,
                            float *__restrict__ vpix, float *__restrict__ loss_out, StopRec *__restrict__ gtstop,
-                           const Batch bt, int rewalk_skipped, int dbg) {
+                           const Batch bt, int rewalk_skipped) {
   __shared__ QuadLists ql;
   static_assert(kSlice <= kTilePix, "one staging thread per Gaussian of the slice");
   __shared__ int sTile[5];
@@ -516,8 +516,7 @@ composite_slice_fwd_kernel(const float4 *__restrict__ splat, const TileTable tt_
     if (tid < kSlice)  // which quadrants each Gaussian of the slice reaches: reused by the exact-stop re-walk
       ws.sliceQ[(size_t)b * kSlice + tid] = (unsigned char)((int)hitq[0] | ((int)hitq[1] << 1) | ((int)hitq[2] << 2) |
                                                             ((int)hitq[3] << 3));
-    int n_mine = build_quad_lists(ql, hitq, s0, rB, tid);
-    if (dbg & 1) n_mine = 0;
+    const int n_mine = build_quad_lists(ql, hitq, s0, rB, tid);
 
     const float4 *lX = ql.X[wv], *lC = ql.C[wv], *lD = ql.D[wv], *lE = ql.E[wv];
     const v2f px2 = {px, px}, py2 = {py, py};
@@ -550,8 +549,7 @@ composite_slice_fwd_kernel(const float4 *__restrict__ splat, const TileTable tt_
 
   float T = 1.f;
   int last = 0, stop_slice = -1;
-  if (ns == 1 || (dbg & 2)) {  // the tile's only slice: nothing to publish, nothing to wait for
-    if (dbg & 2) { if (b != i0) return; }
+  if (ns == 1) {  // the tile's only slice: nothing to publish, nothing to wait for
     if (L >= 0) {
       if (P <= kTStop) stop_slice = 0; else { T = P; last = L; }
     }
@@ -574,7 +572,7 @@ composite_slice_fwd_kernel(const float4 *__restrict__ splat, const TileTable tt_
     __syncthreads();
     if (!s_last) return;  // (whole workgroup)
   }
-  combine_tail<CH, true>(tile, tid, i0, (dbg & 2) ? 1 : ns, inside, i * width + j, T, last, stop_slice, ws, flat, render, alphas,
+  combine_tail<CH, true>(tile, tid, i0, ns, inside, i * width + j, T, last, stop_slice, ws, flat, render, alphas,
                          last_ids, has_loss, gt_p, w_p, loss_scale, vpix, loss_out, gtstop, sRed, rewalk_skipped != 0);
 }
 
@@ -1459,7 +1457,6 @@ static int launch_sliced_fwd(const float4 *splat, const TileTable tt, int channe
   // find an empty list costs 4.5 us, 64 cost 1.3 us); any grid is correct
   // rewalk_hint == EG_REWALK_SPECULATE: no launch at all; a pixel that does stop raises control word 3 instead
   const int skip = rewalk_hint == EG_REWALK_SPECULATE;
-  static const int dbg = getenv("EG_DBG_FWD") ? atoi(getenv("EG_DBG_FWD")) : 0;  // timing ablations only (wrong results)
   static const bool old_fwd = getenv("EG_FWD_OLD") && atoi(getenv("EG_FWD_OLD")) != 0;  // A/B against round 2's kernels
   // The training step (no images wanted, fused loss, segmented tables): the wave-autonomous forward of
   // composite_wave.hip -- speculative while no pixel reaches the transmittance stop, chained (exact stop inside) otherwise
@@ -1492,11 +1489,11 @@ static int launch_sliced_fwd(const float4 *splat, const TileTable tt, int channe
     if (fused)                                                                                                    \
       composite_slice_fwd_kernel<CH, true><<<dim3((unsigned)max_items, C), 256, 0, s>>>(                          \
           splat, tt, total, flatten_ids, width, height, tw, th, ws, render, alphas, last_ids, gt, wmap,           \
-          loss_scale, vpix, loss_out, (StopRec *)gtstop, bt, skip, dbg);                                          \
+          loss_scale, vpix, loss_out, (StopRec *)gtstop, bt, skip);                                               \
     else {                                                                                                        \
       composite_slice_fwd_kernel<CH, false><<<dim3((unsigned)max_items, C), 256, 0, s>>>(                         \
           splat, tt, total, flatten_ids, width, height, tw, th, ws, render, alphas, last_ids, gt, wmap,           \
-          loss_scale, vpix, loss_out, (StopRec *)gtstop, bt, skip, dbg);                                          \
+          loss_scale, vpix, loss_out, (StopRec *)gtstop, bt, skip);                                               \
       composite_combine_fwd_kernel<CH><<<dim3(tw * th, C), 256, 0, s>>>(tt, flatten_ids, width, height, tw, ws,   \
                                                                         render, alphas, last_ids, gt, wmap,       \
                                                                         loss_scale, vpix, loss_out,               \

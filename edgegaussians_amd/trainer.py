@@ -913,11 +913,16 @@ class EdgeTrainer:
         o = 4 * (self.T + self.max_items + 2)
         if r["seen"]:
             self.workspace[o:o + 4].zero_()
-        if r["seen"] != self.rewalk_hint:
-            self.rewalk_hint = r["seen"]
+        # (hysteresis: a window without a stop does not send the forward back to its speculative mode at once -- a scene
+        # whose pixels stop now and then would pay a replayed window at every relapse; four calm windows do)
+        self._calm_windows = 0 if r["seen"] else getattr(self, "_calm_windows", 4) + 1
+        seen = r["seen"] if (r["seen"] or self._calm_windows >= 4 or self.rewalk_hint <= 0) else self.rewalk_hint
+        if seen != self.rewalk_hint:
+            self.rewalk_hint = seen
             self._args_cache = {}
         for b, seen in zip(self._batches.values(), r["batch_seen"]):
-            b["rewalk_hint"] = seen
+            if seen or self._calm_windows >= 4 or b["rewalk_hint"] <= 0:
+                b["rewalk_hint"] = seen
             if seen:
                 b["workspace"][:, o:o + 4].zero_()
         # ... and the tile-sort launch hint from the last step's scan

@@ -136,7 +136,7 @@ int main() {
       CK(hipDeviceSynchronize());
       long long hc[256]; CK(hipMemcpy(hc, cyc, sizeof(hc), hipMemcpyDeviceToHost));
       double s = 0; for (int i = 0; i < 256; ++i) s += hc[i];
-      if (rep) printf("dependent global load (%s, 4 MB working set): %.0f shader-clock ticks per hop (s_memtime @100 MHz => x10 ns)\n",
+      if (rep) printf("dependent global load (%s, 4 MB working set): %.0f shader-clock cycles per hop (s_memtime ticks)\n",
                       dev ? "device scope" : "plain", s / 256 / 256);
     }
   int *ctr; CK(hipMalloc(&ctr, 1 << 20)); CK(hipMemset(ctr, 0, 1 << 20));
