@@ -19,7 +19,11 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libedgegs.so")
 OBJ = os.path.join(HERE, "csrc", "_obj")
 SOURCES = ["project.hip", "binning.hip", "composite.hip", "composite_wave.hip", "densify.hip", "knn.hip", "step.hip"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
+# -fno-slp-vectorize: the SLP pass pairs scalar fp32 operations into v_pk_*_f32, which gfx950's vector pipe issues at
+# exactly the cost of the two plain instructions (tools/microbench/issue_rates.hip: 5.6 vs 2 x 2.8 cycles) -- and the
+# pairs need their operands in adjacent registers: v_mov shuffles and s_nop hazards on top.  Measured on the whole step
+# (profiles/r03_slp_ab.txt): footprint backward -12 % on top of its own rewrite, projection backward -4 %.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-fno-slp-vectorize",
          "-Wall", "-Wno-unused-function"]
 
 

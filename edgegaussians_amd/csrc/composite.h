@@ -42,8 +42,10 @@ __device__ __forceinline__ void quad_pixel(int tid, int &di, int &dj) {
 struct StopRec {
   float gT;
   int stop_id;          // -1: the walk did not stop
-  unsigned stop_depth;  // depth float bits of Gaussian stop_id
+  unsigned stop_depth;  // depth float bits of Gaussian stop_id; 0xffffffff with stop_id == -1, so that the backward's
+                        // "behind the stop" test is ONE unsigned 64-bit compare of (depth bits << 32 | id)
 };
+constexpr unsigned kNoStopDepth = 0xffffffffu;
 static_assert(sizeof(StopRec) == 12, "gtstop is [H,W,3] 32-bit words");
 
 template <int CH>
@@ -75,7 +77,7 @@ __device__ __forceinline__ float finalize_pixel(int p, float T, int last, bool s
     StopRec r;
     r.gT = (T < 1.f) ? v * T : 0.f;
     r.stop_id = stopped ? flat[last] : -1;
-    r.stop_depth = stopped ? (unsigned)__float_as_int(splat[2 * r.stop_id + 1].z) : 0u;
+    r.stop_depth = stopped ? (unsigned)__float_as_int(splat[2 * r.stop_id + 1].z) : kNoStopDepth;
     gtstop[p] = r;
   }
   return l;

@@ -1130,20 +1130,31 @@ struct Moments {
   float w_x, w_y, w_xx, w_xy, w_yy, abs_x, abs_y, v_o;
 };
 
-__device__ __forceinline__ void footprint_visit(const float4 s0, const float4 s1, float thr, int g, int i, int j,
-                                                const StopRec rec, Moments &m) {
-  // One branch on the ellipse test (whole waves fall outside on large footprints), none after it:
+// One cell of a footprint as the walk carries it from the prefetch to the visit: the pixel's record (all zeros: nothing
+// to visit) and the offset of the Gaussian's centre from the pixel's.
+constexpr unsigned kOutOfImage = 0x80000000u;  // a byte offset no gtstop image reaches (launch_footprint_bwd checks)
+struct Cell {
+  float gT;
+  unsigned stop_id, stop_depth;  // the pixel's last contributor, all ones if its walk did not stop
+  float dx, dy;
+};
+
+__device__ __forceinline__ void footprint_visit(const float4 s0, const float4 s1, float thr, unsigned g, unsigned dg,
+                                                const Cell c, Moments &m) {
+  // One branch on the whole acceptance test (whole waves fall outside on large footprints), none after it:
   // the lanes of a wave sit in up to eight footprints, accepted and rejected pixels are mixed, and
-  // further branching only adds exec-mask bookkeeping.  A rejected pixel contributes w = 0.
-  const float gT = rec.gT;
-  const float dx = s0.x - ((float)j + 0.5f), dy = s0.y - ((float)i + 0.5f);
+  // further branching only adds exec-mask bookkeeping.
+  const float gT = c.gT, dx = c.dx, dy = c.dy;
   const float sigma = 0.5f * (s0.z * dx * dx + s1.x * dy * dy) + s0.w * dx * dy;
   // where the walk of this pixel stopped only Gaussians at or before the last contributor count:
-  // (depth bits, id) <= (its depth bits, its id).  Tested before the exp: in dense scenes most visits
-  // of a saturated pixel are behind its stop.
-  const unsigned dg = (unsigned)__float_as_int(s1.z);
-  const bool after_stop = (rec.stop_id >= 0) & ((dg > rec.stop_depth) | ((dg == rec.stop_depth) & (g > rec.stop_id)));
-  if (!(gT != 0.f && sigma >= 0.f && sigma <= thr) || after_stop) return;
+  // (depth bits, id) <= (its depth bits, its id): the borrow of a two-word subtraction (the record's words stay in
+  // the registers the prefetch loaded them into: composing a 64-bit value made the compiler copy them out right
+  // behind the load, waiting for it).  Tested before the exp: in dense scenes most visits of a saturated pixel are
+  // behind its stop.
+  unsigned b0, b1;
+  (void)__builtin_subc(c.stop_id, g, 0u, &b0);
+  (void)__builtin_subc(c.stop_depth, dg, b0, &b1);
+  if (!(gT != 0.f && sigma >= 0.f && sigma <= thr) || b1) return;
   const float vis = __expf(-sigma);
   const float araw = s1.y * vis;
   // forward: skip if min(0.999, araw) < 1/255; gsplat's backward: no gradient through a clamped alpha
@@ -1160,10 +1171,12 @@ __device__ __forceinline__ void footprint_visit(const float4 s0, const float4 s1
 
 // Lane r of n walks cells r, r + n, r + 2n, ... of Gaussian g's sheared box as two interleaved streams
 // (r, r + 2n, ... and r + n, r + 3n, ...: two independent gathers in flight per lane); the records of
-// the NEXT pair are prefetched while this one is evaluated.
+// the NEXT pair are prefetched while this one is evaluated.  The loop body is written out twice with the two
+// register sets swapping roles (a rotating copy cost ten moves per pair of visits), and the prefetch is
+// unconditional: a cell with nothing to visit reads pixel 0's record and is marked by its column.
 __device__ __forceinline__ void footprint_walk(const float4 s0, const float4 s1, int g, int r, int n, int i0,
                                                int pw, int cells, int jlo, int jhi, float thr, float xoff,
-                                               float shear, int width, const StopRec *__restrict__ gtstop,
+                                               float shear, int width, const __amdgpu_buffer_rsrc_t gtstop,
                                                const float4 *__restrict__ splat, Moments &m) {
   const float inv_pw = __builtin_amdgcn_rcpf((float)pw);
   // cell -> (row, column) offsets; the quotient estimate is exact for cells < 2^21, the fix-up is free
@@ -1173,49 +1186,54 @@ __device__ __forceinline__ void footprint_walk(const float4 s0, const float4 s1,
     if (qj < 0) { qj += pw; --qi; }
     if (qj >= pw) { qj -= pw; ++qi; }
   };
-  // (`none` built from literals, the load under a plain `if`: with a constant aggregate the compiler selected between
-  // two ADDRESSES -- the record and the constant's -- and issued a flat load, with a pc-relative address computation, in
-  // every visit)
-  auto make_none = []() -> StopRec {
-    StopRec r;
-    r.gT = 0.f; r.stop_id = -1; r.stop_depth = 0u;  // gT == 0: the visit is skipped
+  const int width12 = width * (int)sizeof(StopRec);
+  // (centre - 0.5 once per Gaussian: the pixel centres are at integer + 0.5)
+  const float xc = s0.x - 0.5f, yc = s0.y - 0.5f;
+  // The record comes through a buffer load: a 32-bit byte offset on the uniform descriptor (two full-rate 24-bit
+  // multiply-adds and the load's own address adder instead of a quarter-rate 64-bit multiply-add per visit), and a
+  // cell with nothing to visit -- past the stream's end or outside the column clip -- asks for an offset beyond the
+  // image: the hardware's range check returns zeros without touching memory, and gT == 0 is "skip".
+  typedef unsigned u32x3 __attribute__((ext_vector_type(3)));
+  auto fetch = [&](int i, int c, bool live) -> Cell {
+    Cell r;
+    r.dy = yc - (float)i;
+    const int j = (int)ceilf(xoff + shear * r.dy) + c;
+    const bool ok = live & (j >= jlo) & (j <= jhi);
+    const unsigned off = ok ? (unsigned)(__mul24(i, width12) + __mul24(j, 12)) : kOutOfImage;
+    const u32x3 t = __builtin_amdgcn_raw_buffer_load_b96(gtstop, (int)off, 0, 0);
+    r.gT = __uint_as_float(t.x);
+    r.stop_id = t.y;
+    r.stop_depth = t.z;
+    r.dx = xc - (float)j;
     return r;
   };
-  const StopRec none = make_none();
-  auto fetch = [&](int i, int c, int &j) -> StopRec {
-    j = (int)ceilf(xoff + shear * (s0.y - ((float)i + 0.5f))) + c;
-    StopRec r = make_none();
-    if (j >= jlo && j <= jhi) {
-      const StopRec t = gtstop[__mul24(i, width) + j];
-      r.gT = t.gT; r.stop_id = t.stop_id; r.stop_depth = t.stop_depth;
-    }
-    return r;
-  };
+  const unsigned ug = (unsigned)g, dg = (unsigned)__float_as_int(s1.z);
   int di, dc;
   divmod(2 * n, di, dc);
   int ia, ca, ib, cb;
   divmod(r, ia, ca);
   divmod(r + n, ib, cb);
   ia += i0; ib += i0;
-  int left_a = cells - r, left_b = cells - r - n;  // > 0 while the stream still has a visit
-  int ja = 0, jb = 0;
-  StopRec na = none, nb = none;
-  if (left_a > 0) na = fetch(ia, ca, ja);
-  if (left_b > 0) nb = fetch(ib, cb, jb);
-  while (left_a > 0) {
-    const StopRec ra = na, rb = nb;
-    const int cia = ia, cja = ja, cib = ib, cjb = jb;
-    left_a -= 2 * n;
-    left_b -= 2 * n;
+  int left = cells - r;  // > 0 while stream a still has a visit (stream b: left - n)
+  auto advance = [&]() {
+    left -= 2 * n;
     ia += di; ca += dc;
     if (ca >= pw) { ca -= pw; ++ia; }
     ib += di; cb += dc;
     if (cb >= pw) { cb -= pw; ++ib; }
-    na = nb = none;
-    if (left_a > 0) na = fetch(ia, ca, ja);
-    if (left_b > 0) nb = fetch(ib, cb, jb);
-    footprint_visit(s0, s1, thr, g, cia, cja, ra, m);
-    footprint_visit(s0, s1, thr, g, cib, cjb, rb, m);  // an exhausted stream holds a zero record
+  };
+  Cell a0 = fetch(ia, ca, left > 0), b0 = fetch(ib, cb, left - n > 0);
+  while (left > 0) {
+    advance();
+    const Cell a1 = fetch(ia, ca, left > 0), b1 = fetch(ib, cb, left - n > 0);
+    footprint_visit(s0, s1, thr, ug, dg, a0, m);
+    footprint_visit(s0, s1, thr, ug, dg, b0, m);  // an exhausted stream holds an unvisitable cell
+    if (left <= 0) break;
+    advance();
+    a0 = fetch(ia, ca, left > 0);
+    b0 = fetch(ib, cb, left - n > 0);
+    footprint_visit(s0, s1, thr, ug, dg, a1, m);
+    footprint_visit(s0, s1, thr, ug, dg, b1, m);
   }
 }
 
@@ -1239,6 +1257,9 @@ footprint_bwd_kernel(const float4 *__restrict__ splat, int N, int width, int hei
   const int wave = blockIdx.x * 4 + wv;
   const int gbase = wave * 8;
   if (gbase >= N) return;  // whole waves leave; there is no workgroup barrier below
+  // descriptor of this view's record image, built from uniform values only
+  const __amdgpu_buffer_rsrc_t rec_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc((void *)gtstop, 0, width * height * (int)sizeof(StopRec), 0x00020000);
 
   // home phase: the 8 lanes of group k all size the footprint of Gaussian gbase + k
   Walk h = walk_of(make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f), width, height);
@@ -1285,7 +1306,7 @@ footprint_bwd_kernel(const float4 *__restrict__ splat, int N, int width, int hei
     s1 = splat[2 * g + 1];
     footprint_walk(s0, s1, g, r, n, __shfl(h.i0, src, 64), max(__shfl(h.pw, src, 64), 1), cells,
                    __shfl(h.jlo, src, 64), __shfl(h.jhi, src, 64), __shfl(h.thr, src, 64),
-                   __shfl(h.xoff, src, 64), __shfl(h.shear, src, 64), width, gtstop, splat, m);
+                   __shfl(h.xoff, src, 64), __shfl(h.shear, src, 64), width, rec_rsrc, splat, m);
   }
   // partial g2d record of this lane: vx vy |vx| |vy| va vb vc vo
   float *mine = &red[wv][lane * 8];
@@ -1598,6 +1619,8 @@ extern "C" int eg_composite_bwd(const float *splat, const int32_t *offsets, cons
 extern "C" int eg_composite_bwd_footprint(const float *splat, int32_t N, int32_t width, int32_t height,
                                           const float *gtstop, float *g2d, eg_stream_t stream) {
   EG_REQUIRE(N >= 0 && width > 0 && height > 0, "bad sizes");
+  EG_REQUIRE((int64_t)width * height * (int64_t)sizeof(StopRec) < (int64_t)kOutOfImage,
+             "image above 2^31 / 12 pixels (the record image is addressed by 32-bit byte offsets)");
   if (N == 0) return EG_OK;
   EG_REQUIRE(splat && gtstop && g2d, "null pointer");
   hipStream_t st = as_stream(stream);
@@ -1623,6 +1646,10 @@ int launch_composite_fwd_segments(const float *splat, const int32_t *tile_start,
 }
 int launch_footprint_bwd(const float *splat, int32_t N, int32_t width, int32_t height, const float *gtstop, float *g2d,
                          const Batch &bt, int C, hipStream_t st, void *workspace, int64_t max_items, float *loss_out) {
+  if ((int64_t)width * height * (int64_t)sizeof(StopRec) >= (int64_t)kOutOfImage) {
+    set_error("composite_bwd_footprint: image above 2^31 / 12 pixels");
+    return EG_ERR_ARG;
+  }
   float *loss_part = nullptr;
   if (workspace && loss_out) loss_part = carve_workspace(workspace, max_items, cdiv(width, kTile) * cdiv(height, kTile)).loss_part;
   footprint_bwd_kernel<<<dim3(cdiv((int64_t)N, 32), C), 256, 0, st>>>((const float4 *)splat, N, width, height,

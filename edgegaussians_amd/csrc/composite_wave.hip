@@ -608,7 +608,7 @@ __device__ __forceinline__ void wave_fwd_body(const float4 *__restrict__ splat, 
       StopRec r;  // (finalize_pixel<1> of composite.h with the stop Gaussian already in registers)
       r.gT = (T < 1.f) ? v * T : 0.f;
       r.stop_id = (cross && found) ? stop_id : -1;
-      r.stop_depth = (cross && found && stop_id >= 0) ? stop_dep : 0u;
+      r.stop_depth = (cross && found && stop_id >= 0) ? stop_dep : kNoStopDepth;
       gtstop[p] = r;
       l = w_p * fabsf(d);
     }
