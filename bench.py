@@ -453,10 +453,12 @@ def measure(name, args, device, rank, world, backend, spread=False, steps=None, 
     return res
 
 
-def measure_operator(name, args, device, steps=200, warmup=30):
+def measure_operator(name, args, device, steps=200, warmup=30, adam="torch"):
     """Throughput of the DROP-IN: the reference's own per-step protocol (edge_gs.py:247-279, train_gaussians.py:
     81-106) through `from gsplat import rasterization` (this repo's operator), torch autograd and four
-    torch.optim.Adam -- what `train_gaussians.py` gets when it runs unchanged on this library."""
+    torch.optim.Adam -- what `train_gaussians.py` gets when it runs unchanged on this library.  adam="native": the
+    same protocol with the four optimizers built from `edgegaussians_amd.optim.Adam` (a one-word change in
+    train_utils.py:50-59; same interface and state layout, one native launch per step)."""
     from edgegaussians_amd import synth
     from gsplat import rasterization  # the name the reference imports (edge_gs.py:8)
     n, n_views, w, h = CONFIGS[name]
@@ -465,7 +467,11 @@ def measure_operator(name, args, device, steps=200, warmup=30):
     P = {"means": torch.nn.Parameter(sc.means.to(device)), "scales": torch.nn.Parameter(sc.log_scales.to(device)),
          "quats": torch.nn.Parameter(sc.quats.to(device)), "opacities": torch.nn.Parameter(sc.logit_opacities.to(device))}
     lrs = {"means": 2e-3 * LR_SCALE, "scales": 1e-4 * LR_SCALE, "quats": 1e-3 * LR_SCALE, "opacities": 0.03 * LR_SCALE}
-    opts = [torch.optim.Adam([P[k]], lr=lrs[k]) for k in P]
+    if adam == "native":
+        from edgegaussians_amd.optim import Adam as adam_cls
+    else:
+        adam_cls = torch.optim.Adam
+    opts = [adam_cls([P[k]], lr=lrs[k]) for k in P]
     absgrads = torch.zeros(n, device=device)
     vms, Ks, gt = sc.viewmats.to(device), sc.Ks.to(device), sc.gt.to(device)
     whole = synth.weight_map("whole", sc.gt[0]).to(device)
@@ -498,8 +504,9 @@ def measure_operator(name, args, device, steps=200, warmup=30):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     return {"value": n * steps / dt, "unit": "Gaussians*views/s", "ms_per_step": 1e3 * dt / steps, "steps": steps,
-            "warmup": warmup, "path": "gsplat.rasterization shim + torch autograd + 4 x torch.optim.Adam "
-                                      "(the reference's protocol, one host read-back per step like gsplat's)",
+            "warmup": warmup, "path": "gsplat.rasterization shim + torch autograd + 4 x "
+                                      + ("edgegaussians_amd.optim.Adam" if adam == "native" else "torch.optim.Adam")
+                                      + " (the reference's protocol, one host read-back per step like gsplat's)",
             "config": {"workload": f"{name}: {n} Gaussians, {n_views} views @{w}x{h}, loss whole", "n_gaussians": n}}
 
 
@@ -538,6 +545,8 @@ def main():
     ap.add_argument("--views-per-step", type=int, default=1,
                     help="C > 1: C views per launch sequence and optimizer step on this GPU (train_step_batched; the "
                          "semantics of C-way data parallelism).  The headline stays at 1: the reference steps per view")
+    ap.add_argument("--operator-adam", default="torch", choices=["torch", "native"],
+                    help="with --path operator: which optimizer class the four Adam instances are built from")
     ap.add_argument("--path", default="fused", choices=["fused", "operator"],
                     help="operator: time the reference's per-step protocol through the gsplat.rasterization shim + torch "
                          "autograd + 4 torch Adam instead of the fused native step")
@@ -567,7 +576,7 @@ def main():
         raise SystemExit("--spread-opacity and --init-opacity exclude each other")
     args.spread_opacity = not args.init_opacity and (args.spread_opacity or args.config != "config1")
     if args.path == "operator":
-        r = measure_operator(args.config, args, device, min(args.steps, 300), min(args.warmup, 50))
+        r = measure_operator(args.config, args, device, min(args.steps, 300), min(args.warmup, 50), adam=args.operator_adam)
         print(json.dumps({"metric": "train-step Gaussians*views/sec", "n_gpus": 1, "higher_is_better": True, "scaling": "weak",
                           "vs_baseline": None, "dtype": "f32", "data": "synthetic", **r}), flush=True)
         return
@@ -610,6 +619,8 @@ def main():
             extra[key] = r
         for name in ("config1", args.config):  # the drop-in operator path (train_gaussians.py unchanged)
             extra[f"{name}_operator_path"] = measure_operator(name, args, device)
+        # ... and with the drop-in optimizer class as well (train_utils.py:50-59 edited to build it)
+        extra[f"{args.config}_operator_path_native_adam"] = measure_operator(args.config, args, device, adam="native")
         out["other_workloads"] = extra
     if single and rank == 0 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(sc, args.cpu_budget, args.cpu_oracle)

@@ -77,6 +77,7 @@ _SIGS = {
     "eg_composite_bwd_footprint": [_vp, _i32, _i32, _i32, _vp, _vp, _vp],
     "eg_backward_fused": [_vp] * 6 + [_i32, _i32, _i32, _f, _u32] + [_vp] * 10 + [C.POINTER(AdamHyper), _vp],
     "eg_adam_multi": [_vp] * 10 + [_i32, AdamHyper, _vp, _vp, _vp],
+    "eg_adam_tensor": [_vp] * 4 + [_i64, C.c_double, C.c_double, C.c_double, C.c_double, _i32, _i32, _vp],
     "eg_adam_emit": [_vp] * 10 + [_i32, AdamHyper, _vp, _vp, _vp, _vp, _i32, _i32, _u32, _vp, _vp, _i32, _vp, _vp, _i32,
                      _vp, _vp, _vp],
     "eg_project_bwd_adam": [_vp] * 6 + [_i32, _i32, _i32, _f, _u32] + [_vp] * 5 + [AdamHyper, _vp],

@@ -1125,6 +1125,49 @@ extern "C" int eg_adam_multi(float *means, float *scales, float *quats, float *o
   return check_launch("adam_multi");
 }
 
+// One torch.optim.Adam step on ONE flat tensor (the drop-in optimizer of edgegaussians_amd/optim.py: the reference
+// keeps four single-tensor optimizers, train_utils.py:50-60, and steps them one by one, train_gaussians.py:104-106):
+// adam1's arithmetic, four elements per thread where the pointers allow it.
+__global__ void __launch_bounds__(256)
+adam_tensor_kernel(float *__restrict__ p, float *__restrict__ g, float *__restrict__ m, float *__restrict__ v, long long n,
+                   const AdamK h, int zero_grad) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool vec = ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0);
+  const long long n4 = vec ? n / 4 : 0;
+  for (long long i = i0; i < n4; i += stride) {
+    float4 pp = ((float4 *)p)[i], gg = ((const float4 *)g)[i], mm = ((float4 *)m)[i], vv = ((float4 *)v)[i];
+    adam1(pp.x, gg.x, mm.x, vv.x, 0, h);
+    adam1(pp.y, gg.y, mm.y, vv.y, 0, h);
+    adam1(pp.z, gg.z, mm.z, vv.z, 0, h);
+    adam1(pp.w, gg.w, mm.w, vv.w, 0, h);
+    ((float4 *)p)[i] = pp; ((float4 *)m)[i] = mm; ((float4 *)v)[i] = vv;
+    if (zero_grad) ((float4 *)g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  for (long long i = 4 * n4 + i0; i < n; i += stride) {
+    float pp = p[i], mm = m[i], vv = v[i];
+    adam1(pp, g[i], mm, vv, 0, h);
+    p[i] = pp; m[i] = mm; v[i] = vv;
+    if (zero_grad) g[i] = 0.f;
+  }
+}
+
+extern "C" int eg_adam_tensor(float *param, float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, double lr,
+                              double beta1, double beta2, double eps, int32_t step, int32_t zero_grad,
+                              eg_stream_t stream) {
+  EG_REQUIRE(n >= 0 && step >= 1, "bad size / step");
+  if (n == 0) return EG_OK;
+  EG_REQUIRE(param && grad && exp_avg && exp_avg_sq, "null pointer");
+  eg_adam_hyper hy = {};
+  hy.lr_means = lr; hy.beta1 = beta1; hy.beta2 = beta2; hy.eps = eps; hy.step = step;
+  hy.group_steps[1] = hy.group_steps[2] = hy.group_steps[3] = -1;
+  const int64_t want = ((n + 3) / 4 + 255) / 256;
+  const int blocks = (int)(want < 1 ? 1 : (want > 2048 ? 2048 : want));
+  adam_tensor_kernel<<<blocks, 256, 0, as_stream(stream)>>>(param, grad, exp_avg, exp_avg_sq, (long long)n,
+                                                                  make_adamk(hy), zero_grad);
+  return check_launch("adam_tensor");
+}
+
 namespace eg {
 // Adam of a regulariser iteration: gradients scaled by lambda on the fly (RegScale above), null pointer = zero gradient
 int launch_adam_regulariser(float *means, float *scales, float *quats, float *opacities, const float *g_means,

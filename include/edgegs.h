@@ -263,6 +263,14 @@ int eg_adam_multi(float *means, float *scales, float *quats, float *opacities,
                                              all-reduced increment of the data-parallel leg)*/,
                   eg_stream_t stream);
 
+/* One torch.optim.Adam step on ONE flat fp32 tensor: what each of the reference's four optimizers does
+ * (train_utils.py:50-60 builds them, train_gaussians.py:104-106 / 116-118 / 128-130 step them one by one) -- the
+ * native leg of the drop-in optimizer class edgegaussians_amd/optim.py:Adam.  Same arithmetic as eg_adam_multi
+ * (torch's update order, bias corrections formed in double on the host); `step` is the optimizer's 1-based count
+ * AFTER this step.  zero_grad != 0 also clears `grad` (opt.zero_grad(set_to_none=False) in the same pass). */
+int eg_adam_tensor(float *param, float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, double lr, double beta1,
+                   double beta2, double eps, int32_t step, int32_t zero_grad, eg_stream_t stream);
+
 /* The same four Adam steps (identical arithmetic) fused with eg_project_emit of the view this rank rasterises NEXT:
  * the tail of a data-parallel step (after the all-reduce of the gradients), one launch and one read of the
  * parameters instead of two.  The step that follows passes eg_step_args.have_projection = 1.  flags as

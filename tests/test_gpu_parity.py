@@ -1557,3 +1557,106 @@ def test_operator_fast_path_equals_the_general_operator(env):
     rc, _, inf_c, _, _ = run(True, cols)
     rc2, _, _, _, _ = run(False, cols)
     assert not isinstance(inf_c, R._LazyInfo) and torch.equal(rc, rc2)
+
+
+def test_drop_in_adam_equals_torch_adam(env):
+    """`edgegaussians_amd.optim.Adam` in place of `torch.optim.Adam` (train_utils.py:50-60): the same interface and state
+    layout, one native launch per step.  25 steps with changing gradients and a learning-rate change through
+    `param_groups` (what MultiStepLR / CustomLRScheduler do), then the reference's own state surgery (edge_gs.py:384-402:
+    cull rows of the parameter and of exp_avg / exp_avg_sq, swap the parameter object) and more steps: parameters and
+    moments against torch's to 2e-6 of their scale; odd sizes and a misaligned view take the scalar tail."""
+    from edgegaussians_amd.optim import Adam
+    g = torch.Generator().manual_seed(11)
+    shapes = [(5000, 3), (5000, 4), (5000, 1), (7,), (1027, 3)]
+    lrs = [2e-3, 1e-3, 1e-4, 0.03, 5e-3]
+    init = [torch.randn(s, generator=g) for s in shapes]
+    mk = lambda cls: [cls([torch.nn.Parameter(t.clone().cuda())], lr=lr) for t, lr in zip(init, lrs)]  # noqa: E731
+    ours, theirs = mk(Adam), mk(torch.optim.Adam)
+    assert all(isinstance(o, torch.optim.Optimizer) for o in ours)
+
+    def steps(k0, k1):
+        for k in range(k0, k1):
+            for o, t in zip(ours, theirs):
+                po, pt = o.param_groups[0]["params"][0], t.param_groups[0]["params"][0]
+                gr = torch.randn(po.shape, generator=g).cuda() * (0.1 + (k % 3))
+                po.grad, pt.grad = gr.clone(), gr.clone()
+                if k == 12:
+                    o.param_groups[0]["lr"] *= 0.1
+                    t.param_groups[0]["lr"] *= 0.1
+                o.step()
+                t.step()
+                o.zero_grad()
+                t.zero_grad()
+
+    def compare(tag):
+        for i, (o, t) in enumerate(zip(ours, theirs)):
+            po, pt = o.param_groups[0]["params"][0], t.param_groups[0]["params"][0]
+            assert_close(po.detach(), pt.detach(), rtol=2e-6, name=f"{tag} param {i}")
+            so, st = o.state[po], t.state[pt]
+            assert set(so) == {"step", "exp_avg", "exp_avg_sq"} and float(so["step"]) == float(st["step"])
+            assert_close(so["exp_avg"], st["exp_avg"], rtol=2e-6, name=f"{tag} exp_avg {i}")
+            assert_close(so["exp_avg_sq"], st["exp_avg_sq"], rtol=2e-6, name=f"{tag} exp_avg_sq {i}")
+
+    steps(0, 25)
+    compare("25 steps")
+    # the reference's remove_from_optim, applied to both
+    for o in (ours[0], theirs[0]):
+        param = o.param_groups[0]["params"][0]
+        keep = (torch.arange(param.shape[0], device="cuda") % 3) != 0
+        new = torch.nn.Parameter(param.detach()[keep].clone())
+        state = o.state[param]
+        del o.state[param]
+        state["exp_avg"] = state["exp_avg"][keep]
+        state["exp_avg_sq"] = state["exp_avg_sq"][keep]
+        del o.param_groups[0]["params"][0]
+        del o.param_groups[0]["params"]
+        o.param_groups[0]["params"] = [new]
+        o.state[new] = state
+    steps(25, 31)
+    compare("after the cull")
+    # fused zero_grad, and a parameter whose storage is not 16-byte aligned
+    base = torch.zeros(4 * 333 + 1, device="cuda")
+    p = torch.nn.Parameter(base[1:])
+    o = Adam([p], lr=1e-2)
+    q = torch.nn.Parameter(torch.zeros(4 * 333, device="cuda"))
+    t = torch.optim.Adam([q], lr=1e-2)
+    for _ in range(3):
+        gr = torch.randn(4 * 333, generator=g).cuda()
+        p.grad, q.grad = gr.clone(), gr.clone()
+        o.step(zero_grad=True)
+        t.step()
+        assert float(p.grad.abs().sum()) == 0.0
+    assert_close(p.detach(), q.detach(), rtol=2e-6, name="misaligned")
+    with pytest.raises(NotImplementedError):
+        Adam([p], lr=1e-2, weight_decay=0.1)
+
+
+def test_operator_protocol_with_the_drop_in_adam(env):
+    """The reference's whole per-step protocol (edge_gs.py:247-279, train_gaussians.py:81-106) through the operator with
+    `edgegaussians_amd.optim.Adam` against the same protocol with `torch.optim.Adam`: five steps, parameters to 1e-5."""
+    _lib, synth, O = env
+    from edgegaussians_amd import rasterizer as R
+    from edgegaussians_amd.optim import Adam
+    sc = _scene(synth, n=4000, w=200, h=136, views=3)
+    N, W, H = sc.means.shape[0], sc.width, sc.height
+    whole = synth.weight_map("whole", sc.gt[0]).cuda()
+
+    def run(cls):
+        P = [torch.nn.Parameter(t.clone().cuda()) for t in (sc.means, sc.quats, sc.log_scales, sc.logit_opacities)]
+        opts = [cls([p], lr=lr) for p, lr in zip(P, (2e-3, 1e-3, 1e-4, 0.03))]
+        for s in range(5):
+            v = s % 3
+            render, _a, info = R.rasterization(P[0], P[1], torch.exp(P[2]), torch.sigmoid(P[3]).squeeze(-1),
+                                               torch.ones(N, 3, device="cuda"), sc.viewmats[v:v + 1].cuda(),
+                                               sc.Ks[v:v + 1].cuda(), W, H, packed=False, absgrad=True,
+                                               rasterize_mode="antialiased")
+            loss = (whole * (torch.clamp(render[0, ..., 0], 0, 1) - sc.gt[v].cuda()).abs()).sum()
+            loss.backward()
+            for o in opts:
+                o.step()
+                o.zero_grad()
+        return [p.detach().clone() for p in P]
+
+    a, b = run(Adam), run(torch.optim.Adam)
+    for x, y, name in zip(a, b, ("means", "quats", "scales", "opacities")):
+        assert_close(x, y, rtol=1e-5, name=name)

@@ -1,6 +1,6 @@
 """Where a reference-protocol step through the drop-in operator spends its time (every section synchronised, then free-running):
 activations + torch.ones, rasterization forward, loss, backward, absgrad, the four torch.optim.Adam steps.
-usage: python tools/operator_profile.py [config2]"""
+usage: python tools/operator_profile.py [config2] [native]   (native: edgegaussians_amd.optim.Adam instead of torch's)"""
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
@@ -13,7 +13,11 @@ sc = synth.make_scene(n, V, w, h, seed=0, anisotropy=5.0, cameras_npz=bench.REAL
 P = {"means": torch.nn.Parameter(sc.means.to(dev)), "scales": torch.nn.Parameter(sc.log_scales.to(dev)),
      "quats": torch.nn.Parameter(sc.quats.to(dev)), "opacities": torch.nn.Parameter(sc.logit_opacities.to(dev))}
 lrs = {"means": 2e-6, "scales": 1e-7, "quats": 1e-6, "opacities": 3e-5}
-opts = [torch.optim.Adam([P[k]], lr=lrs[k]) for k in P]
+if "native" in sys.argv[2:]:
+    from edgegaussians_amd.optim import Adam as adam_cls
+else:
+    adam_cls = torch.optim.Adam
+opts = [adam_cls([P[k]], lr=lrs[k]) for k in P]
 absgrads = torch.zeros(n, device=dev)
 vms, Ks, gt = sc.viewmats.to(dev), sc.Ks.to(dev), sc.gt.to(dev)
 whole = synth.weight_map("whole", sc.gt[0]).to(dev)
