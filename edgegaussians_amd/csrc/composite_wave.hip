@@ -58,10 +58,15 @@ struct WaveListT {
 // whole slice each: 4x the traffic, 61 MB per launch against 14 MB algorithmic), one barrier, then every wave tests
 // all of them against its quadrant out of LDS.  It stays in place: a pixel that stops behind entry k of a list records
 // that Gaussian's id and depth bits for the backward from here (round 2's epilogue: two dependent global loads).
+// Next to the records the copy holds what the quadrant test needs of a Gaussian but not of a quadrant -- the sigma
+// threshold, the extent of the alpha >= 1/255 ellipse, the slopes of its conjugate diameters -- computed ONCE, by the
+// thread that gathered the record, while the workgroup waits for memory anyway (the four quadrant waves used to redo
+// them: a log, three reciprocals and two square roots per test, a third of the staging phase's issue slots).
 template <int CAP>
 struct WgStage {
   float4 A[CAP];  // x y a b
-  float4 B[CAP];  // c o depth radius
+  float4 B[CAP];  // c log2(o) depth thr      (thr = ln(255 o) + margin)
+  float4 D[CAP];  // ex ey -b/a -b/c          (ex < 0: the Gaussian reaches no pixel)
   int gid[CAP];
 };
 static_assert(sizeof(WaveListT<128>) % 16 == 0 && sizeof(WaveListT<256>) % 16 == 0, "float4 alignment of the lists");
@@ -101,6 +106,44 @@ __device__ __forceinline__ void put_entry(WaveList &wl, int pos, const float4 s0
   X[sl] = s0.x; X[2 + sl] = s0.y;
   Cc[sl] = (0.5f * kNegLog2e) * s0.z; Cc[2 + sl] = kNegLog2e * s0.w;
   D[sl] = (0.5f * kNegLog2e) * s1.x; D[2 + sl] = __builtin_amdgcn_logf(s1.y);  // v_log_f32 = log2
+  wl.idx[pos] = (unsigned char)slice_idx;
+}
+
+// the same test on a record of the workgroup's copy (WgStage: the per-Gaussian part is already there)
+__device__ __forceinline__ bool quad_hit_staged(const float4 s0, const float4 sb, const float4 d, float qx, float qy) {
+#pragma clang fp contract(off)
+  const float x = s0.x, y = s0.y, a = s0.z, b = s0.w, c = sb.x, thr = sb.w;
+  const float ex = d.x, ey = d.y, nba = d.z, nbc = d.w;
+  const float rx0 = qx + 0.5f, ry0 = qy + 0.5f, rx1 = qx + 7.5f, ry1 = qy + 7.5f;
+  const bool aabb = (ex >= 0.f) & (x - ex <= rx1) & (x + ex >= rx0) & (y - ey <= ry1) & (y + ey >= ry0);
+  const float u0 = rx0 - x, u1 = rx1 - x, v0 = ry0 - y, v1 = ry1 - y;
+  const bool centre_in = (u0 <= 0.f) & (u1 >= 0.f) & (v0 <= 0.f) & (v1 >= 0.f);
+  const float us0 = fminf(fmaxf(nba * v0, u0), u1), us1 = fminf(fmaxf(nba * v1, u0), u1);
+  const float vs0 = fminf(fmaxf(nbc * u0, v0), v1), vs1 = fminf(fmaxf(nbc * u1, v0), v1);
+  const float best = fminf(fminf(sigma_at(a, b, c, us0, v0), sigma_at(a, b, c, us1, v1)),
+                           fminf(sigma_at(a, b, c, u0, vs0), sigma_at(a, b, c, u1, vs1)));
+  return aabb & (centre_in | (best <= thr * 1.001f + 1e-3f));
+}
+
+// what the gathering thread derives of a Gaussian (s0 = x y a b; c, o): {ex, ey, -b/a, -b/c}, thr -- quad_hit's arithmetic
+__device__ __forceinline__ float4 stage_derive(const float4 s0, float c, float thr) {
+#pragma clang fp contract(off)
+  const float a = s0.z, b = s0.w;
+  const float det = a * c - b * b;
+  const bool valid = (thr > 0.f) & (det > 0.f);
+  const float k2 = 2.f * thr * __builtin_amdgcn_rcpf(det);  // hardware rcp / sqrt: the inflation covers 1 ulp
+  const float ex = __builtin_amdgcn_sqrtf(k2 * c) * 1.001f + 0.01f;
+  const float ey = __builtin_amdgcn_sqrtf(k2 * a) * 1.001f + 0.01f;
+  return make_float4(valid ? ex : -1.f, ey, -b * __builtin_amdgcn_rcpf(a), -b * __builtin_amdgcn_rcpf(c));
+}
+
+template <class WaveList>
+__device__ __forceinline__ void put_entry_staged(WaveList &wl, int pos, const float4 s0, const float4 sb, int slice_idx) {
+  const int pr = pos >> 1, sl = pos & 1;
+  float *X = (float *)&wl.X[pr], *Cc = (float *)&wl.C[pr], *D = (float *)&wl.D[pr];
+  X[sl] = s0.x; X[2 + sl] = s0.y;
+  Cc[sl] = (0.5f * kNegLog2e) * s0.z; Cc[2 + sl] = kNegLog2e * s0.w;
+  D[sl] = (0.5f * kNegLog2e) * sb.x; D[2 + sl] = sb.y;  // (log2(o) is in the copy)
   wl.idx[pos] = (unsigned char)slice_idx;
 }
 
@@ -154,12 +197,13 @@ __device__ __forceinline__ int stage_rounds(WaveList &wl, const float4 *__restri
 // the same from the workgroup's LDS copy of the slice (n Gaussians)
 template <int R, class WaveList, class Stage>
 __device__ __forceinline__ int stage_from_lds(WaveList &wl, const Stage &st, int n, float qx, float qy, int lane) {
-  float4 r0[R], r1[R];
+  float4 r0[R], r1[R], rd[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     const int k = min(lane + 64 * r, n - 1);
     r0[r] = st.A[k];
     r1[r] = st.B[k];
+    rd[r] = st.D[k];
   }
   bool hit[R];
   unsigned long long bal[R];
@@ -167,7 +211,7 @@ __device__ __forceinline__ int stage_from_lds(WaveList &wl, const Stage &st, int
   base[0] = 0;
 #pragma unroll
   for (int r = 0; r < R; ++r) {
-    hit[r] = (lane + 64 * r < n) & quad_hit(r0[r], r1[r], qx, qy);
+    hit[r] = (lane + 64 * r < n) & quad_hit_staged(r0[r], r1[r], rd[r], qx, qy);
     bal[r] = __ballot(hit[r]);
     base[r + 1] = base[r] + __popcll(bal[r]);
   }
@@ -175,7 +219,7 @@ __device__ __forceinline__ int stage_from_lds(WaveList &wl, const Stage &st, int
   const unsigned long long lt = (1ull << lane) - 1ull;
 #pragma unroll
   for (int r = 0; r < R; ++r)
-    if (hit[r]) put_entry(wl, base[r] + __popcll(bal[r] & lt), r0[r], r1[r], lane + 64 * r);
+    if (hit[r]) put_entry_staged(wl, base[r] + __popcll(bal[r] & lt), r0[r], r1[r], lane + 64 * r);
   if (lane < 3) {  // sentinels: log2(opacity) = -1e30 => alpha = 0
     const int e = n_mine + lane, pr = e >> 1, sl = e & 1;
     ((float *)&wl.X[pr])[sl] = 0.f; ((float *)&wl.X[pr])[2 + sl] = 0.f;
@@ -383,21 +427,37 @@ __device__ __forceinline__ void look_back(const unsigned long long *gran, int i0
   }
 }
 
+// What the kernel reads, resolved on the host for a single view (the training step's case): one block of kernel
+// arguments that the compiler loads in ONE batch at the head of the wave.  (Round 3's first version took the general
+// tables -- TileTable, SliceWs, Batch -- by value and adjusted them per view behind null-pointer tests: seven dependent
+// scalar loads and waits before the first byte of the item record was requested.)
+struct WaveArgs {
+  const float4 *splat;
+  const int4 *item_rec;
+  const int *total, *flat;
+  int *cursor_reset;
+  unsigned long long *gran;  // [max_items][256] hand-over granules
+  int *dead_hint, *ctl;
+  float *loss_part;
+  const float *gt, *wmap;
+  StopRec *gtstop;
+  unsigned long long *prof;
+  int width, height, tw, n_tiles;
+  unsigned tag;
+  float loss_scale;
+  int dbg;
+};
+
 // TIMED (EG_FWD_PROF=1, debugging only): shader-clock ticks per phase of every wave of the LAST launch, one 8-word
 // record per wave in prof[(item * 4 + quadrant) * 8 ...] (plain stores: atomics on shared words would serialise and
 // be measured themselves); word 7 = 1 marks a wave that ran (read by eg_debug_fwd_profile)
-template <bool CHAINED, bool TIMED, int SPAN>
-__device__ __forceinline__ void wave_fwd_body(const float4 *__restrict__ splat, const TileTable tt_,
-                                              const int *__restrict__ total, const int *__restrict__ flat, int width,
-                                              int height, int tw, const SliceWs ws_, unsigned tag,
-                                              const float *__restrict__ gt, const float *__restrict__ wmap,
-                                              float loss_scale, StopRec *__restrict__ gtstop, const Batch bt,
-                                              unsigned long long *__restrict__ prof,
-                                              WaveListT<SPAN * kSlice> *lists, WgStage<SPAN * kSlice> &stg, int dbg) {
+template <bool CHAINED, bool TIMED, int SPAN, bool BATCHED>
+__device__ __forceinline__ void wave_fwd_body(WaveArgs a, const Batch &bt, WaveListT<SPAN * kSlice> *lists,
+                                              WgStage<SPAN * kSlice> &stg) {
   typedef WaveListT<SPAN * kSlice> WaveList;
   constexpr int span = SPAN;
   long long t_prev = TIMED ? (long long)__builtin_readcyclecounter() : 0;
-  unsigned long long *my_prof = TIMED ? prof + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 : nullptr;
+  unsigned long long *my_prof = TIMED ? a.prof + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 : nullptr;
 #define EG_TICK(k)                                                                                        \
   do {                                                                                                    \
     if (TIMED) {                                                                                          \
@@ -407,19 +467,34 @@ __device__ __forceinline__ void wave_fwd_body(const float4 *__restrict__ splat, 
       t_prev = now_;                                                                                      \
     }                                                                                                     \
   } while (0)
-  const int bv = blockIdx.y;  // view of a batched step
-  const TileTable tt = view_of(tt_, bt, bv);
-  const SliceWs ws = view_of(ws_, bt, bv);
-  total += 4 * bv; flat += bv * bt.keys; splat += bv * bt.splat4; gtstop += bv * bt.pixels;
-  if (bt.gt[0]) { gt = bt.gt[bv]; wmap = bt.wmap[bv]; }
+  if (BATCHED) {  // view blockIdx.y of a batched step: [C, ...] work buffers
+    const long long bv = blockIdx.y;
+    a.total += 4 * bv; a.flat += bv * bt.keys; a.splat += bv * bt.splat4; a.gtstop += bv * bt.pixels;
+    a.item_rec += bv * bt.items; a.cursor_reset += bv * bt.tiles;
+    a.gran = (unsigned long long *)((char *)a.gran + bv * bt.ws_bytes);
+    a.dead_hint = (int *)((char *)a.dead_hint + bv * bt.ws_bytes); a.ctl = (int *)((char *)a.ctl + bv * bt.ws_bytes);
+    a.loss_part = (float *)((char *)a.loss_part + bv * bt.ws_bytes);
+    a.gt = bt.gt[bv]; a.wmap = bt.wmap[bv];
+  }
+  const float4 *__restrict__ splat = a.splat;
+  const int *__restrict__ flat = a.flat;
+  const float *__restrict__ gt = a.gt, *__restrict__ wmap = a.wmap;
+  StopRec *__restrict__ gtstop = a.gtstop;
+  const int width = a.width, height = a.height, tw = a.tw, dbg = a.dbg;
+  const unsigned tag = a.tag;
+  const float loss_scale = a.loss_scale;
   const int b = blockIdx.x;
-  if (b >= total[2]) return;
+  // where this item lives: ONE 16-byte record left by the sort kernel.  A wave's slice is `span` consecutive items
+  // (span * 128 <= kWaveSlice Gaussians); the workgroups of the items in between have nothing to do.  Requested together
+  // with the item count (the grid covers max_items, the table has max_items entries: a stale record beyond the count is
+  // read and dropped) -- one dependent round trip less at the head of every wave.
+  const int4 ir = a.item_rec[b];
+  const int n_items = a.total[2];
+  // ('|', and a test on the record that never fires: the exit needs BOTH loads, so neither is sunk behind the branch)
+  if ((b >= n_items) | (ir.y < 0)) return;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   if (TIMED && lane < 8) my_prof[lane] = lane == 7 ? 1ull : 0ull;
   WaveList &wl = lists[wv];
-  // where this item lives: ONE 16-byte record left by the sort kernel.  A wave's slice is `span` consecutive items
-  // (span * 128 <= kWaveSlice Gaussians); the workgroups of the items in between have nothing to do
-  const int4 ir = tt.item_rec[b];
   const int s128 = ir.y & 0xffff;
   if (s128 % span) return;
   const int tile = ir.x, s_me = s128 / span, ns = ((ir.y >> 16) + span - 1) / span, slice = span * kSlice;
@@ -431,7 +506,7 @@ __device__ __forceinline__ void wave_fwd_body(const float4 *__restrict__ splat, 
   const int i = qi + (lane >> 3), j = qj + (lane & 7);
   const bool inside = (i < height) && (j < width);
   const float px = (float)j + 0.5f, py = (float)i + 0.5f;
-  if (tt.cursor_reset && s_me == 0 && threadIdx.x == 0) tt.cursor_reset[tile] = 0;
+  if (a.cursor_reset && s_me == 0 && threadIdx.x == 0) a.cursor_reset[tile] = 0;
   // who finalises pixels here: in speculative mode only the tile's last slice, in chained mode any slice may
   const bool finisher = CHAINED || s_me == ns - 1;
   // the pixel's target and loss weight do not depend on the slices: in flight under everything else
@@ -444,17 +519,23 @@ __device__ __forceinline__ void wave_fwd_body(const float4 *__restrict__ splat, 
 #pragma unroll
     for (int r = 0; r < SPAN; ++r) {
       const int t = threadIdx.x + 256 * r, k = t >> 1;
+      // (the two threads of a Gaussian sit in adjacent lanes; both run the shuffles, a thread beyond the slice too)
+      const int g = flat[start + min(k, n - 1)];
+      const float4 rec = splat[2 * g + (t & 1)];
+      // odd thread: c o depth radius -> log2(o) and the sigma threshold ln(255 o) + margin; even thread: x y a b
+      const float lo = __builtin_amdgcn_logf(rec.y);
+      const float thr = (lo + 7.99435343685886f) * 0.693147180559945f + kThrMargin;  // log2(255), ln 2
+      const float c_o = __shfl_xor(rec.x, 1, 64), thr_o = __shfl_xor(thr, 1, 64);
       if (k < n) {
-        const int g = flat[start + k];
-        const float4 rec = splat[2 * g + (t & 1)];
-        if (t & 1) stg.B[k] = rec; else { stg.A[k] = rec; stg.gid[k] = g; }
+        if (t & 1) stg.B[k] = make_float4(rec.x, lo, rec.z, thr);
+        else { stg.A[k] = rec; stg.D[k] = stage_derive(rec, c_o, thr_o); stg.gid[k] = g; }
       }
     }
   }
   __syncthreads();  // (the only one: every wave of the workgroup is still here)
   EG_TICK(0);  // head: the item record, the slice's records (+ the pixel's gt / weight)
 
-  unsigned long long *gran = (unsigned long long *)ws.sliceP;  // [max_items][256] (sliceP and sliceL are contiguous)
+  unsigned long long *gran = a.gran;  // [max_items][256] (sliceP and sliceL of the workspace are contiguous)
   float T = 1.f, l = 0.f;
   bool before = false;  // the pixel stopped in a slice in front of this one
   int looked = 0;       // slices [0, looked) are already folded into T
@@ -468,9 +549,9 @@ __device__ __forceinline__ void wave_fwd_body(const float4 *__restrict__ splat, 
   // quadrant has indeed stopped there it publishes a neutral granule and leaves, otherwise it carries on as usual
   // (late, nothing else).  The hint never changes a result.  Key = tag << 8 | (255 - slice), kept by atomicMax: a later
   // call overrides an earlier one, within a call the smallest slice wins; two arrays alternate with the tag's parity.
-  int *hint_prev = ws.dead_hint + ((tag + 1u) & 1u) * 4 * gridDim_tiles(tw, height), *hint_cur = nullptr;
+  int *hint_prev = a.dead_hint + ((tag + 1u) & 1u) * 4 * a.n_tiles, *hint_cur = nullptr;
   if (CHAINED) {
-    hint_cur = ws.dead_hint + (tag & 1u) * 4 * gridDim_tiles(tw, height) + tile * 4 + wv;
+    hint_cur = a.dead_hint + (tag & 1u) * 4 * a.n_tiles + tile * 4 + wv;
     const int key = hint_prev[tile * 4 + wv];
     const int h = ((unsigned)key >> 8) == ((tag - 1u) & kGranuleTagMask) ? 255 - (key & 255) : 0x7fffffff;
     if (s_me >= h && s_me > 0 && h > 0 && !(dbg & 4)) {
@@ -530,7 +611,7 @@ __device__ __forceinline__ void wave_fwd_body(const float4 *__restrict__ splat, 
     if (__ballot(stop_seen && inside) != 0ull) {
       // the caller speculated that no pixel would stop: tell it (sticky word 3 of the control block); it restores its
       // state and runs the step again in chained mode
-      if (lane == 0) atomicExch(&ws.ctl[3], 1);
+      if (lane == 0) atomicExch(&a.ctl[3], 1);
     }
     if (inside) l = finalize_train(p, T, 0, false, flat, gt_p, w_p, loss_scale, gtstop, splat);
   } else {
@@ -546,7 +627,7 @@ __device__ __forceinline__ void wave_fwd_body(const float4 *__restrict__ splat, 
     cross = cross && inside;
     bool found = false;
     if (__ballot(cross) != 0ull) {
-      if (lane == 0 && ws.ctl[2] == 0) atomicMax(&ws.ctl[2], 1);  // "pixels do stop": the caller's launch-mode hint
+      if (lane == 0 && a.ctl[2] == 0) atomicMax(&a.ctl[2], 1);  // "pixels do stop": the caller's launch-mode hint
       // exact stop from the list still in LDS, sequentially in depth order from T; should float rounding move the
       // crossing past the slice end, the same lanes carry on through the following slices (staged afresh)
       bool live = cross;
@@ -616,34 +697,18 @@ __device__ __forceinline__ void wave_fwd_body(const float4 *__restrict__ splat, 
   // loss terms of this wave's pixels -> one of 64 partial sums
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) l += __shfl_xor(l, d, 64);
-  if (lane == 0 && l != 0.f) unsafeAtomicAdd(&ws.loss_part[(tile * 4 + wv) & 63], l);
+  if (lane == 0 && l != 0.f) unsafeAtomicAdd(&a.loss_part[(tile * 4 + wv) & 63], l);
   EG_TICK(6);  // epilogue
 #undef EG_TICK
 }
 
-// (span 1: eight waves per SIMD -- 64 VGPRs -- are worth more than the few registers the compiler would like on top)
-template <bool CHAINED, bool TIMED>
+// (eight waves per SIMD -- 64 VGPRs -- are worth more than the few registers the compiler would like on top)
+template <bool CHAINED, bool TIMED, bool BATCHED>
 __global__ void __launch_bounds__(256, 8)
-composite_wave_fwd_kernel(const float4 *__restrict__ splat, const TileTable tt, const int *__restrict__ total,
-                          const int *__restrict__ flat, int width, int height, int tw, const SliceWs ws, unsigned tag,
-                          const float *__restrict__ gt, const float *__restrict__ wmap, float loss_scale,
-                          StopRec *__restrict__ gtstop, const Batch bt, unsigned long long *__restrict__ prof, int dbg) {
+composite_wave_fwd_kernel(const WaveArgs a, const Batch bt) {
   __shared__ WaveListT<kSlice> lists[4];
   __shared__ WgStage<kSlice> stg;
-  wave_fwd_body<CHAINED, TIMED, 1>(splat, tt, total, flat, width, height, tw, ws, tag, gt, wmap, loss_scale, gtstop, bt, prof,
-                                   lists, stg, dbg);
-}
-
-template <bool CHAINED, bool TIMED>
-__global__ void __launch_bounds__(256)
-composite_wave2_fwd_kernel(const float4 *__restrict__ splat, const TileTable tt, const int *__restrict__ total,
-                           const int *__restrict__ flat, int width, int height, int tw, const SliceWs ws, unsigned tag,
-                           const float *__restrict__ gt, const float *__restrict__ wmap, float loss_scale,
-                           StopRec *__restrict__ gtstop, const Batch bt, unsigned long long *__restrict__ prof, int dbg) {
-  __shared__ WaveListT<2 * kSlice> lists[4];
-  __shared__ WgStage<2 * kSlice> stg;
-  wave_fwd_body<CHAINED, TIMED, 2>(splat, tt, total, flat, width, height, tw, ws, tag, gt, wmap, loss_scale, gtstop, bt, prof,
-                                   lists, stg, dbg);
+  wave_fwd_body<CHAINED, TIMED, 1, BATCHED>(a, bt, lists, stg);
 }
 
 static unsigned long long *g_prof = nullptr;
@@ -662,27 +727,27 @@ int launch_wave_fwd(const float4 *splat, const TileTable tt, const int32_t *flat
     (void)hipMalloc((void **)&g_prof, (size_t)max_items * 32 * sizeof(unsigned long long));
   }
   if (timed) (void)hipMemsetAsync(g_prof, 0, (size_t)max_items * 32 * sizeof(unsigned long long), s);
-  tag &= kGranuleTagMask;
-  // span: a wave's slice is one 128-Gaussian item (span 1) or two (span 2, EG_WAVE_SPAN=2: an experiment that lost
-  // everywhere it was tried -- twice the LDS per wave takes a quarter of the wave slots away and the kernel lasts as
-  // long as its heaviest waves, which become twice as heavy; config 2 trained-like 46.7 -> 56.2 us)
-  static const int span = (getenv("EG_WAVE_SPAN") && atoi(getenv("EG_WAVE_SPAN")) == 2) ? 2 : 1;
+  // (a wave's slice is one 128-Gaussian item.  Two items per wave -- meant to fit config 2 into one round of wave
+  // slots -- lost everywhere it was tried: twice the LDS per wave takes a quarter of the slots away and the kernel lasts
+  // as long as its heaviest waves, which become twice as heavy; config 2 trained-like 46.7 -> 56.2 us.  Removed.)
   // debugging switches (EG_WAVE_DBG bits): 1 stage from memory per wave instead of the workgroup's LDS copy, 2 exact stop
   // in lockstep from the front instead of per lane from the checkpoints, 4 no dead-slice gating
   static const int dbg = getenv("EG_WAVE_DBG") ? atoi(getenv("EG_WAVE_DBG")) : 0;
   (void)max_tile_hint;
+  WaveArgs a;
+  a.splat = splat; a.item_rec = tt.item_rec; a.total = total; a.flat = flatten_ids; a.cursor_reset = tt.cursor_reset;
+  a.gran = (unsigned long long *)ws.sliceP; a.dead_hint = ws.dead_hint; a.ctl = ws.ctl; a.loss_part = ws.loss_part;
+  a.gt = gt; a.wmap = wmap; a.gtstop = (StopRec *)gtstop; a.prof = g_prof;
+  a.width = width; a.height = height; a.tw = tw; a.n_tiles = tw * th;
+  a.tag = tag & kGranuleTagMask; a.loss_scale = loss_scale; a.dbg = dbg;
+  // one view: everything is resolved here and the kernel never looks at the batch descriptor
+  const bool batched = C > 1;
+  if (!batched && bt.gt[0]) { a.gt = bt.gt[0]; a.wmap = bt.wmap[0]; }
   const dim3 grid((unsigned)max_items, C);
-#define EG_LAUNCH(KN_, CH_, TI_)                                                                                    \
-  KN_<CH_, TI_><<<grid, 256, 0, s>>>(splat, tt, total, flatten_ids, width, height, tw, ws, tag, gt, wmap, loss_scale, \
-                                     (StopRec *)gtstop, bt, g_prof, dbg)
-#define EG_LAUNCH2(CH_, TI_)                                                 \
-  do {                                                                       \
-    if (span == 2) EG_LAUNCH(composite_wave2_fwd_kernel, CH_, TI_);          \
-    else EG_LAUNCH(composite_wave_fwd_kernel, CH_, TI_);                     \
-  } while (0)
-  if (chained) { if (timed) EG_LAUNCH2(true, true); else EG_LAUNCH2(true, false); }
-  else         { if (timed) EG_LAUNCH2(false, true); else EG_LAUNCH2(false, false); }
-#undef EG_LAUNCH2
+#define EG_LAUNCH(CH_, TI_, BA_) composite_wave_fwd_kernel<CH_, TI_, BA_><<<grid, 256, 0, s>>>(a, bt)
+  if (batched) { if (chained) EG_LAUNCH(true, false, true); else EG_LAUNCH(false, false, true); }
+  else if (timed) { if (chained) EG_LAUNCH(true, true, false); else EG_LAUNCH(false, true, false); }
+  else { if (chained) EG_LAUNCH(true, false, false); else EG_LAUNCH(false, false, false); }
 #undef EG_LAUNCH
   timing_mark(kMarkSlice, s);
   timing_mark(kMarkRewalk, s);
