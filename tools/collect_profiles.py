@@ -43,7 +43,9 @@ def main():
               "bench_config4_init_opacity.json": "bench_config4_init_opacity.json",
               "issue_rates.txt": "microbench_issue_rates.txt", "operator_profile_config2.txt": "operator_profile_config2.txt", "fwd_wave_phases_config2.txt": "fwd_wave_phases_config2.txt",
               "bench_config2_force_dp.json": "bench_config2_force_dp.json", "regularizers_timing.json": "regularizers_timing.json",
-              "train_abc_fixture.txt": "train_abc_fixture.txt"}
+              "train_abc_fixture.txt": "train_abc_fixture.txt", "late_epoch_bench.txt": "late_epoch_bench.txt",
+              "bench_config2_operator_torch_adam.json": "bench_config2_operator_torch_adam.json",
+              "bench_config2_operator_native_adam.json": "bench_config2_operator_native_adam.json"}
     for c in ("config1", "config2", "config2i"):
         copies[f"kernel_stats_{c}.txt"] = f"kernel_stats_{c}.txt"
         copies[f"timeline_gaps_{c}.txt"] = f"timeline_gaps_{c}.txt"

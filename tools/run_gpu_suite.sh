@@ -24,6 +24,9 @@ EG_FWD_PROF=1 python tools/fwd_prof.py config2 2>/dev/null | grep -v "^RCCL\|^HI
 timeout 300 python bench.py --force-dp --no-cpu-baseline --no-traffic --no-extra 2>/dev/null | tail -1 > $O/bench_config2_force_dp.json
 timeout 300 python tools/bench_regularizers.py 2>/dev/null | tail -1 > $O/regularizers_timing.json
 timeout 300 python tools/operator_profile.py config2 2>/dev/null | grep -v "^RCCL\|^HIP\|amdgpu.ids" > $O/operator_profile_config2.txt
+( echo "--- with edgegaussians_amd.optim.Adam ---"; timeout 300 python tools/operator_profile.py config2 native 2>/dev/null | grep -v "^RCCL\|^HIP\|amdgpu.ids" ) >> $O/operator_profile_config2.txt
+for a in torch native; do timeout 300 python bench.py --path operator --operator-adam $a --no-cpu-baseline --no-traffic --no-extra 2>/dev/null | tail -1 > $O/bench_config2_operator_${a}_adam.json; done
+timeout 300 python tools/late_epoch_bench.py 2>/dev/null | grep -v "^RCCL\|^HIP\|amdgpu.ids" > $O/late_epoch_bench.txt
 timeout 300 python tools/train_abc_fixture.py 2>/dev/null | tail -5 > $O/train_abc_fixture.txt
 ( echo "--- first run of the process (--cold) ---"; timeout 300 python tools/train_abc_fixture.py --cold 2>/dev/null | tail -2 | head -1 ) >> $O/train_abc_fixture.txt
 cd /tmp && export TMPDIR=/tmp
