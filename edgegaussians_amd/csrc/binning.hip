@@ -305,11 +305,31 @@ struct SegTable {
   // optional output for the wave-autonomous forward (composite_wave.hip): one 16-byte record per item
   // {tile, slice | slices << 16, first key of the slice, end of the TILE's keys}
   int4 *item_rec;
+  // with `total` and `item_rec`: the records are laid out in DISPATCH order, FRONT SLICES FIRST -- slices 0..7 of every
+  // tile (tile by tile, in the order of the item numbering), then the deeper slices of the tiles that have them --
+  // while item_first / item_end / item_tile (and the hand-over storage the forward addresses through
+  // item_first) keep the contiguous per-tile numbering.  The forward takes one workgroup per record in record order:
+  // the front slices of all tiles, which are alive and carry the look-backs and the exact stops, start early, and the
+  // deep slices of the heavy tiles -- mostly behind every pixel's stop -- fill the tail, by which time the granules
+  // they look back on are there.  (Tile-major order put the live slices of the 6-9-slice tiles at the end of the first
+  // round of workgroups, behind the heavy tiles' dead ones: they were the launch's tail.  An exactly slice-major order
+  // measured -3.2 us in the forward but needs a histogram of the slice counts in every sort workgroup: +4.7 us
+  // there; the two classes cost one more running sum.)
+  // A slice still follows all slices in front of it: the look-back's dispatch-order guarantee holds.
+  int slice_major = 0;  // the class boundary (slices), 0 = off
 };
+constexpr int kFrontDefault = 8;  // class boundary of the dispatch order (slices); SegTable::slice_major carries it
 
 // THREADS = number of buckets; CAP = keys per buffer (two buffers).  n_lo < n handled here.
 template <int THREADS, int CAP, bool LARGE>
-__global__ void __launch_bounds__(THREADS)
+// (512-thread variant: two workgroups per CU need 4 waves per SIMD, i.e. at most 128 VGPRs)
+#ifndef EG_SORT_WAVES
+#define EG_SORT_WAVES 4
+#endif
+#ifndef EG_SORT_WAVES_256
+#define EG_SORT_WAVES_256 1
+#endif
+__global__ void __launch_bounds__(THREADS, THREADS == 512 ? EG_SORT_WAVES : (THREADS == 256 ? EG_SORT_WAVES_256 : 1))
 tile_sort_kernel(unsigned long long *__restrict__ keys, const int *__restrict__ offsets, int T,
                  long long capacity, int small_cap, int *__restrict__ flatten_ids,
                  long long *__restrict__ isect_ids, const SegTable seg_, const Batch bt) {
@@ -336,17 +356,19 @@ tile_sort_kernel(unsigned long long *__restrict__ keys, const int *__restrict__ 
   for (int tile = blockIdx.x; tile < T; tile += gridDim.x) {
   __syncthreads();
   long long start, end;
-  __shared__ int s_pre[4][THREADS / 64];
+  __shared__ int s_pre[5][THREADS / 64];
   bool prefix_pending = false;  // (uniform) the tile prefix still has to be finished: see SegTable::total
   int pop_here = 0;
   // after a barrier: every thread sums the waves' partials; thread 0 writes the tile's table entries (and the
   // totals of the view, if this is the last tile), the first threads the item -> tile map
   auto finish_prefix = [&](int kept_) {
-    int isum = 0, msum = 0, cmax = 0, itot = 0;
+    int isum = 0, msum = 0, cmax = 0, itot = 0, front = 0;
 #pragma unroll
     for (int w = 0; w < THREADS / 64; ++w) {
       isum += s_pre[0][w]; msum += s_pre[1][w]; cmax = max(cmax, s_pre[2][w]); itot += s_pre[3][w];
+      front += s_pre[4][w];
     }
+    const int isumf = front & 0xffff, itotf = front >> 16;
     const int first_ = min(isum, seg.max_items);
     const int items_ = min(max(1, (kept_ + 127) >> 7), max(0, seg.max_items - first_));
     if (tid == 0) {
@@ -361,10 +383,19 @@ tile_sort_kernel(unsigned long long *__restrict__ keys, const int *__restrict__ 
         seg.total[3] = cmax;
       }
     }
+    // dispatch index of slice i: class 0 = slices [0, kFront) of all tiles, class 1 = the rest; inside a class tile by
+    // tile in the item numbering's order.  (Every workgroup forms the same sums from
+    // the same cursors.  Not when the item tables overflow: the truncated tiles would leave holes in the record
+    // table, and a stale record could send a wave looking back on a slice nobody publishes.)
+    const bool front_first = !LARGE && seg.slice_major && itot <= seg.max_items;
     for (int i = tid; i < items_; i += THREADS) {
       seg.item_tile[first_ + i] = tile;
       if (seg.item_rec) {
-        seg.item_rec[first_ + i] = make_int4(tile, i | (items_ << 16), tile * seg.seg_cap + i * 128, tile * seg.seg_cap + kept_);
+        int disp = first_ + i;
+        if (front_first)
+          disp = i < seg.slice_major ? isumf + i : itotf + (isum - isumf) + (i - seg.slice_major);
+        if (disp < seg.max_items)
+          seg.item_rec[disp] = make_int4(tile, i | (items_ << 16), tile * seg.seg_cap + i * 128, tile * seg.seg_cap + kept_);
       }
     }
     prefix_pending = false;
@@ -389,6 +420,9 @@ tile_sort_kernel(unsigned long long *__restrict__ keys, const int *__restrict__ 
         pop_here = seg.cursor[tile];
         kept = min(pop_here, seg.seg_cap);
         int isum = 0, msum = 0, cmax = 0, itot = 0;
+        // the same over min(items, kFront): the sum over the tiles in front in the low half, over all tiles in the high
+        // half (at most 2048 * 15 each)
+        int front = 0;
 #pragma unroll
         for (int j = 0; j < kPrefixHereMaxTiles / THREADS; ++j)
           if (pv[j] >= 0) {
@@ -397,16 +431,18 @@ tile_sort_kernel(unsigned long long *__restrict__ keys, const int *__restrict__ 
             const bool before = seg.rank_order ? (pv[j] > pop_here || (pv[j] == pop_here && tj < tile)) : tj < tile;
             isum += before ? it : 0;
             itot += it; msum += kk; cmax = max(cmax, pv[j]);
+            const int itf = min(it, seg.slice_major);
+            front += (before ? itf : 0) + (itf << 16);
           }
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) {
-          isum += __shfl_xor(isum, d, 64);
-          msum += __shfl_xor(msum, d, 64);
-          itot += __shfl_xor(itot, d, 64);
-          cmax = max(cmax, __shfl_xor(cmax, d, 64));
-        }
-        if ((tid & 63) == 0) {
+        // (DPP scans: the totals land in lane 63)
+        isum = wave_scan_dpp(isum, 0, OpAdd());
+        msum = wave_scan_dpp(msum, 0, OpAdd());
+        itot = wave_scan_dpp(itot, 0, OpAdd());
+        cmax = wave_scan_dpp(cmax, 0, OpMaxI());
+        front = wave_scan_dpp(front, 0, OpAdd());
+        if ((tid & 63) == 63) {
           s_pre[0][tid >> 6] = isum; s_pre[1][tid >> 6] = msum; s_pre[2][tid >> 6] = cmax; s_pre[3][tid >> 6] = itot;
+          s_pre[4][tid >> 6] = front;
         }
         prefix_pending = true;
         first = items = 0;
@@ -469,12 +505,9 @@ tile_sort_kernel(unsigned long long *__restrict__ keys, const int *__restrict__ 
     // depth range of the tile: both reductions share one LDS hop and one barrier
     constexpr int NW = THREADS / 64;
     const int lane = tid & 63, wv = tid >> 6;
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-      dmin = min(dmin, (unsigned)__shfl_xor((int)dmin, d, 64));
-      dmax = max(dmax, (unsigned)__shfl_xor((int)dmax, d, 64));
-    }
-    if (lane == 0) { wave_tmp[wv] = dmin; wave_tmp[16 + wv] = dmax; }
+    dmin = (unsigned)wave_scan_dpp((int)dmin, -1, OpMinU());
+    dmax = (unsigned)wave_scan_dpp((int)dmax, 0, OpMaxU());
+    if (lane == 63) { wave_tmp[wv] = dmin; wave_tmp[16 + wv] = dmax; }
     __syncthreads();
     if (prefix_pending) finish_prefix(n);
 #pragma unroll
@@ -489,16 +522,9 @@ tile_sort_kernel(unsigned long long *__restrict__ keys, const int *__restrict__ 
     __syncthreads();
     // exclusive scan of the bucket counts and their maximum, again one hop and one barrier
     const int cnt = hist[tid];
-    int incl = cnt, wmax = cnt;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const int o = __shfl_up(incl, d, 64);
-      if (lane >= d) incl += o;
-    }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) wmax = max(wmax, __shfl_xor(wmax, d, 64));
-    if (lane == 63) wave_tmp2[wv] = (unsigned)incl;
-    if (lane == 0) wave_tmp2[16 + wv] = (unsigned)wmax;
+    const int incl = wave_scan_dpp(cnt, 0, OpAdd());
+    const int wmax = wave_scan_dpp(cnt, 0, OpMaxI());
+    if (lane == 63) { wave_tmp2[wv] = (unsigned)incl; wave_tmp2[16 + wv] = (unsigned)wmax; }
     __syncthreads();
     int pre = 0;
     unsigned fill = 0u;
@@ -715,6 +741,7 @@ extern "C" int eg_sort_segments(uint64_t *keys, int32_t *tile_cursor, int32_t T,
   seg.total = nullptr;
   seg.rank_order = 0;
   seg.item_rec = nullptr;
+  seg.slice_major = 0;
   return launch_tile_sort(keys, nullptr, T, (int64_t)T * seg_cap, flatten_ids, nullptr, max_tile_hint, seg, stream);
 }
 
@@ -729,9 +756,14 @@ int launch_sort_segments(uint64_t *keys, int32_t *tile_cursor, int32_t T, int32_
   seg.item_first = item_first; seg.item_end = item_end;
   seg.item_tile = item_tile; seg.max_items = max_items;
   seg.total = total_prefix_here;
-  static const int rank_order = getenv("EG_TILE_ORDER") ? atoi(getenv("EG_TILE_ORDER")) : 1;
+  // (EG_TILE_ORDER=1: number the items heaviest tile first -- neutral on its own, and worse than tile order once the
+  // front slices are dispatched first; kept as a switch)
+  static const int rank_order = getenv("EG_TILE_ORDER") ? atoi(getenv("EG_TILE_ORDER")) : 0;
   seg.rank_order = rank_order;
   seg.item_rec = (int4 *)item_rec;
+  // EG_FRONT_SLICES: the class boundary of the dispatch order (0 = records in item order); at most 15 (the packed sums)
+  static const int front = getenv("EG_FRONT_SLICES") ? atoi(getenv("EG_FRONT_SLICES")) : kFrontDefault;
+  seg.slice_major = front < 0 ? 0 : (front > 15 ? 15 : front);
   return launch_tile_sort(keys, nullptr, T, (int64_t)T * seg_cap, flatten_ids, nullptr, max_tile_hint, seg,
                           (eg_stream_t)st, bt, C);
 }

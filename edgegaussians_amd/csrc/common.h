@@ -88,6 +88,30 @@ int launch_project_bwd_batched(float *means, float *quats, float *scales, float 
                                hipStream_t st);
 
 inline hipStream_t as_stream(eg_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+#if defined(__HIPCC__)
+// Inclusive scan over the 64 lanes of a wavefront with DPP (row shifts inside the rows of 16, then the two row
+// broadcasts): six VALU instructions, no trip through the LDS crossbar -- `__shfl_xor` / `__shfl_up` compile to
+// ds_bpermute_b32 with a computed lane address, ~100 cycles each and six of them in a dependent chain per reduction.
+// Lane 63 holds the reduction over the wave.  `ident` is the operation's identity (lanes a shift leaves without a
+// source read it).
+#define EG_DPP_STEP(ctrl, rmask) v = op(v, __builtin_amdgcn_update_dpp(ident, v, ctrl, rmask, 0xf, false))
+template <class Op>
+__device__ __forceinline__ int wave_scan_dpp(int v, int ident, Op op) {
+  EG_DPP_STEP(0x111, 0xf);  // row_shr:1
+  EG_DPP_STEP(0x112, 0xf);  // row_shr:2
+  EG_DPP_STEP(0x114, 0xf);  // row_shr:4
+  EG_DPP_STEP(0x118, 0xf);  // row_shr:8
+  EG_DPP_STEP(0x142, 0xa);  // row_bcast:15 -> rows 1 and 3
+  EG_DPP_STEP(0x143, 0xc);  // row_bcast:31 -> rows 2 and 3
+  return v;
+}
+#undef EG_DPP_STEP
+struct OpAdd { __device__ __forceinline__ int operator()(int a, int b) const { return a + b; } };
+struct OpMaxI { __device__ __forceinline__ int operator()(int a, int b) const { return a > b ? a : b; } };
+struct OpMinU { __device__ __forceinline__ int operator()(int a, int b) const { return (unsigned)a < (unsigned)b ? a : b; } };
+struct OpMaxU { __device__ __forceinline__ int operator()(int a, int b) const { return (unsigned)a > (unsigned)b ? a : b; } };
+#endif
+
 inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 // blockIdx -> tile remap: the dispatcher places block b on XCD b % 8 (observed, speed only);

@@ -446,6 +446,7 @@ struct WaveArgs {
   unsigned tag;
   float loss_scale;
   int dbg;
+  const int *item_first;  // [T]: the tile's first item in the contiguous per-tile numbering (hand-over storage)
 };
 
 // TIMED (EG_FWD_PROF=1, debugging only): shader-clock ticks per phase of every wave of the LAST launch, one 8-word
@@ -470,7 +471,7 @@ __device__ __forceinline__ void wave_fwd_body(WaveArgs a, const Batch &bt, WaveL
   if (BATCHED) {  // view blockIdx.y of a batched step: [C, ...] work buffers
     const long long bv = blockIdx.y;
     a.total += 4 * bv; a.flat += bv * bt.keys; a.splat += bv * bt.splat4; a.gtstop += bv * bt.pixels;
-    a.item_rec += bv * bt.items; a.cursor_reset += bv * bt.tiles;
+    a.item_rec += bv * bt.items; a.cursor_reset += bv * bt.tiles; a.item_first += bv * bt.tiles;
     a.gran = (unsigned long long *)((char *)a.gran + bv * bt.ws_bytes);
     a.dead_hint = (int *)((char *)a.dead_hint + bv * bt.ws_bytes); a.ctl = (int *)((char *)a.ctl + bv * bt.ws_bytes);
     a.loss_part = (float *)((char *)a.loss_part + bv * bt.ws_bytes);
@@ -483,7 +484,7 @@ __device__ __forceinline__ void wave_fwd_body(WaveArgs a, const Batch &bt, WaveL
   const int width = a.width, height = a.height, tw = a.tw, dbg = a.dbg;
   const unsigned tag = a.tag;
   const float loss_scale = a.loss_scale;
-  const int b = blockIdx.x;
+  const int b = blockIdx.x;  // the workgroup's item RECORD (records are in dispatch order: slice-major, binning.hip)
   // where this item lives: ONE 16-byte record left by the sort kernel.  A wave's slice is `span` consecutive items
   // (span * 128 <= kWaveSlice Gaussians); the workgroups of the items in between have nothing to do.  Requested together
   // with the item count (the grid covers max_items, the table has max_items entries: a stale record beyond the count is
@@ -499,7 +500,10 @@ __device__ __forceinline__ void wave_fwd_body(WaveArgs a, const Batch &bt, WaveL
   if (s128 % span) return;
   const int tile = ir.x, s_me = s128 / span, ns = ((ir.y >> 16) + span - 1) / span, slice = span * kSlice;
   const int start = ir.z, t_end = ir.w, end = min(t_end, start + slice);
-  const int i0 = b - s128, t_start = start - s128 * kSlice;  // (slice s of the tile publishes under item i0 + s * span)
+  // the tile's slices hand over through granule blocks i0 .. i0 + ns - 1 (the contiguous per-tile item numbering; this
+  // workgroup's RECORD index b follows the dispatch order instead).  Needed after the walk: in flight with the ids.
+  const int i0 = a.item_first[tile], t_start = start - s128 * kSlice;
+  const int b_store = i0 + s_me * span;
   const int ty = tile / tw, tx = tile - ty * tw;
   // wave wv owns the 8x8 quadrant (wv & 1, wv >> 1) of the tile, lane l the pixel (l & 7, l >> 3) inside it
   const int qj = tx * kTile + ((wv & 1) << 3), qi = ty * kTile + ((wv >> 1) << 3);
@@ -561,7 +565,7 @@ __device__ __forceinline__ void wave_fwd_body(WaveArgs a, const Batch &bt, WaveL
         if (s_me < ns - 1) {
           const unsigned long long rec = (unsigned long long)(unsigned)__float_as_int(1.f) |
                                          ((unsigned long long)((tag << 9) | (unsigned)kNoContributor) << 32);
-          __hip_atomic_store(&gran[(size_t)b * kTilePix + threadIdx.x], rec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(&gran[(size_t)b_store * kTilePix + threadIdx.x], rec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (lane == 0) atomicMax(hint_cur, (int)((tag << 8) | (unsigned)(255 - min(h, 255))));
         return;
@@ -592,7 +596,7 @@ __device__ __forceinline__ void wave_fwd_body(WaveArgs a, const Batch &bt, WaveL
   if (s_me < ns - 1) {
     const unsigned long long rec = (unsigned long long)(unsigned)__float_as_int(P) |
                                    ((unsigned long long)((tag << 9) | (unsigned)Lidx) << 32);
-    __hip_atomic_store(&gran[(size_t)b * kTilePix + threadIdx.x], rec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (b = i0 + s_me * span)
+    __hip_atomic_store(&gran[(size_t)b_store * kTilePix + threadIdx.x], rec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   EG_TICK(3);  // publish
   if (!finisher) return;  // (speculative mode: whole wave)
@@ -739,7 +743,7 @@ int launch_wave_fwd(const float4 *splat, const TileTable tt, const int32_t *flat
   a.gran = (unsigned long long *)ws.sliceP; a.dead_hint = ws.dead_hint; a.ctl = ws.ctl; a.loss_part = ws.loss_part;
   a.gt = gt; a.wmap = wmap; a.gtstop = (StopRec *)gtstop; a.prof = g_prof;
   a.width = width; a.height = height; a.tw = tw; a.n_tiles = tw * th;
-  a.tag = tag & kGranuleTagMask; a.loss_scale = loss_scale; a.dbg = dbg;
+  a.tag = tag & kGranuleTagMask; a.loss_scale = loss_scale; a.dbg = dbg; a.item_first = tt.item_first;
   // one view: everything is resolved here and the kernel never looks at the batch descriptor
   const bool batched = C > 1;
   if (!batched && bt.gt[0]) { a.gt = bt.gt[0]; a.wmap = bt.wmap[0]; }

@@ -65,6 +65,14 @@ def test_argument_validation_without_launching(lib):
     assert h.eg_composite_workspace_ctl_bytes(10, 117) % 16 == 0  # (an odd tile count once mis-aligned the granules)
     assert h.eg_composite_workspace_bytes(10, 4) == ctl + 10 * 256 * 8 + 4 * 256 * 12 + 10 * 8 + 10 * 128
     assert h.eg_timing_stage_count() == 7 and h.eg_timing_stage_name(5) == b"footprint_bwd"
+    # the footprint backward addresses the record image with 32-bit byte offsets: an image it could not address is
+    # refused, not truncated (46341^2 pixels x 12 bytes >= 2^31)
+    assert h.eg_composite_bwd_footprint(None, 8, 46341, 46341, None, None, None) == -1
+    assert b"2^31" in h.eg_last_error_string()
+    # the single-tensor Adam behind edgegaussians_amd.optim.Adam: sizes and the step count are checked first
+    assert h.eg_adam_tensor(None, None, None, None, 16, 1e-3, 0.9, 0.999, 1e-8, 0, 0, None) == -1
+    assert h.eg_adam_tensor(None, None, None, None, 16, 1e-3, 0.9, 0.999, 1e-8, 1, 0, None) == -1  # null pointers
+    assert h.eg_adam_tensor(None, None, None, None, 0, 1e-3, 0.9, 0.999, 1e-8, 1, 0, None) == 0    # nothing to do
 
 
 def test_product_never_imports_the_oracle():
