@@ -692,7 +692,8 @@ static int launch_tile_sort(uint64_t *keys, const int32_t *offsets, int32_t T, i
   // want 512 threads (config 2: 16.0 -> 13.1 us; 500 k @1200x680: 45 -> 41) -- unless the grid has thousands of
   // small tiles (200 k @1600x1200: 33 -> 44 with 512), where the extra waves cost more than the fullest tile gains
   // (a batch of C views multiplies the grid: config 2 with 4 views per launch sequence 221 -> 278 us with 512)
-  const bool wide = max_tile_hint > 1536 && (C == 1 ? T <= 4096 : T * C <= 2048);
+  static const int wide_env = getenv("EG_SORT_WIDE") ? atoi(getenv("EG_SORT_WIDE")) : -1;  // (A/B switch)
+  const bool wide = wide_env >= 0 ? wide_env != 0 : (max_tile_hint > 1536 && (C == 1 ? T <= 4096 : T * C <= 2048));
   if (!g_sort_attr_set) {
     (void)hipFuncSetAttribute((const void *)tile_sort_kernel<1024, kLarge, true>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLargeLds);

@@ -106,6 +106,19 @@ __device__ __forceinline__ int wave_scan_dpp(int v, int ident, Op op) {
   return v;
 }
 #undef EG_DPP_STEP
+// sum of a float over the wave, in lane 63 (the same six steps)
+__device__ __forceinline__ float wave_sum_dpp_f(float x) {
+#define EG_DPP_STEPF(ctrl, rmask) \
+  x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), ctrl, rmask, 0xf, false))
+  EG_DPP_STEPF(0x111, 0xf); EG_DPP_STEPF(0x112, 0xf); EG_DPP_STEPF(0x114, 0xf); EG_DPP_STEPF(0x118, 0xf);
+  EG_DPP_STEPF(0x142, 0xa); EG_DPP_STEPF(0x143, 0xc);
+#undef EG_DPP_STEPF
+  return x;
+}
+// the value of the neighbouring lane (lane ^ 1): quad_perm [1, 0, 3, 2]
+__device__ __forceinline__ float lane_xor1_f(float x) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xf, 0xf, false));
+}
 struct OpAdd { __device__ __forceinline__ int operator()(int a, int b) const { return a + b; } };
 struct OpMaxI { __device__ __forceinline__ int operator()(int a, int b) const { return a > b ? a : b; } };
 struct OpMinU { __device__ __forceinline__ int operator()(int a, int b) const { return (unsigned)a < (unsigned)b ? a : b; } };

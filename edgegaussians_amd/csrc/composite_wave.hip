@@ -529,7 +529,7 @@ __device__ __forceinline__ void wave_fwd_body(WaveArgs a, const Batch &bt, WaveL
       // odd thread: c o depth radius -> log2(o) and the sigma threshold ln(255 o) + margin; even thread: x y a b
       const float lo = __builtin_amdgcn_logf(rec.y);
       const float thr = (lo + 7.99435343685886f) * 0.693147180559945f + kThrMargin;  // log2(255), ln 2
-      const float c_o = __shfl_xor(rec.x, 1, 64), thr_o = __shfl_xor(thr, 1, 64);
+      const float c_o = lane_xor1_f(rec.x), thr_o = lane_xor1_f(thr);  // (DPP, not a trip through the LDS crossbar)
       if (k < n) {
         if (t & 1) stg.B[k] = make_float4(rec.x, lo, rec.z, thr);
         else { stg.A[k] = rec; stg.D[k] = stage_derive(rec, c_o, thr_o); stg.gid[k] = g; }
@@ -699,9 +699,8 @@ __device__ __forceinline__ void wave_fwd_body(WaveArgs a, const Batch &bt, WaveL
     }
   }
   // loss terms of this wave's pixels -> one of 64 partial sums
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) l += __shfl_xor(l, d, 64);
-  if (lane == 0 && l != 0.f) unsafeAtomicAdd(&a.loss_part[(tile * 4 + wv) & 63], l);
+  l = wave_sum_dpp_f(l);  // (total in lane 63)
+  if (lane == 63 && l != 0.f) unsafeAtomicAdd(&a.loss_part[(tile * 4 + wv) & 63], l);
   EG_TICK(6);  // epilogue
 #undef EG_TICK
 }
