@@ -322,12 +322,14 @@ constexpr int kFrontDefault = 8;  // class boundary of the dispatch order (slice
 
 // THREADS = number of buckets; CAP = keys per buffer (two buffers).  n_lo < n handled here.
 template <int THREADS, int CAP, bool LARGE>
-// (512-thread variant: two workgroups per CU need 4 waves per SIMD, i.e. at most 128 VGPRs)
+// (512-thread variant: two workgroups per CU need 4 waves per SIMD, i.e. at most 128 VGPRs; the 256-thread variant at
+// 128 VGPRs -- three dwords spilled -- fits FOUR workgroups per CU instead of three: config 3's 7500 tiles 36.9 -> 29.4 us.
+// Pushing either further -- 6 or 8 waves per SIMD -- spills the keys and costs 5-12 us: measured)
 #ifndef EG_SORT_WAVES
 #define EG_SORT_WAVES 4
 #endif
 #ifndef EG_SORT_WAVES_256
-#define EG_SORT_WAVES_256 1
+#define EG_SORT_WAVES_256 4
 #endif
 __global__ void __launch_bounds__(THREADS, THREADS == 512 ? EG_SORT_WAVES : (THREADS == 256 ? EG_SORT_WAVES_256 : 1))
 tile_sort_kernel(unsigned long long *__restrict__ keys, const int *__restrict__ offsets, int T,
