@@ -404,7 +404,8 @@ __device__ __forceinline__ unsigned long long load_granule(const unsigned long l
 constexpr int kLook = 8;
 template <bool CHAINED>
 __device__ __forceinline__ void look_back(const unsigned long long *gran, int i0, int span, int j_begin, int j_end,
-                                          unsigned tag, bool inside, float &T, bool &before) {
+                                          unsigned tag, bool inside, float &T, bool &before, int &front_last) {
+  // front_last: the last contributor among the slices looked over so far, (slice << 9 | slice-local index), -1 = none
   for (int j16 = j_begin; j16 < j_end; j16 += kLook) {
     if (CHAINED && __ballot(!before && inside) == 0ull) break;  // every pixel of the quadrant stopped further in front
     const int nb = min(kLook, j_end - j16);
@@ -422,6 +423,10 @@ __device__ __forceinline__ void look_back(const unsigned long long *gran, int i0
         const float nT = T * __int_as_float((int)(unsigned)G[u]);  // a slice without a contributor holds exactly 1
         before = before | (nT <= kTStop);
         T = before ? T : nT;
+        if (CHAINED) {
+          const int li = (int)((unsigned)(G[u] >> 32) & 511u);
+          front_last = li != kNoContributor ? (((j16 + u) << 9) | li) : front_last;
+        }
       }
     }
   }
@@ -541,6 +546,10 @@ __device__ __forceinline__ void wave_fwd_body(WaveArgs a, const Batch &bt, WaveL
 
   unsigned long long *gran = a.gran;  // [max_items][256] (sliceP and sliceL of the workspace are contiguous)
   float T = 1.f, l = 0.f;
+  int front_last = -1;
+  // (whether the caller has been told already that pixels stop: read here, in flight with everything, not on the
+  // stop-resolution path)
+  const int stops_seen = CHAINED ? a.ctl[2] : 1;
   bool before = false;  // the pixel stopped in a slice in front of this one
   int looked = 0;       // slices [0, looked) are already folded into T
 
@@ -559,7 +568,7 @@ __device__ __forceinline__ void wave_fwd_body(WaveArgs a, const Batch &bt, WaveL
     const int key = hint_prev[tile * 4 + wv];
     const int h = ((unsigned)key >> 8) == ((tag - 1u) & kGranuleTagMask) ? 255 - (key & 255) : 0x7fffffff;
     if (s_me >= h && s_me > 0 && h > 0 && !(dbg & 4)) {
-      look_back<true>(gran, i0, span, 0, h, tag, inside, T, before);
+      look_back<true>(gran, i0, span, 0, h, tag, inside, T, before, front_last);
       looked = h;
       if (__ballot(!before && inside) == 0ull) {  // dead, as last time
         if (s_me < ns - 1) {
@@ -602,7 +611,13 @@ __device__ __forceinline__ void wave_fwd_body(WaveArgs a, const Batch &bt, WaveL
   if (!finisher) return;  // (speculative mode: whole wave)
 
   // ---- look back over the slices in front (those a gated wave has not folded in yet)
-  look_back<CHAINED>(gran, i0, span, looked, s_me, tag, inside, T, before);
+  look_back<CHAINED>(gran, i0, span, looked, s_me, tag, inside, T, before, front_last);
+  // A pixel that stops on the FIRST contributor of this slice's list names a Gaussian of a slice in front as its last
+  // contributor (one stopped pixel in five, i.e. nearly every wave that resolves stops): its sorted position is known
+  // from the granules just read -- the id is requested now, under the exact walk, instead of after it
+  const int front_pos = front_last >= 0 ? t_start + (front_last >> 9) * slice + (front_last & 511) : -1;
+  int front_gid = -1;
+  if (CHAINED && inside && !before && front_pos >= 0) front_gid = flat[front_pos];
   if (CHAINED && s_me > 0 && __ballot(!before && inside) == 0ull && lane == 0)  // this slice was dead: remember for next time
     atomicMax(hint_cur, (int)((tag << 8) | (unsigned)(255 - min(s_me, 255))));
   EG_TICK(4);  // look-back
@@ -631,7 +646,7 @@ __device__ __forceinline__ void wave_fwd_body(WaveArgs a, const Batch &bt, WaveL
     cross = cross && inside;
     bool found = false;
     if (__ballot(cross) != 0ull) {
-      if (lane == 0 && a.ctl[2] == 0) atomicMax(&a.ctl[2], 1);  // "pixels do stop": the caller's launch-mode hint
+      if (lane == 0 && stops_seen == 0) atomicMax(&a.ctl[2], 1);  // "pixels do stop": the caller's launch-mode hint
       // exact stop from the list still in LDS, sequentially in depth order from T; should float rounding move the
       // crossing past the slice end, the same lanes carry on through the following slices (staged afresh)
       bool live = cross;
@@ -669,14 +684,8 @@ __device__ __forceinline__ void wave_fwd_body(WaveArgs a, const Batch &bt, WaveL
         const int lp2 = exact_walk_wave(wl, n2, px, py, live, T, found);
         if (lp2 >= 0) { last = st2 + (int)wl.idx[lp2]; stop_id = -1; }  // (a slice staged by this wave alone: via memory below)
       }
-      if (cross && found && stop_id < 0 && last < 0) {
-        // the stop is the first contributor of its slice: the last contributor sits in a slice in front (whose granule
-        // this lane has seen tagged already)
-        for (int js = s_me - 1; js >= 0; --js) {
-          const unsigned w1 = (unsigned)(load_granule(&gran[(size_t)(i0 + js * span) * kTilePix + threadIdx.x]) >> 32);
-          if ((int)(w1 & 511u) != kNoContributor) { last = t_start + js * slice + (int)(w1 & 511u); break; }
-        }
-      }
+      // the stop is the first contributor of its slice: the last contributor sits in a slice in front
+      if (cross && found && stop_id < 0 && last < 0) last = front_pos;
     }
     if (s_me + 1 < ns && __ballot(inside && !(before || (cross && found))) == 0ull && lane == 0)
       atomicMax(hint_cur, (int)((tag << 8) | (unsigned)(255 - min(s_me + 1, 255))));  // the slices behind are dead
@@ -684,8 +693,8 @@ __device__ __forceinline__ void wave_fwd_body(WaveArgs a, const Batch &bt, WaveL
     // finalise the pixels that stop here (whichever way the exact walk ended) and -- in the last slice -- the pixels
     // that never stop
     if (cross || (inside && !before && s_me == ns - 1)) {
-      if (cross && found && stop_id < 0 && last >= 0) {  // (rare: the last contributor sits in a slice in front)
-        stop_id = flat[last];
+      if (cross && found && stop_id < 0 && last >= 0) {  // (the last contributor sits in a slice in front)
+        stop_id = last == front_pos ? front_gid : flat[last];
         stop_dep = (unsigned)__float_as_int(splat[2 * stop_id + 1].z);
       }
       const float pix = 1.f - T, c0 = fminf(fmaxf(pix, 0.f), 1.f), d = c0 - gt_p;
