@@ -1250,9 +1250,8 @@ footprint_bwd_kernel(const float4 *__restrict__ splat, int N, int width, int hei
     float *lp = (float *)((char *)loss_part + blockIdx.y * bt.ws_bytes);
     float v = lp[lane];
     if (v != 0.f) lp[lane] = 0.f;
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-    if (lane == 0 && v != 0.f) unsafeAtomicAdd(loss_out, v);
+    v = wave_sum_dpp_f(v);
+    if (lane == 63 && v != 0.f) unsafeAtomicAdd(loss_out, v);
   }
   const int wave = blockIdx.x * 4 + wv;
   const int gbase = wave * 8;
@@ -1261,6 +1260,10 @@ footprint_bwd_kernel(const float4 *__restrict__ splat, int N, int width, int hei
   const __amdgpu_buffer_rsrc_t rec_rsrc =
       __builtin_amdgcn_make_buffer_rsrc((void *)gtstop, 0, width * height * (int)sizeof(StopRec), 0x00020000);
 
+  // (Eight Gaussians per wave is the measured optimum at the reference's sizes: what precedes and follows the walk costs
+  // a wave ~400 VALU instructions whatever it holds -- a third of the kernel's issue slots at config 2 -- but sixteen
+  // Gaussians per wave lose more to the coarser lane dealing than they save, +13 % at config 2 and +47 % at
+  // 1600 x 1200; four per wave gain 8 % at 1600 x 1200 and lose 15 % at config 2.)
   // home phase: the 8 lanes of group k all size the footprint of Gaussian gbase + k
   Walk h = walk_of(make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f), width, height);
   {
