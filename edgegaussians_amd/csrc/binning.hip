@@ -305,7 +305,7 @@ struct SegTable {
   // optional output for the wave-autonomous forward (composite_wave.hip): one 16-byte record per item
   // {tile, slice | slices << 16, first key of the slice, end of the TILE's keys}
   int4 *item_rec;
-  // with `total` and `item_rec`: the records are laid out in DISPATCH order, FRONT SLICES FIRST -- slices 0..7 of every
+  // with `total` and `item_rec`: the records are laid out in DISPATCH order, FRONT SLICES FIRST -- slices 0..3 of every
   // tile (tile by tile, in the order of the item numbering), then the deeper slices of the tiles that have them --
   // while item_first / item_end / item_tile (and the hand-over storage the forward addresses through
   // item_first) keep the contiguous per-tile numbering.  The forward takes one workgroup per record in record order:
@@ -318,7 +318,7 @@ struct SegTable {
   // A slice still follows all slices in front of it: the look-back's dispatch-order guarantee holds.
   int slice_major = 0;  // the class boundary (slices), 0 = off
 };
-constexpr int kFrontDefault = 8;  // class boundary of the dispatch order (slices); SegTable::slice_major carries it
+constexpr int kFrontDefault = 4;  // class boundary of the dispatch order (slices); SegTable::slice_major carries it
 
 // THREADS = number of buckets; CAP = keys per buffer (two buffers).  n_lo < n handled here.
 template <int THREADS, int CAP, bool LARGE>

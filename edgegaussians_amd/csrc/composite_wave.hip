@@ -567,7 +567,7 @@ __device__ __forceinline__ void wave_fwd_body(WaveArgs a, const Batch &bt, WaveL
     hint_cur = a.dead_hint + (tag & 1u) * 4 * a.n_tiles + tile * 4 + wv;
     const int key = hint_prev[tile * 4 + wv];
     const int h = ((unsigned)key >> 8) == ((tag - 1u) & kGranuleTagMask) ? 255 - (key & 255) : 0x7fffffff;
-    if (s_me >= h && s_me > 0 && h > 0 && !(dbg & 4)) {
+    if (s_me >= h && s_me >= (dbg >> 8) && s_me > 0 && h > 0 && !(dbg & 4)) {
       look_back<true>(gran, i0, span, 0, h, tag, inside, T, before, front_last);
       looked = h;
       if (__ballot(!before && inside) == 0ull) {  // dead, as last time
@@ -744,7 +744,16 @@ int launch_wave_fwd(const float4 *splat, const TileTable tt, const int32_t *flat
   // as long as its heaviest waves, which become twice as heavy; config 2 trained-like 46.7 -> 56.2 us.  Removed.)
   // debugging switches (EG_WAVE_DBG bits): 1 stage from memory per wave instead of the workgroup's LDS copy, 2 exact stop
   // in lockstep from the front instead of per lane from the checkpoints, 4 no dead-slice gating
-  static const int dbg = getenv("EG_WAVE_DBG") ? atoi(getenv("EG_WAVE_DBG")) : 0;
+  // Dead-slice gating trades latency for work: a gated wave that turns out alive has waited a wave lifetime for nothing
+  // (with the hint taken from ANOTHER view's step, slices 6-7 of the 8-14-slice tiles often do: they were the launch's
+  // slowest waves), a gated wave that is dead skips its staging and walk.  A launch of a few rounds of workgroups lasts
+  // as long as its slowest waves: gating off (config 2: 37.8 -> 36.6 us); a launch of many rounds is bound by its total
+  // work: gating on (500 k @1200x680: 327 -> 221 us).  Decided from the size of the grid (the CU array holds 2048
+  // workgroups of this kernel); EG_WAVE_GATE_MIN = first slice index that may gate (0 = always, 255 = never).
+  static const int gate_env = getenv("EG_WAVE_GATE_MIN") ? atoi(getenv("EG_WAVE_GATE_MIN")) : -1;
+  const int gate_min = gate_env >= 0 ? (gate_env > 255 ? 255 : gate_env) : ((int64_t)max_items * C > 3 * 2048 ? 0 : 255);
+  static const int dbg_env = getenv("EG_WAVE_DBG") ? atoi(getenv("EG_WAVE_DBG")) & 255 : 0;
+  const int dbg = dbg_env | (gate_min << 8);  // (bits 8.. of the kernel's dbg word)
   (void)max_tile_hint;
   WaveArgs a;
   a.splat = splat; a.item_rec = tt.item_rec; a.total = total; a.flat = flatten_ids; a.cursor_reset = tt.cursor_reset;

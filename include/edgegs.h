@@ -432,7 +432,7 @@ typedef struct {
   int32_t ws_tag;
   /* optional (segmented layout): the sort kernel then also leaves one 16-byte record per item -- item_rec [max_items, 4]
    * = {tile, slice | slices << 16, first key of the slice, end of the tile's keys}, in the order the forward dispatches
-   * its workgroups in (on tile grids of <= 2048 tiles: slices 0..7 of every tile first, the deeper slices after them;
+   * its workgroups in (on tile grids of <= 2048 tiles: slices 0..3 of every tile first, the deeper slices after them;
    * the record INDEX is not the item number -- the hand-over storage is addressed through item_first) -- and the step
    * (no images wanted,
    * ws_tag > 0) runs the wave-autonomous forward, whose hand-over granules carry ws_tag: 1 <= ws_tag <= EG_MAX_WS_TAG,
