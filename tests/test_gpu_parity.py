@@ -1660,3 +1660,44 @@ def test_operator_protocol_with_the_drop_in_adam(env):
     a, b = run(Adam), run(torch.optim.Adam)
     for x, y, name in zip(a, b, ("means", "quats", "scales", "opacities")):
         assert_close(x, y, rtol=1e-5, name=name)
+
+
+def test_item_records_follow_the_dispatch_order_contract(env):
+    """What the wave-autonomous forward's look-back relies on (binning.hip, SegTable::slice_major): the records the sort
+    kernel leaves in `item_rec` are a PERMUTATION of all (tile, slice) pairs; a slice's record comes after the records
+    of every slice in front of it in its tile (workgroups are dispatched in record order and only ever wait for lower
+    records: the decoupled look-back cannot deadlock); the front slices of all tiles come before any deeper slice; and
+    the item numbering the hand-over storage uses (item_first / item_end / item_tile) stays contiguous per tile."""
+    import numpy as np
+    _lib, synth, O = env
+    from edgegaussians_amd import EdgeTrainer
+    # Gaussians three times the usual size on a small image: the largest tile holds several thousand (dozens of slices)
+    sc = synth.make_scene(20_000, 2, 330, 200, seed=1, anisotropy=5.0, spread_opacity=True, scale=0.012)
+    tr = EdgeTrainer(sc.means, sc.log_scales, sc.quats, sc.logit_opacities, sc.viewmats, sc.Ks, sc.gt, 330, 200)
+    tr.ensure_capacity()
+    w = synth.weight_map("whole", sc.gt[1]).cuda()
+    tr.grad_step(1, w)
+    torch.cuda.synchronize()
+    n_items = int(tr.total.cpu()[2])
+    T = tr.T
+    rec = tr.item_rec.cpu().numpy()[:n_items]
+    first, end_ = tr.item_offsets.cpu().numpy()[:T], tr.item_end.cpu().numpy()[:T]
+    item_tile = tr.item_tile.cpu().numpy()[:n_items]
+    tile, sl, ns = rec[:, 0], rec[:, 1] & 0xffff, rec[:, 1] >> 16
+    assert n_items > T and ns.max() >= 8, "the scene must have many-slice tiles"
+    # the storage numbering: contiguous runs per tile, in tile order, covering [0, n_items)
+    assert first[0] == 0 and np.array_equal(first[1:], end_[:-1]) and end_[-1] == n_items
+    assert np.array_equal(item_tile, np.repeat(np.arange(T), end_ - first))
+    # the records: every (tile, slice) pair exactly once, consistent with the tables
+    assert np.array_equal(ns, (end_ - first)[tile]) and (sl < ns).all()
+    pairs = tile.astype(np.int64) * 65536 + sl
+    assert len(np.unique(pairs)) == n_items
+    assert np.array_equal(rec[:, 2], tile * tr.seg_cap + sl * 128)  # first key of the slice
+    # dispatch order: inside a tile by slice; front slices (of all tiles) before deeper ones
+    order = np.lexsort((np.arange(n_items), pairs))
+    same_tile = tile[order][1:] == tile[order][:-1]
+    assert (np.diff(order)[same_tile] > 0).all(), "a slice was dispatched before a slice in front of it"
+    front = 4  # kFrontDefault (EG_FRONT_SLICES)
+    if "EG_FRONT_SLICES" not in os.environ:
+        n_front = int(np.minimum(end_ - first, front).sum())
+        assert (sl[:n_front] < front).all() and (sl[n_front:] >= front).all()
