@@ -317,6 +317,7 @@ struct SegTable {
   // there; the two classes cost one more running sum.)
   // A slice still follows all slices in front of it: the look-back's dispatch-order guarantee holds.
   int slice_major = 0;  // the class boundary (slices), 0 = off
+  int middle_out = 0;   // workgroup -> tile assignment of the small sort variant (see the kernel)
 };
 constexpr int kFrontDefault = 4;  // class boundary of the dispatch order (slices); SegTable::slice_major carries it
 
@@ -355,7 +356,12 @@ tile_sort_kernel(unsigned long long *__restrict__ keys, const int *__restrict__ 
 
   const int tid = threadIdx.x;
   // the large variant runs a small grid (<= 256 workgroups of 136 KiB LDS) striding over the tiles
-  for (int tile = blockIdx.x; tile < T; tile += gridDim.x) {
+  for (int wg = blockIdx.x; wg < T; wg += gridDim.x) {
+  // Workgroup -> tile, MIDDLE OUT over the row-major tile index (the small variant: one tile per workgroup, dispatched in
+  // index order, two or three rounds of them): the tiles of the image's middle rows -- where a centred object puts its
+  // thousands of keys -- start in the first round and the near-empty border tiles make up the last one, instead of the
+  // image's lower half with its share of heavy tiles.  Any assignment is correct.
+  const int tile = (!LARGE && seg.middle_out) ? ((wg & 1) ? T / 2 - (wg + 1) / 2 : T / 2 + wg / 2) : wg;
   __syncthreads();
   long long start, end;
   __shared__ int s_pre[5][THREADS / 64];
@@ -767,6 +773,8 @@ int launch_sort_segments(uint64_t *keys, int32_t *tile_cursor, int32_t T, int32_
   // EG_FRONT_SLICES: the class boundary of the dispatch order (0 = records in item order); at most 15 (the packed sums)
   static const int front = getenv("EG_FRONT_SLICES") ? atoi(getenv("EG_FRONT_SLICES")) : kFrontDefault;
   seg.slice_major = front < 0 ? 0 : (front > 15 ? 15 : front);
+  static const int middle_out = getenv("EG_SORT_MIDDLE_OUT") ? atoi(getenv("EG_SORT_MIDDLE_OUT")) : 1;  // (A/B switch)
+  seg.middle_out = middle_out;
   return launch_tile_sort(keys, nullptr, T, (int64_t)T * seg_cap, flatten_ids, nullptr, max_tile_hint, seg,
                           (eg_stream_t)st, bt, C);
 }
