@@ -27,7 +27,7 @@ FLAG_ANTIALIASED = 4
 FLAG_TIGHT_TILES = 8
 FLAG_ABSGRAD_WRITE = 16
 REWALK_SPECULATE = -2  # EG_REWALK_SPECULATE
-MAX_WS_TAG = 0x7ffffe    # EG_MAX_WS_TAG
+MAX_WS_TAG = 0xfffe      # EG_MAX_WS_TAG
 
 
 class AdamHyper(C.Structure):
@@ -101,7 +101,7 @@ _SIGS = {
 EXPORTS = sorted(list(_SIGS) + ["eg_last_error_string", "eg_version", "eg_device_count",
                                  "eg_composite_workspace_bytes", "eg_composite_workspace_ctl_bytes",
                                  "eg_batched_workspace_stride", "eg_knn_auto_dims", "eg_timing_begin", "eg_timing_end",
-                                 "eg_timing_stage_count", "eg_timing_stage_name"])
+                                 "eg_timing_stage_count", "eg_timing_stage_name", "eg_debug_fwd_profile"])
 
 _lib: Optional[C.CDLL] = None
 

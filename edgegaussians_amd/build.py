@@ -25,6 +25,10 @@ SOURCES = ["project.hip", "binning.hip", "composite.hip", "composite_wave.hip", 
 # (profiles/r03_slp_ab.txt): footprint backward -12 % on top of its own rewrite, projection backward -4 %.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-fno-slp-vectorize",
          "-Wall", "-Wno-unused-function"]
+# EG_DEV_SWITCHES=1 at BUILD time compiles the A/B environment switches of the kernels' launchers in (NOTES_r04.md);
+# a release build reads no environment variable on the product path except EG_FWD_PROF (the profiling instantiation)
+if os.environ.get("EG_DEV_SWITCHES"):
+    FLAGS.append("-DEG_DEV_SWITCHES")
 
 
 def _hipcc() -> str:

@@ -6,7 +6,8 @@
 namespace eg {
 
 constexpr int kWaveSlice = 256;               // most Gaussians one wave of the wave-autonomous forward stages at a time
-constexpr unsigned kGranuleTagMask = 0x7fffffu;  // its hand-over granules carry a 23-bit call tag (composite_wave.hip)
+constexpr unsigned kGranuleTagMask = 0xffffu;  // its hand-over granules carry a 16-bit call tag (composite_wave.hip)
+constexpr int kAnchorShift = 3;               // every 8th slice of a tile publishes an inclusive granule (composite_wave.hip)
 constexpr int kSlice = 128;  // Gaussians per item (half the LDS of 256 => 8 workgroups/CU, 2x the items)
 
 // Where a tile's sorted ids and its items (128-Gaussian slices) live.  Classic layout: start = offsets,
@@ -109,8 +110,10 @@ struct SliceWs {
   int *qticket;         // [T][4] slices of the (tile, quadrant) that have published (speculative mode)
   int *qready;          // [max_items][4] chained mode: the caller's tag once the (item, quadrant) record is published
   float *loss_part;     // [64] partial loss sums (spread over 64 addresses; folded into loss_out by the footprint backward)
-  int *dead_hint;       // [2][T][4] chained mode: call tag << 8 | (255 - first slice that lay behind every pixel's stop)
+  int *dead_hint;       // [2][T][4] (the first [T][4] in use) chained mode: call tag << 15 | (32767 - first slice that
+                        // lies behind the stop of every pixel of the quadrant), kept by atomicMax
   unsigned char *sliceL8;  // [max_items][256] slice-local index of the last contributor, 255 = none (aliases sliceL)
+  unsigned long long *anchor;  // [max_items / 8 + 2][256] inclusive granules of the anchor slices (chained mode)
 };
 
 // the per-view copies of a batched step (blockIdx.y = view; strides are zero for a single view)
@@ -132,6 +135,7 @@ __device__ __forceinline__ SliceWs view_of(SliceWs ws, const Batch &bt, int v) {
   ws.qticket = (int *)((char *)ws.qticket + o); ws.qready = (int *)((char *)ws.qready + o);
   ws.loss_part = (float *)((char *)ws.loss_part + o); ws.sliceL8 = ws.sliceL8 + o;
   ws.dead_hint = (int *)((char *)ws.dead_hint + o);
+  ws.anchor = (unsigned long long *)((char *)ws.anchor + o);
   return ws;
 }
 
@@ -139,7 +143,7 @@ __device__ __forceinline__ SliceWs view_of(SliceWs ws, const Batch &bt, int v) {
 //   tile_ticket i32[T] | item_flags i32[max_items] | ctl i32[4] | exit_grp i32[64 x 16] | ready i32[max_items]
 //   | qticket i32[4 T] | qready i32[4 max_items] | loss_part f32[64] | dead_hint i32[2][4 T]
 // then  sliceP f32[max_items][256] | sliceL i32[max_items][256] | stopinfo {i32,f32,i32}[T][256]
-//       | rewalk int2[max_items] | sliceQ u8[max_items][128]
+//       | rewalk int2[max_items] | sliceQ u8[max_items][128] | (8-byte aligned) anchor u64[max_items / 8 + 2][256]
 inline int64_t ctl_bytes_aligned(int64_t max_items, int64_t n_tiles) {
   const int64_t words = n_tiles + 2 * max_items + 4 + 64 * 16 + 4 * n_tiles + 4 * max_items + 64 + 8 * n_tiles;
   return ((words + 3) & ~(int64_t)3) * (int64_t)sizeof(int32_t);
@@ -163,13 +167,14 @@ inline SliceWs carve_workspace(void *workspace, int64_t max_items, int n_tiles) 
   ws.rewalk = (int2 *)(ws.stopinfo + (size_t)n_tiles * kTilePix);
   ws.sliceQ = (unsigned char *)(ws.rewalk + max_items);
   ws.sliceL8 = (unsigned char *)ws.sliceL;
+  ws.anchor = (unsigned long long *)(((uintptr_t)(ws.sliceQ + (size_t)max_items * kSlice) + 7) & ~(uintptr_t)7);
   return ws;
 }
 
 
 // internal launcher of the wave-autonomous forward (composite_wave.hip); chained = 0: speculative (no pixel is expected
 // to reach the transmittance stop: a stop raises ws.ctl[3]), != 0: exact stop inside; tag: this call's granule tag
-// (1 .. kGranuleTagMask, different from every earlier call's on this workspace since its granules were zeroed)
+// (1 .. kGranuleTagMask - 1, different from every earlier call's on this workspace since its granules were zeroed)
 int launch_wave_fwd(const float4 *splat, const TileTable tt, const int32_t *flatten_ids, int width, int height,
                     const float *gt, const float *wmap, float loss_scale, const int32_t *total, int64_t max_items,
                     void *workspace, float *gtstop, int chained, unsigned tag, int max_tile_hint, hipStream_t s,

@@ -1461,7 +1461,8 @@ extern "C" int64_t eg_composite_workspace_bytes(int64_t max_items, int64_t n_til
   if (max_items < 0 || n_tiles < 0) return 0;
   return eg_composite_workspace_ctl_bytes(max_items, n_tiles) +
          max_items * kTilePix * (int64_t)(sizeof(float) + sizeof(int32_t)) +
-         n_tiles * kTilePix * (int64_t)sizeof(StopInfo) + max_items * (int64_t)sizeof(int2) + max_items * (int64_t)kSlice;
+         n_tiles * kTilePix * (int64_t)sizeof(StopInfo) + max_items * (int64_t)sizeof(int2) + max_items * (int64_t)kSlice +
+         8 + ((max_items >> kAnchorShift) + 2) * kTilePix * (int64_t)sizeof(unsigned long long);
 }
 
 // unit colours: slice-parallel forward (slice products + combine by the tile's last workgroup -> exact-stop re-walk)

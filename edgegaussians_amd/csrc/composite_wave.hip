@@ -1,43 +1,48 @@
-// G7 forward of the training step, wave-autonomous form (round 3).
+// G7 forward of the training step, wave-autonomous form (round 3; hand-over rebuilt in round 4).
 //
 // Replaces gsplat 1.0.0 rasterize_to_pixels_fwd as reached from edgegaussians/models/edge_gs.py:250-268 with the
 // clamp (edge_gs.py:279) and the projection loss (edge_gs.py:288-324, weight-map form) fused into the epilogue --
 // the same semantics as composite.hip's slice / chained kernels (restated in oracle/ref_torch.py:230-319), which stay
 // the path of the general C ABI (render / alphas / last_ids outputs, arbitrary colours, re-walk list).
 //
-// What round 2's kernels cost (config 2, 27.9 us; ablations and per-wave phase timings in profiles/r03_fwd_*): the walk
-// 11 us, the hand-over 3 us, and 9 us of STAGING -- the dependent loads at the head of every short-lived workgroup,
-// four exact ellipse-vs-quadrant tests per Gaussian run by two of the four waves while the other two wait, two
-// workgroup barriers around the list compaction, two more around the ticket.  A wave of the first wave-autonomous
-// version lived ~25 k cycles (~40 k with exact stops) of which it issued ~3 k: nine or ten DEPENDENT memory round
-// trips of ~2 k cycles each (item -> tile tables -> ids -> records -> publish -> drain -> flag / ticket -> poll ->
-// read back -> stop Gaussian's id -> its depth), and at 1.6 launch "rounds" of 8192 wave slots the kernel lasted two
-// wave lifetimes.  This version removes round trips and fits the reference's sizes into ONE round:
-//
-//   wave (slice = `span` consecutive 128-Gaussian items of a tile's depth-sorted list, quadrant = 8x8 pixels of the tile;
-//         span = 2 when the launch would not fit one round of wave slots otherwise: the workgroups of the odd items
-//         leave at once)
+//   wave (slice = one 128-Gaussian item of a tile's depth-sorted list, quadrant = 8x8 pixels of the tile)
 //     head    : ONE 16-byte item record left by the sort kernel {tile, item | items << 16, first key, end of the tile}
-//     stage   : every lane fetches up to FOUR of the slice's Gaussians (all loads in flight together) and tests them against
-//               ITS quadrant only (the exact ellipse-vs-rectangle test, one per Gaussian and wave instead of four per
-//               Gaussian on half the waves); ballot + popcount compacts the hits into the wave's OWN list in LDS, in
-//               slice order
+//     stage   : every thread of the workgroup gathers one half record of the slice into the workgroup's LDS copy (ONE
+//               barrier, the only one of the kernel), then every wave tests all 128 Gaussians against ITS quadrant (the
+//               exact ellipse-vs-rectangle test) and ballot-compacts the hits into its OWN list in LDS, in slice order
 //     walk    : 64 pixels x listed Gaussians, four list entries per iteration, broadcast LDS reads.  The entry holds
 //               the conic premultiplied by -log2(e) and log2(opacity), so that alpha = exp2(quadratic form): 14 VALU
 //               operations per (pixel, Gaussian) instead of 18, three b128 LDS reads per PAIR of entries instead of four
 //     hand-over (tiles with more than one slice), per quadrant, no workgroup involved, no flag, no ticket, no drain:
-//               a slice that has slices behind it publishes one DATA-TAGGED 8-byte granule per pixel
+//               a slice that has slices behind it publishes one DATA-TAGGED 8-byte AGGREGATE granule per pixel
 //               {product, tag << 9 | slice-local index of its last contributor} with a single device-scope store and,
-//               in speculative mode, is done.  A reader polls the granules themselves (the tag is the call's; 16 in
-//               flight): in speculative mode only the tile's LAST slice looks back, multiplies the products in depth
-//               order and finalises the 64 pixels (a product that crosses 1e-4 raises the sticky miss word and the
-//               caller replays the step in chained mode); in chained mode EVERY slice looks back over the slices in
-//               front (lower block indices: dispatched earlier, never waiting on this one) and resolves a stop that
-//               falls inside it on the spot, from the list still in this wave's LDS.
+//               in speculative mode, is done.  A reader polls the granules themselves (the tag is the call's).
+//               Speculative mode: only the tile's LAST slice looks back, multiplies the products in depth order and
+//               finalises the 64 pixels (a product that crosses 1e-4 raises the sticky miss word and the caller replays
+//               the step in chained mode).
+//               Chained mode (round 4): EVERY slice needs T_in, the product of the slices in front of it in depth order
+//               with the stop rule applied after every factor.  Every 8th slice of a tile (an ANCHOR) also publishes, once
+//               it knows its T_in, an INCLUSIVE granule {fl(T_in * P) or 0 = "stopped at or in front of me", tag << 16 |
+//               last contributor so far (slice << 7 | index)}.  Slice s reads the inclusive granule of the nearest anchor
+//               a in front of s - 1 and the aggregates of slices a + 1 .. s - 1 -- at most 8 granules, all in flight
+//               together -- and folds them in depth order: the same sequence of fp32 roundings whatever the anchor (an
+//               inclusive granule IS the left fold up to its slice), so every slice of a tile takes the same view of where
+//               a pixel stops.  Round 3 read ALL s aggregates in front (O(ns^2 / 2) block reads per tile, 3.9x the
+//               forward's algorithmic traffic at config 2) and issued 8 loads per batch whatever the batch held.
+//               DEAD SLICES: (tile, quadrant) keeps one word "first slice that lies behind every pixel's stop", raised by
+//               the wave that finds out; every wave reads it (non-blocking) at its head and leaves at once if it is at or
+//               behind that slice -- exact, of THIS call (round 3 guessed from the previous call's other view).  On grids
+//               of many rounds of workgroups a slice behind the first anchor WAITS for its anchor's inclusive granule
+//               before it stages anything (one generation of 8 slices runs in parallel, the next one starts when the
+//               anchor knows whether anything is left to do).
 //
-// There is not a single workgroup barrier in the kernel: the four waves of a workgroup share nothing but the launch
-// slot.  Per-pixel loss terms are summed per wave and added to one of 64 partial sums (4 x tiles same-address atomics
-// would serialise at ~12 ns each); the footprint backward folds the partials into the caller's accumulator.
+// Slices in front have lower record indices: they were dispatched earlier and wait on nobody behind them (the
+// decoupled look-back idiom; binning.hip keeps that order, tests/test_gpu_parity.py::
+// test_item_records_follow_the_dispatch_order_contract).  A poll that has not seen its granule after kSpinLimit rounds
+// raises bit 1 of control word 3 (sticky; the trainer's read-back raises on it) and carries on with a neutral value
+// instead of hanging the GPU.  Per-pixel loss terms are summed per wave and added to one of 64 partial sums (4 x tiles
+// same-address atomics would serialise at ~12 ns each); the footprint backward folds the partials into the caller's
+// accumulator.
 #include <cstdlib>
 
 #include "common.h"
@@ -230,13 +235,12 @@ __device__ __forceinline__ int stage_from_lds(WaveList &wl, const Stage &st, int
   return n_mine;
 }
 
-template <int SPAN, class WaveList>
+// a slice staged by ONE wave from memory (the rare continuation of an exact stop into the following slices)
+template <class WaveList>
 __device__ __forceinline__ int stage_wave(WaveList &wl, const float4 *__restrict__ splat, const int *__restrict__ flat,
                                           int start, int end, float qx, float qy, int lane) {
-  const int n = end - start;  // (wave-uniform)
-  if (n <= 64) return stage_rounds<1>(wl, splat, flat, start, end, qx, qy, lane);
-  if (SPAN == 1 || n <= 128) return stage_rounds<2>(wl, splat, flat, start, end, qx, qy, lane);
-  return stage_rounds<2 * SPAN>(wl, splat, flat, start, end, qx, qy, lane);
+  if (end - start <= 64) return stage_rounds<1>(wl, splat, flat, start, end, qx, qy, lane);  // (wave-uniform)
+  return stage_rounds<2>(wl, splat, flat, start, end, qx, qy, lane);
 }
 
 // alpha of one list entry at pixel (px, py), and whether it counts.  s = log2(o) - log2(e) sigma is evaluated in one
@@ -396,38 +400,117 @@ __device__ __forceinline__ int gridDim_tiles(int tw, int height) { return tw * (
 __device__ __forceinline__ unsigned long long load_granule(const unsigned long long *g) {
   return __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+__device__ __forceinline__ void store_granule(unsigned long long *g, unsigned long long v) {
+  __hip_atomic_store(g, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long make_aggregate(float P, unsigned tag, int lidx) {
+  return (unsigned long long)(unsigned)__float_as_int(P) | ((unsigned long long)((tag << 9) | (unsigned)lidx) << 32);
+}
+// inclusive granule of an anchor slice: {T after the slice (0 = the pixel stopped at or in front of it), tag << 16 | last
+// contributor so far as slice << 7 | slice-local index (0xffff = none)}
+constexpr unsigned kNoFront16 = 0xffffu;
+constexpr int kMaxAnchoredSlices = 510;  // (slice << 7 | index) must stay below kNoFront16
+__device__ __forceinline__ unsigned long long make_inclusive(float T, unsigned tag, int front_last) {
+  const unsigned f16 = front_last >= 0 ? ((unsigned)(front_last >> 9) << 7) | ((unsigned)front_last & 127u) : kNoFront16;
+  return (unsigned long long)(unsigned)__float_as_int(T) | ((unsigned long long)((tag << 16) | f16) << 32);
+}
 
-// Look back over slices [j_begin, j_end) of the tile (in front of the calling wave's): multiply their products onto T in
-// depth order, sixteen granules in flight per lane; a granule that does not carry this call's tag yet is asked for
-// again (the slices in front have lower block indices: they were dispatched earlier and wait on nobody behind them).
+// A poll gives up after this many rounds (each one s_sleep + a device-scope round trip: tens of milliseconds in all)
+constexpr int kSpinLimit = 1 << 16;
+__device__ __forceinline__ void spin_stalled(int *ctl) { atomicOr(&ctl[3], 2); }
+
+// Speculative mode (and tiles of more slices than an inclusive granule can name): look back over slices [j_begin, j_end)
+// of the tile (in front of the calling wave's): multiply their products onto T in depth order, eight granules in flight
+// per lane; a granule that does not carry this call's tag yet is asked for again.
 // `before` becomes true for a pixel once the product crosses the transmittance threshold (its walk stopped in front).
 constexpr int kLook = 8;
 template <bool CHAINED>
-__device__ __forceinline__ void look_back(const unsigned long long *gran, int i0, int span, int j_begin, int j_end,
-                                          unsigned tag, bool inside, float &T, bool &before, int &front_last) {
+__device__ __forceinline__ void look_back(const unsigned long long *gran, int i0, int j_begin, int j_end, unsigned tag,
+                                          bool inside, float &T, bool &before, int &front_last, int *ctl) {
   // front_last: the last contributor among the slices looked over so far, (slice << 9 | slice-local index), -1 = none
-  for (int j16 = j_begin; j16 < j_end; j16 += kLook) {
+  for (int j8 = j_begin; j8 < j_end; j8 += kLook) {
     if (CHAINED && __ballot(!before && inside) == 0ull) break;  // every pixel of the quadrant stopped further in front
-    const int nb = min(kLook, j_end - j16);
+    const int nb = min(kLook, j_end - j8);  // (wave-uniform: the guards below are scalar branches, the loads stay in flight)
     unsigned long long G[kLook];
 #pragma unroll
     for (int u = 0; u < kLook; ++u)
-      G[u] = load_granule(&gran[(size_t)(i0 + (j16 + (u < nb ? u : 0)) * span) * kTilePix + threadIdx.x]);
+      if (u < nb) G[u] = load_granule(&gran[(size_t)(i0 + j8 + u) * kTilePix + threadIdx.x]);
 #pragma unroll
     for (int u = 0; u < kLook; ++u) {
       if (u < nb) {
+        int spins = 0;
         while ((unsigned)(G[u] >> 41) != tag) {  // (rare once the first poll has come back)
+          if (++spins > kSpinLimit) { spin_stalled(ctl); G[u] = make_aggregate(1.f, tag, kNoContributor); break; }
           __builtin_amdgcn_s_sleep(1);
-          G[u] = load_granule(&gran[(size_t)(i0 + (j16 + u) * span) * kTilePix + threadIdx.x]);
+          G[u] = load_granule(&gran[(size_t)(i0 + j8 + u) * kTilePix + threadIdx.x]);
         }
         const float nT = T * __int_as_float((int)(unsigned)G[u]);  // a slice without a contributor holds exactly 1
         before = before | (nT <= kTStop);
         T = before ? T : nT;
         if (CHAINED) {
           const int li = (int)((unsigned)(G[u] >> 32) & 511u);
-          front_last = li != kNoContributor ? (((j16 + u) << 9) | li) : front_last;
+          front_last = li != kNoContributor ? (((j8 + u) << 9) | li) : front_last;
         }
       }
+    }
+  }
+}
+
+// Chained mode: the inclusive granule of anchor slice a (a > 0) -> {T, before, front_last}
+__device__ __forceinline__ void fold_inclusive(unsigned long long GB, float &T, bool &before, int &front_last) {
+  T = __int_as_float((int)(unsigned)GB);
+  before = T == 0.f;
+  const unsigned f16 = (unsigned)(GB >> 32) & 0xffffu;
+  front_last = f16 != kNoFront16 ? (int)(((f16 >> 7) << 9) | (f16 & 127u)) : -1;
+}
+__device__ __forceinline__ unsigned long long poll_inclusive(const unsigned long long *slot, unsigned tag, int *ctl) {
+  unsigned long long GB = load_granule(slot);
+  int spins = 0;
+  while ((unsigned)(GB >> 48) != tag) {
+    if (++spins > kSpinLimit) { spin_stalled(ctl); return make_inclusive(0.f, tag, -1); }
+    __builtin_amdgcn_s_sleep(1);
+    GB = load_granule(slot);
+  }
+  return GB;
+}
+
+// Chained mode, T_in of slice s (> 0): the inclusive granule of anchor a (0: none, then a + 1 .. means 0 ..) and the
+// aggregates of slices a + 1 .. s - 1, at most kLook granules, all requested before the first is waited for.
+// have_anchor: the caller has folded the anchor's granule already (a slice that waited for it before staging).
+__device__ __forceinline__ void look_back_anchored(const unsigned long long *gran, const unsigned long long *anchor, int i0,
+                                                   int a, int s, bool have_anchor, unsigned tag, bool inside, float &T,
+                                                   bool &before, int &front_last, int *ctl) {
+  const int j0 = a > 0 ? a + 1 : 0, nb = s - j0;  // nb <= 8 (a == 0: s <= 8), wave-uniform
+  const unsigned long long *slot = &anchor[(size_t)((i0 + a) >> kAnchorShift) * kTilePix + threadIdx.x];
+  unsigned long long GB = 0ull, G[kLook];
+  const bool need_anchor = a > 0 && !have_anchor;
+  if (need_anchor) GB = load_granule(slot);
+#pragma unroll
+  for (int u = 0; u < kLook; ++u)
+    if (u < nb) G[u] = load_granule(&gran[(size_t)(i0 + j0 + u) * kTilePix + threadIdx.x]);
+  if (need_anchor) {
+    int spins = 0;
+    while ((unsigned)(GB >> 48) != tag) {
+      if (++spins > kSpinLimit) { spin_stalled(ctl); GB = make_inclusive(0.f, tag, -1); break; }
+      __builtin_amdgcn_s_sleep(1);
+      GB = load_granule(slot);
+    }
+    fold_inclusive(GB, T, before, front_last);
+  }
+#pragma unroll
+  for (int u = 0; u < kLook; ++u) {
+    if (u < nb) {
+      int spins = 0;
+      while ((unsigned)(G[u] >> 41) != tag) {
+        if (++spins > kSpinLimit) { spin_stalled(ctl); G[u] = make_aggregate(1.f, tag, kNoContributor); break; }
+        __builtin_amdgcn_s_sleep(1);
+        G[u] = load_granule(&gran[(size_t)(i0 + j0 + u) * kTilePix + threadIdx.x]);
+      }
+      const float nT = T * __int_as_float((int)(unsigned)G[u]);
+      before = before | (nT <= kTStop);
+      T = before ? T : nT;
+      const int li = (int)((unsigned)(G[u] >> 32) & 511u);
+      front_last = li != kNoContributor ? (((j0 + u) << 9) | li) : front_last;
     }
   }
 }
@@ -441,8 +524,9 @@ struct WaveArgs {
   const int4 *item_rec;
   const int *total, *flat;
   int *cursor_reset;
-  unsigned long long *gran;  // [max_items][256] hand-over granules
-  int *dead_hint, *ctl;
+  unsigned long long *gran;    // [max_items][256] aggregate granules
+  unsigned long long *anchor;  // [max_items / 8 + 2][256] inclusive granules of the anchor slices (chained mode)
+  int *dead, *ctl;             // dead: [T][4] first dead slice of (tile, quadrant), tag << 15 | (32767 - slice)
   float *loss_part;
   const float *gt, *wmap;
   StopRec *gtstop;
@@ -450,18 +534,22 @@ struct WaveArgs {
   int width, height, tw, n_tiles;
   unsigned tag;
   float loss_scale;
-  int dbg;
+  int gate_min;  // chained mode: slices >= gate_min (and behind the first anchor) wait for their anchor before staging
   const int *item_first;  // [T]: the tile's first item in the contiguous per-tile numbering (hand-over storage)
 };
+
+__device__ __forceinline__ int dead_key(unsigned tag, int slice) { return (int)((tag << 15) | (unsigned)(32767 - min(slice, 32767))); }
+// first dead slice recorded by THIS call in word `key` (0x7fffffff: none yet)
+__device__ __forceinline__ int dead_from(int key, unsigned tag) {
+  return ((unsigned)key >> 15) == tag ? 32767 - (key & 32767) : 0x7fffffff;
+}
 
 // TIMED (EG_FWD_PROF=1, debugging only): shader-clock ticks per phase of every wave of the LAST launch, one 8-word
 // record per wave in prof[(item * 4 + quadrant) * 8 ...] (plain stores: atomics on shared words would serialise and
 // be measured themselves); word 7 = 1 marks a wave that ran (read by eg_debug_fwd_profile)
-template <bool CHAINED, bool TIMED, int SPAN, bool BATCHED>
-__device__ __forceinline__ void wave_fwd_body(WaveArgs a, const Batch &bt, WaveListT<SPAN * kSlice> *lists,
-                                              WgStage<SPAN * kSlice> &stg) {
-  typedef WaveListT<SPAN * kSlice> WaveList;
-  constexpr int span = SPAN;
+template <bool CHAINED, bool TIMED, bool BATCHED>
+__device__ __forceinline__ void wave_fwd_body(WaveArgs a, const Batch &bt, WaveListT<kSlice> *lists, WgStage<kSlice> &stg) {
+  typedef WaveListT<kSlice> WaveList;
   long long t_prev = TIMED ? (long long)__builtin_readcyclecounter() : 0;
   unsigned long long *my_prof = TIMED ? a.prof + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 : nullptr;
 #define EG_TICK(k)                                                                                        \
@@ -469,7 +557,7 @@ __device__ __forceinline__ void wave_fwd_body(WaveArgs a, const Batch &bt, WaveL
     if (TIMED) {                                                                                          \
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                         \
       const long long now_ = (long long)__builtin_readcyclecounter();                                     \
-      if ((threadIdx.x & 63) == 0) my_prof[k] = (unsigned long long)(now_ - t_prev);                      \
+      if ((threadIdx.x & 63) == 0) my_prof[k] += (unsigned long long)(now_ - t_prev);                     \
       t_prev = now_;                                                                                      \
     }                                                                                                     \
   } while (0)
@@ -478,7 +566,8 @@ __device__ __forceinline__ void wave_fwd_body(WaveArgs a, const Batch &bt, WaveL
     a.total += 4 * bv; a.flat += bv * bt.keys; a.splat += bv * bt.splat4; a.gtstop += bv * bt.pixels;
     a.item_rec += bv * bt.items; a.cursor_reset += bv * bt.tiles; a.item_first += bv * bt.tiles;
     a.gran = (unsigned long long *)((char *)a.gran + bv * bt.ws_bytes);
-    a.dead_hint = (int *)((char *)a.dead_hint + bv * bt.ws_bytes); a.ctl = (int *)((char *)a.ctl + bv * bt.ws_bytes);
+    a.anchor = (unsigned long long *)((char *)a.anchor + bv * bt.ws_bytes);
+    a.dead = (int *)((char *)a.dead + bv * bt.ws_bytes); a.ctl = (int *)((char *)a.ctl + bv * bt.ws_bytes);
     a.loss_part = (float *)((char *)a.loss_part + bv * bt.ws_bytes);
     a.gt = bt.gt[bv]; a.wmap = bt.wmap[bv];
   }
@@ -486,14 +575,13 @@ __device__ __forceinline__ void wave_fwd_body(WaveArgs a, const Batch &bt, WaveL
   const int *__restrict__ flat = a.flat;
   const float *__restrict__ gt = a.gt, *__restrict__ wmap = a.wmap;
   StopRec *__restrict__ gtstop = a.gtstop;
-  const int width = a.width, height = a.height, tw = a.tw, dbg = a.dbg;
+  const int width = a.width, height = a.height, tw = a.tw;
   const unsigned tag = a.tag;
   const float loss_scale = a.loss_scale;
-  const int b = blockIdx.x;  // the workgroup's item RECORD (records are in dispatch order: slice-major, binning.hip)
-  // where this item lives: ONE 16-byte record left by the sort kernel.  A wave's slice is `span` consecutive items
-  // (span * 128 <= kWaveSlice Gaussians); the workgroups of the items in between have nothing to do.  Requested together
-  // with the item count (the grid covers max_items, the table has max_items entries: a stale record beyond the count is
-  // read and dropped) -- one dependent round trip less at the head of every wave.
+  const int b = blockIdx.x;  // the workgroup's item RECORD (records are in dispatch order: front slices first, binning.hip)
+  // where this item lives: ONE 16-byte record left by the sort kernel.  Requested together with the item count (the grid
+  // covers max_items, the table has max_items entries: a stale record beyond the count is read and dropped) -- one
+  // dependent round trip less at the head of every wave.
   const int4 ir = a.item_rec[b];
   const int n_items = a.total[2];
   // ('|', and a test on the record that never fires: the exit needs BOTH loads, so neither is sunk behind the branch)
@@ -501,14 +589,16 @@ __device__ __forceinline__ void wave_fwd_body(WaveArgs a, const Batch &bt, WaveL
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   if (TIMED && lane < 8) my_prof[lane] = lane == 7 ? 1ull : 0ull;
   WaveList &wl = lists[wv];
-  const int s128 = ir.y & 0xffff;
-  if (s128 % span) return;
-  const int tile = ir.x, s_me = s128 / span, ns = ((ir.y >> 16) + span - 1) / span, slice = span * kSlice;
-  const int start = ir.z, t_end = ir.w, end = min(t_end, start + slice);
+  const int tile = ir.x, s_me = ir.y & 0xffff, ns = ir.y >> 16;
+  const int start = ir.z, t_end = ir.w, end = min(t_end, start + kSlice);
+  // ---- chained mode, DEAD SLICES: the (tile, quadrant)'s "first slice behind every pixel's stop" of THIS call, if a
+  // wave in front has found it out already (a non-blocking look: all four words, so that the workgroup can take the
+  // decision to leave without talking to itself).  Requested first: the answer is waited for before anything else.
+  int dead_keys = 0;
+  if (CHAINED && s_me > 0) dead_keys = __hip_atomic_load(&a.dead[tile * 4 + (lane & 3)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   // the tile's slices hand over through granule blocks i0 .. i0 + ns - 1 (the contiguous per-tile item numbering; this
   // workgroup's RECORD index b follows the dispatch order instead).  Needed after the walk: in flight with the ids.
-  const int i0 = a.item_first[tile], t_start = start - s128 * kSlice;
-  const int b_store = i0 + s_me * span;
+  const int i0 = a.item_first[tile], t_start = start - s_me * kSlice;
   const int ty = tile / tw, tx = tile - ty * tw;
   // wave wv owns the 8x8 quadrant (wv & 1, wv >> 1) of the tile, lane l the pixel (l & 7, l >> 3) inside it
   const int qj = tx * kTile + ((wv & 1) << 3), qi = ty * kTile + ((wv >> 1) << 3);
@@ -522,104 +612,131 @@ __device__ __forceinline__ void wave_fwd_body(WaveArgs a, const Batch &bt, WaveL
   const int p = i * width + j;
   const float w_p = (finisher && inside) ? wmap[p] : 0.f;
   const float gt_p = (finisher && inside) ? gt[p] : 0.f;
-  // the workgroup's copy of the slice: one half record per thread and round
-  if (end > start) {
-    const int n = end - start;
-#pragma unroll
-    for (int r = 0; r < SPAN; ++r) {
-      const int t = threadIdx.x + 256 * r, k = t >> 1;
-      // (the two threads of a Gaussian sit in adjacent lanes; both run the shuffles, a thread beyond the slice too)
-      const int g = flat[start + min(k, n - 1)];
-      const float4 rec = splat[2 * g + (t & 1)];
-      // odd thread: c o depth radius -> log2(o) and the sigma threshold ln(255 o) + margin; even thread: x y a b
-      const float lo = __builtin_amdgcn_logf(rec.y);
-      const float thr = (lo + 7.99435343685886f) * 0.693147180559945f + kThrMargin;  // log2(255), ln 2
-      const float c_o = lane_xor1_f(rec.x), thr_o = lane_xor1_f(thr);  // (DPP, not a trip through the LDS crossbar)
-      if (k < n) {
-        if (t & 1) stg.B[k] = make_float4(rec.x, lo, rec.z, thr);
-        else { stg.A[k] = rec; stg.D[k] = stage_derive(rec, c_o, thr_o); stg.gid[k] = g; }
-      }
+
+  unsigned long long *gran = a.gran;
+  const int b_store = i0 + s_me;
+  // anchors: every 8th slice (tiles of more slices than an inclusive granule can name fall back to the full look-back)
+  const bool anchored = CHAINED && ns <= kMaxAnchoredSlices;
+  const bool publishes_anchor = anchored && s_me > 0 && (s_me & ((1 << kAnchorShift) - 1)) == 0 && s_me < ns - 1;
+  const int my_anchor = (anchored && s_me > (1 << kAnchorShift)) ? ((s_me - 1) & ~((1 << kAnchorShift) - 1)) : 0;
+  unsigned long long *anchor_slot = &a.anchor[(size_t)(b_store >> kAnchorShift) * kTilePix + threadIdx.x];
+  // what a slice that turns out to lie behind every stop of its quadrant leaves for the slices behind it: they are dead
+  // too, but one that has not seen the news may be polling
+  auto publish_dead = [&]() {
+    if (s_me < ns - 1) store_granule(&gran[(size_t)b_store * kTilePix + threadIdx.x], make_aggregate(1.f, tag, kNoContributor));
+    if (publishes_anchor) store_granule(anchor_slot, make_inclusive(0.f, tag, -1));
+  };
+  bool my_dead = false;
+  if (CHAINED && s_me > 0) {
+    const int k0 = __builtin_amdgcn_readlane(dead_keys, 0), k1 = __builtin_amdgcn_readlane(dead_keys, 1);
+    const int k2 = __builtin_amdgcn_readlane(dead_keys, 2), k3 = __builtin_amdgcn_readlane(dead_keys, 3);
+    const bool d0 = s_me >= dead_from(k0, tag), d1 = s_me >= dead_from(k1, tag);
+    const bool d2 = s_me >= dead_from(k2, tag), d3 = s_me >= dead_from(k3, tag);
+    my_dead = wv == 0 ? d0 : (wv == 1 ? d1 : (wv == 2 ? d2 : d3));
+    if (d0 & d1 & d2 & d3) {  // (workgroup-uniform) nothing of this item can reach a pixel: not even its records are wanted
+      publish_dead();
+      EG_TICK(0);
+      return;
     }
   }
-  __syncthreads();  // (the only one: every wave of the workgroup is still here)
-  EG_TICK(0);  // head: the item record, the slice's records (+ the pixel's gt / weight)
 
-  unsigned long long *gran = a.gran;  // [max_items][256] (sliceP and sliceL of the workspace are contiguous)
   float T = 1.f, l = 0.f;
   int front_last = -1;
+  bool before = false;       // the pixel stopped in a slice in front of this one
+  bool have_anchor = false;  // the anchor's inclusive granule is folded into T / before / front_last already
+  // ---- chained mode on grids of many rounds of workgroups: a slice behind the first anchor WAITS for its anchor's
+  // inclusive granule before it stages anything.  The eight slices behind an anchor run in parallel; the next eight start
+  // once the anchor in front of them knows whether any pixel is left.  (On a grid of two rounds the wait is a wave
+  // lifetime on the launch's critical path, and the non-blocking look above catches most of what it would.)
+  if (CHAINED && my_anchor > 0 && s_me >= a.gate_min) {
+    if (!my_dead) {
+      const unsigned long long GB =
+          poll_inclusive(&a.anchor[(size_t)((i0 + my_anchor) >> kAnchorShift) * kTilePix + threadIdx.x], tag, a.ctl);
+      fold_inclusive(GB, T, before, front_last);
+      have_anchor = true;
+      my_dead = __ballot(!before && inside) == 0ull;
+      if (my_dead && lane == 0) atomicMax(&a.dead[tile * 4 + wv], dead_key(tag, my_anchor + 1));
+    }
+    if (!__syncthreads_or(!my_dead)) {  // (all four quadrants: leave before the records are asked for)
+      publish_dead();
+      EG_TICK(0);
+      return;
+    }
+  }
+
+  // the workgroup's copy of the slice: one half record per thread
+  if (end > start) {
+    const int n = end - start;
+    const int t = threadIdx.x, k = t >> 1;
+    // (the two threads of a Gaussian sit in adjacent lanes; both run the shuffles, a thread beyond the slice too)
+    const int g = flat[start + min(k, n - 1)];
+    const float4 rec = splat[2 * g + (t & 1)];
+    // odd thread: c o depth radius -> log2(o) and the sigma threshold ln(255 o) + margin; even thread: x y a b
+    const float lo = __builtin_amdgcn_logf(rec.y);
+    const float thr = (lo + 7.99435343685886f) * 0.693147180559945f + kThrMargin;  // log2(255), ln 2
+    const float c_o = lane_xor1_f(rec.x), thr_o = lane_xor1_f(thr);  // (DPP, not a trip through the LDS crossbar)
+    if (k < n) {
+      if (t & 1) stg.B[k] = make_float4(rec.x, lo, rec.z, thr);
+      else { stg.A[k] = rec; stg.D[k] = stage_derive(rec, c_o, thr_o); stg.gid[k] = g; }
+    }
+  }
+  __syncthreads();  // (the staging barrier: every wave of the workgroup is still here)
+  EG_TICK(0);  // head: the item record, the slice's records (+ the pixel's gt / weight)
+  if (my_dead) {  // (this quadrant only: the wave has helped to stage the slice for the others)
+    publish_dead();
+    return;
+  }
+
   // (whether the caller has been told already that pixels stop: read here, in flight with everything, not on the
   // stop-resolution path)
   const int stops_seen = CHAINED ? a.ctl[2] : 1;
-  bool before = false;  // the pixel stopped in a slice in front of this one
-  int looked = 0;       // slices [0, looked) are already folded into T
-
-  // ---- chained mode, DEAD SLICES.  In a trained scene a pixel's walk stops after a few dozen contributors: in a tile
-  // that holds thousands of Gaussians most slices lie behind EVERY pixel's stop and their staging and walk -- most of
-  // the launch's arithmetic -- are for nothing.  Whether a slice is dead is known only once the slices in front have
-  // finished, and waiting for them costs a live slice a whole wave lifetime; so the decision to wait is taken from the
-  // PREVIOUS call's outcome (scenes move slowly between steps): every (tile, quadrant) remembers the first slice that was
-  // dead.  A wave at or behind that slice first looks back over the slices in front of it only; if every pixel of its
-  // quadrant has indeed stopped there it publishes a neutral granule and leaves, otherwise it carries on as usual
-  // (late, nothing else).  The hint never changes a result.  Key = tag << 8 | (255 - slice), kept by atomicMax: a later
-  // call overrides an earlier one, within a call the smallest slice wins; two arrays alternate with the tag's parity.
-  int *hint_prev = a.dead_hint + ((tag + 1u) & 1u) * 4 * a.n_tiles, *hint_cur = nullptr;
-  if (CHAINED) {
-    hint_cur = a.dead_hint + (tag & 1u) * 4 * a.n_tiles + tile * 4 + wv;
-    const int key = hint_prev[tile * 4 + wv];
-    const int h = ((unsigned)key >> 8) == ((tag - 1u) & kGranuleTagMask) ? 255 - (key & 255) : 0x7fffffff;
-    if (s_me >= h && s_me >= (dbg >> 8) && s_me > 0 && h > 0 && !(dbg & 4)) {
-      look_back<true>(gran, i0, span, 0, h, tag, inside, T, before, front_last);
-      looked = h;
-      if (__ballot(!before && inside) == 0ull) {  // dead, as last time
-        if (s_me < ns - 1) {
-          const unsigned long long rec = (unsigned long long)(unsigned)__float_as_int(1.f) |
-                                         ((unsigned long long)((tag << 9) | (unsigned)kNoContributor) << 32);
-          __hip_atomic_store(&gran[(size_t)b_store * kTilePix + threadIdx.x], rec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        if (lane == 0) atomicMax(hint_cur, (int)((tag << 8) | (unsigned)(255 - min(h, 255))));
-        return;
-      }
-    }
-  }
 
   // ---- phase A: this slice's product (and last contributor) over this wave's quadrant
-  constexpr bool CK = CHAINED && SPAN == 1;  // (checkpoints for the exact stop: see walk_list_ck)
   float P = 1.f, ck[4] = {1.f, 1.f, 1.f, 1.f};
   unsigned ckL = 0xffffffffu;
   int Lpos = -1, n_mine = 0;
   if (end > start) {  // (an empty tile's single item has nothing to walk)
     const int n = end - start;
-    if (dbg & 1) n_mine = stage_wave<SPAN>(wl, splat, flat, start, end, (float)qj, (float)qi, lane);
-    else if (n <= 64) n_mine = stage_from_lds<1>(wl, stg, n, (float)qj, (float)qi, lane);
-    else if (SPAN == 1 || n <= 128) n_mine = stage_from_lds<2>(wl, stg, n, (float)qj, (float)qi, lane);
-    else n_mine = stage_from_lds<2 * SPAN>(wl, stg, n, (float)qj, (float)qi, lane);
+    if (n <= 64) n_mine = stage_from_lds<1>(wl, stg, n, (float)qj, (float)qi, lane);
+    else n_mine = stage_from_lds<2>(wl, stg, n, (float)qj, (float)qi, lane);
     EG_TICK(1);  // staging: quadrant tests -> list
-    if (CK) walk_list_ck(wl, n_mine, px, py, P, Lpos, ck, ckL);
-    else walk_list<CHAINED>(wl, n_mine, px, py, P, Lpos);
+    if (CHAINED) walk_list_ck(wl, n_mine, px, py, P, Lpos, ck, ckL);  // (checkpoints for the exact stop)
+    else walk_list<false>(wl, n_mine, px, py, P, Lpos);
     if (TIMED) { float keep = P; asm volatile("" : "+v"(keep)); P = keep; }
     EG_TICK(2);  // walk
   }
   const int Lidx = (CHAINED && Lpos >= 0) ? (int)wl.idx[Lpos] : kNoContributor;
 
   // ---- publish for the slices behind this one: one data-tagged granule per pixel, a single store, nothing to wait for
-  if (s_me < ns - 1) {
-    const unsigned long long rec = (unsigned long long)(unsigned)__float_as_int(P) |
-                                   ((unsigned long long)((tag << 9) | (unsigned)Lidx) << 32);
-    __hip_atomic_store(&gran[(size_t)b_store * kTilePix + threadIdx.x], rec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
+  if (s_me < ns - 1) store_granule(&gran[(size_t)b_store * kTilePix + threadIdx.x], make_aggregate(P, tag, Lidx));
   EG_TICK(3);  // publish
   if (!finisher) return;  // (speculative mode: whole wave)
 
-  // ---- look back over the slices in front (those a gated wave has not folded in yet)
-  look_back<CHAINED>(gran, i0, span, looked, s_me, tag, inside, T, before, front_last);
+  // ---- look back over the slices in front
+  if (s_me > 0) {
+    if (anchored) look_back_anchored(gran, a.anchor, i0, my_anchor, s_me, have_anchor, tag, inside, T, before, front_last, a.ctl);
+    else look_back<CHAINED>(gran, i0, 0, s_me, tag, inside, T, before, front_last, a.ctl);
+  }
+  // chained mode: does the stop fall in this slice?  (decided here, ahead of the exact walk: the anchor's inclusive granule
+  // is on the critical path of the eight slices behind it, the exact stop is not)
+  bool cross = false;
+  if (CHAINED) {
+    if (!before && Lidx != kNoContributor) {
+      const float nT = T * P;
+      if (nT <= kTStop) cross = true; else T = nT;
+    }
+    if (publishes_anchor)
+      store_granule(anchor_slot, make_inclusive((before || cross) ? 0.f : T, tag, Lidx != kNoContributor ? ((s_me << 9) | Lidx) : front_last));
+    cross = cross && inside;
+  }
   // A pixel that stops on the FIRST contributor of this slice's list names a Gaussian of a slice in front as its last
   // contributor (one stopped pixel in five, i.e. nearly every wave that resolves stops): its sorted position is known
   // from the granules just read -- the id is requested now, under the exact walk, instead of after it
-  const int front_pos = front_last >= 0 ? t_start + (front_last >> 9) * slice + (front_last & 511) : -1;
+  const int front_pos = front_last >= 0 ? t_start + (front_last >> 9) * kSlice + (front_last & 511) : -1;
   int front_gid = -1;
-  if (CHAINED && inside && !before && front_pos >= 0) front_gid = flat[front_pos];
-  if (CHAINED && s_me > 0 && __ballot(!before && inside) == 0ull && lane == 0)  // this slice was dead: remember for next time
-    atomicMax(hint_cur, (int)((tag << 8) | (unsigned)(255 - min(s_me, 255))));
+  if (CHAINED && cross && front_pos >= 0) front_gid = flat[front_pos];
+  if (CHAINED && s_me > 0 && __ballot(!before && inside) == 0ull && lane == 0)  // this slice turned out dead: tell the ones behind
+    atomicMax(&a.dead[tile * 4 + wv], dead_key(tag, s_me));
   EG_TICK(4);  // look-back
 
   if (!CHAINED) {
@@ -630,20 +747,13 @@ __device__ __forceinline__ void wave_fwd_body(WaveArgs a, const Batch &bt, WaveL
     if (__ballot(stop_seen && inside) != 0ull) {
       // the caller speculated that no pixel would stop: tell it (sticky word 3 of the control block); it restores its
       // state and runs the step again in chained mode
-      if (lane == 0) atomicExch(&a.ctl[3], 1);
+      if (lane == 0) atomicOr(&a.ctl[3], 1);
     }
     if (inside) l = finalize_train(p, T, 0, false, flat, gt_p, w_p, loss_scale, gtstop, splat);
   } else {
-    // ---- chained mode: does the stop fall in this slice?
     int last = -1;           // sorted index of the last contributor in front of a stop (only when it sits in a slice in front)
     int stop_id = -1;        // ... its Gaussian id and depth bits (read from the list in LDS)
     unsigned stop_dep = 0u;
-    bool cross = false;
-    if (!before && Lidx != kNoContributor) {
-      const float nT = T * P;
-      if (nT <= kTStop) cross = true; else T = nT;
-    }
-    cross = cross && inside;
     bool found = false;
     if (__ballot(cross) != 0ull) {
       if (lane == 0 && stops_seen == 0) atomicMax(&a.ctl[2], 1);  // "pixels do stop": the caller's launch-mode hint
@@ -651,9 +761,9 @@ __device__ __forceinline__ void wave_fwd_body(WaveArgs a, const Batch &bt, WaveL
       // crossing past the slice end, the same lanes carry on through the following slices (staged afresh)
       bool live = cross;
       int lp;
-      if (CK && !(dbg & 2)) {
+      {
         // start behind the last quarter of the list the pixel's transmittance survives
-        constexpr int kSeg = SPAN * kSlice / 4;
+        constexpr int kSeg = kSlice / 4;
         int pos0 = 0, lp0 = 0xff;
         float Ts = T;
         bool adv = true;
@@ -668,8 +778,6 @@ __device__ __forceinline__ void wave_fwd_body(WaveArgs a, const Batch &bt, WaveL
         T = cross ? Ts : T;  // (the other lanes of the wave hold a finished transmittance)
         lp = exact_walk_lane(wl, n_mine, pos0, px, py, live, T, found);
         if (lp < 0 && lp0 != 0xff) lp = lp0;
-      } else {
-        lp = exact_walk_wave(wl, n_mine, px, py, live, T, found);
       }
       if (lp >= 0) {  // (the workgroup's copy of this slice is still in LDS)
         const int k = (int)wl.idx[lp];
@@ -678,8 +786,8 @@ __device__ __forceinline__ void wave_fwd_body(WaveArgs a, const Batch &bt, WaveL
       }
       for (int s2 = s_me + 1; s2 < ns; ++s2) {
         if (__ballot(cross && !found) == 0ull) break;
-        const int st2 = t_start + s2 * slice, en2 = min(t_end, st2 + slice);
-        const int n2 = stage_wave<SPAN>(wl, splat, flat, st2, en2, (float)qj, (float)qi, lane);
+        const int st2 = t_start + s2 * kSlice, en2 = min(t_end, st2 + kSlice);
+        const int n2 = stage_wave(wl, splat, flat, st2, en2, (float)qj, (float)qi, lane);
         live = cross && !found;
         const int lp2 = exact_walk_wave(wl, n2, px, py, live, T, found);
         if (lp2 >= 0) { last = st2 + (int)wl.idx[lp2]; stop_id = -1; }  // (a slice staged by this wave alone: via memory below)
@@ -688,7 +796,7 @@ __device__ __forceinline__ void wave_fwd_body(WaveArgs a, const Batch &bt, WaveL
       if (cross && found && stop_id < 0 && last < 0) last = front_pos;
     }
     if (s_me + 1 < ns && __ballot(inside && !(before || (cross && found))) == 0ull && lane == 0)
-      atomicMax(hint_cur, (int)((tag << 8) | (unsigned)(255 - min(s_me + 1, 255))));  // the slices behind are dead
+      atomicMax(&a.dead[tile * 4 + wv], dead_key(tag, s_me + 1));  // the slices behind are dead
     EG_TICK(5);  // exact stop
     // finalise the pixels that stop here (whichever way the exact walk ended) and -- in the last slice -- the pixels
     // that never stop
@@ -720,7 +828,7 @@ __global__ void __launch_bounds__(256, 8)
 composite_wave_fwd_kernel(const WaveArgs a, const Batch bt) {
   __shared__ WaveListT<kSlice> lists[4];
   __shared__ WgStage<kSlice> stg;
-  wave_fwd_body<CHAINED, TIMED, 1, BATCHED>(a, bt, lists, stg);
+  wave_fwd_body<CHAINED, TIMED, BATCHED>(a, bt, lists, stg);
 }
 
 static unsigned long long *g_prof = nullptr;
@@ -732,6 +840,11 @@ int launch_wave_fwd(const float4 *splat, const TileTable tt, const int32_t *flat
                     const Batch &bt, int C) {
   const int tw = cdiv(width, kTile), th = cdiv(height, kTile);
   const SliceWs ws = carve_workspace(workspace, max_items, tw * th);
+  if (tag == 0 || tag >= kGranuleTagMask) {
+    set_error("composite_fwd(wave): the call tag must lie in 1 .. EG_MAX_WS_TAG (got %u)", tag);
+    return EG_ERR_ARG;
+  }
+  // EG_FWD_PROF=1 (a debugging aid, see eg_debug_fwd_profile; the only state this file keeps): the timed instantiation
   static const bool timed = getenv("EG_FWD_PROF") && atoi(getenv("EG_FWD_PROF")) != 0;
   if (timed && (!g_prof || g_prof_items < max_items)) {
     if (g_prof) (void)hipFree(g_prof);
@@ -739,28 +852,23 @@ int launch_wave_fwd(const float4 *splat, const TileTable tt, const int32_t *flat
     (void)hipMalloc((void **)&g_prof, (size_t)max_items * 32 * sizeof(unsigned long long));
   }
   if (timed) (void)hipMemsetAsync(g_prof, 0, (size_t)max_items * 32 * sizeof(unsigned long long), s);
-  // (a wave's slice is one 128-Gaussian item.  Two items per wave -- meant to fit config 2 into one round of wave
-  // slots -- lost everywhere it was tried: twice the LDS per wave takes a quarter of the slots away and the kernel lasts
-  // as long as its heaviest waves, which become twice as heavy; config 2 trained-like 46.7 -> 56.2 us.  Removed.)
-  // debugging switches (EG_WAVE_DBG bits): 1 stage from memory per wave instead of the workgroup's LDS copy, 2 exact stop
-  // in lockstep from the front instead of per lane from the checkpoints, 4 no dead-slice gating
-  // Dead-slice gating trades latency for work: a gated wave that turns out alive has waited a wave lifetime for nothing
-  // (with the hint taken from ANOTHER view's step, slices 6-7 of the 8-14-slice tiles often do: they were the launch's
-  // slowest waves), a gated wave that is dead skips its staging and walk.  A launch of a few rounds of workgroups lasts
-  // as long as its slowest waves: gating off (config 2: 37.8 -> 36.6 us); a launch of many rounds is bound by its total
-  // work: gating on (500 k @1200x680: 327 -> 221 us).  Decided from the size of the grid (the CU array holds 2048
-  // workgroups of this kernel); EG_WAVE_GATE_MIN = first slice index that may gate (0 = always, 255 = never).
+  // Waiting for the anchor before staging trades latency for work: a launch of a few rounds of workgroups lasts as long
+  // as its slowest waves (no waiting: the non-blocking look at the dead word is all), a launch of many rounds is bound
+  // by its total work (slices behind the first anchor wait).  Decided from the size of the grid: the CU array holds
+  // 2048 workgroups of this kernel.
+  int gate_min = (int64_t)max_items * C > 3 * 2048 ? 0 : 0x7fffffff;
+#ifdef EG_DEV_SWITCHES
   static const int gate_env = getenv("EG_WAVE_GATE_MIN") ? atoi(getenv("EG_WAVE_GATE_MIN")) : -1;
-  const int gate_min = gate_env >= 0 ? (gate_env > 255 ? 255 : gate_env) : ((int64_t)max_items * C > 3 * 2048 ? 0 : 255);
-  static const int dbg_env = getenv("EG_WAVE_DBG") ? atoi(getenv("EG_WAVE_DBG")) & 255 : 0;
-  const int dbg = dbg_env | (gate_min << 8);  // (bits 8.. of the kernel's dbg word)
+  if (gate_env >= 0) gate_min = gate_env;
+#endif
   (void)max_tile_hint;
   WaveArgs a;
   a.splat = splat; a.item_rec = tt.item_rec; a.total = total; a.flat = flatten_ids; a.cursor_reset = tt.cursor_reset;
-  a.gran = (unsigned long long *)ws.sliceP; a.dead_hint = ws.dead_hint; a.ctl = ws.ctl; a.loss_part = ws.loss_part;
+  a.gran = (unsigned long long *)ws.sliceP; a.anchor = ws.anchor; a.dead = ws.dead_hint; a.ctl = ws.ctl;
+  a.loss_part = ws.loss_part;
   a.gt = gt; a.wmap = wmap; a.gtstop = (StopRec *)gtstop; a.prof = g_prof;
   a.width = width; a.height = height; a.tw = tw; a.n_tiles = tw * th;
-  a.tag = tag & kGranuleTagMask; a.loss_scale = loss_scale; a.dbg = dbg; a.item_first = tt.item_first;
+  a.tag = tag; a.loss_scale = loss_scale; a.gate_min = gate_min; a.item_first = tt.item_first;
   // one view: everything is resolved here and the kernel never looks at the batch descriptor
   const bool batched = C > 1;
   if (!batched && bt.gt[0]) { a.gt = bt.gt[0]; a.wmap = bt.wmap[0]; }

@@ -276,6 +276,7 @@ extern "C" int eg_train_steps(const eg_step_args *a, int32_t K, const int32_t *v
                               const float *viewmats /*[V,4,4]*/, const float *Ks /*[V,3,3]*/, const float *gts /*[V,H,W]*/,
                               eg_stream_t stream) {
   EG_REQUIRE(a != nullptr && K >= 0 && (K == 0 || (views_host && wmaps_host)) && viewmats && Ks && gts, "bad arguments");
+  EG_REQUIRE(a->ws_tag <= 0 || (int64_t)a->ws_tag + K - 1 <= EG_MAX_WS_TAG, "ws_tag + K - 1 exceeds EG_MAX_WS_TAG: zero the workspace and start over at 1");
   const size_t hw = (size_t)a->width * a->height;
   for (int k = 0; k < K; ++k) {
     EG_REQUIRE(views_host[k] >= 0 && wmaps_host[k], "bad view / null weight map");

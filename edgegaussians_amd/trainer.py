@@ -290,7 +290,7 @@ class EdgeTrainer:
         return m_max
 
     # ------------------------------------------------------------------ the step
-    def _args(self, view: int, wmap: Tensor, fused_adam: bool) -> StepArgs:
+    def _args(self, view: int, wmap: Tensor, fused_adam: bool, n_tags: int = 1) -> StepArgs:
         a = self._args_cache.get("sa")
         if a is None:  # rebuilt only when a buffer was re-allocated (N or capacity changed)
             a = StepArgs()
@@ -325,7 +325,7 @@ class EdgeTrainer:
         a.wmap = wmap.data_ptr()
         a.loss_scale = self.loss_scale
         a.rewalk_hint = self._rewalk_arg(fused_adam)
-        a.ws_tag = self._next_tag(1) if self.chained_forward else 0
+        a.ws_tag = self._next_tag(n_tags) if self.chained_forward else 0
         if fused_adam:
             a.absgrads = ptr(self.absgrads)
             a.adam_host = self._args_cache["hyper_ptr"]
@@ -348,16 +348,25 @@ class EdgeTrainer:
             return _lib.REWALK_SPECULATE
         return self.rewalk_hint
 
-    def _next_tag(self, n: int) -> int:
-        """First of n fresh, consecutive tags in 1 .. EG_MAX_WS_TAG (23 bits: the forward's hand-over granules carry
-        them).  When the range is used up (every 8 million steps) the workspaces are zeroed and the tags start over, so
-        that a slot last written 2^23 steps ago can never be mistaken for this call's."""
-        if self._ws_tag + n > _lib.MAX_WS_TAG:
+    def _reserve_tags(self, n: int) -> None:
+        """Make sure n fresh, consecutive tags are left in 1 .. EG_MAX_WS_TAG (16 bits: the forward's hand-over granules
+        carry them).  When the range is used up (every 65 534 steps) the journal is flushed -- the sticky words of the
+        control block are about to go: look at them first -- the workspaces are zeroed and the tags start over, so that
+        a granule written 2^16 steps ago can never be mistaken for this call's.  Called BEFORE the steps are journalled
+        and before their arguments are built."""
+        assert 0 < n <= _lib.MAX_WS_TAG, n
+        if self.chained_forward and self._ws_tag + n > _lib.MAX_WS_TAG:
             if self._journal:
-                self.flush()  # (the sticky words of the control block are about to go: look at them first)
+                self.flush()
             for ws in [self.workspace] + [b["workspace"] for b in self._batches.values()]:
-                ws.zero_()
+                if ws is not None:
+                    ws.zero_()
             self._ws_tag = 0
+
+    def _next_tag(self, n: int) -> int:
+        """First of n fresh, consecutive tags (see _reserve_tags, which the public entry points call before they
+        journal; here it only catches a caller that did not)."""
+        self._reserve_tags(n)
         t = self._ws_tag + 1
         self._ws_tag += n
         return t
@@ -379,7 +388,14 @@ class EdgeTrainer:
         return out
 
     def _rewalk_missed(self) -> bool:
-        return any(bool((w.view(-1, 2)[:, 1] != 0).any().item()) for w in self._ctl_words())
+        """Control word 3 of the compositing workspaces: bit 0 = a pixel reached the transmittance stop while the
+        forward speculated that none would (replay in chained mode); bit 1 = a wave of the forward gave up polling a
+        hand-over granule (the dispatch-order contract of the look-back was broken: results are void)."""
+        words = [int(x) for w in self._ctl_words() for x in w.view(-1, 2)[:, 1].reshape(-1).tolist()]
+        if any(x & 2 for x in words):
+            raise RuntimeError("composite forward: a look-back poll gave up (a hand-over granule never arrived); "
+                               "the results of the steps since the last read-back are invalid")
+        return any(x & 1 for x in words)
 
     def _advance_all(self):
         self.adam_step += 1
@@ -399,6 +415,7 @@ class EdgeTrainer:
         `wmap` [H,W]: the per-pixel loss weights of the strategy chosen for this step."""
         if self.capacity == 0:
             self.ensure_capacity()
+        self._reserve_tags(1)
         if self.replay_on_overflow:
             if not self._journal:
                 self._snapshot()
@@ -414,6 +431,7 @@ class EdgeTrainer:
             return
         if self.capacity == 0:
             self.ensure_capacity()
+        self._reserve_tags(K)
         if self.replay_on_overflow:
             if not self._journal:
                 self._snapshot()
@@ -425,9 +443,7 @@ class EdgeTrainer:
         K = len(views)
         self._advance_all()   # step 0's counts; the native loop advances them by k
         self._set_hyper()
-        a = self._args(views[0], wmaps[0], True)
-        if self.chained_forward and K > 1:
-            self._next_tag(K - 1)  # (the native loop uses ws_tag .. ws_tag + K - 1)
+        a = self._args(views[0], wmaps[0], True, n_tags=K)  # (the native loop uses ws_tag .. ws_tag + K - 1)
         va = (C.c_int32 * K)(*views)
         wa = (C.c_void_p * K)(*[w.data_ptr() for w in wmaps])
         for w in wmaps:
@@ -528,6 +544,7 @@ class EdgeTrainer:
         if self.capacity == 0:
             self.ensure_capacity()
         views, wmaps = list(views), list(wmaps)
+        self._reserve_tags(1)
         if self.replay_on_overflow:
             if not self._journal:
                 self._snapshot()
@@ -625,6 +642,7 @@ class EdgeTrainer:
 
     def _journal_push(self, entry) -> None:
         """(kind, a, b, epoch, loss_scale): snapshot the state in front of the first journalled step of a window."""
+        self._reserve_tags(2)  # (a data-parallel step with two half batches takes two)
         if self.replay_on_overflow:
             if not self._journal:
                 self._snapshot()

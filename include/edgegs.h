@@ -11,7 +11,10 @@
  *
  * Conventions
  *   - every pointer is a DEVICE pointer unless the name ends in _host; plain pointers + sizes,
- *     no torch types; the library allocates nothing and keeps no state between calls
+ *     no torch types; the library allocates nothing and keeps no state between calls -- with three stated
+ *     exceptions, all measurement / communication plumbing and none on the default path: the HIP events of an open
+ *     eg_timing_begin window, the per-wave profile buffer of the EG_FWD_PROF=1 debugging build path
+ *     (eg_debug_fwd_profile), and the RCCL communicator handed to eg_dp_init (eg_train_steps_dp)
  *   - all work is enqueued asynchronously on `stream` (a hipStream_t); no call synchronises
  *   - return 0 on success, a negative EG_ERR_* code otherwise (eg_last_error_string() explains)
  *   - fp32 arithmetic; indices int32; sort keys uint64 = (depth_bits << 32) | gaussian_id within
@@ -437,10 +440,13 @@ typedef struct {
    * (no images wanted,
    * ws_tag > 0) runs the wave-autonomous forward, whose hand-over granules carry ws_tag: 1 <= ws_tag <= EG_MAX_WS_TAG,
    * different from the tag of every earlier call on this workspace since the workspace was last zeroed (the WHOLE
-   * workspace must be zero before its first use).  Batched step: [C, max_items, 4]. */
+   * workspace must be zero before its first use; a caller that runs out of tags zeroes it again -- every 65 534
+   * steps).  A wave of that kernel that polls a hand-over granule for tens of milliseconds without seeing it gives up
+   * and raises bit 1 of control word 3 of the workspace (sticky, next to bit 0 = "a pixel stopped in speculative
+   * mode"): the results of that call are void and the caller must say so.  Batched step: [C, max_items, 4]. */
   int32_t *item_rec;
 } eg_step_args;
-#define EG_MAX_WS_TAG 0x7ffffe
+#define EG_MAX_WS_TAG 0xfffe
 
 /* (Segmented layout, tile grids of <= 2048 tiles: eg_train_step / eg_train_steps / eg_train_step_batched run the
  * projection kernels without their ticket + scan tail -- `ticket` is then unused -- let every tile's sort workgroup
@@ -476,6 +482,11 @@ int eg_train_step_batched(const eg_step_args *args_host, int32_t C, const float 
  * once and returns the average microseconds per stage (eg_timing_stage_count() entries, names by
  * eg_timing_stage_name(i)).  Not thread safe; one window at a time. */
 int eg_timing_begin(int32_t n_steps);
+/* debugging aid (process started with EG_FWD_PROF=1: the wave-autonomous forward runs its timed instantiation): the
+ * per-wave phase records of the LAST forward launch, [items][4 quadrants][8] 64-bit words of shader-clock ticks (head,
+ * staging, walk, publish, look-back, exact stop, epilogue; word 7 = 1 marks a wave that ran).  Returns the number of
+ * 8-word records copied to the HOST buffer `out_host` (<= max_records) or a negative code.  Synchronises the device. */
+int64_t eg_debug_fwd_profile(uint64_t *out_host, int64_t max_records);
 int eg_timing_end(float *stage_us_host, int32_t *n_steps_out_host);
 int eg_timing_stage_count(void);
 const char *eg_timing_stage_name(int32_t i);

@@ -63,7 +63,9 @@ def test_argument_validation_without_launching(lib):
     words = (4 + 2 * 10 + 4 + 64 * 16) + (4 * 4 + 4 * 10 + 64 + 8 * 4)
     assert ctl == (words + 3) // 4 * 16 and ctl % 16 == 0
     assert h.eg_composite_workspace_ctl_bytes(10, 117) % 16 == 0  # (an odd tile count once mis-aligned the granules)
-    assert h.eg_composite_workspace_bytes(10, 4) == ctl + 10 * 256 * 8 + 4 * 256 * 12 + 10 * 8 + 10 * 128
+    # ... the aggregate granules, the general path's stop hand-over / re-walk list / quadrant verdicts, and (8-byte
+    # aligned) the inclusive granules of the anchor slices: one block per 8 items + 2
+    assert h.eg_composite_workspace_bytes(10, 4) == ctl + 10 * 256 * 8 + 4 * 256 * 12 + 10 * 8 + 10 * 128 + 8 + (10 // 8 + 2) * 256 * 8
     assert h.eg_timing_stage_count() == 7 and h.eg_timing_stage_name(5) == b"footprint_bwd"
     # the footprint backward addresses the record image with 32-bit byte offsets: an image it could not address is
     # refused, not truncated (46341^2 pixels x 12 bytes >= 2^31)
