@@ -38,9 +38,14 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found: libedgegs.so cannot be built")
 
 
+STAMP = os.path.join(OBJ, "flags.txt")
+
+
 def _stale() -> bool:
     if not os.path.exists(LIB):
         return True
+    if not os.path.exists(STAMP) or open(STAMP).read() != " ".join(FLAGS):
+        return True  # (built with other flags, e.g. a development build with EG_DEV_SWITCHES)
     t = os.path.getmtime(LIB)
     deps = [os.path.join(CSRC, f) for f in SOURCES + ["common.h", "composite.h"]]
     deps.append(os.path.join(HERE, "..", "include", "edgegs.h"))
@@ -71,6 +76,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stderr}")
     os.replace(tmp, LIB)
+    with open(STAMP, "w") as f:
+        f.write(" ".join(FLAGS))
     if verbose:
         print(f"built {LIB}")
     return LIB

@@ -1482,7 +1482,11 @@ static int launch_sliced_fwd(const float4 *splat, const TileTable tt, int channe
   // find an empty list costs 4.5 us, 64 cost 1.3 us); any grid is correct
   // rewalk_hint == EG_REWALK_SPECULATE: no launch at all; a pixel that does stop raises control word 3 instead
   const int skip = rewalk_hint == EG_REWALK_SPECULATE;
+#ifdef EG_DEV_SWITCHES
   static const bool old_fwd = getenv("EG_FWD_OLD") && atoi(getenv("EG_FWD_OLD")) != 0;  // A/B against round 2's kernels
+#else
+  constexpr bool old_fwd = false;
+#endif
   // The training step (no images wanted, fused loss, segmented tables): the wave-autonomous forward of
   // composite_wave.hip -- speculative while no pixel reaches the transmittance stop, chained (exact stop inside) otherwise
   if (!old_fwd && channels == 1 && !render && !alphas && !last_ids && !vpix && gtstop && wmap && tt.item_rec &&

@@ -535,6 +535,7 @@ struct WaveArgs {
   unsigned tag;
   float loss_scale;
   int gate_min;  // chained mode: slices >= gate_min (and behind the first anchor) wait for their anchor before staging
+  int max_anchored;  // tiles of more slices look back over all aggregates (kMaxAnchoredSlices; 0 in an A/B build leg)
   const int *item_first;  // [T]: the tile's first item in the contiguous per-tile numbering (hand-over storage)
 };
 
@@ -616,7 +617,7 @@ __device__ __forceinline__ void wave_fwd_body(WaveArgs a, const Batch &bt, WaveL
   unsigned long long *gran = a.gran;
   const int b_store = i0 + s_me;
   // anchors: every 8th slice (tiles of more slices than an inclusive granule can name fall back to the full look-back)
-  const bool anchored = CHAINED && ns <= kMaxAnchoredSlices;
+  const bool anchored = CHAINED && ns <= a.max_anchored;
   const bool publishes_anchor = anchored && s_me > 0 && (s_me & ((1 << kAnchorShift) - 1)) == 0 && s_me < ns - 1;
   const int my_anchor = (anchored && s_me > (1 << kAnchorShift)) ? ((s_me - 1) & ~((1 << kAnchorShift) - 1)) : 0;
   unsigned long long *anchor_slot = &a.anchor[(size_t)(b_store >> kAnchorShift) * kTilePix + threadIdx.x];
@@ -857,9 +858,12 @@ int launch_wave_fwd(const float4 *splat, const TileTable tt, const int32_t *flat
   // by its total work (slices behind the first anchor wait).  Decided from the size of the grid: the CU array holds
   // 2048 workgroups of this kernel.
   int gate_min = (int64_t)max_items * C > 3 * 2048 ? 0 : 0x7fffffff;
+  int max_anchored = kMaxAnchoredSlices;
 #ifdef EG_DEV_SWITCHES
   static const int gate_env = getenv("EG_WAVE_GATE_MIN") ? atoi(getenv("EG_WAVE_GATE_MIN")) : -1;
   if (gate_env >= 0) gate_min = gate_env;
+  static const int anchor_env = getenv("EG_WAVE_ANCHOR") ? atoi(getenv("EG_WAVE_ANCHOR")) : 1;
+  if (!anchor_env) max_anchored = 0;
 #endif
   (void)max_tile_hint;
   WaveArgs a;
@@ -868,7 +872,7 @@ int launch_wave_fwd(const float4 *splat, const TileTable tt, const int32_t *flat
   a.loss_part = ws.loss_part;
   a.gt = gt; a.wmap = wmap; a.gtstop = (StopRec *)gtstop; a.prof = g_prof;
   a.width = width; a.height = height; a.tw = tw; a.n_tiles = tw * th;
-  a.tag = tag; a.loss_scale = loss_scale; a.gate_min = gate_min; a.item_first = tt.item_first;
+  a.tag = tag; a.loss_scale = loss_scale; a.gate_min = gate_min; a.max_anchored = max_anchored; a.item_first = tt.item_first;
   // one view: everything is resolved here and the kernel never looks at the batch descriptor
   const bool batched = C > 1;
   if (!batched && bt.gt[0]) { a.gt = bt.gt[0]; a.wmap = bt.wmap[0]; }

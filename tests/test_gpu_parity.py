@@ -1666,7 +1666,7 @@ def test_item_records_follow_the_dispatch_order_contract(env):
     """What the wave-autonomous forward's look-back relies on (binning.hip, SegTable::slice_major): the records the sort
     kernel leaves in `item_rec` are a PERMUTATION of all (tile, slice) pairs; a slice's record comes after the records
     of every slice in front of it in its tile (workgroups are dispatched in record order and only ever wait for lower
-    records: the decoupled look-back cannot deadlock); the front slices of all tiles come before any deeper slice; and
+    records: the decoupled look-back cannot deadlock); the front slices of the multi-slice tiles come before any deeper slice, the single-slice tiles last; and
     the item numbering the hand-over storage uses (item_first / item_end / item_tile) stays contiguous per tile."""
     import numpy as np
     _lib, synth, O = env
@@ -1697,7 +1697,16 @@ def test_item_records_follow_the_dispatch_order_contract(env):
     order = np.lexsort((np.arange(n_items), pairs))
     same_tile = tile[order][1:] == tile[order][:-1]
     assert (np.diff(order)[same_tile] > 0).all(), "a slice was dispatched before a slice in front of it"
-    front = 4  # kFrontDefault (EG_FRONT_SLICES)
-    if "EG_FRONT_SLICES" not in os.environ:
-        n_front = int(np.minimum(end_ - first, front).sum())
-        assert (sl[:n_front] < front).all() and (sl[n_front:] >= front).all()
+    # three classes (binning.hip, SegTable::slice_major / singles_last): slices [0, 4) of the multi-slice tiles, their
+    # deeper slices, then the items of the single-slice tiles (the light waves make up the launch's tail)
+    front = 4  # kFrontDefault
+    if not any(k in os.environ for k in ("EG_FRONT_SLICES", "EG_SINGLES_LAST")):
+        per_tile = end_ - first
+        multi = per_tile > 1
+        n_a = int(np.minimum(per_tile[multi], front).sum())
+        n_c = int((~multi).sum())
+        assert n_c > 0, "the scene must have single-slice tiles"
+        a_, b_, c_ = slice(0, n_a), slice(n_a, n_items - n_c), slice(n_items - n_c, n_items)
+        assert (ns[a_] > 1).all() and (sl[a_] < front).all()
+        assert (ns[b_] > 1).all() and (sl[b_] >= front).all()
+        assert (ns[c_] == 1).all() and (np.diff(tile[c_]) > 0).all()
