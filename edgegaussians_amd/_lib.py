@@ -53,7 +53,7 @@ class StepArgs(C.Structure):
         ("v_means", _vp), ("v_quats", _vp), ("v_scales", _vp), ("v_opacities", _vp),
         ("adam_host", C.POINTER(AdamHyper)),
         ("next_viewmat", _vp), ("next_K", _vp), ("have_projection", _i32), ("ws_tag", _i32),
-        ("item_rec", _vp), ("xcd_start", _vp),
+        ("item_rec", _vp),
     ]
 
 

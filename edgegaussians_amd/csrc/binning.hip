@@ -320,12 +320,6 @@ struct SegTable {
   // with slice_major: the items of the SINGLE-slice tiles (at most 128 Gaussians, nothing to hand over: the light
   // waves) form a third class behind the deep slices, so that the launch's tail is made of short-lived waves
   int singles_last = 0;
-  // optional: XCD-aware dispatch of the forward (eg_step_args::xcd_start).  The records stay in item order and the
-  // workgroup of the tile that holds item x * n / 8 (n = items of the view) writes xcd_start[x] = its first item: XCD x
-  // rasterises the whole tiles from there to xcd_start[x + 1].  total_ro: the view's totals when the projection kernel
-  // has formed them (the large path; with `total` the workgroup knows n itself).
-  int *xcd_start = nullptr;
-  const int *total_ro = nullptr;
   int middle_out = 0;   // workgroup -> tile assignment of the small sort variant (see the kernel)
 };
 constexpr int kFrontDefault = 4;  // class boundary of the dispatch order (slices); SegTable::slice_major carries it
@@ -356,8 +350,6 @@ tile_sort_kernel(unsigned long long *__restrict__ keys, const int *__restrict__ 
       seg.item_first += bv * bt.tiles; seg.item_end += bv * bt.tiles; seg.item_tile += bv * bt.items;
       if (seg.total) seg.total += 4 * bv;
       if (seg.item_rec) seg.item_rec += bv * bt.items;
-      if (seg.xcd_start) seg.xcd_start += 16 * bv;
-      if (seg.total_ro) seg.total_ro += 4 * bv;
     }
   }
   unsigned long long *kout = s;      // [CAP] keys scattered by bucket (the fast path keeps its input in registers)
@@ -380,17 +372,6 @@ tile_sort_kernel(unsigned long long *__restrict__ keys, const int *__restrict__ 
   int pop_here = 0;
   // after a barrier: every thread sums the waves' partials; thread 0 writes the tile's table entries (and the
   // totals of the view, if this is the last tile), the first threads the item -> tile map
-  // (thread 0) the run boundaries of the XCD-aware dispatch that fall into this tile's items [first_, first_ + items_)
-  auto publish_xcd = [&](int first_, int items_, int n_) {
-    const int q = n_ >> 3, r = n_ & 7;
-#pragma unroll
-    for (int x = 1; x < 8; ++x) {
-      const int lo = x * q + min(x, r);
-      if (lo >= first_ && lo < first_ + items_) seg.xcd_start[x] = first_;
-    }
-    if (first_ == 0) seg.xcd_start[0] = 0;
-    if (first_ + items_ >= n_) seg.xcd_start[8] = n_;
-  };
   auto finish_prefix = [&](int kept_) {
     int isum = 0, msum = 0, cmax = 0, itot = 0, front = 0, single = 0;
 #pragma unroll
@@ -407,7 +388,6 @@ tile_sort_kernel(unsigned long long *__restrict__ keys, const int *__restrict__ 
       seg.tile_start[tile] = tile * seg.seg_cap;
       seg.tile_end[tile] = tile * seg.seg_cap + kept_;
       seg.item_end[tile] = first_ + items_;
-      if (seg.xcd_start) publish_xcd(first_, items_, min(itot, seg.max_items));
       if (tile == T - 1) {  // (every workgroup has summed ALL tiles: this one leaves the totals of the view)
         seg.total[0] = msum;
         if (cmax > seg.seg_cap || itot > seg.max_items) seg.total[1] = 1;  // sticky: only the host clears it
@@ -493,7 +473,6 @@ tile_sort_kernel(unsigned long long *__restrict__ keys, const int *__restrict__ 
           seg.tile_start[tile] = tile * seg.seg_cap;
           seg.tile_end[tile] = tile * seg.seg_cap + kept;
           seg.item_end[tile] = first + items;
-          if (seg.xcd_start) publish_xcd(first, items, seg.total_ro[2]);
         }
         for (int i = tid; i < items; i += THREADS) {
           seg.item_tile[first + i] = tile;
@@ -791,8 +770,7 @@ namespace eg {
 int launch_sort_segments(uint64_t *keys, int32_t *tile_cursor, int32_t T, int32_t seg_cap, int32_t *flatten_ids,
                          int32_t *tile_start, int32_t *tile_end, int32_t *item_first, int32_t *item_end,
                          int32_t *item_tile, int32_t max_items, int32_t max_tile_hint, const Batch &bt, int C,
-                         hipStream_t st, int32_t *total_prefix_here, int32_t *item_rec, int32_t *xcd_start,
-                         const int32_t *total_ro) {
+                         hipStream_t st, int32_t *total_prefix_here, int32_t *item_rec) {
   SegTable seg;
   seg.cursor = tile_cursor; seg.seg_cap = seg_cap;
   seg.tile_start = tile_start; seg.tile_end = tile_end;
@@ -814,14 +792,7 @@ int launch_sort_segments(uint64_t *keys, int32_t *tile_cursor, int32_t T, int32_
   seg.slice_major = front < 0 ? 0 : (front > 15 ? 15 : front);
   seg.middle_out = middle_out;
   seg.singles_last = singles_last;
-  static const int xcd_remap = getenv("EG_XCD_REMAP") ? atoi(getenv("EG_XCD_REMAP")) : 1;
-  if (!xcd_remap) xcd_start = nullptr;
 #endif
-  if (xcd_start && item_rec) {  // XCD-aware dispatch: records in item order, run starts published (SegTable::xcd_start)
-    seg.xcd_start = xcd_start;
-    seg.total_ro = total_ro;
-    seg.slice_major = 0;
-  }
   return launch_tile_sort(keys, nullptr, T, (int64_t)T * seg_cap, flatten_ids, nullptr, max_tile_hint, seg,
                           (eg_stream_t)st, bt, C);
 }

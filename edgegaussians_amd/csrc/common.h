@@ -51,24 +51,21 @@ int launch_project_emit(const float *means, const float *quats, const float *log
 int launch_sort_segments(uint64_t *keys, int32_t *tile_cursor, int32_t T, int32_t seg_cap, int32_t *flatten_ids,
                          int32_t *tile_start, int32_t *tile_end, int32_t *item_first, int32_t *item_end,
                          int32_t *item_tile, int32_t max_items, int32_t max_tile_hint, const Batch &bt, int C,
-                         hipStream_t st, int32_t *total_prefix_here = nullptr, int32_t *item_rec = nullptr,
-                         int32_t *xcd_start = nullptr, const int32_t *total_ro = nullptr);
+                         hipStream_t st, int32_t *total_prefix_here = nullptr, int32_t *item_rec = nullptr);
 int launch_composite_fwd_segments(const float *splat, const int32_t *tile_start, const int32_t *tile_end,
                                   const int32_t *item_first, const int32_t *item_end, const int32_t *item_tile,
                                   const int32_t *flatten_ids, int32_t width, int32_t height, float loss_scale,
                                   float *loss_out, const int32_t *total, int64_t max_items, void *workspace,
                                   float *gtstop, int32_t rewalk_hint, const Batch &bt, int C, hipStream_t st,
                                   int32_t max_tile_hint, int32_t chain_tag, int32_t *cursor_reset = nullptr,
-                                  const int32_t *item_rec = nullptr, const int32_t *xcd_start = nullptr,
-                                  int32_t seg_cap = 0);
+                                  const int32_t *item_rec = nullptr);
 int composite_fwd_segments_hinted(const float *splat, const int32_t *tile_start, const int32_t *tile_end,
                                   const int32_t *item_first, const int32_t *item_end, const int32_t *item_tile,
                                   const int32_t *flatten_ids, int32_t width, int32_t height, float *render, float *alphas,
                                   int32_t *last_ids, const float *gt, const float *wmap, float loss_scale, float *vpix,
                                   float *loss_out, const int32_t *total, int64_t max_items, void *workspace,
                                   float *gtstop, int32_t rewalk_hint, int32_t max_tile_hint, int32_t chain_tag,
-                                  hipStream_t st, int32_t *cursor_reset = nullptr, const int32_t *item_rec = nullptr,
-                                  const int32_t *xcd_start = nullptr, int32_t seg_cap = 0);
+                                  hipStream_t st, int32_t *cursor_reset = nullptr, const int32_t *item_rec = nullptr);
 // workspace / max_items / loss_out (all three or none): the compositing workspace whose 64 partial loss sums (left by
 // the wave-autonomous forward) block (0, view) folds into *loss_out
 int launch_footprint_bwd(const float *splat, int32_t N, int32_t width, int32_t height, const float *gtstop, float *g2d,

@@ -22,10 +22,6 @@ struct TileTable {
   // optional (training step): the sort kernel's per-item records {tile, slice | slices << 16, first key of the slice,
   // end of the tile's keys}
   const int4 *item_rec;
-  // optional (with item_rec in item order): xcd_start[0..8], the first item of every XCD's run of whole tiles (written
-  // by the sort kernel); slices_bound >= the slices of any tile (sizes the grid: a run is at most items / 8 + that long)
-  const int *xcd_start;
-  int slices_bound;
 };
 
 // pixel of thread `tid` in the slice-parallel kernels: wave w owns the 8x8 quadrant (w & 1, w >> 1)
@@ -126,7 +122,6 @@ __device__ __forceinline__ TileTable view_of(TileTable tt, const Batch &bt, int 
   if (tt.item_tile) tt.item_tile += v * bt.items;
   if (tt.cursor_reset) tt.cursor_reset += v * bt.tiles;
   if (tt.item_rec) tt.item_rec += v * bt.items;
-  if (tt.xcd_start) tt.xcd_start += v * 16;
   return tt;
 }
 __device__ __forceinline__ SliceWs view_of(SliceWs ws, const Batch &bt, int v) {

@@ -537,7 +537,6 @@ struct WaveArgs {
   int gate_min;  // chained mode: slices >= gate_min (and behind the first anchor) wait for their anchor before staging
   int max_anchored;  // tiles of more slices look back over all aggregates (kMaxAnchoredSlices; 0 in an A/B build leg)
   const int *item_first;  // [T]: the tile's first item in the contiguous per-tile numbering (hand-over storage)
-  const int *xcd_start;   // [9] or nullptr: XCD-aware dispatch (records in item order; see below)
 };
 
 __device__ __forceinline__ int dead_key(unsigned tag, int slice) { return (int)((tag << 15) | (unsigned)(32767 - min(slice, 32767))); }
@@ -553,7 +552,7 @@ template <bool CHAINED, bool TIMED, bool BATCHED>
 __device__ __forceinline__ void wave_fwd_body(WaveArgs a, const Batch &bt, WaveListT<kSlice> *lists, WgStage<kSlice> &stg) {
   typedef WaveListT<kSlice> WaveList;
   long long t_prev = TIMED ? (long long)__builtin_readcyclecounter() : 0;
-  unsigned long long *my_prof = nullptr;
+  unsigned long long *my_prof = TIMED ? a.prof + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 : nullptr;
 #define EG_TICK(k)                                                                                        \
   do {                                                                                                    \
     if (TIMED) {                                                                                          \
@@ -572,7 +571,6 @@ __device__ __forceinline__ void wave_fwd_body(WaveArgs a, const Batch &bt, WaveL
     a.dead = (int *)((char *)a.dead + bv * bt.ws_bytes); a.ctl = (int *)((char *)a.ctl + bv * bt.ws_bytes);
     a.loss_part = (float *)((char *)a.loss_part + bv * bt.ws_bytes);
     a.gt = bt.gt[bv]; a.wmap = bt.wmap[bv];
-    if (a.xcd_start) a.xcd_start += 16 * bv;
   }
   const float4 *__restrict__ splat = a.splat;
   const int *__restrict__ flat = a.flat;
@@ -581,31 +579,12 @@ __device__ __forceinline__ void wave_fwd_body(WaveArgs a, const Batch &bt, WaveL
   const int width = a.width, height = a.height, tw = a.tw;
   const unsigned tag = a.tag;
   const float loss_scale = a.loss_scale;
-  int b = blockIdx.x;  // the workgroup's item RECORD (records are in dispatch order: binning.hip)
-  const int n_items = a.total[2];
-  // XCD-AWARE DISPATCH.  The hardware hands workgroup b to XCD b % 8 (observed, MI355X_MICROARCH.md; nothing but speed
-  // rests on it), and every XCD has its own 4 MB L2.  With the records taken in grid order the workgroups of neighbouring
-  // tiles -- which share their Gaussians -- land on all eight XCDs and every L2 ends up fetching the whole array of screen
-  // records (measured: 8 x 3.2 MB of 128-byte line fills at config 2, half of the launch's memory-side traffic; at
-  // 500 k Gaussians the 16 MB array does not even fit an L2 and the record gather is 64 % of a wave's life).  Instead XCD
-  // x rasterises a RUN OF WHOLE TILES, items xcd_start[x] .. xcd_start[x + 1] (about n / 8 each, cut at tile boundaries by
-  // the sort kernel): its L2 sees the records of a band of the image only.  Records are in item order here, so inside a
-  // run -- which holds all slices of its tiles -- a slice is still dispatched after every slice in front of it.
-  if (a.xcd_start) {
-    const int x = b & 7, k = b >> 3;
-    const int q = n_items >> 3, r = n_items & 7;
-    const int lo0 = x * q + min(x, r), lo1 = lo0 + q + (x < r ? 1 : 0);
-    const int s0 = x == 0 ? 0 : (lo0 >= n_items ? n_items : a.xcd_start[x]);
-    const int s1 = (x == 7 || lo1 >= n_items) ? n_items : a.xcd_start[x + 1];
-    b = s0 + k;
-    if (b >= s1) return;
-    b = min(b, n_items - 1);  // (memory safety only: a step whose item tables overflowed is void and replayed)
-  }
-  if (TIMED) my_prof = a.prof + ((size_t)b * 4 + (threadIdx.x >> 6)) * 8;
+  const int b = blockIdx.x;  // the workgroup's item RECORD (records are in dispatch order: front slices first, binning.hip)
   // where this item lives: ONE 16-byte record left by the sort kernel.  Requested together with the item count (the grid
   // covers max_items, the table has max_items entries: a stale record beyond the count is read and dropped) -- one
   // dependent round trip less at the head of every wave.
   const int4 ir = a.item_rec[b];
+  const int n_items = a.total[2];
   // ('|', and a test on the record that never fires: the exit needs BOTH loads, so neither is sunk behind the branch)
   if ((b >= n_items) | (ir.y < 0)) return;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -894,18 +873,10 @@ int launch_wave_fwd(const float4 *splat, const TileTable tt, const int32_t *flat
   a.gt = gt; a.wmap = wmap; a.gtstop = (StopRec *)gtstop; a.prof = g_prof;
   a.width = width; a.height = height; a.tw = tw; a.n_tiles = tw * th;
   a.tag = tag; a.loss_scale = loss_scale; a.gate_min = gate_min; a.max_anchored = max_anchored; a.item_first = tt.item_first;
-  a.xcd_start = tt.xcd_start;
-#ifdef EG_DEV_SWITCHES
-  static const int xcd_remap = getenv("EG_XCD_REMAP") ? atoi(getenv("EG_XCD_REMAP")) : 1;
-  if (!xcd_remap) a.xcd_start = nullptr;
-#endif
   // one view: everything is resolved here and the kernel never looks at the batch descriptor
   const bool batched = C > 1;
   if (!batched && bt.gt[0]) { a.gt = bt.gt[0]; a.wmap = bt.wmap[0]; }
-  // (XCD-aware dispatch: a run is at most items / 8 + the slices of one tile long; a multiple of 8 keeps view v's
-  // workgroup b on XCD b % 8 in a batched launch as well)
-  const int64_t gx = a.xcd_start ? ((max_items + 8 * (int64_t)tt.slices_bound + 7) & ~(int64_t)7) : max_items;
-  const dim3 grid((unsigned)gx, C);
+  const dim3 grid((unsigned)max_items, C);
 #define EG_LAUNCH(CH_, TI_, BA_) composite_wave_fwd_kernel<CH_, TI_, BA_><<<grid, 256, 0, s>>>(a, bt)
   if (batched) { if (chained) EG_LAUNCH(true, false, true); else EG_LAUNCH(false, false, true); }
   else if (timed) { if (chained) EG_LAUNCH(true, true, false); else EG_LAUNCH(false, true, false); }

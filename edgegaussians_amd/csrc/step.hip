@@ -147,7 +147,7 @@ extern "C" int eg_train_step(const eg_step_args *a, eg_stream_t stream) {
     EG_MARK(kMarkEmit);
     rc = launch_sort_segments(a->keys, a->tile_counts, T, a->seg_cap, a->flatten_ids, a->offsets, a->tile_end,
                               a->item_offsets, a->item_end, a->item_tile, (int32_t)a->max_items, a->max_tile_hint, Batch{}, 1,
-                              st, prefix_here ? a->total : nullptr, a->item_rec, a->xcd_start, a->total);
+                              st, prefix_here ? a->total : nullptr, a->item_rec);
     if (rc) return rc;
     EG_MARK(kMarkSort);
     EG_REQUIRE(a->splat && a->offsets && a->flatten_ids && a->total && a->workspace && a->max_items > 0 &&
@@ -157,7 +157,7 @@ extern "C" int eg_train_step(const eg_step_args *a, eg_stream_t stream) {
                                        a->flatten_ids, a->width, a->height, a->render, a->alphas, a->last_ids, a->gt,
                                        a->wmap, a->loss_scale, a->vpix, a->loss, a->total, a->max_items, a->workspace,
                                        a->gtstop, a->rewalk_hint, a->max_tile_hint, a->ws_tag, st,
-                                       prefix_here ? a->tile_counts : nullptr, a->item_rec, a->xcd_start, a->seg_cap);
+                                       prefix_here ? a->tile_counts : nullptr, a->item_rec);
     if (rc) return rc;
   } else {
   // tile_counts is zero on entry (caller zero-initialises it once): the projection counts it up and its
@@ -250,13 +250,12 @@ extern "C" int eg_train_step_batched(const eg_step_args *a, int32_t C, const flo
   if (rc) return rc;
   rc = launch_sort_segments(a->keys, a->tile_counts, T, a->seg_cap, a->flatten_ids, a->offsets, a->tile_end,
                             a->item_offsets, a->item_end, a->item_tile, (int32_t)a->max_items, a->max_tile_hint, bt, C,
-                            st, prefix_here ? a->total : nullptr, a->item_rec, a->xcd_start, a->total);
+                            st, prefix_here ? a->total : nullptr, a->item_rec);
   if (rc) return rc;
   rc = launch_composite_fwd_segments(a->splat, a->offsets, a->tile_end, a->item_offsets, a->item_end, a->item_tile,
                                      a->flatten_ids, a->width, a->height, a->loss_scale, a->loss, a->total,
                                      a->max_items, a->workspace, a->gtstop, a->rewalk_hint, bt, C, st,
-                                     a->max_tile_hint, a->ws_tag, prefix_here ? a->tile_counts : nullptr, a->item_rec,
-                                     a->xcd_start, a->seg_cap);
+                                     a->max_tile_hint, a->ws_tag, prefix_here ? a->tile_counts : nullptr, a->item_rec);
   if (rc) return rc;
   rc = launch_footprint_bwd(a->splat, a->N, a->width, a->height, a->gtstop, a->g2d, bt, C, st, a->workspace, a->max_items,
                             a->loss);

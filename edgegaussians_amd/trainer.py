@@ -203,7 +203,6 @@ class EdgeTrainer:
             self.item_tile = torch.zeros(self.max_items, dtype=torch.int32, device=self.dev)
             # the sort kernel's per-item records for the wave-autonomous forward (composite_wave.hip)
             self.item_rec = torch.zeros(self.max_items, 4, dtype=torch.int32, device=self.dev)
-            self.xcd_start = torch.zeros(16, dtype=torch.int32, device=self.dev)  # eg_step_args.xcd_start
         self.workspace = _lib.composite_workspace(self.max_items, self.T, self.dev)
         self._args_cache = {}
         self._batches = {}
@@ -307,7 +306,6 @@ class EdgeTrainer:
             if self.seg_cap:
                 a.tile_end, a.item_end, a.item_tile = ptr(self.tile_end), ptr(self.item_end), ptr(self.item_tile)
                 a.item_rec = ptr(self.item_rec)
-                a.xcd_start = ptr(self.xcd_start)
             a.tile_counts, a.offsets, a.total = ptr(self.tile_counts), ptr(self.offsets), ptr(self.total)
             a.item_offsets, a.workspace, a.max_items = ptr(self.item_offsets), ptr(self.workspace), self.max_items
             a.tile_mask, a.ticket = ptr(self.tile_mask), ptr(self.ticket)
@@ -481,7 +479,6 @@ class EdgeTrainer:
                  ticket=torch.zeros(Cn, **i32), gtstop=torch.zeros(Cn, self.height, self.width, 3, device=d),
                  workspace=ws, ws_stride=stride, rewalk_hint=-1)
         b["item_rec"] = torch.zeros(Cn, self.max_items, 4, **i32)
-        b["xcd_start"] = torch.zeros(Cn, 16, **i32)
         a = StepArgs()
         a.means, a.quats = ptr(self.means), ptr(self.quats)
         a.log_scales, a.logit_opacities = ptr(self.log_scales), ptr(self.logit_opacities)
@@ -494,7 +491,6 @@ class EdgeTrainer:
         a.item_offsets, a.workspace, a.ticket = ptr(b["item_offsets"]), ptr(ws), ptr(b["ticket"])
         a.keys, a.flatten_ids, a.loss = ptr(b["keys"]), ptr(b["flatten_ids"]), ptr(self.loss_acc)
         a.item_rec = ptr(b["item_rec"])
-        a.xcd_start = ptr(b["xcd_start"])
         b["args"] = a
         b["ptrs"] = [(C.c_void_p * Cn)() for _ in range(4)]
         b["hyper_ptr"] = C.pointer(self._hyper)

@@ -445,12 +445,6 @@ typedef struct {
    * and raises bit 1 of control word 3 of the workspace (sticky, next to bit 0 = "a pixel stopped in speculative
    * mode"): the results of that call are void and the caller must say so.  Batched step: [C, max_items, 4]. */
   int32_t *item_rec;
-  /* optional (with item_rec): [16] int32 per view (batched step: [C, 16]).  XCD-AWARE DISPATCH of the wave-autonomous
-   * forward: the sort kernel then leaves the records in item order (tile by tile) and writes xcd_start[x], x = 0..8: the
-   * first item of the run of whole tiles that XCD x rasterises (runs of ~items / 8, cut at tile boundaries); workgroup
-   * b of the forward takes record xcd_start[b % 8] + b / 8.  Every XCD's L2 then holds the screen records of ITS tiles
-   * only (without it the workgroups of a tile's neighbours land on all eight XCDs and each L2 fetches the whole array). */
-  int32_t *xcd_start;
 } eg_step_args;
 #define EG_MAX_WS_TAG 0xfffe
 

@@ -1693,35 +1693,14 @@ def test_item_records_follow_the_dispatch_order_contract(env):
     pairs = tile.astype(np.int64) * 65536 + sl
     assert len(np.unique(pairs)) == n_items
     assert np.array_equal(rec[:, 2], tile * tr.seg_cap + sl * 128)  # first key of the slice
-    xs = tr.xcd_start.cpu().numpy()[:9]
-    if os.environ.get("EG_XCD_REMAP", "1") != "0":
-        # XCD-AWARE DISPATCH (the default: eg_step_args.xcd_start): records in item order; workgroup b takes record
-        # xcd_start[b % 8] + b // 8 while that lies below xcd_start[b % 8 + 1].  Runs are whole tiles, about n / 8 long.
-        assert np.array_equal(tile, item_tile) and np.array_equal(sl, np.arange(n_items) - first[tile])
-        assert xs[0] == 0 and xs[8] == n_items and (np.diff(xs) >= 0).all()
-        assert np.isin(xs[1:8], first).all(), "a run must start with the first slice of a tile"
-        q, r = divmod(n_items, 8)
-        lo = np.array([x * q + min(x, r) for x in range(9)])
-        assert (xs <= lo).all() and (lo - xs < ns.max()).all(), "run x starts with the tile that holds item x n / 8"
-        # the order the hardware dispatches in: b ascending, i.e. (k, x) lexicographic
-        grid = n_items + 8 * (tr.seg_cap // 128 + 1)
-        order_of = np.full(n_items, -1, np.int64)
-        for bb in range((grid + 7) // 8 * 8):
-            x, k = bb & 7, bb >> 3
-            if xs[x] + k < xs[x + 1]:
-                assert order_of[xs[x] + k] < 0
-                order_of[xs[x] + k] = bb
-        assert (order_of >= 0).all(), "every record is taken by exactly one workgroup of the grid"
-        same = tile[1:] == tile[:-1]
-        assert (np.diff(order_of)[same] > 0).all(), "a slice was dispatched before a slice in front of it"
-    else:
-        # dispatch order: inside a tile by slice; front slices (of the multi-slice tiles) before deeper ones
-        order = np.lexsort((np.arange(n_items), pairs))
-        same_tile = tile[order][1:] == tile[order][:-1]
-        assert (np.diff(order)[same_tile] > 0).all(), "a slice was dispatched before a slice in front of it"
-        # three classes (binning.hip, SegTable::slice_major / singles_last): slices [0, 4) of the multi-slice tiles, their
-        # deeper slices, then the items of the single-slice tiles (the light waves make up the launch's tail)
-        front = 4  # kFrontDefault
+    # dispatch order: inside a tile by slice; front slices (of all tiles) before deeper ones
+    order = np.lexsort((np.arange(n_items), pairs))
+    same_tile = tile[order][1:] == tile[order][:-1]
+    assert (np.diff(order)[same_tile] > 0).all(), "a slice was dispatched before a slice in front of it"
+    # three classes (binning.hip, SegTable::slice_major / singles_last): slices [0, 4) of the multi-slice tiles, their
+    # deeper slices, then the items of the single-slice tiles (the light waves make up the launch's tail)
+    front = 4  # kFrontDefault
+    if not any(k in os.environ for k in ("EG_FRONT_SLICES", "EG_SINGLES_LAST")):
         per_tile = end_ - first
         multi = per_tile > 1
         n_a = int(np.minimum(per_tile[multi], front).sum())
