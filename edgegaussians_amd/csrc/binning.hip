@@ -320,6 +320,12 @@ struct SegTable {
   // with slice_major: the items of the SINGLE-slice tiles (at most 128 Gaussians, nothing to hand over: the light
   // waves) form a third class behind the deep slices, so that the launch's tail is made of short-lived waves
   int singles_last = 0;
+  // without `total` (tile grids above 2048 tiles), optional: the projection's scan of min(items, EG_FRONT_LARGE) over the
+  // tiles, [T + 1] with the total at [T] (EG_FLAG_FRONT_PREFIX).  The records are then written in TWO classes -- slices
+  // [0, 9) of every tile, tile by tile, then the deeper slices -- instead of in item order: a tile's deep slices used to be
+  // dispatched right behind its front ones and sat waiting for their anchor's inclusive granule, half of the forward's
+  // wave slots at 500 k Gaussians; dispatched after every tile's front they find the dead word set and leave at once.
+  const int *item_front = nullptr;
   int middle_out = 0;   // workgroup -> tile assignment of the small sort variant (see the kernel)
 };
 constexpr int kFrontDefault = 4;  // class boundary of the dispatch order (slices); SegTable::slice_major carries it
@@ -477,7 +483,13 @@ tile_sort_kernel(unsigned long long *__restrict__ keys, const int *__restrict__ 
         for (int i = tid; i < items; i += THREADS) {
           seg.item_tile[first + i] = tile;
           if (seg.item_rec) {
-            seg.item_rec[first + i] = make_int4(tile, i | (items << 16), tile * seg.seg_cap + i * 128, tile * seg.seg_cap + kept);
+            int disp = first + i;
+            if (seg.item_front) {
+              const int fpre = seg.item_front[tile], ftot = seg.item_front[T];
+              disp = i < EG_FRONT_LARGE ? fpre + i : ftot + (first - fpre) + (i - EG_FRONT_LARGE);
+            }
+            if (disp < seg.max_items)
+              seg.item_rec[disp] = make_int4(tile, i | (items << 16), tile * seg.seg_cap + i * 128, tile * seg.seg_cap + kept);
           }
         }
       }
@@ -770,7 +782,7 @@ namespace eg {
 int launch_sort_segments(uint64_t *keys, int32_t *tile_cursor, int32_t T, int32_t seg_cap, int32_t *flatten_ids,
                          int32_t *tile_start, int32_t *tile_end, int32_t *item_first, int32_t *item_end,
                          int32_t *item_tile, int32_t max_items, int32_t max_tile_hint, const Batch &bt, int C,
-                         hipStream_t st, int32_t *total_prefix_here, int32_t *item_rec) {
+                         hipStream_t st, int32_t *total_prefix_here, int32_t *item_rec, const int32_t *item_front) {
   SegTable seg;
   seg.cursor = tile_cursor; seg.seg_cap = seg_cap;
   seg.tile_start = tile_start; seg.tile_end = tile_end;
@@ -783,6 +795,7 @@ int launch_sort_segments(uint64_t *keys, int32_t *tile_cursor, int32_t T, int32_
   seg.slice_major = kFrontDefault;
   seg.singles_last = 1;
   seg.middle_out = 1;
+  seg.item_front = total_prefix_here ? nullptr : item_front;
 #ifdef EG_DEV_SWITCHES  // A/B switches of development builds (edgegaussians_amd/build.py, EG_DEV_SWITCHES=1)
   static const int rank_order = getenv("EG_TILE_ORDER") ? atoi(getenv("EG_TILE_ORDER")) : 0;
   static const int front = getenv("EG_FRONT_SLICES") ? atoi(getenv("EG_FRONT_SLICES")) : kFrontDefault;
@@ -792,6 +805,8 @@ int launch_sort_segments(uint64_t *keys, int32_t *tile_cursor, int32_t T, int32_
   seg.slice_major = front < 0 ? 0 : (front > 15 ? 15 : front);
   seg.middle_out = middle_out;
   seg.singles_last = singles_last;
+  static const int front_large = getenv("EG_FRONT_LARGE") ? atoi(getenv("EG_FRONT_LARGE")) : 1;
+  if (!front_large) seg.item_front = nullptr;
 #endif
   return launch_tile_sort(keys, nullptr, T, (int64_t)T * seg_cap, flatten_ids, nullptr, max_tile_hint, seg,
                           (eg_stream_t)st, bt, C);

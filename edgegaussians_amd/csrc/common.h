@@ -51,7 +51,8 @@ int launch_project_emit(const float *means, const float *quats, const float *log
 int launch_sort_segments(uint64_t *keys, int32_t *tile_cursor, int32_t T, int32_t seg_cap, int32_t *flatten_ids,
                          int32_t *tile_start, int32_t *tile_end, int32_t *item_first, int32_t *item_end,
                          int32_t *item_tile, int32_t max_items, int32_t max_tile_hint, const Batch &bt, int C,
-                         hipStream_t st, int32_t *total_prefix_here = nullptr, int32_t *item_rec = nullptr);
+                         hipStream_t st, int32_t *total_prefix_here = nullptr, int32_t *item_rec = nullptr,
+                         const int32_t *item_front = nullptr);
 int launch_composite_fwd_segments(const float *splat, const int32_t *tile_start, const int32_t *tile_end,
                                   const int32_t *item_first, const int32_t *item_end, const int32_t *item_tile,
                                   const int32_t *flatten_ids, int32_t width, int32_t height, float loss_scale,

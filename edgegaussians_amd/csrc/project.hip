@@ -657,6 +657,7 @@ struct SegOut {
   int max_items;
   int *total;       // [4]: M, overflow flag, items, largest tile population
   int *ticket;      // [1]: zero on entry, zero on exit
+  int *item_front;  // optional [T + 1] (EG_FLAG_FRONT_PREFIX): exclusive scan of min(items, EG_FRONT_LARGE), total at [T]
 };
 
 constexpr int kPE = 512;  // threads per workgroup: 512 halves the per-workgroup histogram sweeps and cursor atomics of 256 (config2 16.6 -> 14.6 us, config3 48 -> 33); 1024 loses that again to the longer barriers
@@ -759,20 +760,25 @@ __device__ __forceinline__ void emit_body(const Raw &raw, bool live, int g, cons
       s_hist[t] = __hip_atomic_load(&cursor[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
   }
-  int isum = 0, msum = 0, cmax = 0;
+  int isum = 0, msum = 0, cmax = 0, fsum = 0;
   for (int t = t0; t < t1; ++t) {
     const int pop = LDS_HIST ? s_hist[t] : __hip_atomic_load(&cursor[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int kept = min(pop, seg_cap);
-    isum += max(1, (kept + 127) >> 7); msum += kept; cmax = max(cmax, pop);  // an empty tile owns one (empty) item
+    const int kept = min(pop, seg_cap), it = max(1, (kept + 127) >> 7);  // an empty tile owns one (empty) item
+    isum += it; msum += kept; cmax = max(cmax, pop); fsum += min(it, EG_FRONT_LARGE);
   }
-  int itot, mtot;
+  int itot, mtot, ftot = 0;
   int ie = block_excl_scan<kPE>(isum, s_tmp, itot);
   (void)block_excl_scan<kPE>(msum, s_tmp, mtot);
+  // (dispatch classes of the forward on large tile grids: where the front slices of the tiles before this one end)
+  int fe = out.item_front ? block_excl_scan<kPE>(fsum, s_tmp, ftot) : 0;
   for (int t = t0; t < t1; ++t) {
     const int pop = LDS_HIST ? s_hist[t] : __hip_atomic_load(&cursor[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (LDS_HIST) s_base[t] = ie; else out.item_first[t] = min(ie, out.max_items);
-    ie += max(1, (min(pop, seg_cap) + 127) >> 7);
+    if (out.item_front) out.item_front[t] = fe;
+    const int it = max(1, (min(pop, seg_cap) + 127) >> 7);
+    ie += it; fe += min(it, EG_FRONT_LARGE);
   }
+  if (out.item_front && threadIdx.x == 0) out.item_front[T] = ftot;
   if (LDS_HIST) {
     __syncthreads();
     for (int t = threadIdx.x; t < T; t += kPE) out.item_first[t] = min(s_base[t], out.max_items);
@@ -806,7 +812,7 @@ project_emit_kernel(const float *__restrict__ means, const float *__restrict__ q
   SegOut out = out_;
   splat += bv * bt.splat4; cursor += bv * bt.tiles; keys += bv * bt.keys;
   out.item_first += bv * bt.tiles; out.total += 4 * bv;
-  if (out.ticket) out.ticket += bv;
+  if (out.ticket) out.ticket += bv;  // (EG_FLAG_FRONT_PREFIX is a single-view feature: the batched step does not set it)
   if (bt.viewmat[0]) { viewmat = bt.viewmat[bv]; K = bt.K[bv]; }
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
   const bool live = g < N;
@@ -1009,6 +1015,7 @@ int launch_project_emit(const float *means, const float *quats, const float *log
   SegOut out;
   out.item_first = item_first; out.max_items = max_items;
   out.total = total; out.ticket = ticket;
+  out.item_front = (ticket && (flags & EG_FLAG_FRONT_PREFIX)) ? ticket + 1 : nullptr;
   const dim3 grid(cdiv(N, kPE), C);
   if (2 * T <= 16384)
     project_emit_kernel<true><<<grid, kPE, sizeof(int) * 2 * T, st>>>(
@@ -1082,6 +1089,7 @@ int launch_project_bwd_emit(float *means, float *quats, float *scales, float *op
   SegOut out;
   out.item_first = item_first; out.max_items = max_items;
   out.total = total; out.ticket = ticket;
+  out.item_front = (ticket && (flags & EG_FLAG_FRONT_PREFIX)) ? ticket + 1 : nullptr;
   const bool hoist = N <= 160000;  // up to ~2.5 waves of these threads per SIMD
 #define EG_BWD_EMIT(LDS, HO, SMEM)                                                                                  \
   project_bwd_emit_kernel<LDS, HO><<<cdiv(N, kPE), kPE, SMEM, st>>>(                                               \
@@ -1208,6 +1216,7 @@ extern "C" int eg_adam_emit(float *means, float *scales, float *quats, float *op
   SegOut out;
   out.item_first = item_first; out.max_items = max_items;
   out.total = total; out.ticket = ticket;
+  out.item_front = (ticket && (flags & EG_FLAG_FRONT_PREFIX)) ? ticket + 1 : nullptr;
   hipStream_t st = as_stream(stream);
   if (2 * T <= 16384)
     adam_emit_kernel<true><<<cdiv(N, kPE), kPE, sizeof(int) * 2 * T, st>>>(

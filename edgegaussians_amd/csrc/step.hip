@@ -119,7 +119,10 @@ extern "C" int eg_train_step(const eg_step_args *a, eg_stream_t stream) {
   EG_REQUIRE(a->N > 0 && a->width > 0 && a->height > 0 && a->capacity > 0, "bad sizes");
   EG_REQUIRE(a->seg_cap <= 0 || (a->tile_end && a->item_end && a->item_tile), "segmented binning needs its tables");
   const int tw = cdiv(a->width, kTile), th = cdiv(a->height, kTile), T = tw * th;
-  const uint32_t flags = EG_FLAG_LOG_SCALES | EG_FLAG_LOGIT_OPACITIES | EG_FLAG_ANTIALIASED | EG_FLAG_TIGHT_TILES;
+  // (tile grids above 2048 tiles: the projection's scan also leaves the front-slice prefix in ticket[1..], from which the
+  // sort kernel writes the forward's item records front slices first -- every projection of such a grid sets the flag)
+  const uint32_t flags = EG_FLAG_LOG_SCALES | EG_FLAG_LOGIT_OPACITIES | EG_FLAG_ANTIALIASED | EG_FLAG_TIGHT_TILES |
+                         ((T > kPrefixHereMaxTiles && a->seg_cap > 0 && a->ticket) ? EG_FLAG_FRONT_PREFIX : 0u);
   g_ev_cur = (g_ev && g_ev_next < g_ev_steps) ? &g_ev[(kStages + 1) * g_ev_next] : nullptr;
   hipStream_t st = as_stream(stream);
 #define EG_MARK(k) timing_mark(k, st)
@@ -147,7 +150,8 @@ extern "C" int eg_train_step(const eg_step_args *a, eg_stream_t stream) {
     EG_MARK(kMarkEmit);
     rc = launch_sort_segments(a->keys, a->tile_counts, T, a->seg_cap, a->flatten_ids, a->offsets, a->tile_end,
                               a->item_offsets, a->item_end, a->item_tile, (int32_t)a->max_items, a->max_tile_hint, Batch{}, 1,
-                              st, prefix_here ? a->total : nullptr, a->item_rec);
+                              st, prefix_here ? a->total : nullptr, a->item_rec,
+                              (flags & EG_FLAG_FRONT_PREFIX) ? a->ticket + 1 : nullptr);
     if (rc) return rc;
     EG_MARK(kMarkSort);
     EG_REQUIRE(a->splat && a->offsets && a->flatten_ids && a->total && a->workspace && a->max_items > 0 &&

@@ -176,7 +176,8 @@ class EdgeTrainer:
         self.offsets = torch.zeros(self.T + 1, dtype=torch.int32, device=d)
         self.item_offsets = torch.zeros(self.T + 1, dtype=torch.int32, device=d)
         self.total = torch.zeros(4, dtype=torch.int32, device=d)  # M, overflow, items, largest tile
-        self.ticket = torch.zeros(1, dtype=torch.int32, device=d)  # last-workgroup ticket of the fused scan
+        # [0]: last-workgroup ticket of the fused scan; [1 .. T + 1]: its front-slice prefix (EG_FLAG_FRONT_PREFIX)
+        self.ticket = torch.zeros(self.T + 2, dtype=torch.int32, device=d)
         img = (lambda **k: torch.zeros(H, W, device=d, **k)) if self.keep_images else (lambda **k: None)
         self.render, self.alphas, self.vpix = img(), img(), img()
         self.gtstop = torch.zeros(H, W, 3, device=d)  # {vpix * T_final, stop id, stop depth bits} for the fused backward
@@ -794,6 +795,8 @@ class EdgeTrainer:
         self._drop_projection()
         if next_view is not None and self.seg_cap and self.capacity:
             fl = (_lib.FLAG_LOG_SCALES | _lib.FLAG_LOGIT_OPACITIES | _lib.FLAG_ANTIALIASED | _lib.FLAG_TIGHT_TILES)
+            if self.T > _lib.PREFIX_HERE_MAX_TILES:  # (what eg_train_step's own projection does on such a grid)
+                fl |= _lib.FLAG_FRONT_PREFIX
             call("eg_adam_emit", c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7], c[8], c[9], self.N, self._hyper,
                  c[10], ptr(self.absgrads), self.viewmats.data_ptr() + 64 * next_view, self.Ks.data_ptr() + 36 * next_view,
                  self.width, self.height, fl, ptr(self.splat), ptr(self.tile_counts), self.seg_cap, ptr(self.keys),

@@ -51,6 +51,11 @@ typedef void *eg_stream_t; /* hipStream_t */
 #define EG_FLAG_LOGIT_OPACITIES 2u /* `opacities` holds logits: sigmoid() fused (edge_gs.py:254) */
 #define EG_FLAG_ANTIALIASED 4u     /* rasterize_mode="antialiased" (edge_gs.py:50,266) */
 #define EG_FLAG_ABSGRAD_WRITE 16u   /* eg_project_bwd: absgrads[g] = increment instead of += (data-parallel leg) */
+#define EG_FLAG_FRONT_PREFIX 32u     /* eg_project_emit & co.: `ticket` is [T + 2] int32 and the scan of the last workgroup    \
+                                      also leaves ticket[1 + t] = sum over the tiles before t of min(items, EG_FRONT_LARGE)  \
+                                      and ticket[1 + T] = that sum over all tiles (dispatch classes of the forward on tile   \
+                                      grids above 2048 tiles: the sort kernel then writes the item records front slices first) */
+#define EG_FRONT_LARGE 9
 #define EG_FLAG_TIGHT_TILES 8u     /* bin with the opacity-aware tile box (subset of gsplat's box that \
                                       drops only (Gaussian, tile) pairs contributing exactly nothing) */
 
@@ -404,7 +409,8 @@ typedef struct {
   float *splat, *g2d;
   int32_t *tile_counts, *offsets, *item_offsets, *total; /* [T], [T+1], [T+1], [4] */
   uint32_t *tile_mask;                                   /* [N] */
-  int32_t *ticket;                                       /* [1], zero-initialised once */
+  int32_t *ticket;                                       /* [T + 2], zero-initialised once ([0]: the scan's ticket; [1..T+1]:
+                                                            see EG_FLAG_FRONT_PREFIX, used on tile grids above 2048 tiles) */
   void *workspace;   /* eg_composite_workspace_bytes(max_items, T) bytes, control prefix zeroed at allocation */
   int64_t max_items; /* >= ceil(capacity/128) + T */
   uint64_t *keys;

@@ -1662,29 +1662,37 @@ def test_operator_protocol_with_the_drop_in_adam(env):
         assert_close(x, y, rtol=1e-5, name=name)
 
 
-def test_item_records_follow_the_dispatch_order_contract(env):
-    """What the wave-autonomous forward's look-back relies on (binning.hip, SegTable::slice_major): the records the sort
-    kernel leaves in `item_rec` are a PERMUTATION of all (tile, slice) pairs; a slice's record comes after the records
-    of every slice in front of it in its tile (workgroups are dispatched in record order and only ever wait for lower
-    records: the decoupled look-back cannot deadlock); the front slices of the multi-slice tiles come before any deeper slice, the single-slice tiles last; and
-    the item numbering the hand-over storage uses (item_first / item_end / item_tile) stays contiguous per tile."""
+@pytest.mark.parametrize("size", ["small_grid", "large_grid"])
+def test_item_records_follow_the_dispatch_order_contract(env, size):
+    """What the wave-autonomous forward's look-back relies on (binning.hip, SegTable::slice_major / item_front): the records
+    the sort kernel leaves in `item_rec` are a PERMUTATION of all (tile, slice) pairs; a slice's record comes after the
+    records of every slice in front of it in its tile (workgroups are dispatched in record order and only ever wait for
+    lower records: the decoupled look-back cannot deadlock); the front slices of the multi-slice tiles come before any
+    deeper slice -- on tile grids of <= 2048 tiles the single-slice tiles last, above that slices [0, 9) of EVERY tile
+    first (the projection's scan supplies the prefix: EG_FLAG_FRONT_PREFIX) --; and the item numbering the hand-over
+    storage uses (item_first / item_end / item_tile) stays contiguous per tile."""
     import numpy as np
     _lib, synth, O = env
     from edgegaussians_amd import EdgeTrainer
-    # Gaussians three times the usual size on a small image: the largest tile holds several thousand (dozens of slices)
-    sc = synth.make_scene(20_000, 2, 330, 200, seed=1, anisotropy=5.0, spread_opacity=True, scale=0.012)
-    tr = EdgeTrainer(sc.means, sc.log_scales, sc.quats, sc.logit_opacities, sc.viewmats, sc.Ks, sc.gt, 330, 200)
+    # Gaussians three times the usual size: the largest tile holds several thousand (dozens of slices)
+    if size == "small_grid":
+        W, H, n_g, scale = 330, 200, 20_000, 0.012
+    else:
+        W, H, n_g, scale = 1008, 608, 120_000, 0.012  # 63 x 38 = 2394 tiles: the projection kernel scans the tiles
+    sc = synth.make_scene(n_g, 2, W, H, seed=1, anisotropy=5.0, spread_opacity=True, scale=scale)
+    tr = EdgeTrainer(sc.means, sc.log_scales, sc.quats, sc.logit_opacities, sc.viewmats, sc.Ks, sc.gt, W, H)
     tr.ensure_capacity()
     w = synth.weight_map("whole", sc.gt[1]).cuda()
     tr.grad_step(1, w)
     torch.cuda.synchronize()
     n_items = int(tr.total.cpu()[2])
     T = tr.T
+    assert (T <= 2048) == (size == "small_grid")
     rec = tr.item_rec.cpu().numpy()[:n_items]
     first, end_ = tr.item_offsets.cpu().numpy()[:T], tr.item_end.cpu().numpy()[:T]
     item_tile = tr.item_tile.cpu().numpy()[:n_items]
     tile, sl, ns = rec[:, 0], rec[:, 1] & 0xffff, rec[:, 1] >> 16
-    assert n_items > T and ns.max() >= 8, "the scene must have many-slice tiles"
+    assert n_items > T and ns.max() >= 12, "the scene must have many-slice tiles"
     # the storage numbering: contiguous runs per tile, in tile order, covering [0, n_items)
     assert first[0] == 0 and np.array_equal(first[1:], end_[:-1]) and end_[-1] == n_items
     assert np.array_equal(item_tile, np.repeat(np.arange(T), end_ - first))
@@ -1693,15 +1701,17 @@ def test_item_records_follow_the_dispatch_order_contract(env):
     pairs = tile.astype(np.int64) * 65536 + sl
     assert len(np.unique(pairs)) == n_items
     assert np.array_equal(rec[:, 2], tile * tr.seg_cap + sl * 128)  # first key of the slice
-    # dispatch order: inside a tile by slice; front slices (of all tiles) before deeper ones
+    # dispatch order: inside a tile by slice
     order = np.lexsort((np.arange(n_items), pairs))
     same_tile = tile[order][1:] == tile[order][:-1]
     assert (np.diff(order)[same_tile] > 0).all(), "a slice was dispatched before a slice in front of it"
-    # three classes (binning.hip, SegTable::slice_major / singles_last): slices [0, 4) of the multi-slice tiles, their
-    # deeper slices, then the items of the single-slice tiles (the light waves make up the launch's tail)
-    front = 4  # kFrontDefault
-    if not any(k in os.environ for k in ("EG_FRONT_SLICES", "EG_SINGLES_LAST")):
-        per_tile = end_ - first
+    if any(k in os.environ for k in ("EG_FRONT_SLICES", "EG_SINGLES_LAST", "EG_FRONT_LARGE")):
+        return
+    per_tile = end_ - first
+    if size == "small_grid":
+        # three classes (SegTable::slice_major / singles_last): slices [0, 4) of the multi-slice tiles, their deeper
+        # slices, then the items of the single-slice tiles (the light waves make up the launch's tail)
+        front = 4  # kFrontDefault
         multi = per_tile > 1
         n_a = int(np.minimum(per_tile[multi], front).sum())
         n_c = int((~multi).sum())
@@ -1710,3 +1720,12 @@ def test_item_records_follow_the_dispatch_order_contract(env):
         assert (ns[a_] > 1).all() and (sl[a_] < front).all()
         assert (ns[b_] > 1).all() and (sl[b_] >= front).all()
         assert (ns[c_] == 1).all() and (np.diff(tile[c_]) > 0).all()
+    else:
+        front = 9  # EG_FRONT_LARGE
+        n_a = int(np.minimum(per_tile, front).sum())
+        assert n_a < n_items and (sl[:n_a] < front).all() and (sl[n_a:] >= front).all()
+        assert (np.diff(tile[:n_a]) >= 0).all() and (np.diff(tile[n_a:]) >= 0).all()  # tile by tile inside a class
+        # the prefix the projection's scan left behind (ticket[1 .. T + 1])
+        fp = tr.ticket.cpu().numpy()
+        assert fp[0] == 0 and np.array_equal(fp[1:T + 1], np.concatenate([[0], np.cumsum(np.minimum(per_tile, front))[:-1]]))
+        assert fp[T + 1] == n_a
