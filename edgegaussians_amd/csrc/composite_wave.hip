@@ -31,10 +31,12 @@
 //               forward's algorithmic traffic at config 2) and issued 8 loads per batch whatever the batch held.
 //               DEAD SLICES: (tile, quadrant) keeps one word "first slice that lies behind every pixel's stop", raised by
 //               the wave that finds out; every wave reads it (non-blocking) at its head and leaves at once if it is at or
-//               behind that slice -- exact, of THIS call (round 3 guessed from the previous call's other view).  On grids
-//               of many rounds of workgroups a slice behind the first anchor WAITS for its anchor's inclusive granule
-//               before it stages anything (one generation of 8 slices runs in parallel, the next one starts when the
-//               anchor knows whether anything is left to do).
+//               behind that slice -- exact, of THIS call (round 3 guessed from the previous call's other view).  What
+//               makes the look pay is the DISPATCH ORDER (binning.hip): the deep slices of all tiles are dispatched behind
+//               the front slices of all tiles, so by the time a deep slice starts the word is there (500 k Gaussians
+//               @1200x680: 202 -> 119 us; before that, half of the launch's wave slots held deep slices waiting for the
+//               slices in front).  Waiting for the anchor before staging -- round 3's "gating" -- then buys nothing
+//               (measured equal) and is gone.
 //
 // Slices in front have lower record indices: they were dispatched earlier and wait on nobody behind them (the
 // decoupled look-back idiom; binning.hip keeps that order, tests/test_gpu_parity.py::
@@ -463,27 +465,15 @@ __device__ __forceinline__ void fold_inclusive(unsigned long long GB, float &T, 
   const unsigned f16 = (unsigned)(GB >> 32) & 0xffffu;
   front_last = f16 != kNoFront16 ? (int)(((f16 >> 7) << 9) | (f16 & 127u)) : -1;
 }
-__device__ __forceinline__ unsigned long long poll_inclusive(const unsigned long long *slot, unsigned tag, int *ctl) {
-  unsigned long long GB = load_granule(slot);
-  int spins = 0;
-  while ((unsigned)(GB >> 48) != tag) {
-    if (++spins > kSpinLimit) { spin_stalled(ctl); return make_inclusive(0.f, tag, -1); }
-    __builtin_amdgcn_s_sleep(1);
-    GB = load_granule(slot);
-  }
-  return GB;
-}
-
 // Chained mode, T_in of slice s (> 0): the inclusive granule of anchor a (0: none, then a + 1 .. means 0 ..) and the
 // aggregates of slices a + 1 .. s - 1, at most kLook granules, all requested before the first is waited for.
-// have_anchor: the caller has folded the anchor's granule already (a slice that waited for it before staging).
 __device__ __forceinline__ void look_back_anchored(const unsigned long long *gran, const unsigned long long *anchor, int i0,
-                                                   int a, int s, bool have_anchor, unsigned tag, bool inside, float &T,
-                                                   bool &before, int &front_last, int *ctl) {
+                                                   int a, int s, unsigned tag, bool inside, float &T, bool &before,
+                                                   int &front_last, int *ctl) {
   const int j0 = a > 0 ? a + 1 : 0, nb = s - j0;  // nb <= 8 (a == 0: s <= 8), wave-uniform
   const unsigned long long *slot = &anchor[(size_t)((i0 + a) >> kAnchorShift) * kTilePix + threadIdx.x];
   unsigned long long GB = 0ull, G[kLook];
-  const bool need_anchor = a > 0 && !have_anchor;
+  const bool need_anchor = a > 0;
   if (need_anchor) GB = load_granule(slot);
 #pragma unroll
   for (int u = 0; u < kLook; ++u)
@@ -534,7 +524,6 @@ struct WaveArgs {
   int width, height, tw, n_tiles;
   unsigned tag;
   float loss_scale;
-  int gate_min;  // chained mode: slices >= gate_min (and behind the first anchor) wait for their anchor before staging
   int max_anchored;  // tiles of more slices look back over all aggregates (kMaxAnchoredSlices; 0 in an A/B build leg)
   const int *item_first;  // [T]: the tile's first item in the contiguous per-tile numbering (hand-over storage)
 };
@@ -643,28 +632,7 @@ __device__ __forceinline__ void wave_fwd_body(WaveArgs a, const Batch &bt, WaveL
 
   float T = 1.f, l = 0.f;
   int front_last = -1;
-  bool before = false;       // the pixel stopped in a slice in front of this one
-  bool have_anchor = false;  // the anchor's inclusive granule is folded into T / before / front_last already
-  // ---- chained mode on grids of many rounds of workgroups: a slice behind the first anchor WAITS for its anchor's
-  // inclusive granule before it stages anything.  The eight slices behind an anchor run in parallel; the next eight start
-  // once the anchor in front of them knows whether any pixel is left.  (On a grid of two rounds the wait is a wave
-  // lifetime on the launch's critical path, and the non-blocking look above catches most of what it would.)
-  if (CHAINED && my_anchor > 0 && s_me >= a.gate_min) {
-    if (!my_dead) {
-      const unsigned long long GB =
-          poll_inclusive(&a.anchor[(size_t)((i0 + my_anchor) >> kAnchorShift) * kTilePix + threadIdx.x], tag, a.ctl);
-      fold_inclusive(GB, T, before, front_last);
-      have_anchor = true;
-      my_dead = __ballot(!before && inside) == 0ull;
-      if (my_dead && lane == 0) atomicMax(&a.dead[tile * 4 + wv], dead_key(tag, my_anchor + 1));
-    }
-    if (!__syncthreads_or(!my_dead)) {  // (all four quadrants: leave before the records are asked for)
-      publish_dead();
-      EG_TICK(0);
-      return;
-    }
-  }
-
+  bool before = false;  // the pixel stopped in a slice in front of this one
   // the workgroup's copy of the slice: one half record per thread
   if (end > start) {
     const int n = end - start;
@@ -715,7 +683,7 @@ __device__ __forceinline__ void wave_fwd_body(WaveArgs a, const Batch &bt, WaveL
 
   // ---- look back over the slices in front
   if (s_me > 0) {
-    if (anchored) look_back_anchored(gran, a.anchor, i0, my_anchor, s_me, have_anchor, tag, inside, T, before, front_last, a.ctl);
+    if (anchored) look_back_anchored(gran, a.anchor, i0, my_anchor, s_me, tag, inside, T, before, front_last, a.ctl);
     else look_back<CHAINED>(gran, i0, 0, s_me, tag, inside, T, before, front_last, a.ctl);
   }
   // chained mode: does the stop fall in this slice?  (decided here, ahead of the exact walk: the anchor's inclusive granule
@@ -853,15 +821,8 @@ int launch_wave_fwd(const float4 *splat, const TileTable tt, const int32_t *flat
     (void)hipMalloc((void **)&g_prof, (size_t)max_items * 32 * sizeof(unsigned long long));
   }
   if (timed) (void)hipMemsetAsync(g_prof, 0, (size_t)max_items * 32 * sizeof(unsigned long long), s);
-  // Waiting for the anchor before staging trades latency for work: a launch of a few rounds of workgroups lasts as long
-  // as its slowest waves (no waiting: the non-blocking look at the dead word is all), a launch of many rounds is bound
-  // by its total work (slices behind the first anchor wait).  Decided from the size of the grid: the CU array holds
-  // 2048 workgroups of this kernel.
-  int gate_min = (int64_t)max_items * C > 3 * 2048 ? 0 : 0x7fffffff;
   int max_anchored = kMaxAnchoredSlices;
 #ifdef EG_DEV_SWITCHES
-  static const int gate_env = getenv("EG_WAVE_GATE_MIN") ? atoi(getenv("EG_WAVE_GATE_MIN")) : -1;
-  if (gate_env >= 0) gate_min = gate_env;
   static const int anchor_env = getenv("EG_WAVE_ANCHOR") ? atoi(getenv("EG_WAVE_ANCHOR")) : 1;
   if (!anchor_env) max_anchored = 0;
 #endif
@@ -872,7 +833,7 @@ int launch_wave_fwd(const float4 *splat, const TileTable tt, const int32_t *flat
   a.loss_part = ws.loss_part;
   a.gt = gt; a.wmap = wmap; a.gtstop = (StopRec *)gtstop; a.prof = g_prof;
   a.width = width; a.height = height; a.tw = tw; a.n_tiles = tw * th;
-  a.tag = tag; a.loss_scale = loss_scale; a.gate_min = gate_min; a.max_anchored = max_anchored; a.item_first = tt.item_first;
+  a.tag = tag; a.loss_scale = loss_scale; a.max_anchored = max_anchored; a.item_first = tt.item_first;
   // one view: everything is resolved here and the kernel never looks at the batch descriptor
   const bool batched = C > 1;
   if (!batched && bt.gt[0]) { a.gt = bt.gt[0]; a.wmap = bt.wmap[0]; }
