@@ -316,8 +316,7 @@ struct SegTable {
   // measured -3.2 us in the forward but needs a histogram of the slice counts in every sort workgroup: +4.7 us
   // there; the two classes cost one more running sum.)
   // A slice still follows all slices in front of it: the look-back's dispatch-order guarantee holds.
-  int slice_major = 0;  // != 0: on (classes of slices [0, slice_major), then kClass1End, kClass2End, the rest); 0 = item order
-  int classes = 0;      // number of bounded classes in use: 1 = {[0, slice_major), rest}, 3 = all of kClass*End
+  int slice_major = 0;  // the class boundary (slices), 0 = off
   // with slice_major: the items of the SINGLE-slice tiles (at most 128 Gaussians, nothing to hand over: the light
   // waves) form a third class behind the deep slices, so that the launch's tail is made of short-lived waves
   int singles_last = 0;
@@ -329,11 +328,7 @@ struct SegTable {
   const int *item_front = nullptr;
   int middle_out = 0;   // workgroup -> tile assignment of the small sort variant (see the kernel)
 };
-constexpr int kFrontDefault = 4;  // first class boundary of the dispatch order (slices); SegTable::slice_major carries it
-// further boundaries (SegTable::classes == 3): the deep slices of ALL tiles are dispatched by depth class as well -- a
-// slice then starts when the slices in front of it (other classes, dispatched a round of workgroups earlier) have
-// published or are about to, instead of right behind them
-constexpr int kClass1End = 8, kClass2End = 16;
+constexpr int kFrontDefault = 4;  // class boundary of the dispatch order (slices); SegTable::slice_major carries it
 
 // THREADS = number of buckets; CAP = keys per buffer (two buffers).  n_lo < n handled here.
 template <int THREADS, int CAP, bool LARGE>
@@ -378,21 +373,19 @@ tile_sort_kernel(unsigned long long *__restrict__ keys, const int *__restrict__ 
   const int tile = (!LARGE && seg.middle_out) ? ((wg & 1) ? T / 2 - (wg + 1) / 2 : T / 2 + wg / 2) : wg;
   __syncthreads();
   long long start, end;
-  __shared__ int s_pre[8][THREADS / 64];
+  __shared__ int s_pre[6][THREADS / 64];
   bool prefix_pending = false;  // (uniform) the tile prefix still has to be finished: see SegTable::total
   int pop_here = 0;
   // after a barrier: every thread sums the waves' partials; thread 0 writes the tile's table entries (and the
   // totals of the view, if this is the last tile), the first threads the item -> tile map
   auto finish_prefix = [&](int kept_) {
-    int isum = 0, msum = 0, cmax = 0, itot = 0, front = 0, single = 0, cl1 = 0, cl2 = 0;
+    int isum = 0, msum = 0, cmax = 0, itot = 0, front = 0, single = 0;
 #pragma unroll
     for (int w = 0; w < THREADS / 64; ++w) {
       isum += s_pre[0][w]; msum += s_pre[1][w]; cmax = max(cmax, s_pre[2][w]); itot += s_pre[3][w];
-      front += s_pre[4][w]; single += s_pre[5][w]; cl1 += s_pre[6][w]; cl2 += s_pre[7][w];
+      front += s_pre[4][w]; single += s_pre[5][w];
     }
     const int isumf = front & 0xffff, itotf = front >> 16;
-    // (classes 1 and 2: slices [F, kClass1End) and [kClass1End, kClass2End); zero when only two classes are in use)
-    const int b1 = cl1 & 0xffff, t1 = cl1 >> 16, b2 = cl2 & 0xffff, t2 = cl2 >> 16;
     const int cbef = seg.singles_last ? (single & 0xffff) : 0, ctot = seg.singles_last ? (single >> 16) : 0;
     const int first_ = min(isum, seg.max_items);
     const int items_ = min(max(1, (kept_ + 127) >> 7), max(0, seg.max_items - first_));
@@ -420,11 +413,7 @@ tile_sort_kernel(unsigned long long *__restrict__ keys, const int *__restrict__ 
         if (front_first) {
           // class A: slices [0, F) of the multi-slice tiles; class B: their deeper slices; class C: single-slice tiles
           if (seg.singles_last && items_ == 1) disp = (itot - ctot) + cbef;
-          else if (i < seg.slice_major) disp = (isumf - cbef) + i;
-          else if (seg.classes == 3 && i < kClass1End) disp = (itotf - ctot) + b1 + (i - seg.slice_major);
-          else if (seg.classes == 3 && i < kClass2End) disp = (itotf - ctot) + t1 + b2 + (i - kClass1End);
-          else if (seg.classes == 3) disp = (itotf - ctot) + t1 + t2 + (isum - isumf - b1 - b2) + (i - kClass2End);
-          else disp = (itotf - ctot) + (isum - isumf) + (i - seg.slice_major);
+          else disp = i < seg.slice_major ? (isumf - cbef) + i : (itotf - ctot) + (isum - isumf) + (i - seg.slice_major);
         }
         if (disp < seg.max_items)
           seg.item_rec[disp] = make_int4(tile, i | (items_ << 16), tile * seg.seg_cap + i * 128, tile * seg.seg_cap + kept_);
@@ -455,7 +444,6 @@ tile_sort_kernel(unsigned long long *__restrict__ keys, const int *__restrict__ 
         // the same over min(items, kFront): the sum over the tiles in front in the low half, over all tiles in the high
         // half (at most 2048 * 15 each)
         int front = 0, single = 0;  // (single: tiles of ONE item in front in the low half, all of them in the high half)
-        int cl1 = 0, cl2 = 0;       // (slices of classes 1 and 2, packed the same way: at most 2048 * 8 each)
 #pragma unroll
         for (int j = 0; j < kPrefixHereMaxTiles / THREADS; ++j)
           if (pv[j] >= 0) {
@@ -467,12 +455,6 @@ tile_sort_kernel(unsigned long long *__restrict__ keys, const int *__restrict__ 
             const int itf = min(it, seg.slice_major);
             front += (before ? itf : 0) + (itf << 16);
             single += it == 1 ? ((before ? 1 : 0) + (1 << 16)) : 0;
-            if (seg.classes == 3) {
-              const int c1 = min(max(it - seg.slice_major, 0), kClass1End - seg.slice_major);
-              const int c2 = min(max(it - kClass1End, 0), kClass2End - kClass1End);
-              cl1 += (before ? c1 : 0) + (c1 << 16);
-              cl2 += (before ? c2 : 0) + (c2 << 16);
-            }
           }
         // (DPP scans: the totals land in lane 63)
         isum = wave_scan_dpp(isum, 0, OpAdd());
@@ -481,10 +463,9 @@ tile_sort_kernel(unsigned long long *__restrict__ keys, const int *__restrict__ 
         cmax = wave_scan_dpp(cmax, 0, OpMaxI());
         front = wave_scan_dpp(front, 0, OpAdd());
         single = wave_scan_dpp(single, 0, OpAdd());
-        if (seg.classes == 3) { cl1 = wave_scan_dpp(cl1, 0, OpAdd()); cl2 = wave_scan_dpp(cl2, 0, OpAdd()); }
         if ((tid & 63) == 63) {
           s_pre[0][tid >> 6] = isum; s_pre[1][tid >> 6] = msum; s_pre[2][tid >> 6] = cmax; s_pre[3][tid >> 6] = itot;
-          s_pre[4][tid >> 6] = front; s_pre[5][tid >> 6] = single; s_pre[6][tid >> 6] = cl1; s_pre[7][tid >> 6] = cl2;
+          s_pre[4][tid >> 6] = front; s_pre[5][tid >> 6] = single;
         }
         prefix_pending = true;
         first = items = 0;
@@ -812,7 +793,6 @@ int launch_sort_segments(uint64_t *keys, int32_t *tile_cursor, int32_t T, int32_
   seg.rank_order = 0;
   seg.item_rec = (int4 *)item_rec;
   seg.slice_major = kFrontDefault;
-  seg.classes = 3;
   seg.singles_last = 1;
   seg.middle_out = 1;
   seg.item_front = total_prefix_here ? nullptr : item_front;
@@ -822,9 +802,7 @@ int launch_sort_segments(uint64_t *keys, int32_t *tile_cursor, int32_t T, int32_
   static const int middle_out = getenv("EG_SORT_MIDDLE_OUT") ? atoi(getenv("EG_SORT_MIDDLE_OUT")) : 1;
   static const int singles_last = getenv("EG_SINGLES_LAST") ? atoi(getenv("EG_SINGLES_LAST")) : 1;
   seg.rank_order = rank_order;
-  seg.slice_major = front < 0 ? 0 : (front > 7 ? 7 : front);
-  static const int classes = getenv("EG_CLASSES") ? atoi(getenv("EG_CLASSES")) : 3;
-  seg.classes = classes == 3 ? 3 : 1;
+  seg.slice_major = front < 0 ? 0 : (front > 15 ? 15 : front);
   seg.middle_out = middle_out;
   seg.singles_last = singles_last;
   static const int front_large = getenv("EG_FRONT_LARGE") ? atoi(getenv("EG_FRONT_LARGE")) : 1;
