@@ -44,6 +44,12 @@ ALPHA_MAX = 0.999
 ALPHA_MIN = 1.0 / 255.0
 T_STOP = 1e-4
 FOV_CLAMP = 1.3
+RADIUS_SIGMAS = 3.0      # radius = ceil(3 sqrt(lambda_max))
+RADIUS_DET_FLOOR = 0.01  # lambda_max = b + sqrt(max(0.01, b^2 - det))
+PIXEL_CENTRE = 0.5       # pixel (i, j) is sampled at (j + 0.5, i + 0.5)
+STOP_BEFORE = True       # the walk ends BEFORE the Gaussian that would take T to <= T_STOP (it does not contribute)
+# (every restated constant is a module-level name so that tests/test_oracle_mutations.py can flip it and watch a
+# known-answer test of tests/test_oracle.py fail)
 
 
 # --------------------------------------------------------------------------------------
@@ -150,8 +156,8 @@ def project(
 
     with torch.no_grad():
         bh = 0.5 * (b00 + b11)
-        v1 = bh + torch.sqrt(torch.clamp(bh * bh - det1, min=0.01))
-        radius = torch.ceil(3.0 * torch.sqrt(v1))
+        v1 = bh + torch.sqrt(torch.clamp(bh * bh - det1, min=RADIUS_DET_FLOOR))
+        radius = torch.ceil(RADIUS_SIGMAS * torch.sqrt(v1))
         ok = in_z & det_ok & (radius > radius_clip)
         ok &= ~(
             (mean2d[:, 0] + radius <= 0)
@@ -262,8 +268,8 @@ def composite(
         ii, jj = torch.meshgrid(
             torch.arange(i0, i1), torch.arange(j0, j1), indexing="ij"
         )
-        py = ii.reshape(-1).to(dt) + 0.5
-        px = jj.reshape(-1).to(dt) + 0.5
+        py = ii.reshape(-1).to(dt) + PIXEL_CENTRE
+        px = jj.reshape(-1).to(dt) + PIXEL_CENTRE
         g = fid[s:e]
         xy = means2d[g]
         con = conics[g]
@@ -280,6 +286,8 @@ def composite(
             valid = (sigma >= 0) & (alpha >= ALPHA_MIN)
             a_m = torch.where(valid, alpha, torch.zeros_like(alpha))
             next_T = torch.cumprod(1 - a_m, dim=1)
+            if not STOP_BEFORE:  # (mutation leg only: the Gaussian that crosses the threshold still contributes)
+                next_T = torch.cat([torch.ones_like(next_T[:, :1]), next_T[:, :-1]], dim=1)
             stopped = torch.cummax((next_T <= T_STOP).to(torch.int8), dim=1).values > 0
             contrib = valid & ~stopped
         alpha_c = torch.where(contrib, alpha, torch.zeros_like(alpha))

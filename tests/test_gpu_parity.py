@@ -68,11 +68,23 @@ def test_projection_forward(env):
     torch.cuda.synchronize()
     r = to_np(radii)
     ro = to_np(radii_o)
-    assert ((r > 0) == (ro > 0)).mean() > 0.999
+    # STRICT form (round 4): the scene is NOT cleaned here -- instead the Gaussians whose integer decisions lie within
+    # 2e-5 of a float threshold are identified (oracle/eg_oracle.c: ego_project_borderline, double precision on the
+    # oracle's own fp32 values) and the two sets are held to different standards:
+    #   outside the set: cull decisions and radii IDENTICAL for every Gaussian;
+    #   inside the set:  the outcome is BOUNDED -- the radius differs by at most 1, and a cull decision may differ only
+    #                    where the other side's radius is at most 1 ... or the Gaussian sits on the near plane / screen edge
+    from oracle import c_oracle as CO
+    border = CO.project_borderline(sc.means.numpy(), sc.quats.numpy(), scales.numpy(), sc.viewmats[0].numpy(),
+                                   sc.Ks[0].numpy(), W, H) > 0
+    assert border.mean() <= 0.02, border.mean()
+    assert np.array_equal(r[~border], ro[~border]), f"{int((r[~border] != ro[~border]).sum())} radii differ outside the borderline set"
+    both_b = border & (r > 0) & (ro > 0)
+    assert np.abs(r[both_b] - ro[both_b]).max(initial=0) <= 1
+    record("projection_forward_strict", gaussians=int(N), borderline=int(border.sum()),
+           radius_mismatches_inside=int((r[border] != ro[border]).sum()), cull_flips_inside=int(((r > 0) != (ro > 0))[border].sum()))
     both = (r > 0) & (ro > 0)
     assert both.sum() > 1000 and (ro == 0).sum() >= 50
-    # radius = ceil(3 sqrt(lambda)): identical except where 3 sqrt(lambda) sits within an ulp of an integer
-    assert (r[both] != ro[both]).mean() < 2e-3 and np.abs(r[both] - ro[both]).max() <= 1
     sel = torch.from_numpy(both)
     assert_close(m2d.cpu()[sel], m2d_o[sel], name="means2d")
     assert_close(dep.cpu()[sel], dep_o[sel], name="depths")
@@ -222,6 +234,13 @@ def test_rasterization_matches_oracle(env, strategy, mode):
     e = {"render": rel_err(gpu["render"][0][ok], cpu["render"][0][ok]), "alpha": rel_err(gpu["alpha"][0][ok], cpu["alpha"][0][ok])}
     assert_close(gpu["render"][0][ok], cpu["render"][0][ok], name="render")
     assert_close(gpu["alpha"][0][ok], cpu["alpha"][0][ok], name="alpha")
+    # INSIDE the borderline pixel set the outcome is bounded, not free: the two sides may disagree on ONE decision of the
+    # walk -- a Gaussian at alpha = 1/255 counted or not (|d alpha_pixel| <= T / 255), the walk ending at T = 1e-4 or one
+    # contributor later (<= 1e-4), the 0.999 cap (<= 1e-3 T) -- so the pixel differs by at most 1 / 255 + 1e-4 + 1e-4
+    if bool(border.any()):
+        d_in = (gpu["alpha"][0, ..., 0].cpu()[border] - cpu["alpha"][0, ..., 0][border]).abs().max()
+        e["alpha_diff_inside_borderline"] = float(d_in)
+        assert float(d_in) <= 1.0 / 255.0 + 2e-4, float(d_in)
     assert abs(float(gpu["loss"]) - float(cpu["loss"])) <= 1e-4 * abs(float(cpu["loss"]))
     for k in ("means", "q", "ls", "lo"):
         e[f"grad {k}"] = rel_err(gpu[k].grad, cpu[k].grad)

@@ -74,10 +74,10 @@ def test_alpha_cap_cut_and_early_stop():
     r, a, _ = _render(m, torch.full((1, 3), s), torch.tensor([1.0 / comp]), cxy=c)
     assert float(a[0, 8, 8, 0]) == pytest.approx(0.999, abs=1e-6)
     # cut: alpha just below 1/255 at the centre contributes nowhere
-    r, a, _ = _render(m, torch.full((1, 3), s), torch.tensor([0.99 / 255 / comp]), cxy=c)
+    r, a, _ = _render(m, torch.full((1, 3), s), torch.tensor([0.999 / 255 / comp]), cxy=c)
     assert float(a.abs().max()) == 0.0
-    r, a, _ = _render(m, torch.full((1, 3), s), torch.tensor([1.01 / 255 / comp]), cxy=c)
-    assert float(a[0, 8, 8, 0]) == pytest.approx(1.01 / 255, rel=1e-4)
+    r, a, _ = _render(m, torch.full((1, 3), s), torch.tensor([1.001 / 255 / comp]), cxy=c)
+    assert float(a[0, 8, 8, 0]) == pytest.approx(1.001 / 255, rel=1e-5)
     # stop BEFORE the Gaussian that takes T to <= 1e-4: three stacked alpha = 0.999 layers
     ms = torch.stack([_mean_at(8.5, 8.5, zz, cxy=c) for zz in (2.0, 2.5, 3.0)])
     sc = torch.stack([torch.full((3,), 0.2 * zz / 2.0) for zz in (2.0, 2.5, 3.0)])
@@ -89,6 +89,36 @@ def test_alpha_cap_cut_and_early_stop():
     assert int(info["last_ids"][0, 8, 8]) in range(0, info["flatten_ids"].shape[0])
     tile0 = info["isect_offsets"][0, 0, 0].item()
     assert int(info["last_ids"][0, 8, 8]) == tile0 + 0 and first >= 0
+
+
+def test_transmittance_stop_threshold_from_both_sides():
+    """T after the first layer is 1e-3; a second layer of alpha 0.95 would take it to 5e-5 <= 1e-4 and is NOT composited,
+    one of alpha 0.85 takes it to 1.5e-4 > 1e-4 and IS (pins the 1e-4 against 1e-5 and against 2e-4)."""
+    z, s = 2.0, 0.2
+    c = (8.5, 8.5)
+    v = (FX * s / z) ** 2
+    comp = v / (v + 0.3)
+    ms = torch.stack([_mean_at(8.5, 8.5, zz, cxy=c) for zz in (2.0, 2.5)])
+    sc = torch.stack([torch.full((3,), 0.2 * zz / 2.0) for zz in (2.0, 2.5)])
+    _, a, _ = _render(ms, sc, torch.tensor([1.0 / comp, 0.95 / comp]), cxy=c)
+    assert float(a[0, 8, 8, 0]) == pytest.approx(0.999, abs=1e-6)
+    _, a, _ = _render(ms, sc, torch.tensor([1.0 / comp, 0.85 / comp]), cxy=c)
+    assert float(a[0, 8, 8, 0]) == pytest.approx(1 - 1e-3 * 0.15, abs=2e-6)
+
+
+def test_radius_floor_is_observable():
+    """lambda_max = b + sqrt(max(0.01, b^2 - det)): for an isotropic footprint b^2 - det = 0 and the floor adds 0.1 to
+    the variance -- 3 sqrt(1.1) = 3.15 -> radius 4 where 3 sqrt(1.0) gives 3 (VERDICT r03 listed the floor as
+    unobservable; it is visible in info["radii"] and in the tile box)."""
+    z = 2.0
+    s = z * math.sqrt(0.7) / FX  # 2-D variance 0.7 (+ 0.3 blur = 1.0)
+    c = (20.5, 10.5)
+    _, _, info = _render(_mean_at(20.5, 10.5, z, cxy=c)[None], torch.full((1, 3), s), torch.tensor([0.6]), cxy=c)
+    assert int(info["radii"][0, 0]) == 4
+    # ... and the floor is 0.01, not 0.1: variance 1.3 + 0.3 -> 3 sqrt(1.6 + 0.1) = 3.91 -> 4 (sqrt(0.1) would give 5)
+    s2 = z * math.sqrt(1.3) / FX
+    _, _, info = _render(_mean_at(20.5, 10.5, z, cxy=c)[None], torch.full((1, 3), s2), torch.tensor([0.6]), cxy=c)
+    assert int(info["radii"][0, 0]) == 4
 
 
 def test_two_stacked_gaussians_composite_in_depth_order():
@@ -144,30 +174,24 @@ def test_tile_binning_layout():
 
 
 def test_fov_clamp_enters_the_jacobian():
-    # a Gaussian far outside the 1.3x frustum: J uses the clamped x/z, mean2d the true one
+    """A Gaussian outside the 1.3x frustum whose footprint still reaches the image: its 2-D covariance is formed with
+    the CLAMPED x / z in the Jacobian, its mean2d with the true one."""
     z = 1.0
     lim = 1.3 * 0.5 * W / FX
-    x = 3.0 * lim * z
+    x = 1.5 * lim * z  # mean2d.x = 100 * 0.624 + 32 = 94.4: off-screen (W = 64)
+    sg = 0.15          # ~15 px: the 3-sigma box reaches back into the image
     means = torch.tensor([[x, 0.0, z]])
     vm, K = _cam()
-    s = torch.full((1, 3), 0.05)
-    radii, m2d, dep, conic, comp = O.project(means, torch.tensor([[1.0, 0, 0, 0]]), s, vm, K, W, H)
-    # recompute cov2d by hand with tx = lim * z
+    radii, m2d, dep, conic, comp = O.project(means, torch.tensor([[1.0, 0, 0, 0]]), torch.full((1, 3), sg), vm, K, W, H)
+    assert int(radii[0]) > 0, "the case must not be culled"
+    assert float(m2d[0, 0]) == pytest.approx(FX * x / z + W / 2, rel=1e-6)  # unclamped
     tx = lim * z
     J = torch.tensor([[FX / z, 0, -FX * tx / z ** 2], [0, FY / z, 0.0]])
-    cov = J @ (0.05 ** 2 * torch.eye(3)) @ J.T + 0.3 * torch.eye(2)
+    cov = J @ (sg ** 2 * torch.eye(3)) @ J.T + 0.3 * torch.eye(2)
     want = torch.linalg.inv(cov)
-    # the Gaussian is off-screen (culled): evaluate the maths on an un-culled copy by widening the image
-    radii2, m2d2, _, conic2, _ = O.project(means, torch.tensor([[1.0, 0, 0, 0]]), s, vm,
-                                           torch.tensor([[FX, 0, 400.0], [0, FY, H / 2], [0, 0, 1.0]]), 800, H)
-    lim2 = 1.3 * 0.5 * 800 / FX
-    assert x / z < lim2  # inside the wider frustum: unclamped there
-    assert int(radii[0]) == 0  # culled in the narrow image
-    # narrow-image Jacobian check through autograd-free replay
-    cov_n = J @ (0.05 ** 2 * torch.eye(3)) @ J.T
-    det0 = torch.det(cov_n)
-    assert float(det0) > 0 and want.shape == (2, 2)
-    assert float(m2d2[0, 0]) == pytest.approx(FX * x / z + 400.0, rel=1e-6)
+    assert conic[0].tolist() == pytest.approx([float(want[0, 0]), float(want[0, 1]), float(want[1, 1])], rel=1e-5, abs=1e-9)
+    # (with the unclamped x / z the first entry would be 1 / (225 (1 + 0.624^2) + 0.3) instead of 1 / (225 (1 + 0.416^2) + 0.3))
+    assert abs(float(conic[0, 0]) - 1.0 / (sg ** 2 * FX ** 2 * (1 + (x / z) ** 2) + 0.3)) > 1e-4 * float(conic[0, 0])
 
 
 def test_unit_colour_identity_and_order_independence():

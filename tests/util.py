@@ -119,6 +119,17 @@ def record(name, **metrics):
                                               for k, v in metrics.items()}}) + "\n")
 
 
+def record_cpu(name, **metrics):
+    """The same for the CPU-only tests (oracle against oracle): profiles-bound lines in gpurun_out/parity_report_cpu.jsonl."""
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(root, "gpurun_out", "parity_report_cpu.jsonl"), "a") as f:
+        f.write(json.dumps({"test": name, **{k: (float(v) if isinstance(v, (float, np.floating)) else v)
+                                              for k, v in metrics.items()}}) + "\n")
+
+
 def strict_inputs(sc, view, strategy, seed=3, ratio=1.0):
     """(clean scene, C-oracle forward of `view`, borderline pixel mask, masked weight map, #removed Gaussians)."""
     from edgegaussians_amd import synth
