@@ -218,8 +218,14 @@ def train(tr: EdgeTrainer, model_cfg: Dict, training_cfg: Dict, view_order: Call
                         views_per_step=views_per_step, dp=dp)
         parked.append((epoch, n))
         # (the trainer parks at most 64 epoch sums on the device between two read-backs)
-        if (len(parked) >= max(1, min(sync_every, 60)) or epoch in events or epoch == num_epochs - 1
-                or len(tr._journal) > 4096 or tr.journal_bytes() > (1 << 29)):
+        # (the journal's size is a RANK-LOCAL quantity -- a rank journals the weight maps of its own views only, and with
+        # period-2 draws on two ranks every fresh `bg_edge_ratio` map lands on the same one -- while a read-back is a
+        # collective: under data parallelism the ranks agree on the decision first, or one of them would enter the
+        # read-back's all-reduce while the others go on to the next epoch's gradient all-reduce)
+        big = len(tr._journal) > 4096 or tr.journal_bytes() > (1 << 29)
+        if dp is not None and getattr(dp, "world", 1) > 1:
+            big = bool(dp.reduce_words([int(big)], [])[0][0])
+        if len(parked) >= max(1, min(sync_every, 60)) or epoch in events or epoch == num_epochs - 1 or big:
             read_back()
         changed = False
         if get("if_duplicate_high_pos_grad", True) and epoch in get("dup_high_pos_grads_at_epoch", []):

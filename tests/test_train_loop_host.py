@@ -248,6 +248,9 @@ class FakeDP:
         self.worker.log.append(("dp", self.worker.epoch, views, [w[0] for w in wm]))
         self.worker._journal.append(tuple(views))
 
+    def reduce_words(self, ints, floats):  # (the other rank agrees with this one)
+        return list(ints), list(floats)
+
 
 def test_views_per_step_batches_and_shards_like_the_single_process_run(cfg):
     """C = 2 views per optimizer step: the single-process run issues batched steps over consecutive pairs of the epoch's
@@ -289,3 +292,34 @@ def test_views_per_step_batches_and_shards_like_the_single_process_run(cfg):
     with pytest.raises(ValueError):
         train_loop.train(FakeTrainer(), model_cfg, training_cfg, order, num_epochs=1, views_per_step=3,
                          dp=FakeDP(FakeTrainer(), 0))
+
+
+class FakeDPOtherRankBig:
+    """Two-rank data-parallel driver as train() sees it from rank 0; `other_is_big` plays the other rank's answer."""
+    world, rank = 2, 0
+
+    def __init__(self, tr, other_is_big):
+        self.tr, self.other_is_big, self.asked = tr, other_is_big, 0
+
+    def step(self, view, wmap):
+        self.tr.train_step_batched([view] if isinstance(view, int) else view, [wmap] if isinstance(view, int) else wmap)
+
+    def reduce_words(self, ints, floats):
+        self.asked += 1
+        return [max(i, int(self.other_is_big())) for i in ints], list(floats)
+
+
+def test_read_back_decision_is_collective_under_data_parallelism(cfg):
+    """the journal's size is rank-local (a rank journals only its own views' weight maps), the
+    read-back is a collective.  If rank 1's journal crosses the 512 MB mark, rank 0 -- whose own journal is small --
+    must read back in the same epoch: the ranks agree on the decision through dp.reduce_words every epoch."""
+    model_cfg, training_cfg = dict(cfg["model"]), json.loads(json.dumps(cfg["training"]))
+    model_cfg.update(dup_high_pos_grads_at_epoch=[], cull_opacity_at_epoch=[], cull_gaussians_not_projecting_at_epoch=[])
+    for big_epochs in ({3, 4}, set()):
+        tr = FakeTrainer()
+        dp = FakeDPOtherRankBig(tr, lambda: tr.epoch in big_epochs)
+        train_loop.train(tr, model_cfg, training_cfg, lambda e: [(e + i) % 6 for i in range(6)], edge_masks_u8=object(),
+                         num_epochs=12, sync_every=1000, views_per_step=2, dp=dp)
+        syncs = [x[1] for x in tr.log if x[0] == "sync"]
+        assert dp.asked == 12, "the decision is agreed on once per epoch"
+        assert syncs == (sorted(big_epochs) + [11] if big_epochs else [11]), syncs
