@@ -294,6 +294,11 @@ def measure(name, args, device, rank, world, backend, spread=False, steps=None, 
     dp = egdist.DataParallelStep(tr) if ((world > 1 and not args.replicas) or args.force_dp) else None
     if dp is not None and world == 1:
         dp.world = 2  # issue the collective
+    # the native data-parallel leg (eg_train_steps_dp: grad -> ncclAllReduce on the launch stream -> Adam + next projection,
+    # `chunk` steps per enqueue) whenever RCCL is the backend; EG_NO_NATIVE_DP=1: the Python driver (three enqueues + one
+    # torch.distributed call per step)
+    native_dp = (dp is not None and vps == 1 and backend == "nccl" and not os.environ.get("EG_NO_NATIVE_DP")
+                 and egdist.init_native_comm() >= 1 and dp.native_ready())
     def wmap_for(step, view):
         return ratio(view) if step % 5 == 0 else whole  # configs/ABC_DexiNed.json:85-92
 
@@ -307,6 +312,13 @@ def measure(name, args, device, rank, world, backend, spread=False, steps=None, 
                 ss = range(s0, min(s0 + chunk, step0 + k))
                 vs = [s % n_views for s in ss]
                 tr.train_steps(vs, [wmap_for(s, v) for s, v in zip(ss, vs)])
+            return
+        if native_dp and not dp.time_comm and chunk > 1:
+            for s0 in range(step0, step0 + k, chunk):
+                ss = range(s0, min(s0 + chunk, step0 + k))
+                vs = [egdist.view_for(s, rank, world, n_views) for s in ss]
+                dp.steps(vs, [wmap_for(s, v) for s, v in zip(ss, vs)],
+                         next_view=egdist.view_for(ss[-1] + 1, rank, world, n_views))
             return
         for s in range(step0, step0 + k):
             if dp is None and vps > 1:  # C views per launch sequence and optimizer step
@@ -390,7 +402,9 @@ def measure(name, args, device, rank, world, backend, spread=False, steps=None, 
                    "views_per_step": world * vps,
                    "gaussian_row_order": "morton" if tr.spatial_order else "as given",
                    "binning": "segmented" if tr.segmented else "scan",
-                   "steps_per_native_enqueue": chunk if (dp is None and vps == 1) else 1,
+                   "steps_per_native_enqueue": chunk if ((dp is None or native_dp) and vps == 1) else 1,
+                   "data_parallel_leg": (None if dp is None else ("native: eg_train_steps_dp (ncclAllReduce on the launch stream)"
+                                                                   if native_dp else "python: DataParallelStep.step")),
                    "forward_mode": ("speculative (no pixel reaches the transmittance stop; a stop would replay the window "
                                     "from the step journal)" if tr._rewalk_arg(dp is None) == -2
                                     else "chained (exact transmittance stop resolved inside the forward kernel)"),

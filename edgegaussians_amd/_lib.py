@@ -98,12 +98,16 @@ _SIGS = {
     "eg_regulariser_step": [_i32] + [_vp] * 7 + [_i32, _vp, _i32, _i32, _i32, _i32, _vp, _f, _f, _vp, AdamHyper, _vp],
     "eg_train_step": [C.POINTER(StepArgs), _vp],
     "eg_train_steps": [C.POINTER(StepArgs), _i32, C.POINTER(_i32), C.POINTER(_vp), _vp, _vp, _vp, _vp],
+    "eg_train_steps_dp": [C.POINTER(StepArgs), C.POINTER(AdamHyper), _vp, _i32, C.POINTER(_i32), C.POINTER(_vp), _vp, _vp,
+                          _vp, _i32, _vp],
+    "eg_dp_all_reduce": [_vp, _i64, _vp],
     "eg_train_step_batched": [C.POINTER(StepArgs), _i32, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), _vp],
 }
 EXPORTS = sorted(list(_SIGS) + ["eg_last_error_string", "eg_version", "eg_device_count",
                                  "eg_composite_workspace_bytes", "eg_composite_workspace_ctl_bytes",
                                  "eg_batched_workspace_stride", "eg_knn_auto_dims", "eg_timing_begin", "eg_timing_end",
-                                 "eg_timing_stage_count", "eg_timing_stage_name", "eg_debug_fwd_profile"])
+                                 "eg_timing_stage_count", "eg_timing_stage_name", "eg_debug_fwd_profile",
+                                 "eg_dp_unique_id", "eg_dp_init", "eg_dp_world", "eg_dp_shutdown"])
 
 _lib: Optional[C.CDLL] = None
 
@@ -137,6 +141,12 @@ def load(require_device: bool = True) -> C.CDLL:
         lib.eg_batched_workspace_stride.argtypes = [_i64, _i64]
         lib.eg_knn_auto_dims.restype = _i32
         lib.eg_knn_auto_dims.argtypes = [_i32, _i32]
+        lib.eg_dp_unique_id.argtypes = [C.c_char_p, _vp]
+        lib.eg_dp_init.argtypes = [C.c_char_p, _vp, _i32, _i32]
+        lib.eg_dp_world.argtypes = []
+        lib.eg_dp_shutdown.argtypes = []
+        lib.eg_debug_fwd_profile.restype = _i64
+        lib.eg_debug_fwd_profile.argtypes = [_vp, _i64]
         _lib = lib
     if require_device and not torch.cuda.is_available():
         raise RuntimeError("edgegaussians_amd needs a gfx950 GPU (torch.cuda.is_available() is False); "

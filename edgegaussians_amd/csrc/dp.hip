@@ -1,0 +1,171 @@
+// Native data-parallel step: K consecutive view-sharded optimizer steps enqueued by ONE native call,
+//   per step:  eg_train_step (forward + loss + backward -> the fused [N,12] gradient buffer)
+//              ncclAllReduce(sum, fp32) of that buffer ON THE LAUNCH STREAM (RCCL over xGMI)
+//              eg_adam_emit (the four Adam steps on the reduced gradient + projection / binning of the rank's next view)
+// -- what dist.DataParallelStep.step does from Python with three native enqueues and one torch.distributed call per step
+// (host-bound at 110-140 us per step per rank before any wire time).  The reference itself is
+// single-GPU and steps after every view (train_gaussians.py:104-106,311): a P-way step is a batch of P views, the
+// guarantee is "all-reduced gradient == sum of the per-view gradients at the same parameters".
+//
+// RCCL is NOT a link dependency: librccl.so is dlopen'ed from the path the caller gives (the one PyTorch ships and has
+// loaded already: torch/lib/librccl.so -- the same library instance, so the process holds one RCCL), the communicator is
+// created from a ncclUniqueId the ranks exchange over torch.distributed (edgegaussians_amd/dist.py).  The communicator is
+// process state (one of the stated exceptions in include/edgegs.h).
+#include <dlfcn.h>
+
+#include <cstring>
+
+#include "common.h"
+
+namespace eg {
+
+// the subset of rccl.h this file needs (ABI-stable NCCL 2.x entry points)
+typedef struct { char internal[128]; } NcclUniqueId;
+typedef void *NcclComm;
+constexpr int kNcclFloat = 7, kNcclSum = 0;
+typedef int (*GetUniqueIdFn)(NcclUniqueId *);
+typedef int (*CommInitRankFn)(NcclComm *, int, NcclUniqueId, int);
+typedef int (*CommDestroyFn)(NcclComm);
+typedef int (*AllReduceFn)(const void *, void *, size_t, int, int, NcclComm, hipStream_t);
+typedef const char *(*GetErrorStringFn)(int);
+
+static void *g_rccl = nullptr;
+static GetUniqueIdFn p_get_unique_id = nullptr;
+static CommInitRankFn p_comm_init_rank = nullptr;
+static CommDestroyFn p_comm_destroy = nullptr;
+static AllReduceFn p_all_reduce = nullptr;
+static GetErrorStringFn p_error_string = nullptr;
+static NcclComm g_comm = nullptr;
+static int g_world = 0, g_rank = 0;
+
+static int load_rccl(const char *path) {
+  if (g_rccl) return EG_OK;
+  g_rccl = dlopen(path && path[0] ? path : "librccl.so", RTLD_NOW | RTLD_GLOBAL);
+  if (!g_rccl) {
+    set_error("eg_dp: dlopen(%s) failed: %s", path ? path : "librccl.so", dlerror());
+    return EG_ERR_ARG;
+  }
+  p_get_unique_id = (GetUniqueIdFn)dlsym(g_rccl, "ncclGetUniqueId");
+  p_comm_init_rank = (CommInitRankFn)dlsym(g_rccl, "ncclCommInitRank");
+  p_comm_destroy = (CommDestroyFn)dlsym(g_rccl, "ncclCommDestroy");
+  p_all_reduce = (AllReduceFn)dlsym(g_rccl, "ncclAllReduce");
+  p_error_string = (GetErrorStringFn)dlsym(g_rccl, "ncclGetErrorString");
+  if (!p_get_unique_id || !p_comm_init_rank || !p_comm_destroy || !p_all_reduce) {
+    set_error("eg_dp: %s does not export the NCCL entry points", path ? path : "librccl.so");
+    dlclose(g_rccl);
+    g_rccl = nullptr;
+    return EG_ERR_ARG;
+  }
+  return EG_OK;
+}
+
+static int nccl_check(int rc, const char *what) {
+  if (rc == 0) return EG_OK;
+  set_error("eg_dp: %s failed: %s", what, p_error_string ? p_error_string(rc) : "nccl error");
+  return EG_ERR_LAUNCH;
+}
+
+}  // namespace eg
+
+using namespace eg;
+
+extern "C" int eg_dp_unique_id(const char *librccl_path, void *id_out_host) {
+  EG_REQUIRE(id_out_host != nullptr, "null pointer");
+  const int rc = load_rccl(librccl_path);
+  if (rc) return rc;
+  NcclUniqueId id;
+  const int e = nccl_check(p_get_unique_id(&id), "ncclGetUniqueId");
+  if (e) return e;
+  memcpy(id_out_host, &id, sizeof(id));
+  return EG_OK;
+}
+
+extern "C" int eg_dp_init(const char *librccl_path, const void *id_host, int32_t rank, int32_t world) {
+  EG_REQUIRE(id_host != nullptr && world >= 1 && rank >= 0 && rank < world, "bad arguments");
+  EG_REQUIRE(g_comm == nullptr, "a communicator exists already (eg_dp_shutdown first)");
+  const int rc = load_rccl(librccl_path);
+  if (rc) return rc;
+  NcclUniqueId id;
+  memcpy(&id, id_host, sizeof(id));
+  const int e = nccl_check(p_comm_init_rank(&g_comm, world, id, rank), "ncclCommInitRank");
+  if (e) { g_comm = nullptr; return e; }
+  g_world = world;
+  g_rank = rank;
+  return EG_OK;
+}
+
+extern "C" int eg_dp_world(void) { return g_comm ? g_world : 0; }
+
+extern "C" int eg_dp_shutdown(void) {
+  if (g_comm) {
+    (void)p_comm_destroy(g_comm);
+    g_comm = nullptr;
+  }
+  g_world = g_rank = 0;
+  return EG_OK;
+}
+
+// sum over the ranks of a device buffer of n floats, in place, on `stream` (the regulariser's running loss sum, the
+// read-back's words: small collectives that ride the same communicator)
+extern "C" int eg_dp_all_reduce(float *buf, int64_t n, eg_stream_t stream) {
+  EG_REQUIRE(g_comm != nullptr, "no communicator (eg_dp_init)");
+  EG_REQUIRE(buf != nullptr && n > 0, "bad arguments");
+  return nccl_check(p_all_reduce(buf, buf, (size_t)n, kNcclFloat, kNcclSum, g_comm, as_stream(stream)), "ncclAllReduce");
+}
+
+// `a`: step 0 as for eg_train_step in its gradient form -- adam_host == NULL, v_means / v_quats / v_scales / v_opacities
+// the blocks of ONE contiguous [12 N] buffer starting at v_means (means 3 | quats 4 | log-scales 3 | logit-opacity 1 |
+// absgrad increment 1: a->absgrads points at block 11) -- its viewmat / K / gt / wmap are ignored.  Step k takes view
+// views_host[k] of the [V, ...] arrays and weight map wmaps_host[k]; `hyper` is step 0's Adam state (counts advance by k
+// as in eg_train_steps); absgrads: the accumulator the reduced increment is added to.  have_projection as eg_train_step
+// (step 0 only; inside the run every step's Adam launch projects the next view).  next_view_after: the view this rank
+// rasterises in the step FOLLOWING the run (projected by the last Adam launch), or < 0.
+extern "C" int eg_train_steps_dp(const eg_step_args *a, const eg_adam_hyper *hyper, float *absgrads, int32_t K,
+                                 const int32_t *views_host, const float *const *wmaps_host, const float *viewmats,
+                                 const float *Ks, const float *gts, int32_t next_view_after, eg_stream_t stream) {
+  EG_REQUIRE(a != nullptr && hyper != nullptr && K >= 0 && (K == 0 || (views_host && wmaps_host)) && viewmats && Ks && gts,
+             "bad arguments");
+  EG_REQUIRE(g_comm != nullptr, "no communicator (eg_dp_init)");
+  EG_REQUIRE(a->adam_host == nullptr && a->v_means && a->v_quats == a->v_means + 3 * (size_t)a->N &&
+                 a->v_scales == a->v_means + 7 * (size_t)a->N && a->v_opacities == a->v_means + 10 * (size_t)a->N &&
+                 a->absgrads == a->v_means + 11 * (size_t)a->N,
+             "the gradient blocks must form one contiguous [12 N] buffer (means | quats | scales | opacities | absgrad)");
+  EG_REQUIRE(a->seg_cap > 0 && a->ticket, "the data-parallel run uses the segmented layout");
+  EG_REQUIRE(a->ws_tag <= 0 || (int64_t)a->ws_tag + K - 1 <= EG_MAX_WS_TAG, "ws_tag + K - 1 exceeds EG_MAX_WS_TAG");
+  const size_t hw = (size_t)a->width * a->height;
+  const int T = cdiv(a->width, kTile) * cdiv(a->height, kTile);
+  const uint32_t flags = EG_FLAG_LOG_SCALES | EG_FLAG_LOGIT_OPACITIES | EG_FLAG_ANTIALIASED | EG_FLAG_TIGHT_TILES |
+                         (T > kPrefixHereMaxTiles ? EG_FLAG_FRONT_PREFIX : 0u);
+  float *g = a->v_means;
+  for (int k = 0; k < K; ++k) {
+    EG_REQUIRE(views_host[k] >= 0 && wmaps_host[k], "bad view / null weight map");
+    eg_step_args s = *a;
+    s.viewmat = viewmats + 16 * (size_t)views_host[k];
+    s.K = Ks + 9 * (size_t)views_host[k];
+    s.gt = gts + hw * (size_t)views_host[k];
+    s.wmap = wmaps_host[k];
+    if (a->ws_tag > 0) s.ws_tag = a->ws_tag + k;
+    s.have_projection = k > 0 ? 1 : a->have_projection;
+    s.next_viewmat = s.next_K = nullptr;
+    int rc = eg_train_step(&s, stream);
+    if (rc) return rc;
+    rc = nccl_check(p_all_reduce(g, g, 12 * (size_t)a->N, kNcclFloat, kNcclSum, g_comm, as_stream(stream)), "ncclAllReduce");
+    if (rc) return rc;
+    eg_adam_hyper h = *hyper;
+    h.step += k;
+    for (int i = 0; i < 4; ++i)
+      if (h.group_steps[i] > 0) h.group_steps[i] += k;
+    const int nv = k + 1 < K ? views_host[k + 1] : next_view_after;
+    if (nv >= 0)
+      rc = eg_adam_emit(a->means, a->log_scales, a->quats, a->logit_opacities, g, g + 7 * (size_t)a->N, g + 3 * (size_t)a->N,
+                        g + 10 * (size_t)a->N, a->adam_m, a->adam_v, a->N, h, g + 11 * (size_t)a->N, absgrads,
+                        viewmats + 16 * (size_t)nv, Ks + 9 * (size_t)nv, a->width, a->height, flags, a->splat, a->tile_counts,
+                        a->seg_cap, a->keys, a->item_offsets, (int32_t)a->max_items, a->total,
+                        T <= kPrefixHereMaxTiles ? nullptr : a->ticket, stream);
+    else
+      rc = eg_adam_multi(a->means, a->log_scales, a->quats, a->logit_opacities, g, g + 7 * (size_t)a->N, g + 3 * (size_t)a->N,
+                         g + 10 * (size_t)a->N, a->adam_m, a->adam_v, a->N, h, g + 11 * (size_t)a->N, absgrads, stream);
+    if (rc) return rc;
+  }
+  return EG_OK;
+}

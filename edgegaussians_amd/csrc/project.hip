@@ -1208,10 +1208,13 @@ extern "C" int eg_adam_emit(float *means, float *scales, float *quats, float *op
                             eg_stream_t stream) {
   EG_REQUIRE(N > 0 && hyper.step >= 1 && width > 0 && height > 0 && seg_cap > 0 && max_items > 0, "bad sizes / step");
   EG_REQUIRE(means && scales && quats && opacities && g_means && g_scales && g_quats && g_opacities && m && v &&
-                 next_viewmat && next_K && splat && tile_cursor && keys && item_first && total && ticket,
+                 next_viewmat && next_K && splat && tile_cursor && keys && item_first && total,
              "null pointer");
   EG_REQUIRE(!absgrads || absgrad_inc, "absgrads needs absgrad_inc");
   const int T = cdiv(width, kTile) * cdiv(height, kTile);
+  // (ticket == NULL: no scan tail -- for a following eg_train_step on a tile grid of <= 2048 tiles, whose sort kernel
+  // forms the tile prefix itself)
+  EG_REQUIRE(ticket || T <= kPrefixHereMaxTiles, "ticket may be NULL only on tile grids of <= 2048 tiles");
   EG_REQUIRE((int64_t)T * seg_cap < (1ll << 31), "T * seg_cap must fit 31 bits");
   SegOut out;
   out.item_first = item_first; out.max_items = max_items;

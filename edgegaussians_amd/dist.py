@@ -55,6 +55,39 @@ def init_from_env(backend: Optional[str] = None) -> tuple:
     return rank, local, world
 
 
+def librccl_path() -> str:
+    """The RCCL PyTorch ships (torch/lib/librccl.so): dlopen'ed by the native data-parallel leg, so that the process
+    holds one RCCL whether or not torch.distributed has loaded it already."""
+    p = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+    return p if os.path.exists(p) else "librccl.so"
+
+
+def init_native_comm(group=None) -> int:
+    """Creates the library's RCCL communicator for this process (eg_dp_init) from a ncclUniqueId that rank 0 draws and
+    the ranks exchange over torch.distributed; a single process gets a one-rank communicator.  Returns its size.
+    Idempotent.  (The communicator is separate from torch.distributed's own: the native run enqueues its collectives
+    itself, on the launch stream.)"""
+    import ctypes as C
+    from . import _lib
+    lib = _lib.load()
+    if lib.eg_dp_world() > 0:
+        return int(lib.eg_dp_world())
+    path = librccl_path().encode()
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    buf = (C.c_ubyte * 128)()
+    if rank == 0 and lib.eg_dp_unique_id(path, buf) != 0:
+        raise RuntimeError(lib.eg_last_error_string().decode())
+    if world > 1:
+        dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+        t = torch.tensor(list(buf), dtype=torch.uint8, device=dev)
+        dist.broadcast(t, src=0, group=group)
+        buf = (C.c_ubyte * 128)(*t.cpu().tolist())
+    if lib.eg_dp_init(path, buf, rank, world) != 0:
+        raise RuntimeError(lib.eg_last_error_string().decode())
+    return world
+
+
 def view_for(step: int, rank: int, world: int, n_views: int, views_per_rank: int = 1, slot: int = 0) -> int:
     """Round-robin view sharding: the step's batch is views {(step*world + r) * C + slot}, r = 0..world-1."""
     return ((step * world + rank) * views_per_rank + slot) % n_views
@@ -153,6 +186,33 @@ class DataParallelStep:
             w = self.worker
             w._journal_push(("d", view, (wmap, next_view), w.epoch, w.loss_scale))
         self._step_raw(view, wmap, next_view)
+
+    # ------------------------------------------------------------------ K optimizer steps by one native call
+    def native_ready(self) -> bool:
+        """The worker is an EdgeTrainer on the segmented layout and the library holds an RCCL communicator of this
+        group's size (init_native_comm)."""
+        from . import _lib
+        w = self.worker
+        return (hasattr(w, "_dp_steps_raw") and getattr(w, "seg_cap", 0) > 0
+                and _lib.load().eg_dp_world() == (dist.get_world_size(self.group) if dist.is_initialized() else 1))
+
+    def steps(self, views: Sequence[int], wmaps: Sequence[torch.Tensor], next_view: Optional[int] = None) -> None:
+        """len(views) consecutive single-view steps of this rank (exactly `step(view, wmap, next_view=views[k + 1])` in
+        a loop) enqueued by ONE native call: per step grad -> ncclAllReduce on the launch stream -> Adam + next
+        projection (eg_train_steps_dp).  Journalled like the single steps (a replay runs them one by one through the
+        same kernels).  Falls back to the loop when the native leg is not available (gloo, no communicator)."""
+        views = [int(v) for v in views]
+        nxt = views[1:] + [next_view]
+        if not self.native_ready():
+            for v, w_, n_ in zip(views, wmaps, nxt):
+                self.step(v, w_, next_view=n_)
+            return
+        w = self.worker
+        if self._journals:
+            w._reserve_tags(len(views))
+            for v, w_, n_ in zip(views, wmaps, nxt):
+                w._journal_push(("d", v, (w_, n_), w.epoch, w.loss_scale), reserve=False)
+        w._dp_steps_raw(views, list(wmaps), next_view, journalled=self._journals and w.replay_on_overflow)
 
     def _step_raw(self, view, wmap, next_view=None) -> None:
         """One (grad_step, all-reduce, apply_adam) triple -- also what a collective replay runs."""

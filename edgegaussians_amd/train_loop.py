@@ -119,6 +119,8 @@ def _train_epoch_batched(tr, views, epoch, num_epochs, projection_cfg, orientati
         views = views + views[:C - len(views) % C]
     per_rank = C // world
     n, step_no = 0, tr.step if dp is None else getattr(tr, "_dp_views_seen", tr.step)
+    native = dp is not None and per_rank == 1 and getattr(dp, "native_ready", lambda: False)()
+    pend_v, pend_w = [], []
     for b0 in range(0, len(views), C):
         batch = views[b0:b0 + C]
         mine_v, mine_w = [], []
@@ -134,6 +136,9 @@ def _train_epoch_batched(tr, views, epoch, num_epochs, projection_cfg, orientati
                 tr.weight_map(idx, strategy, ratio, generator, edge_threshold)  # (a host generator must be advanced by drawing)
         if dp is None:
             tr.train_step_batched(mine_v, mine_w)
+        elif per_rank == 1 and native:
+            pend_v.append(mine_v[0])  # (the steps between two regulariser steps go out as ONE native enqueue:
+            pend_w.append(mine_w[0])  #  DataParallelStep.steps -> eg_train_steps_dp)
         elif per_rank == 1:
             dp.step(mine_v[0], mine_w[0])
         else:
@@ -141,6 +146,9 @@ def _train_epoch_batched(tr, views, epoch, num_epochs, projection_cfg, orientati
         n += C
         crossed = (step_no + C) // 5 > step_no // 5  # (a multiple of five views was passed: train_gaussians.py:108)
         step_no += C
+        if pend_v and (((apply_dir or apply_ratio) and crossed) or b0 + C >= len(views)):
+            dp.steps(pend_v, pend_w)
+            pend_v, pend_w = [], []
         if (apply_dir or apply_ratio) and crossed:
             if apply_dir:
                 tr.regulariser_step("direction", None, orientation_cfg["dir_loss_scale_factor"],

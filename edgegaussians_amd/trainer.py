@@ -641,9 +641,10 @@ class EdgeTrainer:
                 return
         raise IsectOverflow("tile-intersection buffers still overflow after 8 doublings")
 
-    def _journal_push(self, entry) -> None:
+    def _journal_push(self, entry, reserve: bool = True) -> None:
         """(kind, a, b, epoch, loss_scale): snapshot the state in front of the first journalled step of a window."""
-        self._reserve_tags(2)  # (a data-parallel step with two half batches takes two)
+        if reserve:
+            self._reserve_tags(2)  # (a data-parallel step with two half batches takes two)
         if self.replay_on_overflow:
             if not self._journal:
                 self._snapshot()
@@ -776,6 +777,35 @@ class EdgeTrainer:
         self.step += 1
         return self.grads
 
+    def _dp_steps_raw(self, views: List[int], wmaps: List[Tensor], next_view: Optional[int], journalled: bool) -> None:
+        """K data-parallel steps of this rank by one native call (eg_train_steps_dp: grad -> RCCL all-reduce on the launch
+        stream -> Adam + projection of the next view); the host-side bookkeeping of K x (grad_step, apply_adam)."""
+        K = len(views)
+        if self.capacity == 0:
+            self.ensure_capacity()
+        for w in wmaps:
+            assert w.is_cuda and w.is_contiguous() and w.shape == (self.height, self.width)
+        self._advance_all()   # step 0's counts; the native loop advances them by k
+        self._set_hyper()
+        a = self._args(views[0], wmaps[0], False, n_tags=K)
+        if journalled:
+            a.rewalk_hint = self._rewalk_arg(True)
+        a.have_projection = 1 if (self._projected == views[0] and self.seg_cap) else 0
+        if a.have_projection:
+            self._projected = None
+        else:
+            self._drop_projection()
+        va = (C.c_int32 * K)(*views)
+        wa = (C.c_void_p * K)(*[w.data_ptr() for w in wmaps])
+        call("eg_train_steps_dp", C.byref(a), C.byref(self._hyper), ptr(self.absgrads), K, va, wa, ptr(self.viewmats),
+             ptr(self.Ks), ptr(self.gt), -1 if next_view is None else int(next_view), stream())
+        a.have_projection = 0
+        for _ in range(K - 1):
+            self._advance_all()
+        self.absgrads_normalize_factor += K
+        self.step += K
+        self._projected = None if next_view is None else int(next_view)
+
     def grad_views(self):
         N, g = self.N, self.grads.view(-1)
         return (g[:3 * N].view(N, 3), g[3 * N:7 * N].view(N, 4), g[7 * N:10 * N].view(N, 3), g[10 * N:11 * N])
@@ -800,7 +830,9 @@ class EdgeTrainer:
             call("eg_adam_emit", c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7], c[8], c[9], self.N, self._hyper,
                  c[10], ptr(self.absgrads), self.viewmats.data_ptr() + 64 * next_view, self.Ks.data_ptr() + 36 * next_view,
                  self.width, self.height, fl, ptr(self.splat), ptr(self.tile_counts), self.seg_cap, ptr(self.keys),
-                 ptr(self.item_offsets), self.max_items, ptr(self.total), ptr(self.ticket), stream())
+                 ptr(self.item_offsets), self.max_items, ptr(self.total),
+                 ptr(self.ticket) if self.T > _lib.PREFIX_HERE_MAX_TILES else None, stream())  # (small grids: the
+            # following step's sort kernel forms the tile prefix itself: no scan tail here)
             self._projected = int(next_view)
         else:
             call("eg_adam_multi", c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7], c[8], c[9], self.N, self._hyper,

@@ -483,6 +483,31 @@ int eg_train_step_batched(const eg_step_args *args_host, int32_t C, const float 
                           const float *const *Ks, const float *const *gts, const float *const *wmaps,
                           eg_stream_t stream);
 
+/* ---- native data-parallel run (edgegaussians_amd/dist.py drives it).  RCCL is dlopen'ed from
+ * `librccl_path` (NULL / "": "librccl.so" by the loader's search path) -- the library PyTorch ships, so that the process
+ * holds ONE RCCL -- and the communicator is created from a 128-byte ncclUniqueId: rank 0 calls eg_dp_unique_id, the
+ * ranks exchange the bytes (torch.distributed broadcast), every rank calls eg_dp_init on ITS device.  One communicator
+ * per process (library state: see the conventions above).  eg_dp_world() = its size, 0 without one. */
+int eg_dp_unique_id(const char *librccl_path, void *id_out_host /*128 bytes*/);
+int eg_dp_init(const char *librccl_path, const void *id_host /*128 bytes*/, int32_t rank, int32_t world);
+int eg_dp_world(void);
+int eg_dp_shutdown(void);
+/* in-place sum over the ranks of n floats on `stream` (small collectives that ride the same communicator) */
+int eg_dp_all_reduce(float *buf, int64_t n, eg_stream_t stream);
+/* K consecutive view-sharded optimizer steps by ONE native call; per step: eg_train_step in its gradient form ->
+ * ncclAllReduce(sum, fp32) of the fused [12 N] gradient buffer on the launch stream -> eg_adam_emit (the four Adam steps
+ * on the reduced gradient + projection / binning of this rank's next view; eg_adam_multi when there is none).  `a`: step
+ * 0 as for eg_train_step with adam_host == NULL and v_means / v_quats / v_scales / v_opacities / absgrads the blocks of
+ * ONE contiguous buffer [means 3N | quats 4N | log-scales 3N | logit-opacity N | absgrad increment N]; its view inputs
+ * are ignored: step k takes view views_host[k] of the [V, ...] arrays and weight map wmaps_host[k].  hyper: step 0's
+ * Adam state (counts advance by k); absgrads: the accumulator that receives the reduced increment; next_view_after: the
+ * view this rank rasterises in the step after the run (its projection rides in the last Adam launch; the caller then
+ * passes have_projection = 1), or < 0.  Same results as the three calls enqueued one by one. */
+int eg_train_steps_dp(const eg_step_args *a, const eg_adam_hyper *hyper, float *absgrads, int32_t K,
+                      const int32_t *views_host, const float *const *wmaps_host, const float *viewmats /*[V,4,4]*/,
+                      const float *Ks /*[V,3,3]*/, const float *gts /*[V,H,W]*/, int32_t next_view_after,
+                      eg_stream_t stream);
+
 /* ---- measurement aid: between eg_timing_begin(n) and eg_timing_end(), the next n eg_train_step
  * calls record HIP events between their stages on the launch stream; eg_timing_end synchronises
  * once and returns the average microseconds per stage (eg_timing_stage_count() entries, names by

@@ -505,6 +505,65 @@ def test_fused_step_small_scene_vs_c_oracle(env):
         check_fused_step_vs_c_oracle(_scene(synth, n=3000), view, strategy, f"small_scene_view{view}")
 
 
+def test_native_data_parallel_run_equals_the_python_driver_single_rank_rccl(env):
+    """eg_train_steps_dp: K view-sharded optimizer steps by ONE native call -- per step grad ->
+    ncclAllReduce on the launch stream (a communicator of the library's own, created from a ncclUniqueId: here one rank)
+    -> Adam + projection of the next view -- against dist.DataParallelStep.step driven from Python step by step through
+    the same kernels and torch.distributed's collective: parameters, moments and absgrads torch.equal.  Also: a native
+    run interrupted by a regulariser-free read-back and continued, the overflow journal holding its steps."""
+    import os
+    import socket
+    import torch.distributed as dist
+    _lib, synth, O = env
+    from edgegaussians_amd import EdgeTrainer, LRSchedule
+    from edgegaussians_amd import dist as egdist
+    sc = _scene(synth, n=2500, w=160, h=112, views=3)
+    sched = LRSchedule(scales_start=0, quats_start=0, opacities_start=0)
+    mk = lambda: EdgeTrainer(sc.means, sc.log_scales, sc.quats, sc.logit_opacities, sc.viewmats, sc.Ks, sc.gt,  # noqa: E731
+                             sc.width, sc.height, schedule=sched)
+    a, b = mk(), mk()
+    a.ensure_capacity()
+    b.ensure_capacity()
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        assert egdist.init_native_comm() == 1 and _lib.load().eg_dp_world() == 1
+        dpa, dpb = egdist.DataParallelStep(a), egdist.DataParallelStep(b)
+        dpb.world = 2  # (the Python driver issues its collective even with one rank)
+        assert dpa.native_ready()
+        order = [0, 2, 1, 1, 0, 2, 2]
+        wm = [synth.weight_map("weighted" if s != 1 else "bg_edge_ratio", sc.gt[v],
+                               generator=torch.Generator().manual_seed(s)).cuda() for s, v in enumerate(order)]
+        dpa.steps(order[:4], wm[:4], next_view=order[4])
+        assert len(a._journal) == 4 and a._projected == order[4]
+        la = a.pop_loss()                      # a read-back in the middle of the epoch: the projection is dropped
+        dpa.steps(order[4:], wm[4:])
+        for s, v in enumerate(order):
+            if s == 4:
+                lb = b.pop_loss()
+            dpb.step(v, wm[s], next_view=order[s + 1] if s + 1 < len(order) else None)
+        torch.cuda.synchronize()
+        assert abs(la - lb) <= 1e-6 * abs(lb)
+        # the small collective that rides the same communicator
+        t = torch.arange(5, dtype=torch.float32, device="cuda")
+        from edgegaussians_amd._lib import call, ptr, stream
+        call("eg_dp_all_reduce", ptr(t), 5, stream())
+        assert torch.equal(t.cpu(), torch.arange(5, dtype=torch.float32))
+    finally:
+        _lib.load().eg_dp_shutdown()
+        dist.destroy_process_group()
+    for x, y, name in ((a.means, b.means, "means"), (a.log_scales, b.log_scales, "scales"), (a.quats, b.quats, "quats"),
+                       (a.logit_opacities, b.logit_opacities, "opac"), (a.absgrads, b.absgrads, "absgrads"),
+                       (a.adam_m, b.adam_m, "m"), (a.adam_v, b.adam_v, "v")):
+        assert torch.equal(x, y), name
+    assert a.step == b.step == len(order) and a.group_steps == b.group_steps
+    assert abs(a.pop_loss() - b.pop_loss()) <= 1e-6
+
+
 def test_data_parallel_leg_on_gpu_single_rank(env):
     """The multi-GPU code path (grad_step -> RCCL all-reduce of the fused [N,12] buffer -> eg_adam_multi)
     on one rank must reproduce the fused single-GPU step: same gradients, same Adam arithmetic."""
