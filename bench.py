@@ -156,6 +156,45 @@ def measure_traffic(config, spread, steps=40):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def measure_kernel_trace(config, spread, steps=300):
+    """Average launch duration of every kernel of the step from rocprofv3's kernel trace of THIS command
+    (`--kernel-trace --stats`, no counters: launches are not serialised) -- the figure the committed
+    profiles/rNN_kernel_stats_*.txt hold; HIP events on the launch stream read ~2.5-5 us more per pair.
+    Returns ({kernel symbol: avg us}, provenance) or (None, reason)."""
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    tmp = tempfile.mkdtemp(prefix="eg_kt_", dir="/tmp")
+    try:
+        cmd = [exe, "--kernel-trace", "--stats", "-d", tmp, "-o", "k", "--", sys.executable, os.path.abspath(__file__),
+               "--config", config, "--steps", str(steps), "--warmup", "20", "--profile-only"] + \
+              (["--spread-opacity"] if spread else ["--init-opacity"])
+        r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=300)
+        db = None
+        for dp_, _, fs in os.walk(tmp):
+            for f in fs:
+                if f.endswith("_results.db"):
+                    db = os.path.join(dp_, f)
+        if r.returncode != 0 or db is None:
+            return None, f"rocprofv3 --kernel-trace failed (rc {r.returncode}): {r.stderr[-200:]}"
+        dur = {}
+        for name, s0, e0 in sqlite3.connect(db).cursor().execute("select name, start, end from kernels"):
+            k = name.split("(")[0].replace("void ", "").replace("eg::", "").split("<")[0]
+            a = dur.setdefault(k, [0, 0.0])
+            a[0] += 1
+            a[1] += (e0 - s0) / 1e3
+        return ({k: a[1] / a[0] for k, a in dur.items() if k in STAGE_OF},
+                "same run: rocprofv3 --kernel-trace --stats over `bench.py --profile-only` (no counters), mean of every launch")
+    except Exception as e:  # noqa: BLE001 -- the bench line must still be printed
+        return None, f"kernel-trace measurement failed: {e!r}"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 2.0  # wave64 VALU instructions/s: 256 CUs x 4 SIMDs, 2 cycles each (MI355X_MICROARCH.md)
 
 
@@ -433,6 +472,13 @@ def measure(name, args, device, rank, world, backend, spread=False, steps=None, 
         else:
             res["allreduce_exposed_us_per_step_by_rank"] = [mine]
         res["allreduce_bytes_per_step"] = 48 * n * (2 if vps > 1 else 1)
+        if native_dp:  # where the host time of the native run goes (eg_dp_host_profile)
+            import ctypes as _C
+            from edgegaussians_amd import _lib as _egl
+            prof = (_C.c_double * 3)()
+            nprof = _egl.load().eg_dp_host_profile(prof)
+            res["native_dp_host_us_per_step"] = {"steps": int(nprof), "grad_step_kernels": prof[0], "ncclAllReduce": prof[1],
+                                                 "adam_and_next_projection": prof[2]}
     if stages and not args.profile_only and vps == 1:
         # ---- per-kernel launch durations: HIP events recorded natively between the kernels of eg_train_step on
         # the launch stream, over a second window of the same steps (one sync).  With N ranks every rank runs the
@@ -621,6 +667,19 @@ def main():
         out["roofline"]["traffic_source"] = src
         if stages:
             out["traffic_bytes_per_step_by_stage"] = stages
+        # the dominant kernel's launch duration as rocprofv3's kernel trace of this very command sees it (what the
+        # committed profiles hold): `avg_launch_us` and `frac` are restated from it, the HIP-event figure stays beside it
+        kt, ktsrc = measure_kernel_trace(args.config, args.spread_opacity)
+        rf = out["roofline"]
+        rf["avg_launch_us_hip_events"] = rf["avg_launch_us"]
+        if kt and rf.get("kernel_symbol") in kt:
+            rf["avg_launch_us"] = kt[rf["kernel_symbol"]]
+            rf["achieved"] = rf["algorithmic_bytes_per_launch"] / (rf["avg_launch_us"] * 1e-6) / 1e9
+            rf["frac"] = rf["achieved"] / HBM_PEAK_GBS
+            rf["avg_launch_us_source"] = ktsrc
+            out["kernel_trace_avg_us"] = kt
+        else:
+            rf["avg_launch_us_source"] = f"HIP events on the launch stream ({ktsrc})"
         issue, isrc = measure_issue(args.config, args.spread_opacity)
         # the issue-side roofline next to the HBM one: with a ~100 MB working set inside the 256 MB Infinity Cache the
         # HBM fraction is structurally small; what bounds these kernels is VALU issue and dependent latency
@@ -647,10 +706,22 @@ def main():
         # ... and with the drop-in optimizer class as well (train_utils.py:50-59 edited to build it)
         extra[f"{args.config}_operator_path_native_adam"] = measure_operator(args.config, args, device, adam="native")
         out["other_workloads"] = extra
+        if "config1" in extra:
+            # north_star quotes its target on config 1 (~30 k Gaussians, 50 views @512x512): carried at the top level next
+            # to the headline (config 2 = BASELINE configs[1], the configuration the metric is quoted on), with its own
+            # roofline -- the full record stays under other_workloads.config1
+            c1 = extra["config1"]
+            out["value_config1"] = c1["value"]
+            out["ms_per_step_config1"] = c1["ms_per_step"]
+            out["roofline_config1"] = c1.get("roofline")
     if single and rank == 0 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(sc, args.cpu_budget, args.cpu_oracle)
     if world > 1 or args.force_dp:
         dist.destroy_process_group()
+    if args.steps < 200:
+        out["warning"] = (f"--steps {args.steps}: a timed window of {args.steps * head['ms_per_step']:.1f} ms; windows below "
+                          "200 steps read up to ~7 % slow / noisy on a freshly started box (ms_per_step_windows holds two "
+                          "repeats; profiles/ holds 1000-step runs)")
     if rank == 0:  # last thing on stdout: the one JSON line
         sys.stdout.flush()
         import ctypes

@@ -59,6 +59,18 @@ class StepArgs(C.Structure):
     ]
 
 
+class OperatorArgs(C.Structure):
+    """eg_operator_args (include/edgegs.h): the drop-in operator's fast path."""
+    _fields_ = [
+        ("means", _vp), ("quats", _vp), ("scales", _vp), ("opacities", _vp), ("colors", _vp), ("color_channels", _i32),
+        ("viewmat", _vp), ("K", _vp), ("N", _i32), ("width", _i32), ("height", _i32), ("flags", _u32),
+        ("splat", _vp), ("alphas", _vp), ("means2d", _vp), ("gtstop", _vp),
+        ("tile_counts", _vp), ("tile_start", _vp), ("tile_end", _vp), ("item_first", _vp), ("item_end", _vp),
+        ("item_tile", _vp), ("item_rec", _vp), ("total", _vp), ("ticket", _vp), ("keys", _vp), ("flatten_ids", _vp),
+        ("seg_cap", _i32), ("max_tile_hint", _i32), ("max_items", _i64), ("workspace", _vp), ("ws_tag", _i32),
+    ]
+
+
 # name -> argtypes; every entry returns int and ends with the stream
 _SIGS = {
     "eg_project_fwd": [_vp] * 6 + [_i32, _i32, _i32, _f, _f, _f, _f, _u32] + [_vp] * 9 + [_vp],
@@ -98,6 +110,8 @@ _SIGS = {
     "eg_regulariser_step": [_i32] + [_vp] * 7 + [_i32, _vp, _i32, _i32, _i32, _i32, _vp, _f, _f, _vp, AdamHyper, _vp],
     "eg_train_step": [C.POINTER(StepArgs), _vp],
     "eg_train_steps": [C.POINTER(StepArgs), _i32, C.POINTER(_i32), C.POINTER(_vp), _vp, _vp, _vp, _vp],
+    "eg_operator_fwd": [C.POINTER(OperatorArgs), _vp],
+    "eg_operator_bwd": [C.POINTER(OperatorArgs), _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "eg_train_steps_dp": [C.POINTER(StepArgs), C.POINTER(AdamHyper), _vp, _i32, C.POINTER(_i32), C.POINTER(_vp), _vp, _vp,
                           _vp, _i32, _vp],
     "eg_dp_all_reduce": [_vp, _i64, _vp],
@@ -107,7 +121,7 @@ EXPORTS = sorted(list(_SIGS) + ["eg_last_error_string", "eg_version", "eg_device
                                  "eg_composite_workspace_bytes", "eg_composite_workspace_ctl_bytes",
                                  "eg_batched_workspace_stride", "eg_knn_auto_dims", "eg_timing_begin", "eg_timing_end",
                                  "eg_timing_stage_count", "eg_timing_stage_name", "eg_debug_fwd_profile",
-                                 "eg_dp_unique_id", "eg_dp_init", "eg_dp_world", "eg_dp_shutdown"])
+                                 "eg_dp_unique_id", "eg_dp_init", "eg_dp_world", "eg_dp_shutdown", "eg_dp_host_profile"])
 
 _lib: Optional[C.CDLL] = None
 
@@ -145,6 +159,8 @@ def load(require_device: bool = True) -> C.CDLL:
         lib.eg_dp_init.argtypes = [C.c_char_p, _vp, _i32, _i32]
         lib.eg_dp_world.argtypes = []
         lib.eg_dp_shutdown.argtypes = []
+        lib.eg_dp_host_profile.argtypes = [C.POINTER(C.c_double)]
+        lib.eg_dp_host_profile.restype = _i64
         lib.eg_debug_fwd_profile.restype = _i64
         lib.eg_debug_fwd_profile.argtypes = [_vp, _i64]
         _lib = lib

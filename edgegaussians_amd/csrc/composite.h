@@ -178,6 +178,6 @@ inline SliceWs carve_workspace(void *workspace, int64_t max_items, int n_tiles) 
 int launch_wave_fwd(const float4 *splat, const TileTable tt, const int32_t *flatten_ids, int width, int height,
                     const float *gt, const float *wmap, float loss_scale, const int32_t *total, int64_t max_items,
                     void *workspace, float *gtstop, int chained, unsigned tag, int max_tile_hint, hipStream_t s,
-                    const Batch &bt, int C);
+                    const Batch &bt, int C, float *alphas = nullptr);
 
 }  // namespace eg

@@ -387,15 +387,6 @@ __device__ __forceinline__ int exact_walk_wave(const WaveList &wl, int n_mine, f
   return lastpos;
 }
 
-// the training step's per-pixel epilogue: fused clamp + weighted L1 + upstream gradient, and the 12-byte record the
-// footprint backward reads (finalize_pixel<1> of composite.h without the optional images)
-__device__ __forceinline__ float finalize_train(int p, float T, int last, bool stopped, const int *__restrict__ flat,
-                                                float gt_p, float w, float loss_scale, StopRec *__restrict__ gtstop,
-                                                const float4 *__restrict__ splat) {
-  return finalize_pixel<1>(p, T, last, stopped, flat, nullptr, nullptr, nullptr, true, gt_p, w, loss_scale, nullptr, gtstop,
-                           splat);
-}
-
 __device__ __forceinline__ int gridDim_tiles(int tw, int height) { return tw * ((height + kTile - 1) / kTile); }
 
 // one pixel's granule of a slice: {product, tag << 9 | index of the last contributor}
@@ -518,7 +509,8 @@ struct WaveArgs {
   unsigned long long *anchor;  // [max_items / 8 + 2][256] inclusive granules of the anchor slices (chained mode)
   int *dead, *ctl;             // dead: [T][4] first dead slice of (tile, quadrant), tag << 15 | (32767 - slice)
   float *loss_part;
-  const float *gt, *wmap;
+  const float *gt, *wmap;      // wmap == nullptr: no fused loss (the drop-in operator): the record carries T_final itself
+  float *alphas;               // optional [H,W] accumulated alpha 1 - T_final (the operator's image)
   StopRec *gtstop;
   unsigned long long *prof;
   int width, height, tw, n_tiles;
@@ -560,6 +552,7 @@ __device__ __forceinline__ void wave_fwd_body(WaveArgs a, const Batch &bt, WaveL
     a.dead = (int *)((char *)a.dead + bv * bt.ws_bytes); a.ctl = (int *)((char *)a.ctl + bv * bt.ws_bytes);
     a.loss_part = (float *)((char *)a.loss_part + bv * bt.ws_bytes);
     a.gt = bt.gt[bv]; a.wmap = bt.wmap[bv];
+    if (a.alphas) a.alphas += bv * bt.pixels;
   }
   const float4 *__restrict__ splat = a.splat;
   const int *__restrict__ flat = a.flat;
@@ -600,8 +593,9 @@ __device__ __forceinline__ void wave_fwd_body(WaveArgs a, const Batch &bt, WaveL
   const bool finisher = CHAINED || s_me == ns - 1;
   // the pixel's target and loss weight do not depend on the slices: in flight under everything else
   const int p = i * width + j;
-  const float w_p = (finisher && inside) ? wmap[p] : 0.f;
-  const float gt_p = (finisher && inside) ? gt[p] : 0.f;
+  const bool has_loss = wmap != nullptr;  // (uniform)
+  const float w_p = (has_loss && finisher && inside) ? wmap[p] : 0.f;
+  const float gt_p = (has_loss && finisher && inside) ? gt[p] : 0.f;
 
   unsigned long long *gran = a.gran;
   const int b_store = i0 + s_me;
@@ -718,7 +712,9 @@ __device__ __forceinline__ void wave_fwd_body(WaveArgs a, const Batch &bt, WaveL
       // state and runs the step again in chained mode
       if (lane == 0) atomicOr(&a.ctl[3], 1);
     }
-    if (inside) l = finalize_train(p, T, 0, false, flat, gt_p, w_p, loss_scale, gtstop, splat);
+    if (inside)
+      l = finalize_pixel<1>(p, T, 0, false, flat, nullptr, a.alphas, nullptr, has_loss, gt_p, w_p, loss_scale, nullptr, gtstop,
+                            splat);
   } else {
     int last = -1;           // sorted index of the last contributor in front of a stop (only when it sits in a slice in front)
     int stop_id = -1;        // ... its Gaussian id and depth bits (read from the list in LDS)
@@ -775,7 +771,9 @@ __device__ __forceinline__ void wave_fwd_body(WaveArgs a, const Batch &bt, WaveL
         stop_dep = (unsigned)__float_as_int(splat[2 * stop_id + 1].z);
       }
       const float pix = 1.f - T, c0 = fminf(fmaxf(pix, 0.f), 1.f), d = c0 - gt_p;
-      const float v = loss_scale * w_p * ((d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f));
+      // (without the fused loss the record carries T_final itself: upstream gradient 1, scaled by the caller's later)
+      const float v = has_loss ? loss_scale * w_p * ((d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f)) : 1.f;
+      if (a.alphas) a.alphas[p] = pix;
       StopRec r;  // (finalize_pixel<1> of composite.h with the stop Gaussian already in registers)
       r.gT = (T < 1.f) ? v * T : 0.f;
       r.stop_id = (cross && found) ? stop_id : -1;
@@ -806,7 +804,7 @@ static int64_t g_prof_items = 0;
 int launch_wave_fwd(const float4 *splat, const TileTable tt, const int32_t *flatten_ids, int width, int height,
                     const float *gt, const float *wmap, float loss_scale, const int32_t *total, int64_t max_items,
                     void *workspace, float *gtstop, int chained, unsigned tag, int max_tile_hint, hipStream_t s,
-                    const Batch &bt, int C) {
+                    const Batch &bt, int C, float *alphas) {
   const int tw = cdiv(width, kTile), th = cdiv(height, kTile);
   const SliceWs ws = carve_workspace(workspace, max_items, tw * th);
   if (tag == 0 || tag >= kGranuleTagMask) {
@@ -831,7 +829,7 @@ int launch_wave_fwd(const float4 *splat, const TileTable tt, const int32_t *flat
   a.splat = splat; a.item_rec = tt.item_rec; a.total = total; a.flat = flatten_ids; a.cursor_reset = tt.cursor_reset;
   a.gran = (unsigned long long *)ws.sliceP; a.anchor = ws.anchor; a.dead = ws.dead_hint; a.ctl = ws.ctl;
   a.loss_part = ws.loss_part;
-  a.gt = gt; a.wmap = wmap; a.gtstop = (StopRec *)gtstop; a.prof = g_prof;
+  a.gt = gt; a.wmap = wmap; a.alphas = alphas; a.gtstop = (StopRec *)gtstop; a.prof = g_prof;
   a.width = width; a.height = height; a.tw = tw; a.n_tiles = tw * th;
   a.tag = tag; a.loss_scale = loss_scale; a.max_anchored = max_anchored; a.item_first = tt.item_first;
   // one view: everything is resolved here and the kernel never looks at the batch descriptor

@@ -13,6 +13,7 @@
 // process state (one of the stated exceptions in include/edgegs.h).
 #include <dlfcn.h>
 
+#include <chrono>
 #include <cstring>
 
 #include "common.h"
@@ -37,6 +38,12 @@ static AllReduceFn p_all_reduce = nullptr;
 static GetErrorStringFn p_error_string = nullptr;
 static NcclComm g_comm = nullptr;
 static int g_world = 0, g_rank = 0;
+// host seconds spent enqueueing {eg_train_step, ncclAllReduce, Adam + next projection} since the last eg_dp_host_profile
+static double g_host_s[3] = {0.0, 0.0, 0.0};
+static long long g_host_steps = 0;
+static inline double now_s() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
 
 static int load_rccl(const char *path) {
   if (g_rccl) return EG_OK;
@@ -147,10 +154,13 @@ extern "C" int eg_train_steps_dp(const eg_step_args *a, const eg_adam_hyper *hyp
     if (a->ws_tag > 0) s.ws_tag = a->ws_tag + k;
     s.have_projection = k > 0 ? 1 : a->have_projection;
     s.next_viewmat = s.next_K = nullptr;
+    const double t0 = now_s();
     int rc = eg_train_step(&s, stream);
     if (rc) return rc;
+    const double t1 = now_s();
     rc = nccl_check(p_all_reduce(g, g, 12 * (size_t)a->N, kNcclFloat, kNcclSum, g_comm, as_stream(stream)), "ncclAllReduce");
     if (rc) return rc;
+    const double t2 = now_s();
     eg_adam_hyper h = *hyper;
     h.step += k;
     for (int i = 0; i < 4; ++i)
@@ -166,6 +176,20 @@ extern "C" int eg_train_steps_dp(const eg_step_args *a, const eg_adam_hyper *hyp
       rc = eg_adam_multi(a->means, a->log_scales, a->quats, a->logit_opacities, g, g + 7 * (size_t)a->N, g + 3 * (size_t)a->N,
                          g + 10 * (size_t)a->N, a->adam_m, a->adam_v, a->N, h, g + 11 * (size_t)a->N, absgrads, stream);
     if (rc) return rc;
+    g_host_s[0] += t1 - t0; g_host_s[1] += t2 - t1; g_host_s[2] += now_s() - t2;
+    ++g_host_steps;
   }
   return EG_OK;
+}
+
+// measurement aid: mean HOST microseconds per step spent enqueueing {the gradient step's kernels, the all-reduce, Adam +
+// the next projection} by eg_train_steps_dp since the last call of this function; returns the number of steps
+extern "C" int64_t eg_dp_host_profile(double *us_out_host /*[3]*/) {
+  const long long n = g_host_steps;
+  for (int i = 0; i < 3; ++i) {
+    if (us_out_host) us_out_host[i] = n ? 1e6 * g_host_s[i] / (double)n : 0.0;
+    g_host_s[i] = 0.0;
+  }
+  g_host_steps = 0;
+  return n;
 }

@@ -198,11 +198,12 @@ class _Compositing(torch.autograd.Function):
 # work buffers cached per (N, width, height, device), one host read-back at the END of the forward (M, the sticky
 # overflow flag, the unit-colour verdict) where the general path -- like gsplat -- reads M in the middle, and an `info`
 # whose gsplat-layout binning tensors are computed only if somebody asks for them.
+import ctypes as C
 import weakref
 
 
 class _FastBuffers:
-    """Cached work buffers of the fast path for one (N, width, height, device)."""
+    """Cached work buffers (and the native argument block over them) of the fast path for one (N, width, height, device)."""
 
     def __init__(self, N, width, height, dev):
         self.N, self.width, self.height, self.dev = N, width, height, dev
@@ -214,10 +215,16 @@ class _FastBuffers:
         self.tile_end = torch.zeros(self.T, **i32)
         self.item_first = torch.zeros(self.T + 1, **i32)
         self.item_end = torch.zeros(self.T, **i32)
-        self.total = torch.zeros(4, **i32)
-        self.ticket = torch.zeros(1, **i32)
+        self.total = torch.zeros(8, **i32)            # [0..3] M, sticky overflow flag, items, largest tile; [4] colours == 1
+        self.ticket = torch.zeros(self.T + 2, **i32)  # [0] scan ticket, [1..] front-slice prefix (tile grids above 2048)
         self.seg_cap = self.max_items = 0
         self.max_tile = 0
+        self.tag = 0
+        self.args = _lib.OperatorArgs()
+        a = self.args
+        a.N, a.width, a.height = N, width, height
+        a.tile_counts, a.tile_start, a.tile_end = ptr(self.tile_counts), ptr(self.tile_start), ptr(self.tile_end)
+        a.item_first, a.item_end, a.total, a.ticket = ptr(self.item_first), ptr(self.item_end), ptr(self.total), ptr(self.ticket)
 
     def size(self, m: int, tile_max: int) -> None:
         """(Re)allocate the intersection buffers for M = m, largest tile population tile_max (with head-room)."""
@@ -232,10 +239,27 @@ class _FastBuffers:
         self.keys = torch.empty(self.T * self.seg_cap, dtype=torch.int64, device=self.dev)
         self.flatten_ids = torch.empty(self.T * self.seg_cap, **i32)
         self.item_tile = torch.zeros(self.max_items, **i32)
+        self.item_rec = torch.zeros(self.max_items, 4, **i32)
         self.workspace = _lib.composite_workspace(self.max_items, self.T, self.dev)
+        self.tag = 0
+        self.reset()
+        a = self.args
+        a.keys, a.flatten_ids, a.item_tile, a.item_rec = ptr(self.keys), ptr(self.flatten_ids), ptr(self.item_tile), ptr(self.item_rec)
+        a.workspace, a.seg_cap, a.max_items = ptr(self.workspace), self.seg_cap, self.max_items
+
+    def reset(self) -> None:
+        """The state a call expects to find: sticky overflow flag clear, tile cursors and the scan ticket at zero (a call
+        that overflowed -- or was interrupted by an exception -- leaves them anywhere)."""
         self.total.zero_()
         self.tile_counts.zero_()
         self.ticket.zero_()
+
+    def next_tag(self) -> int:
+        if self.tag >= _lib.MAX_WS_TAG:  # (every 65 534 calls: granules of 2^16 calls ago must not look fresh)
+            self.workspace.zero_()
+            self.tag = 0
+        self.tag += 1
+        return self.tag
 
 
 _FAST: Dict = {}
@@ -252,53 +276,54 @@ def _fast_buffers(N, width, height, dev) -> _FastBuffers:
 
 
 class _UnitRasterization(torch.autograd.Function):
+    """ONE native call forward (eg_operator_fwd), ONE backward (eg_operator_bwd): csrc/operator.hip."""
+
     @staticmethod
-    def forward(ctx, means, quats, scales, opacities, viewmat, K, width, height, flags, unit_flag, holder):
+    def forward(ctx, means, quats, scales, opacities, viewmat, K, width, height, flags, colors, holder):
         N, dev = means.shape[0], means.device
         fb = _fast_buffers(N, width, height, dev)
         means_c, quats_c, scales_c, opac_c = means.contiguous(), quats.contiguous(), scales.contiguous(), opacities.contiguous()
-        vm, Kc = viewmat.contiguous(), K.contiguous()
-        fl = flags | _lib.FLAG_TIGHT_TILES
+        vm, Kc, col = viewmat.contiguous(), K.contiguous(), colors.contiguous()
         st = stream()
         if fb.seg_cap == 0:  # first call for this shape: a count-only sweep sizes the buffers (one extra sync, once)
             splat0 = torch.empty(N, 8, device=dev)
             call("eg_project_fwd", ptr(means_c), ptr(quats_c), ptr(scales_c), ptr(opac_c), ptr(vm), ptr(Kc), N, width, height,
-                 0.01, 1e10, 0.3, 0.0, fl, ptr(splat0), None, None, None, None, None, None, ptr(fb.tile_counts), None, st)
+                 0.01, 1e10, 0.3, 0.0, flags | _lib.FLAG_TIGHT_TILES, ptr(splat0), None, None, None, None, None, None,
+                 ptr(fb.tile_counts), None, st)
             offs = torch.empty(fb.T + 1, dtype=torch.int32, device=dev)
             call("eg_tile_offsets", ptr(fb.tile_counts), fb.T, 1 << 40, ptr(offs), ptr(fb.item_first), ptr(fb.total), st)
             tot = fb.total.tolist()
-            fb.tile_counts.zero_()
             fb.size(int(tot[0]), int(tot[3]))
-        while True:
+            fb.reset()
+        a = fb.args
+        a.means, a.quats, a.scales, a.opacities = ptr(means_c), ptr(quats_c), ptr(scales_c), ptr(opac_c)
+        a.colors, a.color_channels = ptr(col), int(col.shape[-1])
+        a.viewmat, a.K, a.flags = ptr(vm), ptr(Kc), flags
+        for attempt in range(6):  # (bounded: a scene that outgrows the cached buffers doubles them and runs again)
             splat = torch.empty(N, 8, device=dev)
             alphas = torch.empty(1, height, width, 1, device=dev)
-            last_ids = torch.empty(1, height, width, dtype=torch.int32, device=dev)
+            means2d = torch.empty(1, N, 2, device=dev)
             gtstop = torch.empty(height, width, 3, device=dev)
-            call("eg_project_emit", ptr(means_c), ptr(quats_c), ptr(scales_c), ptr(opac_c), ptr(vm), ptr(Kc), N, width, height,
-                 fl, ptr(splat), ptr(fb.tile_counts), fb.seg_cap, ptr(fb.keys), ptr(fb.item_first), fb.max_items,
-                 ptr(fb.total), ptr(fb.ticket), st)
-            call("eg_sort_segments", ptr(fb.keys), ptr(fb.tile_counts), fb.T, fb.seg_cap, ptr(fb.flatten_ids),
-                 ptr(fb.tile_start), ptr(fb.tile_end), ptr(fb.item_first), ptr(fb.item_end), ptr(fb.item_tile), fb.max_items,
-                 fb.max_tile, st)
-            call("eg_composite_fwd_segments", ptr(splat), ptr(fb.tile_start), ptr(fb.tile_end), ptr(fb.item_first),
-                 ptr(fb.item_end), ptr(fb.item_tile), ptr(fb.flatten_ids), width, height, ptr(alphas), ptr(alphas),
-                 ptr(last_ids), None, None, 1.0, None, None, ptr(fb.total), fb.max_items, ptr(fb.workspace), ptr(gtstop),
-                 -1, st)
-            # the ONE host read-back of the call, after everything has been enqueued: M, sticky overflow flag, items,
-            # largest tile -- and the verdict on the colours
-            vals = torch.cat([fb.total, unit_flag.to(torch.int32).reshape(1)]).tolist()
-            m, overflow, _items, tile_max, unit = (int(v) for v in vals)
+            a.splat, a.alphas, a.means2d, a.gtstop = ptr(splat), ptr(alphas), ptr(means2d), ptr(gtstop)
+            a.max_tile_hint, a.ws_tag = fb.max_tile, fb.next_tag()
+            try:
+                call("eg_operator_fwd", C.byref(a), st)
+                # the ONE host read-back of the call, after everything has been enqueued: M, sticky overflow flag, items,
+                # largest tile -- and the verdict on the colours
+                m, overflow, _items, tile_max, unit = fb.total.tolist()[:5]
+            except Exception:
+                fb.reset()
+                raise
             holder["unit"] = bool(unit)
             if not overflow:
                 break
+            fb.reset()
             fb.size(2 * max(m, 1), 2 * max(tile_max, 1))  # the scene outgrew the cached buffers: grow, run again
+        else:
+            raise RuntimeError("rasterization: the intersection buffers still overflow after six doublings")
         fb.max_tile = max(fb.max_tile, tile_max)
         if m * 1.15 > (fb.max_items - fb.T) * 128 or tile_max * 1.15 > fb.seg_cap:
             fb.size(m, tile_max)  # grow ahead of the drift (the next call finds room)
-        means2d = splat[:, 0:2].clone().view(1, N, 2)
-        # the last contributor of every pixel as a Gaussian id (the cached sorted ids are overwritten by the next call;
-        # gsplat's `last_ids` -- an index into ITS intersection list -- is derived from this on demand)
-        holder["last_gid"] = torch.index_select(fb.flatten_ids, 0, last_ids.view(-1)).view(height, width)
         ctx.save_for_backward(means_c, quats_c, scales_c, opac_c, vm, Kc, splat, gtstop)
         ctx.cfg = (width, height, flags)
         ctx.holder = holder
@@ -310,30 +335,29 @@ class _UnitRasterization(torch.autograd.Function):
         means, quats, scales, opac, vm, Kc, splat, gtstop = ctx.saved_tensors
         width, height, flags = ctx.cfg
         N, dev = means.shape[0], means.device
-        # the upstream gradient scales the record {T_final, stop id, stop depth} the forward left per pixel
+        out = torch.empty(11 * N, device=dev)  # v_means 3N | v_quats 4N | v_scales 3N | v_opacities N
+        if v_alphas is None:
+            return (out[:3 * N].zero_().view(N, 3), out[3 * N:7 * N].zero_().view(N, 4), out[7 * N:10 * N].zero_().view(N, 3),
+                    out[10 * N:].zero_(), None, None, None, None, None, None, None)
         # (unit colours: every colour channel IS the accumulated alpha, the caller's `render` is an expanded view of it, so
         # autograd has already summed dL/drender over the channels into v_alphas)
-        v = v_alphas[0, ..., 0] if v_alphas is not None else None
-        g2d = torch.empty(N, 8, device=dev)
-        if v is None:
-            g2d.zero_()
-        else:
-            rec = gtstop.clone()
-            rec[..., 0] *= v
-            call("eg_composite_bwd_footprint", ptr(splat), N, width, height, ptr(rec), ptr(g2d), stream())
+        v = v_alphas if v_alphas.is_contiguous() else v_alphas.contiguous()
+        work = torch.empty(8 * N + 3 * height * width, device=dev)  # g2d [N,8] | rec [H,W,3]
         m2d = ctx.holder.get("means2d")
         m2d = m2d() if m2d is not None else None
-        if m2d is not None and ctx.holder.get("absgrad"):
-            m2d.absgrad = g2d[:, 2:4].clone().view(1, N, 2)  # what the caller reads (edge_gs.py:612)
-        if v_means2d is not None:  # (somebody differentiated through info["means2d"])
-            g2d[:, 0:2] += v_means2d[0]
-        v_means = torch.empty(N, 3, device=dev)
-        v_quats = torch.empty(N, 4, device=dev)
-        v_scales = torch.empty(N, 3, device=dev)
-        v_opac = torch.empty(N, device=dev)
-        call("eg_project_bwd", ptr(means), ptr(quats), ptr(scales), ptr(opac), ptr(vm), ptr(Kc), N, width, height, 0.3, flags,
-             ptr(splat), ptr(g2d), None, None, ptr(v_means), ptr(v_quats), ptr(v_scales), ptr(v_opac), None, stream())
-        return v_means, v_quats, v_scales, v_opac, None, None, None, None, None, None, None
+        absg = torch.empty(1, N, 2, device=dev) if (m2d is not None and ctx.holder.get("absgrad")) else None
+        vm2 = v_means2d.contiguous() if v_means2d is not None else None  # (somebody differentiated through info["means2d"])
+        a = _lib.OperatorArgs()
+        a.means, a.quats, a.scales, a.opacities, a.viewmat, a.K = ptr(means), ptr(quats), ptr(scales), ptr(opac), ptr(vm), ptr(Kc)
+        a.N, a.width, a.height, a.flags = N, width, height, flags
+        a.splat, a.gtstop = ptr(splat), ptr(gtstop)
+        g0, o0 = work.data_ptr(), out.data_ptr()
+        call("eg_operator_bwd", C.byref(a), ptr(v), 1, g0 + 32 * N, g0, ptr(absg) if absg is not None else None,
+             ptr(vm2) if vm2 is not None else None, o0, o0 + 12 * N, o0 + 28 * N, o0 + 40 * N, stream())
+        if absg is not None:
+            m2d.absgrad = absg  # what the caller reads (edge_gs.py:612)
+        return (out[:3 * N].view(N, 3), out[3 * N:7 * N].view(N, 4), out[7 * N:10 * N].view(N, 3), out[10 * N:],
+                None, None, None, None, None, None, None)
 
 
 class _LazyInfo(dict):
@@ -372,14 +396,13 @@ def _fast_rasterization(means, quats, scales, opacities, colors, viewmats, Ks, w
     tw, th = math.ceil(width / TILE), math.ceil(height / TILE)
     flags = _lib.FLAG_ANTIALIASED if antialiased else 0
     holder: Dict = {"absgrad": bool(absgrad)}
-    unit_flag = (colors == 1).all()
     alphas, means2d = _UnitRasterization.apply(
-        means, quats, scales, opacities, viewmats[0], Ks[0], width, height, flags, unit_flag, holder)
+        means, quats, scales, opacities, viewmats[0], Ks[0], width, height, flags, colors, holder)
     if not holder["unit"]:
         return None
     render = alphas.expand(1, height, width, colors.shape[-1])  # colours == 1: every channel is the accumulated alpha
     holder["means2d"] = weakref.ref(means2d)
-    splat, last_gid, alpha_img = holder.pop("splat"), holder.pop("last_gid"), alphas.detach()
+    splat = holder.pop("splat")
 
     def make(key):
         if key in ("radii", "depths", "conics", "opacities"):
@@ -394,16 +417,13 @@ def _fast_rasterization(means, quats, scales, opacities, colors, viewmats, Ks, w
             call("eg_tile_count", ptr(m2), ptr(radii), N, width, height, ptr(tpg), ptr(counts), stream())
             offsets, flat, ids, M, _io, _tot, _ni = isect_tiles_and_sort(m2, radii, splat[:, 6].contiguous(), counts, width,
                                                                         height)
-            # gsplat's last_ids: the position of the pixel's last contributor in ITS list = the entry (tile of the pixel,
-            # that Gaussian); pixels nothing contributed to hold 0
-            dev = means.device
-            tile_of_entry = torch.bucketize(torch.arange(M, device=dev), offsets[1:].long(), right=True)
-            skey, perm = torch.sort(tile_of_entry * N + flat.long())
-            ys, xs = torch.arange(height, device=dev) // TILE, torch.arange(width, device=dev) // TILE
-            q = (ys[:, None] * tw + xs[None, :]) * N + last_gid.long()
-            pos = torch.searchsorted(skey, q.reshape(-1)).clamp_(max=max(M - 1, 0))
-            hit = (skey[pos] == q.reshape(-1)) & (alpha_img.reshape(-1) > 0) if M > 0 else torch.zeros_like(pos, dtype=torch.bool)
-            last = torch.where(hit, perm[pos] if M > 0 else pos, torch.zeros_like(pos)).to(torch.int32).view(1, height, width)
+            # gsplat's last_ids (the position of the pixel's last contributor in ITS list): its walk over ITS lists, on
+            # this call's packed records -- the general compositing kernel, run only when somebody asks
+            last = torch.zeros(1, height, width, dtype=torch.int32, device=means.device)
+            img = torch.empty(height, width, device=means.device)
+            if M > 0:
+                call("eg_composite_fwd", ptr(splat), None, 1, ptr(offsets), ptr(flat), width, height, ptr(img), ptr(img),
+                     ptr(last), None, None, 1.0, None, None, None, None, 0, None, None, -1, stream())
         return {"tiles_per_gauss": tpg[None], "isect_ids": ids, "flatten_ids": flat,
                 "isect_offsets": offsets[:-1].reshape(1, th, tw), "last_ids": last}
 

@@ -483,6 +483,38 @@ int eg_train_step_batched(const eg_step_args *args_host, int32_t C, const float 
                           const float *const *Ks, const float *const *gts, const float *const *wmaps,
                           eg_stream_t stream);
 
+/* ---- the drop-in operator's fast path in two calls (edgegaussians_amd/rasterizer.py: the reference's own call of
+ * gsplat.rasterization -- one camera, colours == 1 without grad, edge_gs.py:247-279 -- and its autograd backward).
+ * eg_operator_fwd: projection + exact tile binning -> per-tile sort -> the training step's wave-autonomous forward in its
+ * exact mode, with the accumulated-alpha image as output and T_final in the gtstop record (no fused loss); means2d is
+ * copied out of the packed record; total[4] = 1 iff every entry of `colors` is 1.  The per-call outputs (splat, alphas,
+ * means2d, gtstop) are the caller's fresh tensors, everything else its cached work buffers; total is [8] int32
+ * ([0..3] as everywhere, [1] the sticky overflow flag: the caller reads total[0..4] back ONCE after the call).
+ * eg_operator_bwd: rec = gtstop with word 0 scaled by the upstream gradient v_alphas[p * v_stride] -> footprint backward
+ * -> absgrad_out [N,2] = sum over pixels of |dL/dmean2d| (what the reference reads as means2d.absgrad, edge_gs.py:612)
+ * -> (+ v_means2d when someone differentiates through info["means2d"]) -> projection backward. */
+typedef struct {
+  const float *means, *quats, *scales, *opacities, *colors; /* colors [N, color_channels] or NULL */
+  int32_t color_channels;
+  const float *viewmat, *K;
+  int32_t N, width, height;
+  uint32_t flags;                      /* EG_FLAG_ANTIALIASED | EG_FLAG_LOG_SCALES | EG_FLAG_LOGIT_OPACITIES */
+  float *splat, *alphas, *means2d, *gtstop; /* [N,8], [H,W], [N,2]|NULL, [H,W,3] */
+  int32_t *tile_counts, *tile_start, *tile_end, *item_first, *item_end, *item_tile, *item_rec;
+  int32_t *total;                      /* [8] */
+  int32_t *ticket;                     /* [T + 2], zero-initialised once */
+  uint64_t *keys;
+  int32_t *flatten_ids;
+  int32_t seg_cap, max_tile_hint;
+  int64_t max_items;
+  void *workspace;                     /* eg_composite_workspace_bytes(max_items, T), zeroed at allocation */
+  int32_t ws_tag;                      /* as eg_step_args.ws_tag: fresh per call, 1 .. EG_MAX_WS_TAG */
+} eg_operator_args;
+int eg_operator_fwd(const eg_operator_args *a, eg_stream_t stream);
+int eg_operator_bwd(const eg_operator_args *a, const float *v_alphas, int64_t v_stride, float *rec /*[H,W,3] scratch*/,
+                    float *g2d /*[N,8]*/, float *absgrad_out /*[N,2]|NULL*/, const float *v_means2d /*[N,2]|NULL*/,
+                    float *v_means, float *v_quats, float *v_scales, float *v_opacities, eg_stream_t stream);
+
 /* ---- native data-parallel run (edgegaussians_amd/dist.py drives it).  RCCL is dlopen'ed from
  * `librccl_path` (NULL / "": "librccl.so" by the loader's search path) -- the library PyTorch ships, so that the process
  * holds ONE RCCL -- and the communicator is created from a 128-byte ncclUniqueId: rank 0 calls eg_dp_unique_id, the
@@ -494,6 +526,9 @@ int eg_dp_world(void);
 int eg_dp_shutdown(void);
 /* in-place sum over the ranks of n floats on `stream` (small collectives that ride the same communicator) */
 int eg_dp_all_reduce(float *buf, int64_t n, eg_stream_t stream);
+/* measurement aid: mean HOST microseconds per step that eg_train_steps_dp spent enqueueing {the gradient step's kernels,
+ * ncclAllReduce, Adam + next projection} since the last call; returns the number of steps averaged */
+int64_t eg_dp_host_profile(double *us_out_host /*[3]*/);
 /* K consecutive view-sharded optimizer steps by ONE native call; per step: eg_train_step in its gradient form ->
  * ncclAllReduce(sum, fp32) of the fused [12 N] gradient buffer on the launch stream -> eg_adam_emit (the four Adam steps
  * on the reduced gradient + projection / binning of this rank's next view; eg_adam_multi when there is none).  `a`: step

@@ -1520,6 +1520,22 @@ def test_bench_line_contract(env):
     assert d["ms_per_step_windows"][0] == d["ms_per_step"]  # `value` is the contract's window, the repeats are extra
     assert d["ms_per_step_min"] == min(d["ms_per_step_windows"]) and d["ms_per_step_median"] in d["ms_per_step_windows"]
     assert d["config"]["forward_mode"].startswith(("speculative", "chained")) and "opacity" in d["config"]["workload"]
+    # round 4: a window of fewer than 200 steps says so on the line
+    assert "warning" in d and "--steps 20" in d["warning"]
+
+
+def test_bench_kernel_trace_pass(env):
+    """`roofline.avg_launch_us` comes from a same-run rocprofv3 --kernel-trace pass over bench.py itself (the figure the
+    committed profiles hold; HIP events read a few us more per pair): the pass returns every kernel of the step."""
+    import shutil
+    import bench
+    if not (shutil.which("rocprofv3") or os.path.exists("/opt/rocm/bin/rocprofv3")):
+        pytest.skip("rocprofv3 not installed")
+    kt, src = bench.measure_kernel_trace("config1", False, steps=40)
+    assert kt is not None, src
+    for k in ("composite_wave_fwd_kernel", "footprint_bwd_kernel", "tile_sort_kernel", "project_bwd_emit_kernel"):
+        assert k in kt and 1.0 < kt[k] < 200.0, (k, kt)
+    assert "kernel-trace" in src
 
 
 def test_bench_issue_roofline_pass(env):
