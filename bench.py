@@ -524,6 +524,63 @@ def measure(name, args, device, rank, world, backend, spread=False, steps=None, 
     return res
 
 
+def measure_scenes(name, args, device, S, steps=400, warmup=50, spread=False):
+    """BASELINE config 5 on ONE GPU: S independent scenes (S EdgeTrainers, seeds seed .. seed + S - 1) trained side by side,
+    each on its own HIP stream and driven by its own host thread (the native calls release the GIL: S cores enqueue, one
+    GPU runs the S launch sequences concurrently).  At the reference's sizes a single scene leaves most of the chip idle --
+    its four dependent launches per step sit at their latency floor -- so scenes are the axis that fills it.  No
+    collective, no shared state; every trainer's result equals its solo run (tests/test_gpu_parity.py).
+    Returns {"value": aggregate Gaussians*views/s, "ms_per_step_per_scene": ..., ...}."""
+    import threading
+    n, n_views, w, h = CONFIGS[name]
+    chunk = max(1, args.chunk)
+    trs, streams = [], []
+    for i in range(S):
+        tr, sc, whole, ratio, poses = build_trainer(name, args.seed + i, device, spread)
+        tr.ensure_capacity()
+        trs.append((tr, whole, ratio))
+        streams.append(torch.cuda.Stream(device=device))
+
+    def drive(i, k, step0):
+        tr, whole, ratio = trs[i]
+        with torch.cuda.stream(streams[i]):
+            for s0 in range(step0, step0 + k, chunk):
+                ss = range(s0, min(s0 + chunk, step0 + k))
+                vs = [s % n_views for s in ss]
+                tr.train_steps(vs, [ratio(v) if s % 5 == 0 else whole for s, v in zip(ss, vs)])
+
+    def run_all(k, step0):
+        th = [threading.Thread(target=drive, args=(i, k, step0)) for i in range(S)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+
+    for rep in range(3):  # pre-warm through the same path
+        run_all(200, rep * 200)
+    torch.cuda.synchronize()
+    for i in range(S):
+        with torch.cuda.stream(streams[i]):
+            trs[i][0].pop_loss()
+    run_all(warmup, 600)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run_all(steps, 600 + warmup)
+    t_enq = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    for i in range(S):
+        with torch.cuda.stream(streams[i]):
+            loss = trs[i][0].pop_loss()  # raises if a step of this scene overflowed
+            if not math.isfinite(loss) or trs[i][0].overflow_events or trs[i][0].rewalk_misses:
+                raise SystemExit(f"invalid run: scene {i} replayed steps")
+    return {"scenes_per_gpu": S, "value": n * steps * S / dt, "unit": "Gaussians*views/s", "ms_per_step_per_scene": 1e3 * dt / steps,
+            "aggregate_us_per_scene_step": 1e6 * dt / (steps * S), "host_enqueue_ms_per_step": 1e3 * t_enq / steps,
+            "steps": steps, "warmup": warmup,
+            "config": {"workload": f"{S} x {name}: {n} Gaussians each (seeds {args.seed}..{args.seed + S - 1}), {n_views} views "
+                                   f"@{w}x{h}, one scene per HIP stream + host thread, no collective (BASELINE config 5 on one GPU)"}}
+
+
 def measure_operator(name, args, device, steps=200, warmup=30, adam="torch"):
     """Throughput of the DROP-IN: the reference's own per-step protocol (edge_gs.py:247-279, train_gaussians.py:
     81-106) through `from gsplat import rasterization` (this repo's operator), torch autograd and four
@@ -621,6 +678,11 @@ def main():
     ap.add_argument("--path", default="fused", choices=["fused", "operator"],
                     help="operator: time the reference's per-step protocol through the gsplat.rasterization shim + torch "
                          "autograd + 4 torch Adam instead of the fused native step")
+    ap.add_argument("--scenes-per-gpu", type=int, default=0,
+                    help="S > 0: S independent scenes side by side on this GPU (one stream + host thread each; BASELINE "
+                         "config 5), aggregate throughput")
+    ap.add_argument("--roctx", action="store_true",
+                    help="wrap the stages of every step in roctx ranges (eg_roctx_enable; for rocprofv3 --marker-trace)")
     ap.add_argument("--no-extra", action="store_true",
                     help="only the headline workload (skip the config1 and trained-like lines under other_workloads)")
     args = ap.parse_args()
@@ -643,9 +705,18 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=0, world_size=1)
 
+    if args.roctx:
+        from edgegaussians_amd import _lib as _egl
+        if _egl.load().eg_roctx_enable(1) != 0:
+            raise SystemExit(_egl.load().eg_last_error_string().decode())
     if args.spread_opacity and args.init_opacity:
         raise SystemExit("--spread-opacity and --init-opacity exclude each other")
     args.spread_opacity = not args.init_opacity and (args.spread_opacity or args.config != "config1")
+    if args.scenes_per_gpu > 0:
+        r = measure_scenes(args.config, args, device, args.scenes_per_gpu, max(args.steps, 200), args.warmup, args.spread_opacity)
+        print(json.dumps({"metric": "train-step Gaussians*views/sec", "n_gpus": 1, "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "f32", "data": "synthetic", **r}), flush=True)
+        return
     if args.path == "operator":
         r = measure_operator(args.config, args, device, min(args.steps, 300), min(args.warmup, 50), adam=args.operator_adam)
         print(json.dumps({"metric": "train-step Gaussians*views/sec", "n_gpus": 1, "higher_is_better": True, "scaling": "weak",
@@ -705,6 +776,10 @@ def main():
             extra[f"{name}_operator_path"] = measure_operator(name, args, device)
         # ... and with the drop-in optimizer class as well (train_utils.py:50-59 edited to build it)
         extra[f"{args.config}_operator_path_native_adam"] = measure_operator(args.config, args, device, adam="native")
+        # BASELINE config 5 (one scene per GPU, 115 scans): S scenes side by side on ONE GPU, aggregate throughput
+        extra["config1_scenes_per_gpu"] = {str(S): {k: v for k, v in measure_scenes("config1", args, device, S).items()
+                                                    if k in ("value", "ms_per_step_per_scene", "aggregate_us_per_scene_step",
+                                                             "host_enqueue_ms_per_step")} for S in (1, 2, 4)}
         out["other_workloads"] = extra
         if "config1" in extra:
             # north_star quotes its target on config 1 (~30 k Gaussians, 50 views @512x512): carried at the top level next

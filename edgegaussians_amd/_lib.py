@@ -121,7 +121,7 @@ EXPORTS = sorted(list(_SIGS) + ["eg_last_error_string", "eg_version", "eg_device
                                  "eg_composite_workspace_bytes", "eg_composite_workspace_ctl_bytes",
                                  "eg_batched_workspace_stride", "eg_knn_auto_dims", "eg_timing_begin", "eg_timing_end",
                                  "eg_timing_stage_count", "eg_timing_stage_name", "eg_debug_fwd_profile",
-                                 "eg_dp_unique_id", "eg_dp_init", "eg_dp_world", "eg_dp_shutdown", "eg_dp_host_profile"])
+                                 "eg_dp_unique_id", "eg_dp_init", "eg_dp_world", "eg_dp_shutdown", "eg_dp_host_profile", "eg_roctx_enable"])
 
 _lib: Optional[C.CDLL] = None
 
@@ -159,6 +159,7 @@ def load(require_device: bool = True) -> C.CDLL:
         lib.eg_dp_init.argtypes = [C.c_char_p, _vp, _i32, _i32]
         lib.eg_dp_world.argtypes = []
         lib.eg_dp_shutdown.argtypes = []
+        lib.eg_roctx_enable.argtypes = [_i32]
         lib.eg_dp_host_profile.argtypes = [C.POINTER(C.c_double)]
         lib.eg_dp_host_profile.restype = _i64
         lib.eg_debug_fwd_profile.restype = _i64

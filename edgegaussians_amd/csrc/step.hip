@@ -11,6 +11,8 @@
 // 6 launches per step in the segmented layout (project+emit+scan, sort, slice+combine, re-walk [a bare launch
 // when no pixel stops], footprint, project-bwd+Adam; a second sort launch only when a tile holds > 4096 keys)
 // instead of ~60 (torch glue + gsplat + CUB passes + 4 unfused Adams).
+#include <dlfcn.h>
+
 #include <cstdarg>
 #include <cstdio>
 
@@ -67,7 +69,37 @@ static hipEvent_t *g_ev_cur = nullptr;  // events of the step being enqueued (nu
 void timing_mark(int mark, hipStream_t stream) {
   if (g_ev_cur) (void)hipEventRecord(g_ev_cur[mark], stream);
 }
+
+// ---- optional roctx ranges around the stages of eg_train_step (tracing): off unless eg_roctx_enable(1) found
+// the ROCTx library; rocprofv3 --marker-trace then shows project_bin / tile_sort / composite_fwd / footprint_bwd /
+// project_bwd_adam ranges on the host timeline next to the kernel trace.  No link dependency: dlopen'ed on request.
+typedef int (*RoctxPushFn)(const char *);
+typedef int (*RoctxPopFn)(void);
+static RoctxPushFn g_roctx_push = nullptr;
+static RoctxPopFn g_roctx_pop = nullptr;
+struct RoctxRange {
+  bool on;
+  explicit RoctxRange(const char *name) : on(g_roctx_push != nullptr) { if (on) (void)g_roctx_push(name); }
+  ~RoctxRange() { if (on && g_roctx_pop) (void)g_roctx_pop(); }
+};
 }  // namespace eg
+
+extern "C" int eg_roctx_enable(int32_t on) {
+  if (!on) { g_roctx_push = nullptr; g_roctx_pop = nullptr; return EG_OK; }
+  if (g_roctx_push) return EG_OK;
+  void *h = nullptr;
+  for (const char *name : {"librocprofiler-sdk-roctx.so", "libroctx64.so"})
+    if ((h = dlopen(name, RTLD_NOW | RTLD_GLOBAL)) != nullptr) break;
+  if (!h) { set_error("eg_roctx_enable: no ROCTx library found (%s)", dlerror()); return EG_ERR_ARG; }
+  g_roctx_push = (RoctxPushFn)dlsym(h, "roctxRangePushA");
+  g_roctx_pop = (RoctxPopFn)dlsym(h, "roctxRangePop");
+  if (!g_roctx_push || !g_roctx_pop) {
+    g_roctx_push = nullptr; g_roctx_pop = nullptr;
+    set_error("eg_roctx_enable: roctxRangePushA / roctxRangePop not exported");
+    return EG_ERR_ARG;
+  }
+  return EG_OK;
+}
 
 extern "C" int eg_timing_begin(int32_t n_steps) {
   EG_REQUIRE(n_steps > 0 && n_steps <= 4096, "n_steps out of range");
@@ -138,6 +170,7 @@ extern "C" int eg_train_step(const eg_step_args *a, eg_stream_t stream) {
     const bool prefix_here = T <= kPrefixHereMaxTiles;
     EG_REQUIRE((int64_t)T * a->seg_cap < (1ll << 31), "T * seg_cap must fit 31 bits");
     if (!a->have_projection) {
+      RoctxRange range("eg:project_bin");
       rc = prefix_here ? launch_project_emit(a->means, a->quats, a->log_scales, a->logit_opacities, a->viewmat, a->K, a->N,
                                              a->width, a->height, flags, a->splat, a->tile_counts, a->seg_cap, a->keys,
                                              a->item_offsets, (int32_t)a->max_items, a->total, nullptr, Batch{}, 1, st)
@@ -148,15 +181,19 @@ extern "C" int eg_train_step(const eg_step_args *a, eg_stream_t stream) {
     }
     EG_MARK(kMarkProjectBin);
     EG_MARK(kMarkEmit);
+    {
+    RoctxRange range("eg:tile_sort");
     rc = launch_sort_segments(a->keys, a->tile_counts, T, a->seg_cap, a->flatten_ids, a->offsets, a->tile_end,
                               a->item_offsets, a->item_end, a->item_tile, (int32_t)a->max_items, a->max_tile_hint, Batch{}, 1,
                               st, prefix_here ? a->total : nullptr, a->item_rec,
                               (flags & EG_FLAG_FRONT_PREFIX) ? a->ticket + 1 : nullptr);
+    }
     if (rc) return rc;
     EG_MARK(kMarkSort);
     EG_REQUIRE(a->splat && a->offsets && a->flatten_ids && a->total && a->workspace && a->max_items > 0 &&
                    (a->gtstop ? a->wmap != nullptr : (a->render && a->alphas && a->last_ids)) && (!a->wmap || a->gt),
                "bad compositing arguments");
+    RoctxRange range("eg:composite_fwd");
     rc = composite_fwd_segments_hinted(a->splat, a->offsets, a->tile_end, a->item_offsets, a->item_end, a->item_tile,
                                        a->flatten_ids, a->width, a->height, a->render, a->alphas, a->last_ids, a->gt,
                                        a->wmap, a->loss_scale, a->vpix, a->loss, a->total, a->max_items, a->workspace,
@@ -186,10 +223,14 @@ extern "C" int eg_train_step(const eg_step_args *a, eg_stream_t stream) {
   // (slice / re-walk marks are recorded inside eg_composite_fwd)
   // backward: footprint compositing VJP, then projection VJP + absgrad (+ Adam)
   EG_REQUIRE(a->splat && a->gtstop && a->g2d, "null pointer");
+  {
+  RoctxRange range("eg:footprint_bwd");
   rc = launch_footprint_bwd(a->splat, a->N, a->width, a->height, a->gtstop, a->g2d, Batch{}, 1, st,
                             a->seg_cap > 0 ? a->workspace : nullptr, a->max_items, a->loss);
+  }
   if (rc) return rc;
   // (the footprint mark is recorded inside eg_composite_bwd_footprint)
+  RoctxRange range_bwd("eg:project_bwd_adam");
   if (a->adam_host && a->next_viewmat && a->next_K && a->seg_cap > 0)
     // projection backward + absgrad + Adam of this view, projection + binning + tile scan of the next one
     rc = launch_project_bwd_emit(a->means, a->quats, a->log_scales, a->logit_opacities, a->viewmat, a->K,

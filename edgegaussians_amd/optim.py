@@ -11,7 +11,11 @@ place (edge_gs.py:384-402, 431-451), work unchanged; `step()` is one native laun
 arithmetic of `eg_adam_multi`).
 
 Not supported (the reference uses none of them): weight decay, amsgrad, maximize, closures that re-evaluate the loss,
-sparse gradients, non-fp32 or non-contiguous parameters -- each raises instead of falling back.
+sparse gradients, non-fp32 or non-contiguous parameters, step pre / post hooks -- each raises instead of falling back.
+
+Rounding: the native kernel forms 1 / (sqrt(v_hat) + eps) with the hardware square root and reciprocal (1 ulp each),
+torch's with IEEE sqrt and a division: the two agree to ~2e-7 relative per step (tests: 2e-6 over 31 steps incl. the
+reference's in-place state surgery), NOT bit for bit.
 """
 from __future__ import annotations
 
@@ -63,6 +67,14 @@ class Adam(torch.optim.Optimizer):
     # torch.optim.Optimizer wraps `step` of every subclass in a profiler range + pre/post-hook dispatch unless it is
     # marked as hooked already: ~25 us of host time per call, four calls per training step.  This class has no step hooks.
     step.hooked = True
+
+    def register_step_pre_hook(self, hook):
+        raise NotImplementedError("edgegaussians_amd.optim.Adam: step hooks are not dispatched (step() skips torch's "
+                                  "hook wrapper); use torch.optim.Adam if you need them")
+
+    def register_step_post_hook(self, hook):
+        raise NotImplementedError("edgegaussians_amd.optim.Adam: step hooks are not dispatched (step() skips torch's "
+                                  "hook wrapper); use torch.optim.Adam if you need them")
 
     def zero_grad(self, set_to_none: bool = True):
         """torch's semantics (gradients dropped, or zeroed in place with set_to_none=False) without its profiler range

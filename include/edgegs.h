@@ -548,6 +548,10 @@ int eg_train_steps_dp(const eg_step_args *a, const eg_adam_hyper *hyper, float *
  * once and returns the average microseconds per stage (eg_timing_stage_count() entries, names by
  * eg_timing_stage_name(i)).  Not thread safe; one window at a time. */
 int eg_timing_begin(int32_t n_steps);
+/* tracing aid: eg_roctx_enable(1) dlopen's the ROCTx library and makes eg_train_step wrap its stages in
+ * roctx ranges (eg:project_bin, eg:tile_sort, eg:composite_fwd, eg:footprint_bwd, eg:project_bwd_adam) -- rocprofv3
+ * --marker-trace shows them next to the kernel trace; eg_roctx_enable(0) turns them off again (the default). */
+int eg_roctx_enable(int32_t on);
 /* debugging aid (process started with EG_FWD_PROF=1: the wave-autonomous forward runs its timed instantiation): the
  * per-wave phase records of the LAST forward launch, [items][4 quadrants][8] 64-bit words of shader-clock ticks (head,
  * staging, walk, publish, look-back, exact stop, epilogue; word 7 = 1 marks a wave that ran).  Returns the number of

@@ -1524,6 +1524,69 @@ def test_bench_line_contract(env):
     assert "warning" in d and "--steps 20" in d["warning"]
 
 
+def test_scenes_side_by_side_on_streams_and_threads_equal_their_solo_runs(env):
+    """BASELINE config 5 on one GPU (bench.py --scenes-per-gpu): S independent EdgeTrainers, each on its own HIP stream and
+    driven by its own host thread, the S launch sequences running concurrently.  Nothing is shared: every trainer ends
+    bit-identical to the same trainer run alone on the default stream."""
+    import threading
+    _lib, synth, O = env
+    from edgegaussians_amd import EdgeTrainer
+    S, K = 3, 24
+    scs = [_scene(synth, n=2500 + 300 * i, w=160, h=112, views=3, seed=10 + i) for i in range(S)]
+    mk = lambda sc: EdgeTrainer(sc.means, sc.log_scales, sc.quats, sc.logit_opacities, sc.viewmats, sc.Ks, sc.gt,  # noqa: E731
+                                sc.width, sc.height)
+    views = [k % 3 for k in range(K)]
+
+    def steps(tr, sc):
+        w = [synth.weight_map("weighted", sc.gt[v]).cuda() for v in range(3)]
+        torch.cuda.current_stream().synchronize()
+        for k0 in range(0, K, 8):
+            tr.train_steps(views[k0:k0 + 8], [w[v] for v in views[k0:k0 + 8]])
+        return tr.pop_loss()
+
+    solo = []
+    for sc in scs:
+        tr = mk(sc)
+        solo.append((steps(tr, sc), tr))
+    side, streams, out = [mk(sc) for sc in scs], [torch.cuda.Stream() for _ in scs], [None] * S
+
+    def drive(i):
+        with torch.cuda.stream(streams[i]):
+            out[i] = steps(side[i], scs[i])
+
+    th = [threading.Thread(target=drive, args=(i,)) for i in range(S)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    torch.cuda.synchronize()
+    for i in range(S):
+        a, b = solo[i][1], side[i]
+        assert abs(out[i] - solo[i][0]) <= 1e-6 * abs(solo[i][0]), (i, out[i], solo[i][0])  # (a sum of float atomics)
+        for x, y in ((a.means, b.means), (a.log_scales, b.log_scales), (a.quats, b.quats), (a.logit_opacities, b.logit_opacities),
+                     (a.adam_m, b.adam_m), (a.adam_v, b.adam_v), (a.absgrads, b.absgrads)):
+            assert torch.equal(x, y), i
+
+
+def test_roctx_ranges_do_not_change_a_step(env):
+    """eg_roctx_enable(1) wraps the stages of eg_train_step in roctx ranges (SURVEY 5: tracing; rocprofv3 --marker-trace);
+    with or without them the step is the same."""
+    _lib, synth, O = env
+    from edgegaussians_amd import EdgeTrainer
+    sc = _scene(synth, n=1500, w=96, h=80)
+    w = synth.weight_map("weighted", sc.gt[0]).cuda()
+    out = []
+    for on in (0, 1):
+        assert _lib.load().eg_roctx_enable(on) == 0, _lib.load().eg_last_error_string()
+        tr = EdgeTrainer(sc.means, sc.log_scales, sc.quats, sc.logit_opacities, sc.viewmats, sc.Ks, sc.gt, 96, 80)
+        tr.train_step(0, w)
+        tr.train_steps([1, 0], [w, w])
+        out.append((tr.means.clone(), tr.adam_v.clone(), tr.pop_loss()))
+    _lib.load().eg_roctx_enable(0)
+    assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
+    assert abs(out[0][2] - out[1][2]) <= 1e-6 * abs(out[0][2])
+
+
 def test_bench_kernel_trace_pass(env):
     """`roofline.avg_launch_us` comes from a same-run rocprofv3 --kernel-trace pass over bench.py itself (the figure the
     committed profiles hold; HIP events read a few us more per pair): the pass returns every kernel of the step."""

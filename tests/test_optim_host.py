@@ -45,3 +45,15 @@ def test_step_without_the_hip_library_raises():
     with pytest.raises(RuntimeError):
         o.step()
     assert float(p.detach().abs().sum()) == 0.0  # nothing was updated by some fallback
+
+
+def test_step_hooks_are_refused_not_silently_dropped():
+    """step() skips torch's hook wrapper, so a registered hook would never fire -- registering one raises."""
+    import pytest
+    import torch
+    from edgegaussians_amd.optim import Adam
+    opt = Adam([torch.nn.Parameter(torch.zeros(4))], lr=1e-3)
+    with pytest.raises(NotImplementedError):
+        opt.register_step_pre_hook(lambda *a: None)
+    with pytest.raises(NotImplementedError):
+        opt.register_step_post_hook(lambda *a: None)
