@@ -220,6 +220,13 @@ class _FastBuffers:
         self.seg_cap = self.max_items = 0
         self.max_tile = 0
         self.tag = 0
+        # deferred read-back (see _UnitRasterization.forward): a pinned host mirror of `total`, the event behind the copy,
+        # the number of consecutive calls whose verdicts came back clean with room to spare
+        self.host = torch.empty(8, dtype=torch.int32).pin_memory()
+        self.event = torch.cuda.Event()
+        self.pending = False
+        self.confident = 0
+        self.last_m = 0
         self.args = _lib.OperatorArgs()
         a = self.args
         a.N, a.width, a.height = N, width, height
@@ -254,6 +261,30 @@ class _FastBuffers:
         self.tile_counts.zero_()
         self.ticket.zero_()
 
+    def roomy(self, m: int, tile_max: int) -> bool:
+        """The last call left at least 30 % of head-room in both capacities (views of a scene differ by less)."""
+        return m * 1.3 <= (self.max_items - self.T) * 128 and tile_max * 1.3 <= self.seg_cap
+
+    def settle(self) -> None:
+        """Looks at the verdicts of a call whose read-back was deferred.  An overflow or non-unit colours there mean that
+        the results ALREADY handed out were wrong: that is raised, never passed over in silence."""
+        if not self.pending:
+            return
+        self.pending = False
+        self.event.synchronize()
+        m, overflow, _items, tile_max, unit = self.host.tolist()[:5]
+        self.max_tile, self.last_m = max(self.max_tile, tile_max), m
+        if overflow or not unit:
+            self.confident = 0
+            self.reset()
+            raise RuntimeError(
+                "rasterization (fast path, deferred read-back): the previous call " +
+                ("overflowed its intersection buffers" if overflow else "was given colours that are not all ones") +
+                " after a run of calls that had not -- its outputs were invalid.  Set EG_OPERATOR_DEFER=0 to have every "
+                "call read its verdicts back before it returns (one host synchronisation per call).")
+        if not self.roomy(m, tile_max):
+            self.confident = 0  # (the next call reads back at once and grows the buffers ahead of the drift)
+
     def next_tag(self) -> int:
         if self.tag >= _lib.MAX_WS_TAG:  # (every 65 534 calls: granules of 2^16 calls ago must not look fresh)
             self.workspace.zero_()
@@ -263,6 +294,7 @@ class _FastBuffers:
 
 
 _FAST: Dict = {}
+_DEFER = _os.environ.get("EG_OPERATOR_DEFER", "1") != "0"
 
 
 def _fast_buffers(N, width, height, dev) -> _FastBuffers:
@@ -282,9 +314,17 @@ class _UnitRasterization(torch.autograd.Function):
     def forward(ctx, means, quats, scales, opacities, viewmat, K, width, height, flags, colors, holder):
         N, dev = means.shape[0], means.device
         fb = _fast_buffers(N, width, height, dev)
+        fb.settle()  # (a call whose backward never ran: its deferred verdicts are looked at now)
         means_c, quats_c, scales_c, opac_c = means.contiguous(), quats.contiguous(), scales.contiguous(), opacities.contiguous()
         vm, Kc, col = viewmat.contiguous(), K.contiguous(), colors.contiguous()
         st = stream()
+        # DEFERRED READ-BACK.  The call's verdicts -- did the intersection buffers overflow, are the colours all ones -- sit
+        # on the device; reading them back before returning costs a host synchronisation per call (the host waits out the
+        # forward's ~60 us of kernels instead of enqueueing the loss).  After two consecutive calls whose verdicts were clean
+        # with >= 30 % of head-room in both capacities the read-back becomes an asynchronous copy into pinned memory that
+        # the BACKWARD (or the next forward) looks at: a verdict that turns out bad then RAISES there (the outputs were
+        # already handed out).  EG_OPERATOR_DEFER=0: always read back at once.
+        defer = _DEFER and fb.confident >= 2
         if fb.seg_cap == 0:  # first call for this shape: a count-only sweep sizes the buffers (one extra sync, once)
             splat0 = torch.empty(N, 8, device=dev)
             call("eg_project_fwd", ptr(means_c), ptr(quats_c), ptr(scales_c), ptr(opac_c), ptr(vm), ptr(Kc), N, width, height,
@@ -308,14 +348,23 @@ class _UnitRasterization(torch.autograd.Function):
             a.max_tile_hint, a.ws_tag = fb.max_tile, fb.next_tag()
             try:
                 call("eg_operator_fwd", C.byref(a), st)
-                # the ONE host read-back of the call, after everything has been enqueued: M, sticky overflow flag, items,
-                # largest tile -- and the verdict on the colours
-                m, overflow, _items, tile_max, unit = fb.total.tolist()[:5]
+                if defer:
+                    fb.host.copy_(fb.total, non_blocking=True)
+                    fb.event.record()
+                    fb.pending = True
+                    m, overflow, tile_max, unit = fb.last_m, 0, fb.max_tile, 1
+                else:
+                    # the ONE host read-back of the call, after everything has been enqueued: M, sticky overflow flag,
+                    # items, largest tile -- and the verdict on the colours
+                    m, overflow, _items, tile_max, unit = fb.total.tolist()[:5]
+                    fb.last_m = m
             except Exception:
                 fb.reset()
                 raise
             holder["unit"] = bool(unit)
             if not overflow:
+                if not defer:
+                    fb.confident = fb.confident + 1 if (unit and fb.roomy(m, tile_max)) else 0
                 break
             fb.reset()
             fb.size(2 * max(m, 1), 2 * max(tile_max, 1))  # the scene outgrew the cached buffers: grow, run again
@@ -327,6 +376,7 @@ class _UnitRasterization(torch.autograd.Function):
         ctx.save_for_backward(means_c, quats_c, scales_c, opac_c, vm, Kc, splat, gtstop)
         ctx.cfg = (width, height, flags)
         ctx.holder = holder
+        ctx.fb = fb
         holder["splat"] = splat
         return alphas, means2d
 
@@ -335,6 +385,7 @@ class _UnitRasterization(torch.autograd.Function):
         means, quats, scales, opac, vm, Kc, splat, gtstop = ctx.saved_tensors
         width, height, flags = ctx.cfg
         N, dev = means.shape[0], means.device
+        ctx.fb.settle()  # (deferred verdicts of the forward: long since on the host)
         out = torch.empty(11 * N, device=dev)  # v_means 3N | v_quats 4N | v_scales 3N | v_opacities N
         if v_alphas is None:
             return (out[:3 * N].zero_().view(N, 3), out[3 * N:7 * N].zero_().view(N, 4), out[7 * N:10 * N].zero_().view(N, 3),

@@ -1524,6 +1524,56 @@ def test_bench_line_contract(env):
     assert "warning" in d and "--steps 20" in d["warning"]
 
 
+def test_operator_deferred_read_back_is_exact_and_fails_loudly(env):
+    """The fast path's verdicts (overflow, colours == 1) are read back asynchronously once two consecutive calls came back
+    clean with room to spare (rasterizer.py: DEFERRED READ-BACK).  (1) Calls in deferred mode return exactly what calls that
+    synchronise return.  (2) A verdict that turns out bad after the outputs were handed out RAISES at the next look (the
+    backward, or the next call) -- never silently wrong."""
+    _lib, synth, O = env
+    from edgegaussians_amd import rasterization
+    from edgegaussians_amd import rasterizer as R
+    sc = _scene(synth, n=2000, w=112, h=80, views=3)
+    dev = "cuda"
+    p = [t.clone().to(dev).requires_grad_(True) for t in (sc.means, sc.quats, sc.log_scales, sc.logit_opacities)]
+    vm, K = sc.viewmats.to(dev), sc.Ks.to(dev)
+
+    def run(view, colors):
+        for t in p:
+            t.grad = None
+        render, alpha, info = rasterization(means=p[0], quats=p[1], scales=torch.exp(p[2]), opacities=torch.sigmoid(p[3]).squeeze(-1),
+                                            colors=colors, viewmats=vm[view:view + 1], Ks=K[view:view + 1], width=112, height=80,
+                                            packed=False, absgrad=True, rasterize_mode="antialiased")
+        info["means2d"].retain_grad()
+        (render[0, ..., 0] * sc.gt[view].to(dev)).sum().backward()
+        return render.detach().clone(), [t.grad.clone() for t in p], info["means2d"].absgrad.clone()
+
+    ones = lambda: torch.ones(2000, 3, device=dev)  # noqa: E731
+    R._FAST.clear()
+    outs = [run(v % 3, ones()) for v in range(6)]
+    fb = next(iter(R._FAST.values()))
+    assert fb.confident >= 2 and not fb.pending, "calls 3.. must have run with a deferred read-back (settled in backward)"
+    old = R._DEFER
+    try:
+        R._DEFER = False
+        R._FAST.clear()
+        ref = [run(v % 3, ones()) for v in range(6)]
+    finally:
+        R._DEFER = old
+    for a, b in zip(outs, ref):
+        assert torch.equal(a[0], b[0]) and torch.equal(a[2], b[2]) and all(torch.equal(x, y) for x, y in zip(a[1], b[1]))
+    # (2) colours that stop being ones while the path is in deferred mode
+    R._FAST.clear()
+    for v in range(4):
+        run(v % 3, ones())
+    bad = ones()
+    bad[5, 1] = 0.5
+    with pytest.raises(RuntimeError, match="not all ones"):
+        run(0, bad)       # raised by the backward's look at the forward's verdicts
+    out = run(1, bad)     # the path has fallen back to reading back at once: the general operator takes the call
+    assert float((out[0][0, ..., 0] - out[0][0, ..., 1]).abs().max()) > 0  # (colours really differ per channel)
+    R._FAST.clear()
+
+
 def test_scenes_side_by_side_on_streams_and_threads_equal_their_solo_runs(env):
     """BASELINE config 5 on one GPU (bench.py --scenes-per-gpu): S independent EdgeTrainers, each on its own HIP stream and
     driven by its own host thread, the S launch sequences running concurrently.  Nothing is shared: every trainer ends

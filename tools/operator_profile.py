@@ -21,6 +21,15 @@ opts = [adam_cls([P[k]], lr=lrs[k]) for k in P]
 absgrads = torch.zeros(n, device=dev)
 vms, Ks, gt = sc.viewmats.to(dev), sc.Ks.to(dev), sc.gt.to(dev)
 whole = synth.weight_map("whole", sc.gt[0]).to(dev)
+# host-only time of the operator's two autograd hooks (no synchronisation added: what the host spends inside them)
+from edgegaussians_amd import rasterizer as _R
+H = {"fwd": 0.0, "bwd": 0.0, "n": 0}
+_f0, _b0 = _R._UnitRasterization.forward, _R._UnitRasterization.backward
+def _fw(ctx, *a):
+    t = time.perf_counter(); r = _f0(ctx, *a); H["fwd"] += time.perf_counter() - t; H["n"] += 1; return r
+def _bw(ctx, *a):
+    t = time.perf_counter(); r = _b0(ctx, *a); H["bwd"] += time.perf_counter() - t; return r
+_R._UnitRasterization.forward, _R._UnitRasterization.backward = staticmethod(_fw), staticmethod(_bw)
 T = {}
 def tick(k, t0):
     torch.cuda.synchronize(); T[k] = T.get(k, 0.0) + time.perf_counter() - t0; return time.perf_counter()
@@ -53,7 +62,10 @@ for s in range(K): step(s, True)
 tot = sum(T.values())
 for k, v in T.items(): print(f"{k:22s} {1e6 * v / K:8.1f} us")
 print(f"{'sum (every section synchronised)':22s} {1e6 * tot / K:8.1f} us")
+H.update(fwd=0.0, bwd=0.0, n=0)
 t0 = time.perf_counter()
 for s in range(K): step(s, False)
 torch.cuda.synchronize()
 print(f"free-running              {1e6 * (time.perf_counter() - t0) / K:8.1f} us/step")
+print(f"host time inside the operator's hooks, free-running: forward {1e6 * H['fwd'] / max(H['n'], 1):6.1f} us, "
+      f"backward {1e6 * H['bwd'] / max(H['n'], 1):6.1f} us per call (EG_OPERATOR_DEFER={os.environ.get('EG_OPERATOR_DEFER', '1')})")
