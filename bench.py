@@ -336,8 +336,16 @@ def measure(name, args, device, rank, world, backend, spread=False, steps=None, 
     # the native data-parallel leg (eg_train_steps_dp: grad -> ncclAllReduce on the launch stream -> Adam + next projection,
     # `chunk` steps per enqueue) whenever RCCL is the backend; EG_NO_NATIVE_DP=1: the Python driver (three enqueues + one
     # torch.distributed call per step)
-    native_dp = (dp is not None and vps == 1 and backend == "nccl" and not os.environ.get("EG_NO_NATIVE_DP")
-                 and egdist.init_native_comm() >= 1 and dp.native_ready())
+    native_dp = False
+    if dp is not None and vps == 1 and backend == "nccl" and not os.environ.get("EG_NO_NATIVE_DP"):
+        try:
+            native_dp = egdist.init_native_comm() >= 1 and dp.native_ready()
+        except Exception as e:  # noqa: BLE001 -- the Python driver is the same computation: say so and carry on
+            print(f"[bench] native data-parallel leg unavailable ({e!r}): using dist.DataParallelStep.step", file=sys.stderr)
+        if world > 1:  # every rank must take the same leg (the collectives differ)
+            t = torch.tensor([int(native_dp)], device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            native_dp = bool(int(t.item()))
     def wmap_for(step, view):
         return ratio(view) if step % 5 == 0 else whole  # configs/ABC_DexiNed.json:85-92
 
