@@ -1,5 +1,5 @@
 #!/bin/bash
-# Full evidence run on the GPU box (round 3): parity tests + report, bench lines (headline with same-run PMC traffic,
+# Full evidence run on the GPU box (round 4): parity tests + report, bench lines (headline with same-run PMC traffic,
 # config1, trained-like, batched views, operator path, config3/4), rocprofv3 kernel stats + launch gaps, SQ counters.
 #   gpurun --timeout 3000 -- 'bash tools/run_gpu_suite.sh'
 # Everything lands in gpurun_out/ev/; copy what should be judged into profiles/ (tools/collect_profiles.py).
@@ -15,12 +15,14 @@ cp $R/gpurun_out/parity_report.jsonl $O/parity_report.jsonl 2>/dev/null
 timeout 600 python bench.py --config config1 --no-extra 2>/dev/null | tail -1 > $O/bench_config1.json
 timeout 600 python bench.py --config config2 --init-opacity --no-cpu-baseline --no-extra 2>/dev/null | tail -1 > $O/bench_config2_init_opacity.json
 for c in config3 config4; do
-  timeout 600 python bench.py --config $c --no-cpu-baseline --no-traffic --no-extra 2>/dev/null | tail -1 > $O/bench_${c}.json
+  timeout 900 python bench.py --config $c --no-cpu-baseline --no-extra 2>/dev/null | tail -1 > $O/bench_${c}.json
   timeout 600 python bench.py --config $c --init-opacity --no-cpu-baseline --no-traffic --no-extra 2>/dev/null | tail -1 > $O/bench_${c}_init_opacity.json
 done
 tools/microbench/issue_rates > $O/issue_rates.txt 2>&1
 EG_FWD_PROF=1 python tools/fwd_prof.py config2 --spread 2>/dev/null | grep -v "^RCCL\|^HIP\|amdgpu.ids" > $O/fwd_wave_phases_config2.txt
 EG_FWD_PROF=1 python tools/fwd_prof.py config2 2>/dev/null | grep -v "^RCCL\|^HIP\|amdgpu.ids" >> $O/fwd_wave_phases_config2.txt
+EG_FWD_PROF=1 python tools/fwd_prof.py config4 --spread 2>/dev/null | grep -v "^RCCL\|^HIP\|amdgpu.ids" > $O/fwd_wave_phases_config4.txt
+for S in 1 2 4; do timeout 300 python bench.py --config config1 --scenes-per-gpu $S 2>/dev/null | tail -1 > $O/bench_config1_scenes$S.json; done
 timeout 300 python bench.py --force-dp --no-cpu-baseline --no-traffic --no-extra 2>/dev/null | tail -1 > $O/bench_config2_force_dp.json
 timeout 300 python tools/bench_regularizers.py 2>/dev/null | tail -1 > $O/regularizers_timing.json
 timeout 300 python tools/operator_profile.py config2 2>/dev/null | grep -v "^RCCL\|^HIP\|amdgpu.ids" > $O/operator_profile_config2.txt
@@ -30,7 +32,28 @@ timeout 300 python tools/late_epoch_bench.py 2>/dev/null | grep -v "^RCCL\|^HIP\
 timeout 300 python tools/train_abc_fixture.py 2>/dev/null | tail -5 > $O/train_abc_fixture.txt
 ( echo "--- first run of the process (--cold) ---"; timeout 300 python tools/train_abc_fixture.py --cold 2>/dev/null | tail -2 | head -1 ) >> $O/train_abc_fixture.txt
 cd /tmp && export TMPDIR=/tmp
-for c in config1 config2 config2i; do
+rm -rf /tmp/ev_roctx
+timeout 300 rocprofv3 --kernel-trace --marker-trace --stats -d /tmp/ev_roctx -o r -- python $R/bench.py --config config2 --roctx --steps 100 --warmup 10 --profile-only > /dev/null 2>$O/prof_roctx.err
+python - > $O/roctx_ranges_config2.txt 2>&1 <<PY
+import sqlite3, glob
+db = glob.glob("/tmp/ev_roctx/**/*_results.db", recursive=True)
+cur = sqlite3.connect(db[0]).cursor()
+tabs = [r[0] for r in cur.execute("select name from sqlite_master where type in ('table','view')")]
+print("rocprofv3 --kernel-trace --marker-trace over bench.py --config config2 --roctx: tables/views with markers:", [t for t in tabs if 'mark' in t.lower() or 'region' in t.lower()][:8])
+for t in ("regions", "markers", "rocpd_region"):
+    if t in tabs:
+        cols = [r[1] for r in cur.execute(f"pragma table_info({t})")]
+        nm = "name" if "name" in cols else None
+        if nm and "start" in cols and "end" in cols:
+            agg = {}
+            for n, s0, e0 in cur.execute(f"select {nm}, start, end from {t}"):
+                if str(n).startswith("eg:"):
+                    a = agg.setdefault(n, [0, 0.0]); a[0] += 1; a[1] += (e0 - s0) / 1e3
+            for n, a in sorted(agg.items()):
+                print(f"{n:24s} ranges {a[0]:6d}  mean host span {a[1] / a[0]:8.2f} us")
+            break
+PY
+for c in config1 config2 config2i config3 config4; do
   rm -rf /tmp/ev_$c /tmp/evsq_$c
   a="--config $c"; [ $c = config2i ] && a="--config config2 --init-opacity"
   timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/ev_$c -o r -- python $R/bench.py $a --steps 300 --warmup 20 --profile-only > /dev/null 2>$O/prof_$c.err
