@@ -40,10 +40,11 @@ db = glob.glob("/tmp/ev_roctx/**/*_results.db", recursive=True)
 cur = sqlite3.connect(db[0]).cursor()
 tabs = [r[0] for r in cur.execute("select name from sqlite_master where type in ('table','view')")]
 print("rocprofv3 --kernel-trace --marker-trace over bench.py --config config2 --roctx: tables/views with markers:", [t for t in tabs if 'mark' in t.lower() or 'region' in t.lower()][:8])
-for t in ("regions", "markers", "rocpd_region"):
+for t in ("regions", "rocpd_region", "markers"):
     if t in tabs:
         cols = [r[1] for r in cur.execute(f"pragma table_info({t})")]
-        nm = "name" if "name" in cols else None
+        print(t, "columns:", cols)
+        nm = next((c for c in ("name", "region_name", "message") if c in cols), None)
         if nm and "start" in cols and "end" in cols:
             agg = {}
             for n, s0, e0 in cur.execute(f"select {nm}, start, end from {t}"):
@@ -51,7 +52,8 @@ for t in ("regions", "markers", "rocpd_region"):
                     a = agg.setdefault(n, [0, 0.0]); a[0] += 1; a[1] += (e0 - s0) / 1e3
             for n, a in sorted(agg.items()):
                 print(f"{n:24s} ranges {a[0]:6d}  mean host span {a[1] / a[0]:8.2f} us")
-            break
+            if agg:
+                break
 PY
 for c in config1 config2 config2i config3 config4; do
   rm -rf /tmp/ev_$c /tmp/evsq_$c
