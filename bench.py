@@ -744,6 +744,13 @@ def main():
         stages, src = measure_traffic(args.config, args.spread_opacity)
         out["roofline"]["traffic"] = stages.get(out["roofline"]["kernel"]) if stages else None
         out["roofline"]["traffic_source"] = src
+        # (the counter was calibrated on this kernel's own access patterns, tools/traffic_calib.py ->
+        # profiles/r04_traffic_counter_calibration.txt: FETCH_SIZE counts a 128-byte line fill as 64 bytes whatever the
+        # access width -- the x2 holds for coalesced 4 / 8 / 16 B per lane and for device-scope 8 B loads --, WRITE_SIZE is
+        # exact, and a gather of 32-byte records costs a full line per record)
+        out["roofline"]["traffic_calibration"] = ("profiles/r04_traffic_counter_calibration.txt: reads x2 confirmed for this kernel's "
+                                                  "patterns, writes exact; the record gather fills a 128-byte line per 32-byte record, "
+                                                  "and each of the 8 XCD L2s fills the whole record array once per launch")
         if stages:
             out["traffic_bytes_per_step_by_stage"] = stages
         # the dominant kernel's launch duration as rocprofv3's kernel trace of this very command sees it (what the
