@@ -7,7 +7,7 @@
 //             wave-autonomous forward of the training step in its exact (chained) mode with the alpha image as an extra
 //             output and no fused loss (the record carries T_final) -> means2d copied out of the packed record -> "are
 //             the colours all ones" folded into total[4] (the caller's ONE read-back tells it together with M and the
-//             overflow flag)
+//             overflow flag; total[5] carries the forward's "a look-back poll gave up" bit)
 //   backward: record x upstream gradient -> footprint backward -> absgrad copied out -> projection backward
 #include "common.h"
 #include "composite.h"
@@ -20,7 +20,9 @@ __global__ void colors_are_ones_kernel(const float *__restrict__ c, long long n,
     ok = ok && (c[i] == 1.f);
   if (__ballot(!ok) != 0ull && (threadIdx.x & 63) == 0) atomicAnd(flag, 0);
 }
-__global__ void set_int_kernel(int *p, int v) { *p = v; }
+// total[4] = 1 (colours are ones until a mismatch clears it), total[5] = control word 3 of the compositing workspace
+// (bit 1: a look-back poll of the forward gave up; sticky)
+__global__ void verdict_words_kernel(int *total, const int *ctl) { total[4] = 1; total[5] = ctl[3]; }
 
 // rec[p] = {gtstop[p].gT * v[p], stop id, stop depth}
 __global__ void scale_record_kernel(const StopRec *__restrict__ src, const float *__restrict__ v, long long v_stride,
@@ -75,7 +77,7 @@ extern "C" int eg_operator_fwd(const eg_operator_args *a, eg_stream_t stream) {
                        hipMemcpyDeviceToDevice, st) != hipSuccess)
     return check_launch("operator_fwd(means2d)");
   // total[4] = 1 iff every colour entry equals 1 (read back by the caller together with total[0..3])
-  set_int_kernel<<<1, 1, 0, st>>>(a->total + 4, 1);
+  verdict_words_kernel<<<1, 1, 0, st>>>(a->total, carve_workspace(a->workspace, a->max_items, T).ctl);
   if (a->colors && a->color_channels > 0) {
     const long long n = (long long)a->N * a->color_channels;
     colors_are_ones_kernel<<<(unsigned)min((long long)1024, (n + 255) / 256), 256, 0, st>>>(a->colors, n, a->total + 4);

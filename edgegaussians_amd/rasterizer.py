@@ -272,7 +272,8 @@ class _FastBuffers:
             return
         self.pending = False
         self.event.synchronize()
-        m, overflow, _items, tile_max, unit = self.host.tolist()[:5]
+        m, overflow, _items, tile_max, unit, ctl3 = self.host.tolist()[:6]
+        _check_stall(ctl3)
         self.max_tile, self.last_m = max(self.max_tile, tile_max), m
         if overflow or not unit:
             self.confident = 0
@@ -291,6 +292,12 @@ class _FastBuffers:
             self.tag = 0
         self.tag += 1
         return self.tag
+
+
+def _check_stall(ctl3: int) -> None:
+    if ctl3 & 2:
+        raise RuntimeError("rasterization: a look-back poll of the compositing forward gave up (a hand-over granule never "
+                           "arrived): the outputs of that call are invalid")
 
 
 _FAST: Dict = {}
@@ -356,7 +363,8 @@ class _UnitRasterization(torch.autograd.Function):
                 else:
                     # the ONE host read-back of the call, after everything has been enqueued: M, sticky overflow flag,
                     # items, largest tile -- and the verdict on the colours
-                    m, overflow, _items, tile_max, unit = fb.total.tolist()[:5]
+                    m, overflow, _items, tile_max, unit, ctl3 = fb.total.tolist()[:6]
+                    _check_stall(ctl3)
                     fb.last_m = m
             except Exception:
                 fb.reset()

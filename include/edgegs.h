@@ -487,7 +487,8 @@ int eg_train_step_batched(const eg_step_args *args_host, int32_t C, const float 
  * gsplat.rasterization -- one camera, colours == 1 without grad, edge_gs.py:247-279 -- and its autograd backward).
  * eg_operator_fwd: projection + exact tile binning -> per-tile sort -> the training step's wave-autonomous forward in its
  * exact mode, with the accumulated-alpha image as output and T_final in the gtstop record (no fused loss); means2d is
- * copied out of the packed record; total[4] = 1 iff every entry of `colors` is 1.  The per-call outputs (splat, alphas,
+ * copied out of the packed record; total[4] = 1 iff every entry of `colors` is 1, total[5] = control word 3 of the workspace
+ * (bit 1: a look-back poll of the forward gave up: the outputs are void).  The per-call outputs (splat, alphas,
  * means2d, gtstop) are the caller's fresh tensors, everything else its cached work buffers; total is [8] int32
  * ([0..3] as everywhere, [1] the sticky overflow flag: the caller reads total[0..4] back ONCE after the call).
  * eg_operator_bwd: rec = gtstop with word 0 scaled by the upstream gradient v_alphas[p * v_stride] -> footprint backward

@@ -34,27 +34,7 @@ timeout 300 python tools/train_abc_fixture.py 2>/dev/null | tail -5 > $O/train_a
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/ev_roctx
 timeout 300 rocprofv3 --kernel-trace --marker-trace --stats -d /tmp/ev_roctx -o r -- python $R/bench.py --config config2 --roctx --steps 100 --warmup 10 --profile-only > /dev/null 2>$O/prof_roctx.err
-python - > $O/roctx_ranges_config2.txt 2>&1 <<PY
-import sqlite3, glob
-db = glob.glob("/tmp/ev_roctx/**/*_results.db", recursive=True)
-cur = sqlite3.connect(db[0]).cursor()
-tabs = [r[0] for r in cur.execute("select name from sqlite_master where type in ('table','view')")]
-print("rocprofv3 --kernel-trace --marker-trace over bench.py --config config2 --roctx: tables/views with markers:", [t for t in tabs if 'mark' in t.lower() or 'region' in t.lower()][:8])
-for t in ("regions", "rocpd_region", "markers"):
-    if t in tabs:
-        cols = [r[1] for r in cur.execute(f"pragma table_info({t})")]
-        print(t, "columns:", cols)
-        nm = next((c for c in ("name", "region_name", "message") if c in cols), None)
-        if nm and "start" in cols and "end" in cols:
-            agg = {}
-            for n, s0, e0 in cur.execute(f"select {nm}, start, end from {t}"):
-                if str(n).startswith("eg:"):
-                    a = agg.setdefault(n, [0, 0.0]); a[0] += 1; a[1] += (e0 - s0) / 1e3
-            for n, a in sorted(agg.items()):
-                print(f"{n:24s} ranges {a[0]:6d}  mean host span {a[1] / a[0]:8.2f} us")
-            if agg:
-                break
-PY
+python $R/tools/roctx_summary.py /tmp/ev_roctx/r_results.db $O/roctx_ranges_config2.txt > /dev/null 2>&1
 for c in config1 config2 config2i config3 config4; do
   rm -rf /tmp/ev_$c /tmp/evsq_$c
   a="--config $c"; [ $c = config2i ] && a="--config config2 --init-opacity"
