@@ -108,6 +108,7 @@ _SIGS = {
     "eg_direction_loss": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp],
     "eg_ratio_loss": [_vp, _i32, _vp, _vp, _vp],
     "eg_regulariser_step": [_i32] + [_vp] * 7 + [_i32, _vp, _i32, _i32, _i32, _i32, _vp, _f, _f, _vp, AdamHyper, _vp],
+    "eg_regulariser_step_fixed": [_i32] + [_vp] * 7 + [_i32, _vp, _i32, _i32, _i32, _i32, _vp, _f, _f, _vp, AdamHyper, _vp, _vp],
     "eg_train_step": [C.POINTER(StepArgs), _vp],
     "eg_train_steps": [C.POINTER(StepArgs), _i32, C.POINTER(_i32), C.POINTER(_vp), _vp, _vp, _vp, _vp],
     "eg_operator_fwd": [C.POINTER(OperatorArgs), _vp],

@@ -386,21 +386,55 @@ __device__ __forceinline__ void block_sum_add(float acc, float *__restrict__ sum
   }
 }
 
+// ---- ORDER-INDEPENDENT accumulation (data-parallel runs: replicas must stay bit-identical).  Float atomics
+// add in the order the hardware happens to take them; 64-bit FIXED-POINT integer atomics (2^-32 resolution, |x| < 2^31)
+// are associative: every rank quantises the same fp32 terms to the same integers and the sums are equal whatever the
+// order.  The accumulators live in a caller-supplied int64 scratch [3 N + 1] (gradient of the means, then the loss sum),
+// zero on entry; fixed_finish_kernel converts them to the float gradient block / sum and hands the scratch back zeroed.
+constexpr float kFixedScale = 4294967296.f;               // 2^32
+constexpr double kFixedInv = 2.3283064365386963e-10;     // 2^-32
+__device__ __forceinline__ unsigned long long to_fixed(float x) { return (unsigned long long)__float2ll_rn(x * kFixedScale); }
+__device__ __forceinline__ void block_sum_add_fixed(float acc, unsigned long long *__restrict__ sum_out) {
+  __shared__ unsigned long long s_part64[4];
+  unsigned long long v = to_fixed(acc);  // (quantised per thread: integer sums from here on)
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+  if ((threadIdx.x & 63) == 0) s_part64[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned long long t = s_part64[0] + s_part64[1] + s_part64[2] + s_part64[3];
+    if (t != 0ull) atomicAdd(sum_out, t);
+  }
+}
+__global__ void __launch_bounds__(256)
+fixed_finish_kernel(unsigned long long *__restrict__ fixed, long long n, float *__restrict__ out, float *__restrict__ sum_out) {
+  const long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (e > n) return;
+  const long long v = (long long)fixed[e];
+  fixed[e] = 0ull;
+  const float f = (float)((double)v * kFixedInv);
+  if (e < n) { if (out) out[e] = f; }
+  else *sum_out = f;  // (element n: the loss sum)
+}
+
 constexpr int kMaxDirNN = 32;
+template <bool FIXED>
 __global__ void __launch_bounds__(256)
 direction_loss_kernel(const float *__restrict__ means, const float *__restrict__ quats,
                       const float *__restrict__ log_scales, const int *__restrict__ nn, int nn_stride, int N, int K,
                       int top_k, float *__restrict__ g_means, float *__restrict__ g_quats,
-                      float *__restrict__ sum_out) {
+                      float *__restrict__ sum_out, unsigned long long *__restrict__ fixed) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   float acc = 0.f;
   // Gradients w.r.t. the means of the workgroup's OWN 256 rows are collected in LDS and flushed with three global
   // atomics per row; with the rows in spatial order most neighbours of a row sit in the same workgroup, so the 18
   // device-scope float atomics per Gaussian (15 scattered to neighbours, 3 to itself) drop to 3 + the neighbours
   // that live in other workgroups
-  __shared__ float s_g[256 * 3];
+  __shared__ float s_g[FIXED ? 1 : 256 * 3];
+  __shared__ unsigned long long s_g64[FIXED ? 256 * 3 : 1];
   const int b0 = blockIdx.x * 256;
-  s_g[threadIdx.x] = 0.f; s_g[256 + threadIdx.x] = 0.f; s_g[512 + threadIdx.x] = 0.f;
+  if (FIXED) { s_g64[threadIdx.x] = 0ull; s_g64[256 + threadIdx.x] = 0ull; s_g64[512 + threadIdx.x] = 0ull; }
+  else { s_g[threadIdx.x] = 0.f; s_g[256 + threadIdx.x] = 0.f; s_g[512 + threadIdx.x] = 0.f; }
   __syncthreads();
   if (i < N) {
     float w = quats[4 * i], x = quats[4 * i + 1], y = quats[4 * i + 2], z = quats[4 * i + 3];
@@ -456,7 +490,22 @@ direction_loss_kernel(const float *__restrict__ means, const float *__restrict__
       const float gx = (sg * mx - vu * ux) * inv, gy = (sg * my - vu * uy) * inv, gz = (sg * mz - vu * uz) * inv;
       vpx += gx; vpy += gy; vpz += gz;
       const unsigned jl = (unsigned)(j - b0);
-      if (jl < 256u) {
+      if (FIXED) {
+        if (jl < 256u) {
+          atomicAdd(&s_g64[3 * jl], to_fixed(-gx));
+          atomicAdd(&s_g64[3 * jl + 1], to_fixed(-gy));
+          atomicAdd(&s_g64[3 * jl + 2], to_fixed(-gz));
+        } else {
+          atomicAdd(&fixed[3 * (size_t)j], to_fixed(-gx));
+          atomicAdd(&fixed[3 * (size_t)j + 1], to_fixed(-gy));
+          atomicAdd(&fixed[3 * (size_t)j + 2], to_fixed(-gz));
+        }
+        // (this row's own term, neighbour by neighbour: a float sum over k first would be deterministic as well -- one
+        // thread, fixed order -- but then the quantised terms of the two sides of an edge would no longer cancel exactly)
+        atomicAdd(&s_g64[3 * threadIdx.x], to_fixed(gx));
+        atomicAdd(&s_g64[3 * threadIdx.x + 1], to_fixed(gy));
+        atomicAdd(&s_g64[3 * threadIdx.x + 2], to_fixed(gz));
+      } else if (jl < 256u) {
         atomicAdd(&s_g[3 * jl], -gx);
         atomicAdd(&s_g[3 * jl + 1], -gy);
         atomicAdd(&s_g[3 * jl + 2], -gz);
@@ -466,9 +515,11 @@ direction_loss_kernel(const float *__restrict__ means, const float *__restrict__
         unsafeAtomicAdd(&g_means[3 * j + 2], -gz);
       }
     }
-    atomicAdd(&s_g[3 * threadIdx.x], vpx);
-    atomicAdd(&s_g[3 * threadIdx.x + 1], vpy);
-    atomicAdd(&s_g[3 * threadIdx.x + 2], vpz);
+    if (!FIXED) {
+      atomicAdd(&s_g[3 * threadIdx.x], vpx);
+      atomicAdd(&s_g[3 * threadIdx.x + 1], vpy);
+      atomicAdd(&s_g[3 * threadIdx.x + 2], vpz);
+    }
     // rotation column c -> normalised quaternion -> raw quaternion
     float vR[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     vR[c] = vmx; vR[3 + c] = vmy; vR[6 + c] = vmz;
@@ -486,17 +537,24 @@ direction_loss_kernel(const float *__restrict__ means, const float *__restrict__
 #pragma unroll
   for (int k = 0; k < 3; ++k) {  // coalesced flush of the workgroup's 768 accumulators
     const int e = k * 256 + threadIdx.x;
-    const float v = s_g[e];
-    if (v != 0.f && 3 * (size_t)b0 + e < 3 * (size_t)N) unsafeAtomicAdd(&g_means[3 * (size_t)b0 + e], v);
+    if (3 * (size_t)b0 + e >= 3 * (size_t)N) continue;
+    if (FIXED) {
+      const unsigned long long v = s_g64[e];
+      if (v != 0ull) atomicAdd(&fixed[3 * (size_t)b0 + e], v);
+    } else {
+      const float v = s_g[e];
+      if (v != 0.f) unsafeAtomicAdd(&g_means[3 * (size_t)b0 + e], v);
+    }
   }
-  block_sum_add(acc, sum_out);
+  if (FIXED) block_sum_add_fixed(acc, &fixed[3 * (size_t)N]);
+  else block_sum_add(acc, sum_out);
 }
 
 // ratio loss (edge_gs.py:375-380): mean_i second-largest / largest scale.  Value (sum of ratios) and
 // unscaled gradient w.r.t. the LOG-scales: d r / d ls_second = r, d r / d ls_first = -r.
 __global__ void __launch_bounds__(256)
 ratio_loss_kernel(const float *__restrict__ log_scales, int N, float *__restrict__ g_scales,
-                  float *__restrict__ sum_out) {
+                  float *__restrict__ sum_out, unsigned long long *__restrict__ fixed_sum) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   float r = 0.f;
   if (i < N) {
@@ -514,7 +572,8 @@ ratio_loss_kernel(const float *__restrict__ log_scales, int N, float *__restrict
     g_scales[3 * i] = g[0]; g_scales[3 * i + 1] = g[1]; g_scales[3 * i + 2] = g[2];
   }
   float acc = r;
-  block_sum_add(acc, sum_out);
+  if (fixed_sum) block_sum_add_fixed(acc, fixed_sum);  // (uniform: the order-independent sum of a data-parallel run)
+  else block_sum_add(acc, sum_out);
 }
 
 
@@ -616,8 +675,8 @@ extern "C" int eg_direction_loss(const float *means, const float *quats, const f
   EG_REQUIRE(N >= 0 && K >= 1 && K <= kMaxDirNN, "bad sizes (K <= 32)");
   if (N == 0) return EG_OK;
   EG_REQUIRE(means && quats && log_scales && nn_idx && g_means && g_quats && sum_out, "null pointer");
-  direction_loss_kernel<<<cdiv(N, 256), 256, 0, as_stream(stream)>>>(means, quats, log_scales, nn_idx, K, N, K, top_k,
-                                                                   g_means, g_quats, sum_out);
+  direction_loss_kernel<false><<<cdiv(N, 256), 256, 0, as_stream(stream)>>>(means, quats, log_scales, nn_idx, K, N, K, top_k,
+                                                                   g_means, g_quats, sum_out, nullptr);
   return check_launch("direction_loss");
 }
 
@@ -626,7 +685,7 @@ extern "C" int eg_ratio_loss(const float *log_scales, int32_t N, float *g_scales
   EG_REQUIRE(N >= 0, "bad sizes");
   if (N == 0) return EG_OK;
   EG_REQUIRE(log_scales && g_scales && sum_out, "null pointer");
-  ratio_loss_kernel<<<cdiv(N, 256), 256, 0, as_stream(stream)>>>(log_scales, N, g_scales, sum_out);
+  ratio_loss_kernel<<<cdiv(N, 256), 256, 0, as_stream(stream)>>>(log_scales, N, g_scales, sum_out, nullptr);
   return check_launch("ratio_loss");
 }
 
@@ -636,11 +695,14 @@ extern "C" int eg_ratio_loss(const float *log_scales, int32_t N, float *g_scales
 // (means 3N | quats 4N | scales 3N | opacities N).  kind 0 = direction (nn: [N, nn_stride] neighbour table, the K
 // columns from nn_offset on are used; top_k as eg_direction_loss), 1 = ratio.  loss_sum: device scalar (the running
 // projection-loss sum) or NULL -> loss_sum_host.  work: 2 floats of scratch (sum, loss value = work[1] afterwards).
-extern "C" int eg_regulariser_step(int32_t kind, float *means, float *quats, float *log_scales,
-                                   float *logit_opacities, float *adam_m, float *adam_v, float *grads, int32_t N,
-                                   const int32_t *nn, int32_t nn_stride, int32_t nn_offset, int32_t K, int32_t top_k,
-                                   const float *loss_sum, float loss_sum_host, float scale_factor, float *work,
-                                   eg_adam_hyper hyper, eg_stream_t stream) {
+// fixed != nullptr (eg_regulariser_step_fixed): the neighbour gradients and the loss sum are accumulated in 64-bit fixed
+// point (order-independent: bit-identical on every rank of a data-parallel run) in that scratch, [3 N + 1], zero on entry
+// and on exit.
+static int regulariser_step_impl(int32_t kind, float *means, float *quats, float *log_scales,
+                                 float *logit_opacities, float *adam_m, float *adam_v, float *grads, int32_t N,
+                                 const int32_t *nn, int32_t nn_stride, int32_t nn_offset, int32_t K, int32_t top_k,
+                                 const float *loss_sum, float loss_sum_host, float scale_factor, float *work,
+                                 eg_adam_hyper hyper, eg_stream_t stream, unsigned long long *fixed) {
   EG_REQUIRE(N >= 0 && (kind == 0 || kind == 1), "bad arguments");
   if (N == 0) return EG_OK;
   EG_REQUIRE(means && quats && log_scales && logit_opacities && adam_m && adam_v && grads && work, "null pointer");
@@ -652,10 +714,16 @@ extern "C" int eg_regulariser_step(int32_t kind, float *means, float *quats, flo
   int rc;
   if (kind == 0) {
     EG_REQUIRE(nn && K >= 1 && K <= kMaxDirNN && nn_offset >= 0 && nn_offset + K <= nn_stride, "bad neighbour table");
-    if (hipMemsetAsync(gm, 0, sizeof(float) * 3 * (size_t)N, st) != hipSuccess)  // (accumulated with atomics)
-      return check_launch("regulariser_step memset");
-    direction_loss_kernel<<<cdiv(N, 256), 256, 0, st>>>(means, quats, log_scales, nn + nn_offset, nn_stride, N, K,
-                                                        top_k, gm, gq, work);
+    if (fixed) {
+      direction_loss_kernel<true><<<cdiv(N, 256), 256, 0, st>>>(means, quats, log_scales, nn + nn_offset, nn_stride, N, K,
+                                                               top_k, gm, gq, work, fixed);
+      fixed_finish_kernel<<<cdiv(3 * (int64_t)N + 1, 256), 256, 0, st>>>(fixed, 3 * (long long)N, gm, work);
+    } else {
+      if (hipMemsetAsync(gm, 0, sizeof(float) * 3 * (size_t)N, st) != hipSuccess)  // (accumulated with atomics)
+        return check_launch("regulariser_step memset");
+      direction_loss_kernel<false><<<cdiv(N, 256), 256, 0, st>>>(means, quats, log_scales, nn + nn_offset, nn_stride, N, K,
+                                                                top_k, gm, gq, work, nullptr);
+    }
     rc = check_launch("regulariser_step");
     if (rc) return rc;
     const int used = (top_k > 0 && top_k < K) ? top_k : K;
@@ -663,9 +731,30 @@ extern "C" int eg_regulariser_step(int32_t kind, float *means, float *quats, flo
                                    work, loss_sum, loss_sum_host, scale_factor, (float)(-1.0 / ((double)N * used)), 0,
                                    work + 1, st);
   }
-  ratio_loss_kernel<<<cdiv(N, 256), 256, 0, st>>>(log_scales, N, gs, work);
+  ratio_loss_kernel<<<cdiv(N, 256), 256, 0, st>>>(log_scales, N, gs, work, fixed ? fixed + 3 * (size_t)N : nullptr);
+  if (fixed) fixed_finish_kernel<<<1, 256, 0, st>>>(fixed + 3 * (size_t)N, 0, nullptr, work);
   rc = check_launch("regulariser_step");
   if (rc) return rc;
   return launch_adam_regulariser(means, log_scales, quats, logit_opacities, nullptr, gs, nullptr, adam_m, adam_v, N, hyper,
                                  work, loss_sum, loss_sum_host, scale_factor, 0.f, 1, work + 1, st);
+}
+
+extern "C" int eg_regulariser_step(int32_t kind, float *means, float *quats, float *log_scales,
+                                   float *logit_opacities, float *adam_m, float *adam_v, float *grads, int32_t N,
+                                   const int32_t *nn, int32_t nn_stride, int32_t nn_offset, int32_t K, int32_t top_k,
+                                   const float *loss_sum, float loss_sum_host, float scale_factor, float *work,
+                                   eg_adam_hyper hyper, eg_stream_t stream) {
+  return regulariser_step_impl(kind, means, quats, log_scales, logit_opacities, adam_m, adam_v, grads, N, nn, nn_stride,
+                               nn_offset, K, top_k, loss_sum, loss_sum_host, scale_factor, work, hyper, stream, nullptr);
+}
+
+extern "C" int eg_regulariser_step_fixed(int32_t kind, float *means, float *quats, float *log_scales,
+                                         float *logit_opacities, float *adam_m, float *adam_v, float *grads, int32_t N,
+                                         const int32_t *nn, int32_t nn_stride, int32_t nn_offset, int32_t K, int32_t top_k,
+                                         const float *loss_sum, float loss_sum_host, float scale_factor, float *work,
+                                         eg_adam_hyper hyper, int64_t *fixed, eg_stream_t stream) {
+  EG_REQUIRE(fixed != nullptr, "null pointer");
+  return regulariser_step_impl(kind, means, quats, log_scales, logit_opacities, adam_m, adam_v, grads, N, nn, nn_stride,
+                               nn_offset, K, top_k, loss_sum, loss_sum_host, scale_factor, work, hyper, stream,
+                               (unsigned long long *)fixed);
 }

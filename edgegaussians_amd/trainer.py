@@ -907,17 +907,25 @@ class EdgeTrainer:
             # data parallel: the epoch's running loss sum is the sum over the ranks' views (every replica forms the
             # same lambda, train_gaussians.py:113,125); a copy is reduced, the local accumulator keeps its own share
             avg_loss_sum = self._dp.all_reduce_(avg_loss_sum.detach().clone().reshape(1))
-        call("eg_regulariser_step", 0 if kind == "direction" else 1, ptr(self.means), ptr(self.quats),
-             ptr(self.log_scales), ptr(self.logit_opacities), ptr(self.adam_m), ptr(self.adam_v), ptr(self.grads), self.N,
-             ptr(nn) if nn is not None else None, K + 1, 1, K, top_k, ptr(avg_loss_sum) if dev_sum else None,
-             0.0 if dev_sum else float(avg_loss_sum), float(scale_factor), ptr(work), self._hyper, stream())
-        if self._dp is not None and self._dp.world > 1:
-            # the regulariser kernels sum neighbour gradients with float atomics: every rank computes the SAME step up to
-            # the order of those additions, i.e. up to an ulp -- and replicas must stay bit-identical (densify / cull
-            # decisions, the sharded views' gradients).  Rank 0's result is the result: 128 bytes per Gaussian, every
-            # fifth view, on the same stream
-            for t in (self.means, self.log_scales, self.quats, self.adam_m, self.adam_v):
-                self._dp.broadcast_(t)
+        # Under data parallelism every rank takes this step from the same state and must END in the same state (densify /
+        # cull decisions, the sharded views' gradients): the neighbour gradients and the loss sums are then accumulated in
+        # 64-bit fixed point (eg_regulariser_step_fixed: integer atomics are order-independent), so the replicas stay
+        # bit-identical without exchanging anything -- round 3 summed with float atomics and had rank 0 broadcast its
+        # parameters and moments after every regulariser step (128 bytes per Gaussian).  `deterministic_regularisers`
+        # asks for the same on a single GPU (run-to-run reproducibility; one more small launch).
+        if (self._dp is not None and self._dp.world > 1) or getattr(self, "deterministic_regularisers", False):
+            fx = self.__dict__.get("_reg_fixed")
+            if fx is None or fx.numel() != 3 * self.N + 1:
+                fx = self._reg_fixed = torch.zeros(3 * self.N + 1, dtype=torch.int64, device=self.dev)
+            call("eg_regulariser_step_fixed", 0 if kind == "direction" else 1, ptr(self.means), ptr(self.quats),
+                 ptr(self.log_scales), ptr(self.logit_opacities), ptr(self.adam_m), ptr(self.adam_v), ptr(self.grads), self.N,
+                 ptr(nn) if nn is not None else None, K + 1, 1, K, top_k, ptr(avg_loss_sum) if dev_sum else None,
+                 0.0 if dev_sum else float(avg_loss_sum), float(scale_factor), ptr(work), self._hyper, ptr(fx), stream())
+        else:
+            call("eg_regulariser_step", 0 if kind == "direction" else 1, ptr(self.means), ptr(self.quats),
+                 ptr(self.log_scales), ptr(self.logit_opacities), ptr(self.adam_m), ptr(self.adam_v), ptr(self.grads), self.N,
+                 ptr(nn) if nn is not None else None, K + 1, 1, K, top_k, ptr(avg_loss_sum) if dev_sum else None,
+                 0.0 if dev_sum else float(avg_loss_sum), float(scale_factor), ptr(work), self._hyper, stream())
         return work[1]
 
     # ------------------------------------------------------------------ read-backs (these sync)

@@ -380,6 +380,15 @@ int eg_regulariser_step(int32_t kind, float *means, float *quats, float *log_sca
                         float *adam_m, float *adam_v, float *grads, int32_t N, const int32_t *nn, int32_t nn_stride,
                         int32_t nn_offset, int32_t K, int32_t top_k, const float *loss_sum, float loss_sum_host,
                         float scale_factor, float *work /*[2]*/, eg_adam_hyper hyper, eg_stream_t stream);
+/* The same with ORDER-INDEPENDENT sums (data-parallel runs, SURVEY 8e: every rank must take bit-identical regulariser
+ * steps): the neighbour gradients of the direction loss and the loss sums are accumulated with 64-bit fixed-point integer
+ * atomics (2^-32 resolution) instead of float atomics, in `fixed` -- int64 [3 N + 1], zero on entry, handed back zeroed.
+ * Agrees with eg_regulariser_step to ~1e-7 relative; equal bit for bit from run to run and from rank to rank. */
+int eg_regulariser_step_fixed(int32_t kind, float *means, float *quats, float *log_scales, float *logit_opacities,
+                              float *adam_m, float *adam_v, float *grads, int32_t N, const int32_t *nn, int32_t nn_stride,
+                              int32_t nn_offset, int32_t K, int32_t top_k, const float *loss_sum, float loss_sum_host,
+                              float scale_factor, float *work /*[2]*/, eg_adam_hyper hyper, int64_t *fixed /*[3 N + 1]*/,
+                              eg_stream_t stream);
 
 /* ---- the per-pixel loss weights of the 'bg_edge_ratio' strategy (edge_gs.py:298-314 in weight-map form) built on
  * the device: out[p] = [gt_p >= thr] / n_edge + [p among perm[0 .. n_sel)] / n_sel; perm = a random permutation

@@ -1524,6 +1524,40 @@ def test_bench_line_contract(env):
     assert "warning" in d and "--steps 20" in d["warning"]
 
 
+def test_regulariser_step_with_order_independent_sums(env):
+    """eg_regulariser_step_fixed (round 4): the direction loss's neighbour gradients and both loss sums accumulated with
+    64-bit fixed-point integer atomics.  (1) Bit-identical from run to run -- what a data-parallel run needs of its
+    replicas, where float atomics differ in the last bits with the order the hardware takes them; (2) equal to the float
+    path to ~1e-6 after a step (the two differ by the quantisation, 2^-32 per term, and by the float path's own order)."""
+    _lib, synth, O = env
+    from edgegaussians_amd import EdgeTrainer, LRSchedule
+    sc = _scene(synth, n=6000, w=96, h=80)
+    sc.log_scales[:, 0] += 1.0  # (a clear major axis)
+    sched = LRSchedule(scales_start=0, quats_start=0, opacities_start=0)
+
+    def run(det, kinds=("direction", "ratio", "direction")):
+        tr = EdgeTrainer(sc.means, sc.log_scales, sc.quats, sc.logit_opacities, sc.viewmats, sc.Ks, sc.gt, 96, 80, schedule=sched)
+        tr.deterministic_regularisers = det
+        tr.epoch = 60
+        w = synth.weight_map("weighted", sc.gt[0]).cuda()
+        tr.train_step(0, w)
+        vals = [tr.regulariser_step(k, None, 0.01, 5, "enforce_full") for k in kinds]
+        torch.cuda.synchronize()
+        return tr, vals
+
+    a, va = run(True)
+    b, vb = run(True)
+    for x, y in ((a.means, b.means), (a.quats, b.quats), (a.log_scales, b.log_scales), (a.adam_m, b.adam_m), (a.adam_v, b.adam_v)):
+        assert torch.equal(x, y)
+    assert va == vb
+    c, vc = run(False)
+    for x, y, name in ((a.means, c.means, "means"), (a.quats, c.quats, "quats"), (a.log_scales, c.log_scales, "scales")):
+        assert_close(x, y, rtol=2e-6, name=name)
+    for p_, q_ in zip(va, vc):
+        assert abs(p_ - q_) <= 1e-5 * abs(q_)
+    assert int(a._reg_fixed.abs().sum()) == 0, "the fixed-point scratch is handed back zeroed"
+
+
 def test_operator_deferred_read_back_is_exact_and_fails_loudly(env):
     """The fast path's verdicts (overflow, colours == 1) are read back asynchronously once two consecutive calls came back
     clean with room to spare (rasterizer.py: DEFERRED READ-BACK).  (1) Calls in deferred mode return exactly what calls that
