@@ -364,8 +364,44 @@ tile_sort_kernel(unsigned long long *__restrict__ keys, const int *__restrict__ 
   __shared__ unsigned wave_tmp[32], wave_tmp2[32];  // two hops per tile, never the same array twice in a row
 
   const int tid = threadIdx.x;
-  // the large variant runs a small grid (<= 256 workgroups of 136 KiB LDS) striding over the tiles
-  for (int wg = blockIdx.x; wg < T; wg += gridDim.x) {
+  // The large variant runs a small grid (<= 256 workgroups of 136 KiB LDS) over the tiles that outgrew the small one.
+  // Round 4: every workgroup first FINDS them -- all its threads look at the T ranges at once and collect the oversized
+  // tiles in LDS (sorted by tile index, so that all workgroups hold the same list) -- and then takes entries blockIdx.x,
+  // blockIdx.x + gridDim.x, ... of that list; striding over ALL tiles with a barrier and two dependent loads per tile to
+  // find a handful cost 14 us at 500 k Gaussians @1200x680 (3225 tiles, a dozen above 4096 keys).
+  constexpr int kBigList = 512;
+  __shared__ int s_big[LARGE ? kBigList : 1], s_big_sorted[LARGE ? kBigList : 1];
+  __shared__ int s_nbig;
+  int n_loop = T;
+  bool by_list = false;
+  if (LARGE) {
+    if (tid == 0) s_nbig = 0;
+    __syncthreads();
+    for (int t = tid; t < T; t += THREADS) {
+      long long a_, b_;
+      if (seg.cursor) { a_ = seg.tile_start[t]; b_ = seg.tile_end[t]; }
+      else { a_ = offsets[t]; b_ = offsets[t + 1]; if (b_ > capacity) b_ = capacity; }
+      if (b_ - a_ > small_cap) {
+        const int k = atomicAdd(&s_nbig, 1);
+        if (k < kBigList) s_big[k] = t;
+      }
+    }
+    __syncthreads();
+    const int nb = s_nbig;
+    if (nb <= kBigList) {  // (else: more oversized tiles than the list holds -- stride over all tiles as before)
+      for (int i = tid; i < nb; i += THREADS) {
+        const int me = s_big[i];
+        int rank = 0;
+        for (int q = 0; q < nb; ++q) rank += s_big[q] < me ? 1 : 0;
+        s_big_sorted[rank] = me;
+      }
+      __syncthreads();
+      by_list = true;
+      n_loop = nb;
+    }
+  }
+  for (int it = blockIdx.x; it < n_loop; it += gridDim.x) {
+  const int wg = by_list ? s_big_sorted[it] : it;
   // Workgroup -> tile, MIDDLE OUT over the row-major tile index (the small variant: one tile per workgroup, dispatched in
   // index order, two or three rounds of them): the tiles of the image's middle rows -- where a centred object puts its
   // thousands of keys -- start in the first round and the near-empty border tiles make up the last one, instead of the
