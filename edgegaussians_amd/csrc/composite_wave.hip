@@ -518,7 +518,6 @@ struct WaveArgs {
   float loss_scale;
   int max_anchored;  // tiles of more slices look back over all aggregates (kMaxAnchoredSlices; 0 in an A/B build leg)
   const int *item_first;  // [T]: the tile's first item in the contiguous per-tile numbering (hand-over storage)
-  int *queue;             // [16] persistent launch: tickets handed out by each of 8 queues, [8] = workgroups that have left
 };
 
 __device__ __forceinline__ int dead_key(unsigned tag, int slice) { return (int)((tag << 15) | (unsigned)(32767 - min(slice, 32767))); }
@@ -531,11 +530,10 @@ __device__ __forceinline__ int dead_from(int key, unsigned tag) {
 // record per wave in prof[(item * 4 + quadrant) * 8 ...] (plain stores: atomics on shared words would serialise and
 // be measured themselves); word 7 = 1 marks a wave that ran (read by eg_debug_fwd_profile)
 template <bool CHAINED, bool TIMED, bool BATCHED>
-__device__ __forceinline__ void wave_fwd_body(WaveArgs a, const Batch &bt, WaveListT<kSlice> *lists, WgStage<kSlice> &stg,
-                                              const int b /* the workgroup's item RECORD */) {
+__device__ __forceinline__ void wave_fwd_body(WaveArgs a, const Batch &bt, WaveListT<kSlice> *lists, WgStage<kSlice> &stg) {
   typedef WaveListT<kSlice> WaveList;
   long long t_prev = TIMED ? (long long)__builtin_readcyclecounter() : 0;
-  unsigned long long *my_prof = TIMED ? a.prof + ((size_t)b * 4 + (threadIdx.x >> 6)) * 8 : nullptr;
+  unsigned long long *my_prof = TIMED ? a.prof + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 : nullptr;
 #define EG_TICK(k)                                                                                        \
   do {                                                                                                    \
     if (TIMED) {                                                                                          \
@@ -563,7 +561,7 @@ __device__ __forceinline__ void wave_fwd_body(WaveArgs a, const Batch &bt, WaveL
   const int width = a.width, height = a.height, tw = a.tw;
   const unsigned tag = a.tag;
   const float loss_scale = a.loss_scale;
-  // (records are in dispatch order: front slices first, binning.hip)
+  const int b = blockIdx.x;  // the workgroup's item RECORD (records are in dispatch order: front slices first, binning.hip)
   // where this item lives: ONE 16-byte record left by the sort kernel.  Requested together with the item count (the grid
   // covers max_items, the table has max_items entries: a stale record beyond the count is read and dropped) -- one
   // dependent round trip less at the head of every wave.
@@ -797,58 +795,7 @@ __global__ void __launch_bounds__(256, 8)
 composite_wave_fwd_kernel(const WaveArgs a, const Batch bt) {
   __shared__ WaveListT<kSlice> lists[4];
   __shared__ WgStage<kSlice> stg;
-  wave_fwd_body<CHAINED, TIMED, BATCHED>(a, bt, lists, stg, (int)blockIdx.x);
-}
-
-// PERSISTENT launch (round 4): the grid is what the CU array holds (2048 workgroups) and a workgroup takes records until
-// there are none left -- its first one is its block index, the following ones come from 8 ticket queues (queue x = block
-// index % 8 hands out records 8 k + x: a shared counter per XCD, ~400 returning atomics per word over the launch; a single
-// word would serialise, NOTES_r03) with the NEXT ticket requested before the current item is worked on.  Records are
-// taken in increasing order from every queue and a workgroup works its tickets off in order, so the look-back's contract
-// holds: a record is only ever taken when every lower record of its queue has been taken by a workgroup that is running,
-// and the lowest unfinished record of the launch always belongs to a workgroup whose earlier records are done (no
-// co-residency is assumed: a workgroup that is not resident has taken nothing).  What it buys over one workgroup per
-// record: no dispatch of ~1200 second-round workgroups into a full machine, and dead items cost a ticket and a record.
-// The last workgroup out returns the queues to zero.
-constexpr int kPersistMaxIter = 1 << 22;
-template <bool CHAINED, bool BATCHED>
-__global__ void __launch_bounds__(256, 8)
-composite_wave_fwd_persistent_kernel(const WaveArgs a, const Batch bt) {
-  __shared__ WaveListT<kSlice> lists[4];
-  __shared__ WgStage<kSlice> stg;
-  __shared__ int s_cur;
-  int *queue = a.queue;
-  const int *total = a.total;
-  if (BATCHED) { queue = (int *)((char *)queue + blockIdx.y * bt.ws_bytes); total += 4 * blockIdx.y; }
-  const int x = blockIdx.x & 7, first_dynamic = (int)(gridDim.x >> 3);
-  const int n_items = total[2];
-  int cur = (int)blockIdx.x, nxt = 0;
-  for (int iter = 0; iter < kPersistMaxIter; ++iter) {
-    if (cur >= n_items) break;  // (uniform)
-    if (threadIdx.x == 0) nxt = __hip_atomic_fetch_add(&queue[x], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // in flight under this item
-    {
-      // (the arguments are RE-READ from the kernel-argument segment for every item -- scalar loads out of the constant
-      // cache -- instead of living in registers across the loop: kept live, they pushed 83 SGPRs and 15 VGPRs of the body
-      // into scratch memory)
-      typedef const __attribute__((address_space(4))) char *KargPtr;
-      KargPtr kp = (KargPtr)__builtin_amdgcn_kernarg_segment_ptr();
-      asm volatile("" : "+s"(kp));
-      const WaveArgs a_item = *(const __attribute__((address_space(4))) WaveArgs *)kp;
-      const Batch bt_item = *(const __attribute__((address_space(4))) Batch *)(kp + ((sizeof(WaveArgs) + 7) & ~(size_t)7));
-      wave_fwd_body<CHAINED, false, BATCHED>(a_item, bt_item, lists, stg, cur);
-    }
-    __syncthreads();  // every wave is out of the workgroup's copy of the slice (and of its lists)
-    if (threadIdx.x == 0) s_cur = 8 * (first_dynamic + nxt) + x;
-    __syncthreads();
-    cur = s_cur;
-  }
-  if (threadIdx.x == 0) {
-    const int gone = __hip_atomic_fetch_add(&queue[8], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (gone == (int)gridDim.x - 1) {  // (every other workgroup has made its last queue access)
-#pragma unroll
-      for (int i = 0; i < 9; ++i) __hip_atomic_store(&queue[i], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
+  wave_fwd_body<CHAINED, TIMED, BATCHED>(a, bt, lists, stg);
 }
 
 static unsigned long long *g_prof = nullptr;
@@ -885,29 +832,15 @@ int launch_wave_fwd(const float4 *splat, const TileTable tt, const int32_t *flat
   a.gt = gt; a.wmap = wmap; a.alphas = alphas; a.gtstop = (StopRec *)gtstop; a.prof = g_prof;
   a.width = width; a.height = height; a.tw = tw; a.n_tiles = tw * th;
   a.tag = tag; a.loss_scale = loss_scale; a.max_anchored = max_anchored; a.item_first = tt.item_first;
-  a.queue = ws.qticket;
   // one view: everything is resolved here and the kernel never looks at the batch descriptor
   const bool batched = C > 1;
   if (!batched && bt.gt[0]) { a.gt = bt.gt[0]; a.wmap = bt.wmap[0]; }
   const dim3 grid((unsigned)max_items, C);
-  // persistent launch: the CU array holds 256 CUs x 8 workgroups of this kernel; a multiple of 8 (the queues)
-  bool persist = !timed;
-#ifdef EG_DEV_SWITCHES
-  static const int persist_env = getenv("EG_WAVE_PERSIST") ? atoi(getenv("EG_WAVE_PERSIST")) : 1;
-  persist = persist && persist_env != 0;
-#endif
-  const int64_t want = ((max_items + 7) / 8) * 8;
-  const dim3 pgrid((unsigned)(want < 2048 / C ? want : ((2048 / C + 7) / 8) * 8), C);
 #define EG_LAUNCH(CH_, TI_, BA_) composite_wave_fwd_kernel<CH_, TI_, BA_><<<grid, 256, 0, s>>>(a, bt)
-#define EG_LAUNCH_P(CH_, BA_) composite_wave_fwd_persistent_kernel<CH_, BA_><<<pgrid, 256, 0, s>>>(a, bt)
-  if (persist) {
-    if (batched) { if (chained) EG_LAUNCH_P(true, true); else EG_LAUNCH_P(false, true); }
-    else { if (chained) EG_LAUNCH_P(true, false); else EG_LAUNCH_P(false, false); }
-  } else if (batched) { if (chained) EG_LAUNCH(true, false, true); else EG_LAUNCH(false, false, true); }
+  if (batched) { if (chained) EG_LAUNCH(true, false, true); else EG_LAUNCH(false, false, true); }
   else if (timed) { if (chained) EG_LAUNCH(true, true, false); else EG_LAUNCH(false, true, false); }
   else { if (chained) EG_LAUNCH(true, false, false); else EG_LAUNCH(false, false, false); }
 #undef EG_LAUNCH
-#undef EG_LAUNCH_P
   timing_mark(kMarkSlice, s);
   timing_mark(kMarkRewalk, s);
   return check_launch("composite_fwd(wave)");
