@@ -29,6 +29,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-ato
 # a release build reads no environment variable on the product path except EG_FWD_PROF (the profiling instantiation)
 if os.environ.get("EG_DEV_SWITCHES"):
     FLAGS.append("-DEG_DEV_SWITCHES")
+FLAGS += os.environ.get("EG_EXTRA_HIPCC_FLAGS", "").split()  # (development: compile-time A/B legs)
 
 
 def _hipcc() -> str:

@@ -317,9 +317,9 @@ struct SegTable {
   // there; the two classes cost one more running sum.)
   // A slice still follows all slices in front of it: the look-back's dispatch-order guarantee holds.
   int slice_major = 0;  // the class boundary (slices), 0 = off
-  // with slice_major: the items of the SINGLE-slice tiles (at most 128 Gaussians, nothing to hand over: the light
-  // waves) form a third class behind the deep slices, so that the launch's tail is made of short-lived waves
-  int singles_last = 0;
+  // (round 4 tried a third class -- the items of the single-slice tiles behind the deep slices, so that the launch's tail
+  // is made of short-lived waves: same-box A/B at config 2, forward 33.4 -> 32.6 us and sort 11.2 -> 11.0 WITHOUT it on the
+  // trained-like scene, 0.7 us the other way on the initial-opacity one.  Removed.)
   // without `total` (tile grids above 2048 tiles), optional: the projection's scan of min(items, EG_FRONT_LARGE) over the
   // tiles, [T + 1] with the total at [T] (EG_FLAG_FRONT_PREFIX).  The records are then written in TWO classes -- slices
   // [0, 9) of every tile, tile by tile, then the deeper slices -- instead of in item order: a tile's deep slices used to be
@@ -409,20 +409,19 @@ tile_sort_kernel(unsigned long long *__restrict__ keys, const int *__restrict__ 
   const int tile = (!LARGE && seg.middle_out) ? ((wg & 1) ? T / 2 - (wg + 1) / 2 : T / 2 + wg / 2) : wg;
   __syncthreads();
   long long start, end;
-  __shared__ int s_pre[6][THREADS / 64];
+  __shared__ int s_pre[5][THREADS / 64];
   bool prefix_pending = false;  // (uniform) the tile prefix still has to be finished: see SegTable::total
   int pop_here = 0;
   // after a barrier: every thread sums the waves' partials; thread 0 writes the tile's table entries (and the
   // totals of the view, if this is the last tile), the first threads the item -> tile map
   auto finish_prefix = [&](int kept_) {
-    int isum = 0, msum = 0, cmax = 0, itot = 0, front = 0, single = 0;
+    int isum = 0, msum = 0, cmax = 0, itot = 0, front = 0;
 #pragma unroll
     for (int w = 0; w < THREADS / 64; ++w) {
       isum += s_pre[0][w]; msum += s_pre[1][w]; cmax = max(cmax, s_pre[2][w]); itot += s_pre[3][w];
-      front += s_pre[4][w]; single += s_pre[5][w];
+      front += s_pre[4][w];
     }
     const int isumf = front & 0xffff, itotf = front >> 16;
-    const int cbef = seg.singles_last ? (single & 0xffff) : 0, ctot = seg.singles_last ? (single >> 16) : 0;
     const int first_ = min(isum, seg.max_items);
     const int items_ = min(max(1, (kept_ + 127) >> 7), max(0, seg.max_items - first_));
     if (tid == 0) {
@@ -446,11 +445,8 @@ tile_sort_kernel(unsigned long long *__restrict__ keys, const int *__restrict__ 
       seg.item_tile[first_ + i] = tile;
       if (seg.item_rec) {
         int disp = first_ + i;
-        if (front_first) {
-          // class A: slices [0, F) of the multi-slice tiles; class B: their deeper slices; class C: single-slice tiles
-          if (seg.singles_last && items_ == 1) disp = (itot - ctot) + cbef;
-          else disp = i < seg.slice_major ? (isumf - cbef) + i : (itotf - ctot) + (isum - isumf) + (i - seg.slice_major);
-        }
+        if (front_first)
+          disp = i < seg.slice_major ? isumf + i : itotf + (isum - isumf) + (i - seg.slice_major);
         if (disp < seg.max_items)
           seg.item_rec[disp] = make_int4(tile, i | (items_ << 16), tile * seg.seg_cap + i * 128, tile * seg.seg_cap + kept_);
       }
@@ -479,7 +475,7 @@ tile_sort_kernel(unsigned long long *__restrict__ keys, const int *__restrict__ 
         int isum = 0, msum = 0, cmax = 0, itot = 0;
         // the same over min(items, kFront): the sum over the tiles in front in the low half, over all tiles in the high
         // half (at most 2048 * 15 each)
-        int front = 0, single = 0;  // (single: tiles of ONE item in front in the low half, all of them in the high half)
+        int front = 0;
 #pragma unroll
         for (int j = 0; j < kPrefixHereMaxTiles / THREADS; ++j)
           if (pv[j] >= 0) {
@@ -490,7 +486,6 @@ tile_sort_kernel(unsigned long long *__restrict__ keys, const int *__restrict__ 
             itot += it; msum += kk; cmax = max(cmax, pv[j]);
             const int itf = min(it, seg.slice_major);
             front += (before ? itf : 0) + (itf << 16);
-            single += it == 1 ? ((before ? 1 : 0) + (1 << 16)) : 0;
           }
         // (DPP scans: the totals land in lane 63)
         isum = wave_scan_dpp(isum, 0, OpAdd());
@@ -498,10 +493,9 @@ tile_sort_kernel(unsigned long long *__restrict__ keys, const int *__restrict__ 
         itot = wave_scan_dpp(itot, 0, OpAdd());
         cmax = wave_scan_dpp(cmax, 0, OpMaxI());
         front = wave_scan_dpp(front, 0, OpAdd());
-        single = wave_scan_dpp(single, 0, OpAdd());
         if ((tid & 63) == 63) {
           s_pre[0][tid >> 6] = isum; s_pre[1][tid >> 6] = msum; s_pre[2][tid >> 6] = cmax; s_pre[3][tid >> 6] = itot;
-          s_pre[4][tid >> 6] = front; s_pre[5][tid >> 6] = single;
+          s_pre[4][tid >> 6] = front;
         }
         prefix_pending = true;
         first = items = 0;
@@ -825,25 +819,23 @@ int launch_sort_segments(uint64_t *keys, int32_t *tile_cursor, int32_t T, int32_
   seg.item_first = item_first; seg.item_end = item_end;
   seg.item_tile = item_tile; seg.max_items = max_items;
   seg.total = total_prefix_here;
-  // the forward's dispatch order (SegTable): front slices first, single-slice tiles last; tiles taken middle-out
+  // the forward's dispatch order (SegTable): front slices first; tiles taken middle-out
   seg.rank_order = 0;
   seg.item_rec = (int4 *)item_rec;
   seg.slice_major = kFrontDefault;
-  seg.singles_last = 1;
   seg.middle_out = 1;
   seg.item_front = total_prefix_here ? nullptr : item_front;
 #ifdef EG_DEV_SWITCHES  // A/B switches of development builds (edgegaussians_amd/build.py, EG_DEV_SWITCHES=1)
   static const int rank_order = getenv("EG_TILE_ORDER") ? atoi(getenv("EG_TILE_ORDER")) : 0;
   static const int front = getenv("EG_FRONT_SLICES") ? atoi(getenv("EG_FRONT_SLICES")) : kFrontDefault;
   static const int middle_out = getenv("EG_SORT_MIDDLE_OUT") ? atoi(getenv("EG_SORT_MIDDLE_OUT")) : 1;
-  static const int singles_last = getenv("EG_SINGLES_LAST") ? atoi(getenv("EG_SINGLES_LAST")) : 1;
   seg.rank_order = rank_order;
   seg.slice_major = front < 0 ? 0 : (front > 15 ? 15 : front);
   seg.middle_out = middle_out;
-  seg.singles_last = singles_last;
   static const int front_large = getenv("EG_FRONT_LARGE") ? atoi(getenv("EG_FRONT_LARGE")) : 1;
   if (!front_large) seg.item_front = nullptr;
 #endif
+
   return launch_tile_sort(keys, nullptr, T, (int64_t)T * seg_cap, flatten_ids, nullptr, max_tile_hint, seg,
                           (eg_stream_t)st, bt, C);
 }

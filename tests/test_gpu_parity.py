@@ -1909,7 +1909,7 @@ def test_item_records_follow_the_dispatch_order_contract(env, size):
     the sort kernel leaves in `item_rec` are a PERMUTATION of all (tile, slice) pairs; a slice's record comes after the
     records of every slice in front of it in its tile (workgroups are dispatched in record order and only ever wait for
     lower records: the decoupled look-back cannot deadlock); the front slices of the multi-slice tiles come before any
-    deeper slice -- on tile grids of <= 2048 tiles the single-slice tiles last, above that slices [0, 9) of EVERY tile
+    deeper slice -- on tile grids of <= 2048 tiles slices [0, 4) of every tile first, above that slices [0, 9)
     first (the projection's scan supplies the prefix: EG_FLAG_FRONT_PREFIX) --; and the item numbering the hand-over
     storage uses (item_first / item_end / item_tile) stays contiguous per tile."""
     import numpy as np
@@ -1946,21 +1946,15 @@ def test_item_records_follow_the_dispatch_order_contract(env, size):
     order = np.lexsort((np.arange(n_items), pairs))
     same_tile = tile[order][1:] == tile[order][:-1]
     assert (np.diff(order)[same_tile] > 0).all(), "a slice was dispatched before a slice in front of it"
-    if any(k in os.environ for k in ("EG_FRONT_SLICES", "EG_SINGLES_LAST", "EG_FRONT_LARGE")):
+    if any(k in os.environ for k in ("EG_FRONT_SLICES", "EG_FRONT_LARGE")):
         return
     per_tile = end_ - first
     if size == "small_grid":
-        # three classes (SegTable::slice_major / singles_last): slices [0, 4) of the multi-slice tiles, their deeper
-        # slices, then the items of the single-slice tiles (the light waves make up the launch's tail)
+        # two classes (SegTable::slice_major): slices [0, 4) of every tile, tile by tile, then the deeper slices
         front = 4  # kFrontDefault
-        multi = per_tile > 1
-        n_a = int(np.minimum(per_tile[multi], front).sum())
-        n_c = int((~multi).sum())
-        assert n_c > 0, "the scene must have single-slice tiles"
-        a_, b_, c_ = slice(0, n_a), slice(n_a, n_items - n_c), slice(n_items - n_c, n_items)
-        assert (ns[a_] > 1).all() and (sl[a_] < front).all()
-        assert (ns[b_] > 1).all() and (sl[b_] >= front).all()
-        assert (ns[c_] == 1).all() and (np.diff(tile[c_]) > 0).all()
+        n_a = int(np.minimum(per_tile, front).sum())
+        assert n_a < n_items and (sl[:n_a] < front).all() and (sl[n_a:] >= front).all()
+        assert (np.diff(tile[:n_a]) >= 0).all() and (np.diff(tile[n_a:]) >= 0).all()
     else:
         front = 9  # EG_FRONT_LARGE
         n_a = int(np.minimum(per_tile, front).sum())
