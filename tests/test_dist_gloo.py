@@ -95,6 +95,17 @@ def _worker(rank, world, port, ret):
             dist.broadcast(ref_t, src=0)
             ok &= bool(torch.equal(ref_t, t))
     ok &= wk.announced == [egdist.view_for(1, rank, world, 4), None]
+    # DataParallelStep.steps (round 4: K steps per call; natively eg_train_steps_dp on an EdgeTrainer with an RCCL
+    # communicator): on a worker without the native leg it is exactly the loop of step() with the next view announced
+    ok &= not dp.native_ready()
+    views = [egdist.view_for(s_, rank, world, 4) for s_ in (2, 3)]
+    n0 = len(wk.announced)
+    dp.steps(views, [wmaps[v] for v in views], next_view=egdist.view_for(4, rank, world, 4))
+    ok &= wk.announced[n0:] == [views[1], egdist.view_for(4, rank, world, 4)]
+    for t in wk.p + [wk.absgrads]:
+        ref_t = t.clone()
+        dist.broadcast(ref_t, src=0)
+        ok &= bool(torch.equal(ref_t, t))
     ret[rank] = ok
     dist.destroy_process_group()
 
