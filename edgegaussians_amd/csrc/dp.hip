@@ -158,8 +158,13 @@ extern "C" int eg_train_steps_dp(const eg_step_args *a, const eg_adam_hyper *hyp
     int rc = eg_train_step(&s, stream);
     if (rc) return rc;
     const double t1 = now_s();
-    rc = nccl_check(p_all_reduce(g, g, 12 * (size_t)a->N, kNcclFloat, kNcclSum, g_comm, as_stream(stream)), "ncclAllReduce");
-    if (rc) return rc;
+    // (a sum over ONE rank is the identity: RCCL implements a one-rank allReduce through the copy engine -- fill + copy
+    // blits with ~90 us of stream stalls, profiles/r04_timeline_gaps_config2_dp_native.txt -- which a one-GPU run of this
+    // leg would measure instead of the leg; eg_dp_all_reduce still goes through RCCL whatever the size)
+    if (g_world > 1) {
+      rc = nccl_check(p_all_reduce(g, g, 12 * (size_t)a->N, kNcclFloat, kNcclSum, g_comm, as_stream(stream)), "ncclAllReduce");
+      if (rc) return rc;
+    }
     const double t2 = now_s();
     eg_adam_hyper h = *hyper;
     h.step += k;
