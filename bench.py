@@ -450,8 +450,13 @@ def measure(name, args, device, rank, world, backend, spread=False, steps=None, 
                    "gaussian_row_order": "morton" if tr.spatial_order else "as given",
                    "binning": "segmented" if tr.segmented else "scan",
                    "steps_per_native_enqueue": chunk if ((dp is None or native_dp) and vps == 1) else 1,
-                   "data_parallel_leg": (None if dp is None else ("native: eg_train_steps_dp (ncclAllReduce on the launch stream)"
-                                                                   if native_dp else "python: DataParallelStep.step")),
+                   "data_parallel_leg": (None if dp is None else
+                                         (f"native: eg_train_steps_dp (ncclAllReduce of the [12 N] buffer over {world} ranks on the launch stream)"
+                                          if native_dp and world > 1 else
+                                          "native: eg_train_steps_dp, ONE rank: the gradient-form step WITHOUT a collective (a one-rank sum is skipped)"
+                                          if native_dp else
+                                          f"python: DataParallelStep.step (torch.distributed all_reduce, backend {backend}"
+                                          + (", staged through the host: test mode" if backend == "gloo" else "") + ")")),
                    "forward_mode": ("speculative (no pixel reaches the transmittance stop; a stop would replay the window "
                                     "from the step journal)" if tr._rewalk_arg(dp is None) == -2
                                     else "chained (exact transmittance stop resolved inside the forward kernel)"),
@@ -467,10 +472,27 @@ def measure(name, args, device, rank, world, backend, spread=False, steps=None, 
     if dp is not None:
         # exposed all-reduce time on the compute stream (events around the collective), over a short extra window:
         # every rank runs it (the collective is collective), every rank's figure is gathered onto rank 0
-        dp.time_comm = True
-        run(min(steps, 50), warmup + steps)
-        mine = dp.comm_us() or 0.0
-        dp.time_comm = False
+        comm_n, comm_max = 0, None
+        if native_dp:
+            # HIP events recorded natively around the [12 N] ncclAllReduce on the launch stream (eg_dp_comm_timing_*): the
+            # same enqueue path as the timed window
+            import ctypes as _C
+            from edgegaussians_amd import _lib as _egl
+            kk = min(steps, 50)
+            if _egl.load().eg_dp_comm_timing_begin(kk) != 0:
+                raise SystemExit(_egl.load().eg_last_error_string().decode())
+            run(kk, warmup + steps)
+            mean_us, max_us, cnt = _C.c_float(), _C.c_float(), _C.c_int32()
+            if _egl.load().eg_dp_comm_timing_end(_C.byref(mean_us), _C.byref(max_us), _C.byref(cnt)) != 0:
+                raise SystemExit(_egl.load().eg_last_error_string().decode())
+            mine, comm_max, comm_n = float(mean_us.value), float(max_us.value), int(cnt.value)
+            if world > 1 and comm_n != kk:
+                raise SystemExit(f"rank {rank}: {comm_n} gradient collectives timed in {kk} steps of the native data-parallel run")
+        else:
+            dp.time_comm = True
+            run(min(steps, 50), warmup + steps)
+            mine = dp.comm_us() or 0.0
+            dp.time_comm = False
         tr.pop_loss()
         if world > 1:
             t = torch.tensor([mine], device=device if backend == "nccl" else "cpu", dtype=torch.float64)
@@ -479,7 +501,34 @@ def measure(name, args, device, rank, world, backend, spread=False, steps=None, 
             res["allreduce_exposed_us_per_step_by_rank"] = [float(x.item()) for x in allv]
         else:
             res["allreduce_exposed_us_per_step_by_rank"] = [mine]
-        res["allreduce_bytes_per_step"] = 48 * n * (2 if vps > 1 else 1)
+        res["allreduce_bytes_per_step"] = 48 * n * (2 if vps > 1 else 1) if (world > 1 or not native_dp) else 0
+        res["allreduce_exposed_us_source"] = ("HIP events recorded by eg_train_steps_dp around its ncclAllReduce on the launch stream"
+                                              if native_dp else "torch.cuda events around DataParallelStep's all_reduce")
+        # what proves the collective ran over N ranks: RCCL's own count for the native communicator, the torch process
+        # group's size, and the number of [12 N] collectives the native run issued in this process
+        import ctypes as _C
+        from edgegaussians_amd import _lib as _egl
+        fl = _C.c_int64()
+        ncalls = int(_egl.load().eg_dp_grad_all_reduces(_C.byref(fl)))
+        proof = {"torch_distributed_world_size": dist.get_world_size() if dist.is_initialized() else 1,
+                 "torch_distributed_backend": dist.get_backend() if dist.is_initialized() else None,
+                 "native_ncclCommCount": int(_egl.load().eg_dp_comm_count()) if native_dp else None,
+                 "native_grad_all_reduce_calls": ncalls, "native_grad_all_reduce_floats_per_call": (fl.value // ncalls) if ncalls else 0,
+                 "devices_visible": torch.cuda.device_count()}
+        if world > 1:
+            ranks_dev = [None] * world
+            dist.all_gather_object(ranks_dev, (rank, torch.cuda.current_device(), os.getpid()))
+            proof["rank_device_pid"] = ranks_dev
+            if native_dp:
+                t = torch.tensor([proof["native_ncclCommCount"]], device=device)
+                lo, hi = t.clone(), t.clone()
+                dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+                dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+                if int(lo.item()) != world or int(hi.item()) != world:
+                    raise SystemExit(f"ncclCommCount over the ranks in [{int(lo.item())}, {int(hi.item())}] != WORLD_SIZE {world}")
+                if ncalls <= 0:
+                    raise SystemExit("the native data-parallel run issued no gradient collective")
+        res["collective_proof"] = proof
         if native_dp:  # where the host time of the native run goes (eg_dp_host_profile)
             import ctypes as _C
             from edgegaussians_amd import _lib as _egl
@@ -646,6 +695,26 @@ def measure_operator(name, args, device, steps=200, warmup=30, adam="torch"):
             "config": {"workload": f"{name}: {n} Gaussians, {n_views} views @{w}x{h}, loss whole", "n_gaussians": n}}
 
 
+def self_launch(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher (WORLD_SIZE unset): re-run this very command line under
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free>` -- the
+    launch the contract names -- and hand its exit code on.  stdout / stderr are inherited: the ranks' rank 0 prints
+    the JSON line.  Never degrades to fewer ranks: torch.distributed.run fails the run when a rank does."""
+    import socket
+    import subprocess
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print(f"[bench] no launcher in the environment: starting {n} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -699,11 +768,20 @@ def main():
     # EG_DIST_BACKEND=gloo lets the N-rank flow be exercised on a box with fewer GPUs than ranks (RCCL
     # refuses two ranks on one device); the driver's runs use the default, RCCL.
     backend = os.environ.get("EG_DIST_BACKEND", "nccl")
-    rank, local, world = egdist.init_from_env(backend)
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    if backend != "gloo" and torch.cuda.device_count() < args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but only {torch.cuda.device_count()} device(s) are visible: refusing to print a line "
+                         f"for fewer GPUs than asked for (EG_DIST_BACKEND=gloo shares devices between ranks: test mode)")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher: this process becomes the launcher of its own N ranks (one per GPU), exactly the command the
+        # contract names; their rank 0 prints the line, a rank that fails takes the whole run down with it
+        raise SystemExit(self_launch(args.gpus))
+    rank, local, world = egdist.init_from_env(backend)
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the line's n_gpus would not be what was asked for")
     local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     device = f"cuda:{local}"
@@ -713,6 +791,9 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=0, world_size=1)
 
+    if os.environ.get("EG_FOOTPRINT_ROWS_MIN"):  # development A/B of the footprint backward's two walks (tools/r5_fp.sh)
+        from edgegaussians_amd import _lib as _egl0
+        _egl0.load().eg_debug_footprint_rows_min_cells(int(os.environ["EG_FOOTPRINT_ROWS_MIN"]))
     if args.roctx:
         from edgegaussians_amd import _lib as _egl
         if _egl.load().eg_roctx_enable(1) != 0:

@@ -515,8 +515,10 @@ tile_sort_kernel(unsigned long long *__restrict__ keys, const int *__restrict__ 
           if (seg.item_rec) {
             int disp = first + i;
             if (seg.item_front) {
+              // (ftot < 0: the view overflowed the item capacity and the projection's scan said so -- item order, which
+              // has no holes when tiles are truncated; the caller grows the buffers and replays)
               const int fpre = seg.item_front[tile], ftot = seg.item_front[T];
-              disp = i < EG_FRONT_LARGE ? fpre + i : ftot + (first - fpre) + (i - EG_FRONT_LARGE);
+              if (ftot >= 0) disp = i < EG_FRONT_LARGE ? fpre + i : ftot + (first - fpre) + (i - EG_FRONT_LARGE);
             }
             if (disp < seg.max_items)
               seg.item_rec[disp] = make_int4(tile, i | (items << 16), tile * seg.seg_cap + i * 128, tile * seg.seg_cap + kept);

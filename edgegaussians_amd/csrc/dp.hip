@@ -29,6 +29,7 @@ typedef int (*CommInitRankFn)(NcclComm *, int, NcclUniqueId, int);
 typedef int (*CommDestroyFn)(NcclComm);
 typedef int (*AllReduceFn)(const void *, void *, size_t, int, int, NcclComm, hipStream_t);
 typedef const char *(*GetErrorStringFn)(int);
+typedef int (*CommCountFn)(NcclComm, int *);
 
 static void *g_rccl = nullptr;
 static GetUniqueIdFn p_get_unique_id = nullptr;
@@ -36,8 +37,16 @@ static CommInitRankFn p_comm_init_rank = nullptr;
 static CommDestroyFn p_comm_destroy = nullptr;
 static AllReduceFn p_all_reduce = nullptr;
 static GetErrorStringFn p_error_string = nullptr;
+static CommCountFn p_comm_count = nullptr;
 static NcclComm g_comm = nullptr;
 static int g_world = 0, g_rank = 0;
+// eg_dp_force_all_reduce: issue the [12 N] collective of eg_train_steps_dp even through a one-rank communicator (tests)
+static int g_force_all_reduce = 0;
+// [12 N] ncclAllReduce calls issued by eg_train_steps_dp since eg_dp_init, and the floats they carried
+static long long g_grad_all_reduces = 0, g_grad_all_reduce_floats = 0;
+// eg_dp_comm_timing: HIP events on the launch stream around each [12 N] collective of the next n steps
+static hipEvent_t *g_comm_ev = nullptr;  // [2 * g_comm_ev_cap]
+static int g_comm_ev_cap = 0, g_comm_ev_n = 0;
 // host seconds spent enqueueing {eg_train_step, ncclAllReduce, Adam + next projection} since the last eg_dp_host_profile
 static double g_host_s[3] = {0.0, 0.0, 0.0};
 static long long g_host_steps = 0;
@@ -57,6 +66,7 @@ static int load_rccl(const char *path) {
   p_comm_destroy = (CommDestroyFn)dlsym(g_rccl, "ncclCommDestroy");
   p_all_reduce = (AllReduceFn)dlsym(g_rccl, "ncclAllReduce");
   p_error_string = (GetErrorStringFn)dlsym(g_rccl, "ncclGetErrorString");
+  p_comm_count = (CommCountFn)dlsym(g_rccl, "ncclCommCount");
   if (!p_get_unique_id || !p_comm_init_rank || !p_comm_destroy || !p_all_reduce) {
     set_error("eg_dp: %s does not export the NCCL entry points", path ? path : "librccl.so");
     dlclose(g_rccl);
@@ -98,12 +108,82 @@ extern "C" int eg_dp_init(const char *librccl_path, const void *id_host, int32_t
   if (e) { g_comm = nullptr; return e; }
   g_world = world;
   g_rank = rank;
+  g_grad_all_reduces = g_grad_all_reduce_floats = 0;
   return EG_OK;
 }
 
 extern "C" int eg_dp_world(void) { return g_comm ? g_world : 0; }
 
+// what RCCL itself says the communicator's size is (ncclCommCount), 0 without a communicator, < 0 on an error
+extern "C" int eg_dp_comm_count(void) {
+  if (!g_comm) return 0;
+  EG_REQUIRE(p_comm_count != nullptr, "librccl does not export ncclCommCount");
+  int n = 0;
+  const int e = nccl_check(p_comm_count(g_comm, &n), "ncclCommCount");
+  return e ? e : n;
+}
+
+extern "C" int eg_dp_force_all_reduce(int32_t on) {
+  g_force_all_reduce = on ? 1 : 0;
+  return EG_OK;
+}
+
+extern "C" int64_t eg_dp_grad_all_reduces(int64_t *floats_out_host) {
+  if (floats_out_host) *floats_out_host = g_grad_all_reduce_floats;
+  return g_grad_all_reduces;
+}
+
+static void comm_timing_free() {
+  for (int i = 0; i < 2 * g_comm_ev_cap; ++i) (void)hipEventDestroy(g_comm_ev[i]);
+  delete[] g_comm_ev;
+  g_comm_ev = nullptr;
+  g_comm_ev_cap = g_comm_ev_n = 0;
+}
+
+extern "C" int eg_dp_comm_timing_begin(int32_t n_steps) {
+  EG_REQUIRE(n_steps > 0 && n_steps <= (1 << 16), "bad step count");
+  if (g_comm_ev) comm_timing_free();
+  g_comm_ev = new hipEvent_t[2 * (size_t)n_steps];
+  for (int i = 0; i < 2 * n_steps; ++i)
+    if (hipEventCreate(&g_comm_ev[i]) != hipSuccess) {
+      g_comm_ev_cap = i / 2;
+      comm_timing_free();
+      set_error("eg_dp_comm_timing_begin: hipEventCreate failed");
+      return EG_ERR_LAUNCH;
+    }
+  g_comm_ev_cap = n_steps;
+  g_comm_ev_n = 0;
+  return EG_OK;
+}
+
+extern "C" int eg_dp_comm_timing_end(float *mean_us_host, float *max_us_host, int32_t *n_out_host) {
+  EG_REQUIRE(g_comm_ev != nullptr, "no timing window open");
+  const int n = g_comm_ev_n;
+  double sum = 0.0;
+  float mx = 0.f;
+  if (n > 0) {
+    if (hipEventSynchronize(g_comm_ev[2 * (n - 1) + 1]) != hipSuccess) {
+      set_error("eg_dp_comm_timing_end: hipEventSynchronize failed");
+      comm_timing_free();
+      return EG_ERR_LAUNCH;
+    }
+    for (int i = 0; i < n; ++i) {
+      float ms = 0.f;
+      (void)hipEventElapsedTime(&ms, g_comm_ev[2 * i], g_comm_ev[2 * i + 1]);
+      sum += ms;
+      mx = ms > mx ? ms : mx;
+    }
+  }
+  if (mean_us_host) *mean_us_host = n ? (float)(1e3 * sum / n) : 0.f;
+  if (max_us_host) *max_us_host = 1e3f * mx;
+  if (n_out_host) *n_out_host = n;
+  comm_timing_free();
+  return EG_OK;
+}
+
 extern "C" int eg_dp_shutdown(void) {
+  if (g_comm_ev) comm_timing_free();
+  g_force_all_reduce = 0;
   if (g_comm) {
     (void)p_comm_destroy(g_comm);
     g_comm = nullptr;
@@ -161,9 +241,14 @@ extern "C" int eg_train_steps_dp(const eg_step_args *a, const eg_adam_hyper *hyp
     // (a sum over ONE rank is the identity: RCCL implements a one-rank allReduce through the copy engine -- fill + copy
     // blits with ~90 us of stream stalls, profiles/r04_timeline_gaps_config2_dp_native.txt -- which a one-GPU run of this
     // leg would measure instead of the leg; eg_dp_all_reduce still goes through RCCL whatever the size)
-    if (g_world > 1) {
+    if (g_world > 1 || g_force_all_reduce) {
+      const bool timed = g_comm_ev && g_comm_ev_n < g_comm_ev_cap;
+      if (timed) (void)hipEventRecord(g_comm_ev[2 * g_comm_ev_n], as_stream(stream));
       rc = nccl_check(p_all_reduce(g, g, 12 * (size_t)a->N, kNcclFloat, kNcclSum, g_comm, as_stream(stream)), "ncclAllReduce");
       if (rc) return rc;
+      if (timed) (void)hipEventRecord(g_comm_ev[2 * g_comm_ev_n++ + 1], as_stream(stream));
+      ++g_grad_all_reduces;
+      g_grad_all_reduce_floats += 12 * (long long)a->N;
     }
     const double t2 = now_s();
     eg_adam_hyper h = *hyper;

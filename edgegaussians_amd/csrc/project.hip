@@ -778,7 +778,9 @@ __device__ __forceinline__ void emit_body(const Raw &raw, bool live, int g, cons
     const int it = max(1, (min(pop, seg_cap) + 127) >> 7);
     ie += it; fe += min(it, EG_FRONT_LARGE);
   }
-  if (out.item_front && threadIdx.x == 0) out.item_front[T] = ftot;
+  // (an overflowing view keeps the records in item order -- the sort kernel sees the -1: the tiles truncated by the item
+  // capacity write no records, which in the two-class order would leave holes of stale records below total[2])
+  if (out.item_front && threadIdx.x == 0) out.item_front[T] = itot > out.max_items ? -1 : ftot;
   if (LDS_HIST) {
     __syncthreads();
     for (int t = threadIdx.x; t < T; t += kPE) out.item_first[t] = min(s_base[t], out.max_items);

@@ -70,21 +70,42 @@ def init_native_comm(group=None) -> int:
     import ctypes as C
     from . import _lib
     lib = _lib.load()
-    if lib.eg_dp_world() > 0:
-        return int(lib.eg_dp_world())
-    path = librccl_path().encode()
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
+    if world > 1 and dist.get_backend(group) != "nccl":
+        # (gloo = the several-ranks-per-GPU test mode: RCCL refuses two ranks on one device, the Python driver runs)
+        raise RuntimeError(f"the native communicator needs the RCCL backend, the process group runs {dist.get_backend(group)}")
+    have = int(lib.eg_dp_world())
+    if have == world:
+        return have
+    if have > 0:  # a communicator of another size (an earlier group): never reported as ready for this one
+        lib.eg_dp_shutdown()
+    path = librccl_path().encode()
     buf = (C.c_ubyte * 128)()
+    # rank 0's verdict travels with the id: a failure there must raise on EVERY rank, not leave the others in the broadcast
+    err = ""
     if rank == 0 and lib.eg_dp_unique_id(path, buf) != 0:
-        raise RuntimeError(lib.eg_last_error_string().decode())
+        err = lib.eg_last_error_string().decode()
     if world > 1:
-        dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
-        t = torch.tensor(list(buf), dtype=torch.uint8, device=dev)
+        t = torch.tensor([0 if not err else 1] + list(buf), dtype=torch.uint8, device="cuda")
         dist.broadcast(t, src=0, group=group)
-        buf = (C.c_ubyte * 128)(*t.cpu().tolist())
-    if lib.eg_dp_init(path, buf, rank, world) != 0:
-        raise RuntimeError(lib.eg_last_error_string().decode())
+        vals = t.cpu().tolist()
+        if vals[0] != 0:
+            raise RuntimeError("eg_dp_unique_id failed on rank 0" + (f": {err}" if err else ""))
+        buf = (C.c_ubyte * 128)(*vals[1:])
+    elif err:
+        raise RuntimeError(err)
+    ok = lib.eg_dp_init(path, buf, rank, world) == 0
+    msg = "" if ok else lib.eg_last_error_string().decode()
+    if world > 1:  # ... and so must a failure of ncclCommInitRank on any rank
+        t = torch.tensor([int(ok)], device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+        if int(t.item()) == 0:
+            if ok:
+                lib.eg_dp_shutdown()
+            raise RuntimeError("eg_dp_init failed on " + ("this rank: " + msg if not ok else "another rank"))
+    elif not ok:
+        raise RuntimeError(msg)
     return world
 
 

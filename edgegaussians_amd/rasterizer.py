@@ -273,7 +273,13 @@ class _FastBuffers:
         self.pending = False
         self.event.synchronize()
         m, overflow, _items, tile_max, unit, ctl3 = self.host.tolist()[:6]
-        _check_stall(ctl3)
+        if not overflow:  # (a stall next to an overflow is the overflow's: the forward ran on truncated item tables)
+            try:
+                _check_stall(ctl3)
+            except RuntimeError:
+                self.confident = 0
+                self.reset()
+                raise
         self.max_tile, self.last_m = max(self.max_tile, tile_max), m
         if overflow or not unit:
             self.confident = 0
@@ -304,10 +310,38 @@ _FAST: Dict = {}
 _DEFER = _os.environ.get("EG_OPERATOR_DEFER", "1") != "0"
 
 
+def settle_all() -> None:
+    """Looks at the deferred verdicts of EVERY cached shape (raises on a bad one).  Called when a call arrives for a
+    shape not seen before -- N changed after a densification, the final test renders -- and at interpreter exit, so that
+    the last call for a shape is never left unexamined."""
+    err = None
+    for fb in list(_FAST.values()):
+        try:
+            fb.settle()
+        except RuntimeError as e:  # (look at all of them; report the first)
+            err = err or e
+    if err is not None:
+        raise err
+
+
+def _settle_at_exit() -> None:
+    try:
+        settle_all()
+    except RuntimeError as e:
+        import sys
+        print(f"edgegaussians_amd: {e}", file=sys.stderr, flush=True)
+        _os._exit(1)  # the process handed out an invalid render: it must not report success
+
+
+import atexit as _atexit
+_atexit.register(_settle_at_exit)
+
+
 def _fast_buffers(N, width, height, dev) -> _FastBuffers:
     key = (N, width, height, str(dev))
     fb = _FAST.get(key)
     if fb is None:
+        settle_all()
         if len(_FAST) > 8:
             _FAST.clear()
         fb = _FAST[key] = _FastBuffers(N, width, height, dev)
@@ -331,7 +365,9 @@ class _UnitRasterization(torch.autograd.Function):
         # with >= 30 % of head-room in both capacities the read-back becomes an asynchronous copy into pinned memory that
         # the BACKWARD (or the next forward) looks at: a verdict that turns out bad then RAISES there (the outputs were
         # already handed out).  EG_OPERATOR_DEFER=0: always read back at once.
-        defer = _DEFER and fb.confident >= 2
+        # Never when nobody will run a backward through this call (grad mode off, no input requires grad: evaluation
+        # renders, the last calls of a process): the verdicts are then read before the call returns.
+        defer = _DEFER and fb.confident >= 2 and holder.get("will_backward", False)
         if fb.seg_cap == 0:  # first call for this shape: a count-only sweep sizes the buffers (one extra sync, once)
             splat0 = torch.empty(N, 8, device=dev)
             call("eg_project_fwd", ptr(means_c), ptr(quats_c), ptr(scales_c), ptr(opac_c), ptr(vm), ptr(Kc), N, width, height,
@@ -364,7 +400,8 @@ class _UnitRasterization(torch.autograd.Function):
                     # the ONE host read-back of the call, after everything has been enqueued: M, sticky overflow flag,
                     # items, largest tile -- and the verdict on the colours
                     m, overflow, _items, tile_max, unit, ctl3 = fb.total.tolist()[:6]
-                    _check_stall(ctl3)
+                    if not overflow:  # (an overflowing call is run again below, whatever its waves did on the way)
+                        _check_stall(ctl3)
                     fb.last_m = m
             except Exception:
                 fb.reset()
@@ -454,7 +491,8 @@ def _fast_rasterization(means, quats, scales, opacities, colors, viewmats, Ks, w
     N = means.shape[0]
     tw, th = math.ceil(width / TILE), math.ceil(height / TILE)
     flags = _lib.FLAG_ANTIALIASED if antialiased else 0
-    holder: Dict = {"absgrad": bool(absgrad)}
+    holder: Dict = {"absgrad": bool(absgrad),
+                    "will_backward": torch.is_grad_enabled() and any(t.requires_grad for t in (means, quats, scales, opacities))}
     alphas, means2d = _UnitRasterization.apply(
         means, quats, scales, opacities, viewmats[0], Ks[0], width, height, flags, colors, holder)
     if not holder["unit"]:

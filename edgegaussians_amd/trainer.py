@@ -97,6 +97,7 @@ class EdgeTrainer:
         self._projected: Optional[int] = None  # view already projected + binned by apply_adam(next_view=...)
         self._dp = None  # the DataParallelStep driving this trainer (dist.py), if any: read-backs and replays are collective
         self._ws_tag = 0       # tags of the chained forward (eg_step_args.ws_tag): one fresh value per enqueued step
+        self._replaying = False  # inside _recover_from_overflow's replay of the journal
         self.chained_forward = bool(int(os.environ.get("EG_CHAINED", "1")))
         # noise of duplicate() comes from a dedicated generator seeded with (seed, event number): identical
         # on every data-parallel rank whatever else the ranks drew (edge_gs.py:462-467 uses the global RNG)
@@ -354,15 +355,23 @@ class EdgeTrainer:
         carry them).  When the range is used up (every 65 534 steps) the journal is flushed -- the sticky words of the
         control block are about to go: look at them first -- the workspaces are zeroed and the tags start over, so that
         a granule written 2^16 steps ago can never be mistaken for this call's.  Called BEFORE the steps are journalled
-        and before their arguments are built."""
+        and before their arguments are built.  (A replay reserves the tags of its whole journal before it starts,
+        _recover_from_overflow: inside one this function never wraps.)"""
         assert 0 < n <= _lib.MAX_WS_TAG, n
         if self.chained_forward and self._ws_tag + n > _lib.MAX_WS_TAG:
+            assert not self._replaying, "a replay reserves its tags up front"
             if self._journal:
                 self.flush()
-            for ws in [self.workspace] + [b["workspace"] for b in self._batches.values()]:
-                if ws is not None:
-                    ws.zero_()
-            self._ws_tag = 0
+            else:  # nothing to replay, but the stall bit of control word 3 must not be zeroed unread
+                if self._ctl_bits()[1]:
+                    raise RuntimeError(self._STALL_MSG)
+            self._zero_workspaces()
+
+    def _zero_workspaces(self) -> None:
+        for ws in [self.workspace] + [b["workspace"] for b in self._batches.values()]:
+            if ws is not None:
+                ws.zero_()
+        self._ws_tag = 0
 
     def _next_tag(self, n: int) -> int:
         """First of n fresh, consecutive tags (see _reserve_tags, which the public entry points call before they
@@ -388,15 +397,16 @@ class EdgeTrainer:
             out.append(b["workspace"][:, o:o + 8].contiguous().view(torch.int32))
         return out
 
-    def _rewalk_missed(self) -> bool:
-        """Control word 3 of the compositing workspaces: bit 0 = a pixel reached the transmittance stop while the
-        forward speculated that none would (replay in chained mode); bit 1 = a wave of the forward gave up polling a
-        hand-over granule (the dispatch-order contract of the look-back was broken: results are void)."""
+    _STALL_MSG = ("composite forward: a look-back poll gave up (a hand-over granule never arrived); "
+                  "the results of the steps since the last read-back are invalid")
+
+    def _ctl_bits(self):
+        """Control word 3 of the compositing workspaces, as (missed, stalled): bit 0 = a pixel reached the transmittance
+        stop while the forward speculated that none would (replay in chained mode); bit 1 = a wave of the forward gave
+        up polling a hand-over granule -- the dispatch-order contract of the look-back was broken (results are void), or
+        the view overflowed its item table and the forward ran on a truncated one (the overflow handling repairs it)."""
         words = [int(x) for w in self._ctl_words() for x in w.view(-1, 2)[:, 1].reshape(-1).tolist()]
-        if any(x & 2 for x in words):
-            raise RuntimeError("composite forward: a look-back poll gave up (a hand-over granule never arrived); "
-                               "the results of the steps since the last read-back are invalid")
-        return any(x & 1 for x in words)
+        return any(x & 1 for x in words), any(x & 2 for x in words)
 
     def _advance_all(self):
         self.adam_step += 1
@@ -586,59 +596,82 @@ class EdgeTrainer:
         dropped intersections (buffers too small) or hit a transmittance stop while the re-walk launch was being
         skipped.  Grow / switch the re-walk on, put the state back, run the journalled steps again; repeat until
         clean."""
+        def flags():
+            # (missed, stalled, overflowed) -- of ANY rank under data parallelism: every rank repairs what any rank
+            # tripped over, and every rank raises when one must (nobody is left waiting in a collective)
+            (missed, stall), over = self._ctl_bits(), self.overflowed()
+            if self._dp is not None and self._dp.world > 1:
+                (missed, stall, over), _ = self._dp.reduce_words([int(missed), int(stall), int(over)], [])
+            return bool(missed), bool(stall), bool(over)
+
+        missed, stall, over = flags()
         if not (self.replay_on_overflow and self._journal and self._snap is not None):
             self.clear_overflow()
             self.tile_counts.zero_()
             for b in self._batches.values():
                 b["tile_counts"].zero_()
+            if stall and not over:
+                for w in self._ctl_words():
+                    w.view(-1, 2)[:, 1].zero_()
+                raise RuntimeError(self._STALL_MSG + " and cannot be replayed (journal off or data-parallel leg)")
             self._grow_isect(2.0)  # leave usable buffers behind for a caller that catches and restarts
             raise IsectOverflow("tile-intersection buffers overflowed and the steps since the last read-back "
                                 "cannot be replayed (journal off or data-parallel leg): results are invalid; "
                                 "buffers were grown, restart from the last checkpoint")
         journal = list(self._journal)
         epoch_now, ls_now = self.epoch, self.loss_scale
-        for _ in range(8):
-            missed, over = self._rewalk_missed(), self.overflowed()
-            if self._dp is not None and self._dp.world > 1:  # every rank repairs what ANY rank tripped over
-                (missed, over), _ = self._dp.reduce_words([int(missed), int(over)], [])
-            if missed:
-                self.rewalk_hint = -1  # stops exist: launch the re-walk from now on (the next read-back sizes it)
+        assert 2 * len(journal) <= _lib.MAX_WS_TAG, "journal longer than the tag range"
+        self._replaying = True
+        try:
+            for attempt in range(9):
+                if attempt > 0:
+                    missed, stall, over = flags()
+                    if not (missed or stall or over):
+                        self.epoch, self.loss_scale = epoch_now, ls_now
+                        return
+                    if attempt == 8:
+                        break
+                if stall and not over:  # (a stall next to an overflow is the overflow's: truncated item tables)
+                    raise RuntimeError(self._STALL_MSG)
+                if missed:
+                    self.rewalk_hint = -1  # stops exist: launch the re-walk from now on (the next read-back sizes it)
+                    for b in self._batches.values():
+                        b["rewalk_hint"] = -1
+                    self.rewalk_misses += 1
+                if missed or stall:
+                    for w in self._ctl_words():
+                        w.view(-1, 2)[:, 1].zero_()
+                    o = 4 * (self.T + self.max_items + 3)
+                    self.workspace[o:o + 4].zero_()
+                    for b in self._batches.values():
+                        b["workspace"][:, o:o + 4].zero_()
+                if over:
+                    self.overflow_events += 1
+                    self._grow_isect(2.0)  # (drops the batched work buffers as well: re-allocated, flags clear)
+                # the replayed steps draw fresh tags: reserve the whole journal's now (two per entry at most), so that the
+                # range cannot wrap -- flush, zero the workspaces -- in the middle of the replay
+                if self.chained_forward and self._ws_tag + 2 * len(journal) > _lib.MAX_WS_TAG:
+                    self._zero_workspaces()
+                self.total.zero_()
+                self.tile_counts.zero_()  # (a step that ran out of items leaves the cursors of the unserved tiles behind)
                 for b in self._batches.values():
-                    b["rewalk_hint"] = -1
-                for w in self._ctl_words():
-                    w.view(-1, 2)[:, 1].zero_()
-                o = 4 * (self.T + self.max_items + 3)
-                self.workspace[o:o + 4].zero_()
-                for b in self._batches.values():
-                    b["workspace"][:, o:o + 4].zero_()
-                self.rewalk_misses += 1
-            if over:
-                self.overflow_events += 1
-                self._grow_isect(2.0)  # (drops the batched work buffers as well: re-allocated, flags clear)
-            self.total.zero_()
-            self.tile_counts.zero_()  # (a step that ran out of items leaves the cursors of the unserved tiles behind)
-            for b in self._batches.values():
-                b["total"].zero_()
-                b["tile_counts"].zero_()
-            self._restore()  # (the running loss sum included)
-            for kind, view, wmap, epoch, ls in journal:
-                self.epoch, self.loss_scale = epoch, ls
-                if kind == "1":
-                    self._step_raw(view, wmap)
-                elif kind == "r":
-                    self._regulariser_raw(view, self.loss_acc[0], *wmap)
-                elif kind == "e":
-                    self._mark_raw(view)
-                elif kind == "d":  # a data-parallel step: every rank replays it, the collective included
-                    self._dp._step_raw(view, wmap[0], wmap[1])
-                else:
-                    self._batched_raw(view, wmap, True)
-            again = self.overflowed() or self._rewalk_missed()
-            if self._dp is not None and self._dp.world > 1:
-                again = bool(self._dp.reduce_words([int(again)], [])[0][0])
-            if not again:
-                self.epoch, self.loss_scale = epoch_now, ls_now
-                return
+                    b["total"].zero_()
+                    b["tile_counts"].zero_()
+                self._restore()  # (the running loss sum included)
+                for kind, view, wmap, epoch, ls in journal:
+                    self.epoch, self.loss_scale = epoch, ls
+                    if kind == "1":
+                        self._step_raw(view, wmap)
+                    elif kind == "r":
+                        self._regulariser_raw(view, self.loss_acc[0], *wmap)
+                    elif kind == "e":
+                        self._mark_raw(view)
+                    elif kind == "d":  # a data-parallel step: every rank replays it, the collective included
+                        self._dp._step_raw(view, wmap[0], wmap[1])
+                    else:
+                        self._batched_raw(view, wmap, True)
+        finally:
+            self._replaying = False
         raise IsectOverflow("tile-intersection buffers still overflow after 8 doublings")
 
     def _journal_push(self, entry, reserve: bool = True) -> None:

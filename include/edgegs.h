@@ -245,6 +245,12 @@ typedef struct {
 int eg_composite_bwd_footprint(const float *splat, int32_t N, int32_t width, int32_t height,
                                const float *gtstop /*[H,W,3]*/, float *g2d /*[N,8] written*/,
                                eg_stream_t stream);
+/* debugging / test aid (library state, like the timing window): a wavefront of the footprint backward walks its eight
+ * footprints row by row (exact ellipse intervals, groups of four cells: the walk of LARGE footprints) when their sheared
+ * boxes hold at least min_cells cells together, cell by cell with a stride otherwise.  min_cells >= 0 sets the threshold
+ * (0: always rows, INT32_MAX: never), < 0 only asks; returns the previous value.  Both walks compute the same sums in a
+ * different order. */
+int eg_debug_footprint_rows_min_cells(int32_t min_cells);
 
 /* ---- whole backward of the fused path: eg_composite_bwd_footprint, then eg_project_bwd_adam
  * (hyper_host != NULL: absgrads accumulated, Adam applied) or eg_project_bwd (hyper_host == NULL:
@@ -534,6 +540,20 @@ int eg_dp_unique_id(const char *librccl_path, void *id_out_host /*128 bytes*/);
 int eg_dp_init(const char *librccl_path, const void *id_host /*128 bytes*/, int32_t rank, int32_t world);
 int eg_dp_world(void);
 int eg_dp_shutdown(void);
+/* the communicator's size as RCCL reports it (ncclCommCount): what bench.py puts on its line as the proof that RCCL saw
+ * N ranks; 0 without a communicator, negative on an error */
+int eg_dp_comm_count(void);
+/* test switch: on != 0 makes eg_train_steps_dp issue its [12 N] ncclAllReduce through a ONE-rank communicator too (a sum
+ * over one rank is the identity, the run skips it by default: RCCL does it with copy-engine blits that stall the
+ * stream).  Reset by eg_dp_shutdown. */
+int eg_dp_force_all_reduce(int32_t on);
+/* [12 N] gradient collectives issued by eg_train_steps_dp since eg_dp_init (and the floats they carried) */
+int64_t eg_dp_grad_all_reduces(int64_t *floats_out_host /*NULL ok*/);
+/* measurement aid: HIP events on the launch stream around the [12 N] collective of the next n_steps steps of
+ * eg_train_steps_dp; _end synchronises once: mean / max microseconds the collective occupied the launch stream
+ * (everything in it is exposed at one view per rank), number of collectives timed */
+int eg_dp_comm_timing_begin(int32_t n_steps);
+int eg_dp_comm_timing_end(float *mean_us_host, float *max_us_host, int32_t *n_out_host);
 /* in-place sum over the ranks of n floats on `stream` (small collectives that ride the same communicator) */
 int eg_dp_all_reduce(float *buf, int64_t n, eg_stream_t stream);
 /* measurement aid: mean HOST microseconds per step that eg_train_steps_dp spent enqueueing {the gradient step's kernels,
