@@ -791,9 +791,6 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=0, world_size=1)
 
-    if os.environ.get("EG_FOOTPRINT_ROWS_MIN"):  # development A/B of the footprint backward's two walks (tools/r5_fp.sh)
-        from edgegaussians_amd import _lib as _egl0
-        _egl0.load().eg_debug_footprint_rows_min_cells(int(os.environ["EG_FOOTPRINT_ROWS_MIN"]))
     if args.roctx:
         from edgegaussians_amd import _lib as _egl
         if _egl.load().eg_roctx_enable(1) != 0:

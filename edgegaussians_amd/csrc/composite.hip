@@ -1237,99 +1237,10 @@ __device__ __forceinline__ void footprint_walk(const float4 s0, const float4 s1,
   }
 }
 
-// The walk of LARGE footprints (round 5).  The stride dealing above pays ~22 issue slots per visit for knowing where it
-// is (cell -> row / column with a carry, the row's first column through a ceil, the clip, two 24-bit multiplies for the
-// address) and visits the whole sheared box, of which pi/4 lies inside the ellipse.  Where a row is many cells wide
-// that bookkeeping belongs to the ROW: lane r of n takes rows i0 + r, i0 + r + n, ... of its Gaussian, computes the
-// row's EXACT interval  x_g + (b/a) dy -/+ sqrt(2 a thr - det dy^2) / a  (clipped like the box) once, and then walks it
-// left to right in groups of four cells: the record address advances by 12 bytes (the loads' immediate offsets), dx by
-// one, sigma = dx (a/2 dx + b dy) + c/2 dy^2 is two multiply-adds on per-row constants, and the second moments of
-// w = dL/dsigma are taken per row in powers of dx alone (sum w, sum w dx, sum w dx^2; dy is constant in a row) and
-// folded when the row ends.  The row change is a masked branch -- with 64 lanes in different phases of their rows some
-// lane takes it in nearly every iteration, which is why it is only worth it per GROUP of cells and on wide rows: the
-// kernel chooses per wave, by the wave's cell count (g_rows_min_cells).  The accept test of a cell is the one of the
-// stride walk (the interval only has to be a superset of the accepted cells: same 0.1 % + 0.01 px inflation).
-__device__ __forceinline__ void footprint_rows(const float4 s0, const float4 s1, int g, int r, int n, int i0, int fh,
-                                               int jlo, int jhi, float thr, int width,
-                                               const __amdgpu_buffer_rsrc_t gtstop, Moments &m) {
-  typedef unsigned u32x3 __attribute__((ext_vector_type(3)));
-  const float a = s0.z, b = s0.w, c = s1.x, o = s1.y;
-  const float inv_a = __builtin_amdgcn_rcpf(a);
-  const float ha = 0.5f * a, sh = b * inv_a;
-  const float det = a * c - b * b;
-  const float disc0 = 2.f * a * thr;
-  const float xc = s0.x - 0.5f, yc = s0.y - 0.5f;  // (pixel centres sit at integer + 0.5)
-  const unsigned ug = (unsigned)g, dg = (unsigned)__float_as_int(s1.z);
-  const int width12 = width * (int)sizeof(StopRec);
-  const int iend = i0 + fh;
-  int i = i0 + r - n;                 // the row before this lane's first
-  int cnt = 0;                        // cells left in the current row (<= 0: take the next row)
-  unsigned off = kOutOfImage;         // byte offset of the group's first record
-  float dx = 0.f;                     // x_g - (column + 0.5) of the group's first cell
-  float dy = 0.f, p = 0.f, q = 0.f, cdy = 0.f;  // row constants: b dy, c/2 dy^2, c dy
-  float S0 = 0.f, S1 = 0.f, S2 = 0.f;          // sum w, sum w dx, sum w dx^2 of the current row
-  bool done = false;
-  for (;;) {
-    if (cnt <= 0 && !done) {
-      // the row just finished goes into the moments (the first time round: zeros)
-      m.w_x += S1; m.w_y += dy * S0; m.w_xx += S2; m.w_xy += dy * S1; m.w_yy += dy * dy * S0;
-      S0 = S1 = S2 = 0.f;
-      i += n;
-      if (i < iend) {
-        dy = yc - (float)i;
-        const float disc = disc0 - det * dy * dy;
-        const float hwid = __builtin_amdgcn_sqrtf(fmaxf(disc, 0.f)) * inv_a * 1.001f + 0.01f;
-        const float xm = xc + sh * dy;
-        const int lo = max(jlo, (int)ceilf(xm - hwid)), hi = min(jhi, (int)floorf(xm + hwid));
-        cnt = disc >= 0.f ? hi - lo + 1 : 0;   // (an empty row costs one group of rejected cells)
-        off = cnt > 0 ? (unsigned)(__mul24(i, width12) + __mul24(lo, 12)) : kOutOfImage;
-        dx = xc - (float)lo;
-        p = b * dy; cdy = c * dy; q = 0.5f * cdy * dy;
-      } else {
-        done = true;
-        off = kOutOfImage;             // (the range check answers zeros: gT == 0 rejects)
-        cnt = 0x40000000;
-      }
-    }
-    if (__builtin_amdgcn_ballot_w64(!done) == 0ull) break;
-    const u32x3 t0 = __builtin_amdgcn_raw_buffer_load_b96(gtstop, (int)off, 0, 0);
-    const u32x3 t1 = __builtin_amdgcn_raw_buffer_load_b96(gtstop, (int)off + 12, 0, 0);
-    const u32x3 t2 = __builtin_amdgcn_raw_buffer_load_b96(gtstop, (int)off + 24, 0, 0);
-    const u32x3 t3 = __builtin_amdgcn_raw_buffer_load_b96(gtstop, (int)off + 36, 0, 0);
-    auto visit = [&](const u32x3 t, const int k) {
-      const float gT = __uint_as_float(t.x), dxk = dx - (float)k;
-      const float sigma = dxk * (ha * dxk + p) + q;
-      unsigned b0, b1;
-      (void)__builtin_subc(t.y, ug, 0u, &b0);
-      (void)__builtin_subc(t.z, dg, b0, &b1);
-      if (!(k < cnt && gT != 0.f && sigma >= 0.f && sigma <= thr) || b1) return;
-      const float vis = __expf(-sigma);
-      const float araw = o * vis;
-      const bool ok = (araw >= kAlphaMin) & (araw <= kAlphaMax);
-      const float v_alpha = ok ? gT * __builtin_amdgcn_rcpf(1.f - araw) : 0.f;
-      m.v_o += vis * v_alpha;
-      const float w = -araw * v_alpha;
-      const float wx = w * dxk;
-      S0 += w; S1 += wx; S2 += wx * dxk;
-      m.abs_x += fabsf(w) * fabsf(a * dxk + p);
-      m.abs_y += fabsf(w) * fabsf(b * dxk + cdy);
-    };
-    visit(t0, 0);
-    visit(t1, 1);
-    visit(t2, 2);
-    visit(t3, 3);
-    cnt -= 4; dx -= 4.f; off += 48u;
-  }
-}
-
-// waves whose eight footprints hold at least this many cells of their sheared boxes walk rows (footprint_rows), the
-// others cells (footprint_walk); eg_debug_footprint_rows_min_cells overrides it (tests run both walks on the same scenes)
-static int g_rows_min_cells = 2048;
-
 __global__ void __launch_bounds__(256)
 footprint_bwd_kernel(const float4 *__restrict__ splat, int N, int width, int height,
                      const StopRec *__restrict__ gtstop, float *__restrict__ g2d, const Batch bt,
-                     float *__restrict__ loss_part, float *__restrict__ loss_out, const int rows_min_cells) {
+                     float *__restrict__ loss_part, float *__restrict__ loss_out) {
   __shared__ float red[4][64 * 8];
   splat += blockIdx.y * bt.splat4; gtstop += blockIdx.y * bt.pixels; g2d += blockIdx.y * bt.splat4 * 4;  // view
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -1396,13 +1307,9 @@ footprint_bwd_kernel(const float4 *__restrict__ splat, int N, int width, int hei
     const int cells = r < n ? __shfl(h.cells, src, 64) : 0;
     s0 = splat[2 * g];
     s1 = splat[2 * g + 1];
-    if (__builtin_amdgcn_readfirstlane(total) >= rows_min_cells)
-      footprint_rows(s0, s1, g, r, n, __shfl(h.i0, src, 64), cells > 0 ? __shfl(h.fh, src, 64) : 0, __shfl(h.jlo, src, 64),
-                     __shfl(h.jhi, src, 64), __shfl(h.thr, src, 64), width, rec_rsrc, m);
-    else
-      footprint_walk(s0, s1, g, r, n, __shfl(h.i0, src, 64), max(__shfl(h.pw, src, 64), 1), cells,
-                     __shfl(h.jlo, src, 64), __shfl(h.jhi, src, 64), __shfl(h.thr, src, 64),
-                     __shfl(h.xoff, src, 64), __shfl(h.shear, src, 64), width, rec_rsrc, splat, m);
+    footprint_walk(s0, s1, g, r, n, __shfl(h.i0, src, 64), max(__shfl(h.pw, src, 64), 1), cells,
+                   __shfl(h.jlo, src, 64), __shfl(h.jhi, src, 64), __shfl(h.thr, src, 64),
+                   __shfl(h.xoff, src, 64), __shfl(h.shear, src, 64), width, rec_rsrc, splat, m);
   }
   // partial g2d record of this lane: vx vy |vx| |vy| va vb vc vo
   float *mine = &red[wv][lane * 8];
@@ -1726,16 +1633,9 @@ extern "C" int eg_composite_bwd_footprint(const float *splat, int32_t N, int32_t
   EG_REQUIRE(splat && gtstop && g2d, "null pointer");
   hipStream_t st = as_stream(stream);
   footprint_bwd_kernel<<<cdiv((int64_t)N, 32), 256, 0, st>>>((const float4 *)splat, N, width, height,
-                                                            (const StopRec *)gtstop, g2d, Batch{}, nullptr, nullptr,
-                                                            g_rows_min_cells);
+                                                            (const StopRec *)gtstop, g2d, Batch{}, nullptr, nullptr);
   timing_mark(kMarkFootprint, st);
   return check_launch("composite_bwd_footprint");
-}
-
-extern "C" int eg_debug_footprint_rows_min_cells(int32_t min_cells) {
-  const int old = g_rows_min_cells;
-  if (min_cells >= 0) g_rows_min_cells = min_cells;
-  return old;
 }
 
 namespace eg {
@@ -1761,8 +1661,7 @@ int launch_footprint_bwd(const float *splat, int32_t N, int32_t width, int32_t h
   float *loss_part = nullptr;
   if (workspace && loss_out) loss_part = carve_workspace(workspace, max_items, cdiv(width, kTile) * cdiv(height, kTile)).loss_part;
   footprint_bwd_kernel<<<dim3(cdiv((int64_t)N, 32), C), 256, 0, st>>>((const float4 *)splat, N, width, height,
-                                                                     (const StopRec *)gtstop, g2d, bt, loss_part, loss_out,
-                                                                     g_rows_min_cells);
+                                                                     (const StopRec *)gtstop, g2d, bt, loss_part, loss_out);
   timing_mark(kMarkFootprint, st);
   return check_launch("composite_bwd_footprint");
 }

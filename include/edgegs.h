@@ -245,12 +245,6 @@ typedef struct {
 int eg_composite_bwd_footprint(const float *splat, int32_t N, int32_t width, int32_t height,
                                const float *gtstop /*[H,W,3]*/, float *g2d /*[N,8] written*/,
                                eg_stream_t stream);
-/* debugging / test aid (library state, like the timing window): a wavefront of the footprint backward walks its eight
- * footprints row by row (exact ellipse intervals, groups of four cells: the walk of LARGE footprints) when their sheared
- * boxes hold at least min_cells cells together, cell by cell with a stride otherwise.  min_cells >= 0 sets the threshold
- * (0: always rows, INT32_MAX: never), < 0 only asks; returns the previous value.  Both walks compute the same sums in a
- * different order. */
-int eg_debug_footprint_rows_min_cells(int32_t min_cells);
 
 /* ---- whole backward of the fused path: eg_composite_bwd_footprint, then eg_project_bwd_adam
  * (hyper_host != NULL: absgrads accumulated, Adam applied) or eg_project_bwd (hyper_host == NULL:

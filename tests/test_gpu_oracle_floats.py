@@ -149,19 +149,8 @@ def test_composite_backward_on_oracle_floats(env, kind):
     # (i) fused path: sliced forward with the loss epilogue -> gtstop -> footprint backward
     out = _composite_fwd(_lib, splat, offs, flat, W, H, True, gt_d, w_d)
     assert abs(float(out["loss"]) - loss_o) <= 1e-4 * abs(loss_o)
-    # both walks of the footprint backward (round 5): cell by cell with a stride (small footprints) and row by row over
-    # exact ellipse intervals (large ones) -- the kernel chooses per wavefront, the test forces each on every wave
-    lib = _lib.load()
-    default_min = lib.eg_debug_footprint_rows_min_cells(0)
-    try:
-        g2d_r = torch.full((N, 8), float("nan"), device="cuda")
-        call("eg_composite_bwd_footprint", ptr(splat), N, W, H, ptr(out["gtstop"]), ptr(g2d_r), stream())
-        lib.eg_debug_footprint_rows_min_cells(2**31 - 1)
-        g2d_f = torch.full((N, 8), float("nan"), device="cuda")
-        call("eg_composite_bwd_footprint", ptr(splat), N, W, H, ptr(out["gtstop"]), ptr(g2d_f), stream())
-    finally:
-        lib.eg_debug_footprint_rows_min_cells(default_min)
-    assert lib.eg_debug_footprint_rows_min_cells(-1) == default_min > 0
+    g2d_f = torch.full((N, 8), float("nan"), device="cuda")
+    call("eg_composite_bwd_footprint", ptr(splat), N, W, H, ptr(out["gtstop"]), ptr(g2d_f), stream())
     # (ii) operator path: item-parallel backward from (alphas, last_ids, vpix)
     g2d_i = torch.zeros(N, 8, device="cuda")
     call("eg_composite_bwd", ptr(splat), ptr(offs), ptr(flat), W, H, ptr(out["alphas"]), ptr(out["last"]),
@@ -175,7 +164,7 @@ def test_composite_backward_on_oracle_floats(env, kind):
     names = ("v_means2d", "v_means2d_abs", "v_conics", "v_opacity")
     cols = ((0, 2), (2, 4), (4, 7), (7, 8))
     errs = {}
-    for tag, g in (("footprint", g2d_f), ("footprint_rows", g2d_r), ("item", g2d_i), ("tile", g2d_t)):
+    for tag, g in (("footprint", g2d_f), ("item", g2d_i), ("tile", g2d_t)):
         g = g.cpu()
         for name, (c0, c1) in zip(names, cols):
             a, b = g[vis][:, c0:c1], torch.from_numpy(ref)[vis][:, c0:c1]

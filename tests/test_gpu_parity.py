@@ -485,17 +485,6 @@ def test_fused_backward_big_footprints(env):
     _lib, synth, O = env
     sc = synth.make_scene(200, 2, 320, 256, seed=4, spread_opacity=True, scale=0.12, anisotropy=3.0)
     _grad_step_vs_torch_oracle(env, sc, 0, "big_footprints")
-    # ... and with each of the kernel's two walks forced on every wavefront (rows / cells: round 5)
-    lib = _lib.load()
-    default_min = lib.eg_debug_footprint_rows_min_cells(-1)
-    try:
-        for mode, v in (("rows", 0), ("cells", 2**31 - 1)):
-            lib.eg_debug_footprint_rows_min_cells(v)
-            _grad_step_vs_torch_oracle(env, sc, 1, f"big_footprints_{mode}")
-            sc2 = synth.make_scene(3000, 2, 160, 128, seed=14, spread_opacity=True, scale=0.01, anisotropy=5.0)
-            _grad_step_vs_torch_oracle(env, sc2, 0, f"thin_footprints_{mode}")
-    finally:
-        lib.eg_debug_footprint_rows_min_cells(default_min)
 
 
 def test_fused_step_with_transmittance_stops(env):
