@@ -439,13 +439,30 @@ def measure(name, args, device, rank, world, backend, spread=False, steps=None, 
         # (a replayed window would have been timed twice)
         raise SystemExit(f"invalid run: overflow events={tr.overflow_events} re-walk misses={tr.rewalk_misses} loss={loss_sum}")
     m_last = tr.last_m()
+    # M of EVERY view (count-only passes, one host sync each; the parameters are practically stationary: LR_SCALE): the
+    # line's M -- and the algorithmic bytes of the roofline -- are MEANS over the views a measurement covered, not the M
+    # of whatever view came last (frac moved by 10 % from run to run with it)
+    m_by_view = [tr.count_intersections(v) for v in range(n_views)]
+
+    def step_views(s):
+        if dp is None:
+            return [(s * vps + i) % n_views for i in range(vps)]
+        return [egdist.view_for(s, rank, world, n_views, vps, i) for i in range(vps)]
+
+    def mean_m(step0, k):
+        vs = [v for s in range(step0, step0 + k) for v in step_views(s)]
+        return sum(m_by_view[v] for v in vs) / max(len(vs), 1)
+
+    m_timed, m_all = mean_m(warmup, steps), sum(m_by_view) / n_views
     res = {
         "value": n * steps * world * vps / dt, "ms_per_step": 1e3 * dt / steps, "steps": steps, "warmup": warmup,
         "config": {"workload": f"{name}: {n} Gaussians (5:1 anisotropic, scale 0.004, opacity "
                                f"{'U(0.05,0.9)' if spread else '0.08'}), {n_views} views @{w}x{h}, {poses}, "
                                f"synthetic wireframe edge maps, loss whole/bg_edge_ratio 4:1",
                    "n_gaussians": n, "views": n_views, "width": w, "height": h, "lr_scale": LR_SCALE, "poses": poses,
-                   "tile_intersections_M": m_last, "largest_tile_population": int(tr.max_tile_seen),
+                   "tile_intersections_M": m_timed, "tile_intersections_M_is": "mean over the views of the timed window (this rank's)",
+                   "tile_intersections_M_all_views": m_all, "tile_intersections_M_last_view": m_last, "tile_intersections_M_min_max": [min(m_by_view), max(m_by_view)],
+                   "largest_tile_population": int(tr.max_tile_seen),
                    "views_per_step": world * vps,
                    "gaussian_row_order": "morton" if tr.spatial_order else "as given",
                    "binning": "segmented" if tr.segmented else "scan",
@@ -548,15 +565,19 @@ def measure(name, args, device, rank, world, backend, spread=False, steps=None, 
         barrier()
         tr.pop_loss()
         if rank == 0:
-            ab = algorithmic_bytes(n, m_last, w * h)
+            m_stage = mean_m(warmup + steps, k)   # the views of THIS window
+            ab = algorithmic_bytes(n, m_stage, w * h)
+            ab_all = algorithmic_bytes(n, m_all, w * h)  # ... and of a pass over all views (the kernel-trace pass)
             if tr.segmented:  # projection and key emission are one kernel; the emit stage is an empty pair of events
-                ab["project_bin"] += ab.pop("tile_emit")
+                for x in (ab, ab_all):
+                    x["project_bin"] += x.pop("tile_emit")
                 stage_us.pop("tile_emit", None)
             if dp is None and vps == 1 and chunk > 1 and tr.segmented:
                 # inside a native run of steps the projection of view k+1 rides in the last kernel of step k
                 key = "project_bwd_adam+next_project_bin"
                 stage_us[key] = stage_us.pop("project_bwd_adam") + stage_us.pop("project_bin")
-                ab[key] = ab.pop("project_bwd_adam") + ab.pop("project_bin")
+                for x in (ab, ab_all):
+                    x[key] = x.pop("project_bwd_adam") + x.pop("project_bin")
             # the wave-autonomous forward resolves the exact stop inside the one kernel: the re-walk stage's pair of
             # events brackets NOTHING -- what it measures is what a pair of event records costs on this queue
             wave_fwd = tr.segmented and os.environ.get("EG_FWD_OLD", "0") in ("", "0")
@@ -569,14 +590,16 @@ def measure(name, args, device, rank, world, backend, spread=False, steps=None, 
             res["roofline"] = {"bound": "hbm", "kernel": dom, "kernel_symbol": symbol, "achieved": achieved,
                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                                "algorithmic_bytes_per_launch": ab[dom], "avg_launch_us": stage_us[dom],
+                               "algorithmic_bytes_M": m_stage, "algorithmic_bytes_per_launch_all_views": ab_all[dom],
+                               "algorithmic_bytes_M_all_views": m_all,
                                # HIP events on the launch stream; an event pair with nothing in between reads this
                                # many us here, part of which hides under a kernel: rocprofv3's kernel-trace average of
                                # the same command (profiles/) is ~2.5 us below avg_launch_us
                                "hip_event_empty_pair_us": empty_pair}
             res["stages_us"] = stage_us
-            res["step_roofline"] = {"algorithmic_bytes_per_step": ab["step_total"],
-                                    "achieved_GBps": ab["step_total"] / (dt / steps) / 1e9,
-                                    "frac": ab["step_total"] / (dt / steps) / 1e9 / HBM_PEAK_GBS}
+            ab_t = algorithmic_bytes(n, m_timed, w * h)["step_total"]  # (the contract window's own views)
+            res["step_roofline"] = {"algorithmic_bytes_per_step": ab_t, "achieved_GBps": ab_t / (dt / steps) / 1e9,
+                                    "frac": ab_t / (dt / steps) / 1e9 / HBM_PEAK_GBS}
     res["_scene"] = sc
     return res
 
@@ -838,6 +861,10 @@ def main():
         rf["avg_launch_us_hip_events"] = rf["avg_launch_us"]
         if kt and rf.get("kernel_symbol") in kt:
             rf["avg_launch_us"] = kt[rf["kernel_symbol"]]
+            # (that pass launches the kernel on every view of the scene in turn: the bytes of the mean M over all views)
+            rf["algorithmic_bytes_per_launch_hip_events_window"] = rf["algorithmic_bytes_per_launch"]
+            rf["algorithmic_bytes_per_launch"] = rf.pop("algorithmic_bytes_per_launch_all_views")
+            rf["algorithmic_bytes_M"] = rf.pop("algorithmic_bytes_M_all_views")
             rf["achieved"] = rf["algorithmic_bytes_per_launch"] / (rf["avg_launch_us"] * 1e-6) / 1e9
             rf["frac"] = rf["achieved"] / HBM_PEAK_GBS
             rf["avg_launch_us_source"] = ktsrc
@@ -860,8 +887,10 @@ def main():
                                        (f"{args.config}_4_views_per_step", args.config, args.spread_opacity, 4)):
             if name == args.config and spread == args.spread_opacity and vps == args.views_per_step:
                 continue
+            # (siblings, not the contract window: never shorter than 200 steps whatever --steps says -- a 20-step window
+            # of config 1 lasts under a millisecond and read 15 % slow on the driver's box)
             r = measure(name, args, device, rank, world, backend, spread=spread, vps=vps,
-                        steps=max(args.steps // vps, 20), warmup=max(args.warmup // vps, 5))
+                        steps=max(args.steps, 200) // vps, warmup=max(args.warmup // vps, 5))
             r.pop("_scene")
             r["unit"] = "Gaussians*views/s"
             extra[key] = r

@@ -1130,33 +1130,48 @@ struct Moments {
   float w_x, w_y, w_xx, w_xy, w_yy, abs_x, abs_y, v_o;
 };
 
-// One cell of a footprint as the walk carries it from the prefetch to the visit: the pixel's record (all zeros: nothing
-// to visit) and the offset of the Gaussian's centre from the pixel's.
+// One PAIR of horizontally adjacent cells of a footprint as the walk carries it from the prefetch to the visit: the two
+// pixels' records (all zeros: nothing to visit) and the offset of the Gaussian's centre from the LEFT pixel's (the right
+// pixel's is one less in x).
 constexpr unsigned kOutOfImage = 0x80000000u;  // a byte offset no gtstop image reaches (launch_footprint_bwd checks)
-struct Cell {
-  float gT;
-  unsigned stop_id, stop_depth;  // the pixel's last contributor, all ones if its walk did not stop
+typedef unsigned u32x3 __attribute__((ext_vector_type(3)));
+struct Pair {
+  u32x3 rec0, rec1;  // {gT bits, stop id, stop depth bits}: the pixel's last contributor, all ones if its walk did not stop
   float dx, dy;
 };
 
-__device__ __forceinline__ void footprint_visit(const float4 s0, const float4 s1, float thr, unsigned g, unsigned dg,
-                                                const Cell c, Moments &m) {
-  // One branch on the whole acceptance test (whole waves fall outside on large footprints), none after it:
-  // the lanes of a wave sit in up to eight footprints, accepted and rejected pixels are mixed, and
-  // further branching only adds exec-mask bookkeeping.
-  const float gT = c.gT, dx = c.dx, dy = c.dy;
-  const float sigma = 0.5f * (s0.z * dx * dx + s1.x * dy * dy) + s0.w * dx * dy;
-  // where the walk of this pixel stopped only Gaussians at or before the last contributor count:
-  // (depth bits, id) <= (its depth bits, its id): the borrow of a two-word subtraction (the record's words stay in
-  // the registers the prefetch loaded them into: composing a 64-bit value made the compiler copy them out right
-  // behind the load, waiting for it).  Tested before the exp: in dense scenes most visits of a saturated pixel are
-  // behind its stop.
-  unsigned b0, b1;
-  (void)__builtin_subc(c.stop_id, g, 0u, &b0);
-  (void)__builtin_subc(c.stop_depth, dg, b0, &b1);
-  if (!(gT != 0.f && sigma >= 0.f && sigma <= thr) || b1) return;
-  const float vis = __expf(-sigma);
-  const float araw = s1.y * vis;
+// The quadratic form of a Gaussian as a visit uses it (round 5): sigma log2(e) = dx hx + dy hy with the HALF gradients
+// hx = A dx + B dy, hy = B dx + C dy -- six operations give sigma and both components of d sigma / d (dx, dy), which the
+// absgrad sums need anyway (|dL/dmean2d| of one pixel = |w| |a dx + b dy|, |w| |b dx + c dy|): the accepted part of a
+// visit no longer forms a wx + b wy, b wx + c wy (six operations, now two), the exponential takes sigma log2(e) as it
+// is, and the sums of |w| |h| are scaled by 2 / log2(e) once per lane.  One step to the right (dx - 1) takes A off hx
+// and B off hy: the pair's second cell costs four operations.
+struct Quad {
+  float A, B, C;  // log2(e) / 2 * (a, b, c)
+  float thr2;     // log2(e) * sigma threshold (> 0)
+  float o;        // opacity
+};
+constexpr float kLog2e = 1.44269504088896341f;
+
+__device__ __forceinline__ void footprint_cell(const Quad qd, unsigned g, unsigned dg, const u32x3 rec, float s2, float hx,
+                                               float hy, float dx, float dy, Moments &m) {
+  // One branch on the whole acceptance test (whole waves fall outside on large footprints, and on the steps whose
+  // weight map is sparse), none after it: the lanes of a wave sit in up to eight footprints, accepted and rejected
+  // pixels are mixed, and further branching only adds exec-mask bookkeeping.  The compares are what costs here (a
+  // v_cmp takes the vector pipe ~1.5x as long as a multiply-add, tools/microbench): four of them --
+  //   0 <= s2 <= thr2 as ONE unsigned compare of the bit patterns (a negative or NaN s2 has a pattern above any
+  //   positive float's; s2 = -0 cannot arise: dx hx and dy hy would both have to be -0);
+  //   where the walk of this pixel stopped only Gaussians at or before its last contributor count, (depth bits, id) <=
+  //   (its depth bits, its id): "in front by depth" is one compare, the tie (the last contributor itself, or a twin at
+  //   the very same depth) is looked at under a wave-uniform branch that is rarely taken.
+  const float gT = __uint_as_float(rec.x);
+  const bool in = __float_as_uint(s2) <= __float_as_uint(qd.thr2);
+  bool counts = rec.z > dg;
+  const bool tie = rec.z == dg;
+  if (__builtin_amdgcn_ballot_w64(tie) != 0ull) counts |= tie & (rec.y >= g);
+  if (!(gT != 0.f && in && counts)) return;
+  const float vis = __builtin_amdgcn_exp2f(-s2);
+  const float araw = qd.o * vis;
   // forward: skip if min(0.999, araw) < 1/255; gsplat's backward: no gradient through a clamped alpha
   const bool ok = (araw >= kAlphaMin) & (araw <= kAlphaMax);
   const float v_alpha = ok ? gT * __builtin_amdgcn_rcpf(1.f - araw) : 0.f;
@@ -1165,79 +1180,91 @@ __device__ __forceinline__ void footprint_visit(const float4 s0, const float4 s1
   const float wx = w * dx, wy = w * dy;
   m.w_x += wx; m.w_y += wy;
   m.w_xx += wx * dx; m.w_xy += wx * dy; m.w_yy += wy * dy;
-  m.abs_x += fabsf(s0.z * wx + s0.w * wy);
-  m.abs_y += fabsf(s0.w * wx + s1.x * wy);
+  m.abs_x = fmaf(fabsf(w), fabsf(hx), m.abs_x);
+  m.abs_y = fmaf(fabsf(w), fabsf(hy), m.abs_y);
 }
 
-// Lane r of n walks cells r, r + n, r + 2n, ... of Gaussian g's sheared box as two interleaved streams
-// (r, r + 2n, ... and r + n, r + 3n, ...: two independent gathers in flight per lane); the records of
-// the NEXT pair are prefetched while this one is evaluated.  The loop body is written out twice with the two
-// register sets swapping roles (a rotating copy cost ten moves per pair of visits), and the prefetch is
-// unconditional: a cell with nothing to visit reads pixel 0's record and is marked by its column.
-__device__ __forceinline__ void footprint_walk(const float4 s0, const float4 s1, int g, int r, int n, int i0,
-                                               int pw, int cells, int jlo, int jhi, float thr, float xoff,
-                                               float shear, int width, const __amdgpu_buffer_rsrc_t gtstop,
-                                               const float4 *__restrict__ splat, Moments &m) {
-  const float inv_pw = __builtin_amdgcn_rcpf((float)pw);
-  // cell -> (row, column) offsets; the quotient estimate is exact for cells < 2^21, the fix-up is free
+__device__ __forceinline__ void footprint_visit(const Quad qd, unsigned g, unsigned dg, const Pair c, Moments &m) {
+  const float dx = c.dx, dy = c.dy;
+  const float hx = fmaf(qd.A, dx, qd.B * dy);
+  const float hy = fmaf(qd.C, dy, qd.B * dx);
+  const float s2 = fmaf(dx, hx, dy * hy);  // sigma log2(e)
+  const float dx1 = dx - 1.f, hx1 = hx - qd.A, hy1 = hy - qd.B;
+  const float s21 = fmaf(dx1, hx1, dy * hy1);
+  footprint_cell(qd, g, dg, c.rec0, s2, hx, hy, dx, dy, m);
+  footprint_cell(qd, g, dg, c.rec1, s21, hx1, hy1, dx1, dy, m);
+}
+
+// Lane r of n walks the PAIRS r, r + n, r + 2n, ... of Gaussian g's sheared box (its rows are cut into
+// ceil(pw / 2) pairs of neighbouring cells; the odd cell out of an odd row's last pair lies outside the box, hence
+// outside the ellipse: its own sigma test rejects it).  What a visit has to know about where it is -- row, first column
+// of the row, the clip, the byte offset -- is worked out once per pair (round 5: it was once per cell, and together with
+// the compares of the accept test it, not the accepted part, was where this kernel's time went: with the accepted part
+// compiled out the launch at 1600 x 1200 took 152 of 174 us, with the loads compiled out as well 146); the two
+// records of a pair are 24 contiguous bytes.  The records of the NEXT pair are prefetched while this one is evaluated;
+// the loop body is written out twice with the two register sets swapping roles (a rotating copy cost ten moves per pair
+// of visits), and the prefetch is unconditional: a cell with nothing to visit asks for an offset beyond the image.
+__device__ __forceinline__ void footprint_walk(const float4 s0, const float4 s1, int g, int r, int n, int i0, int fh,
+                                               int pw, int jlo, int jhi, float thr, float xoff,
+                                               float shear, int width, const __amdgpu_buffer_rsrc_t gtstop, Moments &m) {
+  const int ppr = (pw + 1) >> 1;  // pairs per row
+  const float inv_ppr = __builtin_amdgcn_rcpf((float)ppr);
+  // pair -> (row, pair in the row); the quotient estimate is exact for pairs < 2^21, the fix-up is free
   auto divmod = [&](int q, int &qi, int &qj) {
-    qi = (int)(((float)q + 0.5f) * inv_pw);
-    qj = q - __mul24(qi, pw);
-    if (qj < 0) { qj += pw; --qi; }
-    if (qj >= pw) { qj -= pw; ++qi; }
+    qi = (int)(((float)q + 0.5f) * inv_ppr);
+    qj = q - __mul24(qi, ppr);
+    if (qj < 0) { qj += ppr; --qi; }
+    if (qj >= ppr) { qj -= ppr; ++qi; }
   };
   const int width12 = width * (int)sizeof(StopRec);
   // (centre - 0.5 once per Gaussian: the pixel centres are at integer + 0.5)
   const float xc = s0.x - 0.5f, yc = s0.y - 0.5f;
-  // The record comes through a buffer load: a 32-bit byte offset on the uniform descriptor (two full-rate 24-bit
+  // The records come through buffer loads: a 32-bit byte offset on the uniform descriptor (two full-rate 24-bit
   // multiply-adds and the load's own address adder instead of a quarter-rate 64-bit multiply-add per visit), and a
-  // cell with nothing to visit -- past the stream's end or outside the column clip -- asks for an offset beyond the
-  // image: the hardware's range check returns zeros without touching memory, and gT == 0 is "skip".
-  typedef unsigned u32x3 __attribute__((ext_vector_type(3)));
-  auto fetch = [&](int i, int c, bool live) -> Cell {
-    Cell r;
-    r.dy = yc - (float)i;
-    const int j = (int)ceilf(xoff + shear * r.dy) + c;
-    const bool ok = live & (j >= jlo) & (j <= jhi);
-    const unsigned off = ok ? (unsigned)(__mul24(i, width12) + __mul24(j, 12)) : kOutOfImage;
-    const u32x3 t = __builtin_amdgcn_raw_buffer_load_b96(gtstop, (int)off, 0, 0);
-    r.gT = __uint_as_float(t.x);
-    r.stop_id = t.y;
-    r.stop_depth = t.z;
-    r.dx = xc - (float)j;
-    return r;
+  // cell with nothing to visit -- past the lane's last pair or outside the column clip -- asks for an offset beyond the
+  // image: the hardware's range check returns zeros without touching memory, and gT == 0 is "skip".  "Nothing to
+  // visit" is the sign bit of (j - jlo) | (jhi - j) | (pairs left - 1), moved into the offset's top bit: no compare.
+  auto fetch = [&](int i, int cp, int live1) -> Pair {
+    Pair p;
+    p.dy = yc - (float)i;
+    const int j = (int)ceilf(xoff + shear * p.dy) + 2 * cp;
+    const int t1 = j - jlo, t2 = jhi - j;
+    const unsigned bad0 = (unsigned)(t1 | t2 | live1) & kOutOfImage;
+    const unsigned bad1 = (unsigned)((t1 + 1) | (t2 - 1) | live1) & kOutOfImage;
+    const unsigned base = (unsigned)(__mul24(i, width12) + __mul24(j, 12));
+    p.rec0 = __builtin_amdgcn_raw_buffer_load_b96(gtstop, (int)(bad0 | base), 0, 0);
+    p.rec1 = __builtin_amdgcn_raw_buffer_load_b96(gtstop, (int)(bad1 | (base + 12u)), 0, 0);
+    p.dx = xc - (float)j;
+    return p;
   };
   const unsigned ug = (unsigned)g, dg = (unsigned)__float_as_int(s1.z);
+  const Quad qd = {0.5f * kLog2e * s0.z, 0.5f * kLog2e * s0.w, 0.5f * kLog2e * s1.x, kLog2e * thr, s1.y};
   int di, dc;
-  divmod(2 * n, di, dc);
-  int ia, ca, ib, cb;
+  divmod(n, di, dc);
+  int ia, ca;
   divmod(r, ia, ca);
-  divmod(r + n, ib, cb);
-  ia += i0; ib += i0;
-  int left = cells - r;  // > 0 while stream a still has a visit (stream b: left - n)
+  ia += i0;
+  int left = __mul24(fh, ppr) - r;  // > 0 while the lane still has a pair
   auto advance = [&]() {
-    left -= 2 * n;
-    ia += di; ca += dc;
-    if (ca >= pw) { ca -= pw; ++ia; }
-    ib += di; cb += dc;
-    if (cb >= pw) { cb -= pw; ++ib; }
+    left -= n;
+    // (the carry without a compare: t = c + dc - ppr, its sign mask is -1 for "no carry")
+    const int t = ca + dc - ppr, sm = t >> 31;
+    ca = t + (ppr & sm);
+    ia += di + 1 + sm;
   };
-  Cell a0 = fetch(ia, ca, left > 0), b0 = fetch(ib, cb, left - n > 0);
+  Pair p0 = fetch(ia, ca, left - 1);
   while (left > 0) {
     advance();
-    const Cell a1 = fetch(ia, ca, left > 0), b1 = fetch(ib, cb, left - n > 0);
-    footprint_visit(s0, s1, thr, ug, dg, a0, m);
-    footprint_visit(s0, s1, thr, ug, dg, b0, m);  // an exhausted stream holds an unvisitable cell
+    const Pair p1 = fetch(ia, ca, left - 1);
+    footprint_visit(qd, ug, dg, p0, m);
     if (left <= 0) break;
     advance();
-    a0 = fetch(ia, ca, left > 0);
-    b0 = fetch(ib, cb, left - n > 0);
-    footprint_visit(s0, s1, thr, ug, dg, a1, m);
-    footprint_visit(s0, s1, thr, ug, dg, b1, m);
+    p0 = fetch(ia, ca, left - 1);
+    footprint_visit(qd, ug, dg, p1, m);
   }
 }
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8)))
 footprint_bwd_kernel(const float4 *__restrict__ splat, int N, int width, int height,
                      const StopRec *__restrict__ gtstop, float *__restrict__ g2d, const Batch bt,
                      float *__restrict__ loss_part, float *__restrict__ loss_out) {
@@ -1307,13 +1334,15 @@ footprint_bwd_kernel(const float4 *__restrict__ splat, int N, int width, int hei
     const int cells = r < n ? __shfl(h.cells, src, 64) : 0;
     s0 = splat[2 * g];
     s1 = splat[2 * g + 1];
-    footprint_walk(s0, s1, g, r, n, __shfl(h.i0, src, 64), max(__shfl(h.pw, src, 64), 1), cells,
-                   __shfl(h.jlo, src, 64), __shfl(h.jhi, src, 64), __shfl(h.thr, src, 64),
-                   __shfl(h.xoff, src, 64), __shfl(h.shear, src, 64), width, rec_rsrc, splat, m);
+    footprint_walk(s0, s1, g, r, n, __shfl(h.i0, src, 64), cells > 0 ? __shfl(h.fh, src, 64) : 0,
+                   max(__shfl(h.pw, src, 64), 1), __shfl(h.jlo, src, 64), __shfl(h.jhi, src, 64), __shfl(h.thr, src, 64),
+                   __shfl(h.xoff, src, 64), __shfl(h.shear, src, 64), width, rec_rsrc, m);
   }
   // partial g2d record of this lane: vx vy |vx| |vy| va vb vc vo
   float *mine = &red[wv][lane * 8];
-  *(float4 *)mine = make_float4(s0.z * m.w_x + s0.w * m.w_y, s0.w * m.w_x + s1.x * m.w_y, m.abs_x, m.abs_y);
+  // (the absgrad sums were taken over |w| |h|, h = log2(e) / 2 times the gradient of sigma: footprint_visit)
+  *(float4 *)mine = make_float4(s0.z * m.w_x + s0.w * m.w_y, s0.w * m.w_x + s1.x * m.w_y, (2.f / kLog2e) * m.abs_x,
+                                (2.f / kLog2e) * m.abs_y);
   *(float4 *)(mine + 4) = make_float4(0.5f * m.w_xx, m.w_xy, 0.5f * m.w_yy, m.v_o);
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();

@@ -447,37 +447,9 @@ def test_grad_step_equals_autograd_path(env, segmented):
 
 
 def _grad_step_vs_torch_oracle(env, sc, view, label, strategy="whole"):
-    """fused eg_train_step (no Adam) against the dense PyTorch oracle's AUTOGRAD (a backward derived
-    independently of every hand-written one) on the same inputs; 1e-4 on every element."""
-    _lib, synth, O = env
-    from edgegaussians_amd import EdgeTrainer
-    sc, fw, border, w, removed = strict_inputs(sc, view, strategy)
-    N = sc.means.shape[0]
-    tr = EdgeTrainer(sc.means, sc.log_scales, sc.quats, sc.logit_opacities, sc.viewmats, sc.Ks, sc.gt,
-                     sc.width, sc.height)
-    tr.ensure_capacity()
-    tr.grad_step(view, w.cuda())
-    got = [t.clone().cpu() for t in tr.grad_views()] + [tr.grads.view(-1)[11 * N:].clone().cpu()]
-    loss_g = tr.pop_loss()
-    assert not tr.overflowed()
-    p = [t.clone().requires_grad_(True) for t in (sc.means, sc.quats, sc.log_scales, sc.logit_opacities)]
-    render, alpha, info = O.rasterization(
-        means=p[0], quats=p[1], scales=torch.exp(p[2]), opacities=torch.sigmoid(p[3]).squeeze(-1),
-        colors=torch.ones(N, 3), viewmats=sc.viewmats[view:view + 1], Ks=sc.Ks[view:view + 1], width=sc.width,
-        height=sc.height, packed=False, absgrad=True, rasterize_mode="antialiased")
-    info["means2d"].retain_grad()
-    loss = O.edge_step_loss(render[0, ..., 0], sc.gt[view], w)
-    loss.backward()
-    assert abs(loss_g - float(loss)) <= 1e-4 * abs(float(loss)), (loss_g, float(loss))
-    want = [p[0].grad, p[1].grad, p[2].grad, p[3].grad.view(-1), info["means2d"].absgrad[0].norm(dim=-1)]
-    stopped = float((alpha > 1 - 1.1e-4).float().mean())
-    names = ("means", "quats", "scales", "opac", "absgrad")
-    errs = {k: rel_err(a, b) for a, b, k in zip(got, want, names)}
-    record("fused_grad_step_vs_torch_oracle", scene=label, removed_borderline_gaussians=removed,
-           borderline_pixels=int(border.sum()), pixels=int(border.numel()), stopped_pixel_frac=stopped, max_rel_err=errs)
-    for a, b, k in zip(got, want, names):
-        assert_close(a, b, rtol=1e-4, name=f"{label} {k}")
-    return stopped
+    """fused eg_train_step (no Adam) against the dense PyTorch oracle's AUTOGRAD (tests/util.py)."""
+    from tests.util import check_grad_step_vs_torch_oracle
+    return check_grad_step_vs_torch_oracle(sc, view, label, strategy)
 
 
 def test_fused_backward_big_footprints(env):
@@ -1586,6 +1558,15 @@ def test_bench_line_contract(env):
     assert d["config"]["forward_mode"].startswith(("speculative", "chained")) and "opacity" in d["config"]["workload"]
     # round 4: a window of fewer than 200 steps says so on the line
     assert "warning" in d and "--steps 20" in d["warning"]
+    # round 5: M on the line is a MEAN over the views a measurement covered (the last view's M moved frac by 10 % from run
+    # to run), and the roofline's algorithmic bytes follow from the M they name
+    cfg = d["config"]
+    lo, hi = cfg["tile_intersections_M_min_max"]
+    assert lo <= cfg["tile_intersections_M"] <= hi and lo <= cfg["tile_intersections_M_all_views"] <= hi and lo < hi
+    assert lo <= rf["algorithmic_bytes_M"] <= hi
+    if rf["kernel"] == "composite_slice_fwd":
+        assert abs(rf["algorithmic_bytes_per_launch"] - (28 * rf["algorithmic_bytes_M"] + 20 * cfg["width"] * cfg["height"])) < 1.0
+    assert abs(rf["achieved"] - rf["algorithmic_bytes_per_launch"] / (rf["avg_launch_us"] * 1e-6) / 1e9) <= 1e-6 * rf["achieved"]
 
 
 def test_bench_launches_its_own_ranks(env):

@@ -32,6 +32,84 @@ def assert_close(a, b, rtol=1e-4, max_bad=0.0, name="", atol_floor=0.0):
     assert fb <= max_bad, f"{name}: {fb:.2e} of elements off by > {rtol} (allowed {max_bad}); norm-rel {rel_err(a, b):.3e}"
 
 
+def elementwise_report(a, b, floors=(1e-1, 1e-2, 1e-3)):
+    """The element-wise statement of the float tolerance (assert_close is a max-norm check --
+    |a - b| <= 1e-4 max|b| + 1e-4 |b| -- under which an element 100x below the maximum may be 1 % off).  For every floor f:
+    the largest and the 99.9th-percentile RELATIVE error |a - b| / |b| over the elements with |b| >= f max|b|, and their
+    number; below the smallest floor a histogram of the relative errors by decade (a sum of ~10^3 signed fp32 terms
+    that cancels to 1e-3 of the largest element has lost three digits in BOTH implementations: its relative error is
+    reported, not bounded)."""
+    a, b = to_np(a).astype(np.float64).reshape(-1), to_np(b).astype(np.float64).reshape(-1)
+    mx = max(np.abs(b).max() if b.size else 0.0, 1e-300)
+    rel = np.abs(a - b) / np.maximum(np.abs(b), 1e-300)
+    out = {"elements": int(b.size), "max_abs_ref": float(mx)}
+    for f in floors:
+        sel = np.abs(b) >= f * mx
+        r = rel[sel]
+        out[f"ge_{f:g}"] = {"n": int(sel.sum()), "max_rel": float(r.max()) if r.size else 0.0,
+                            "p999_rel": float(np.quantile(r, 0.999)) if r.size else 0.0}
+    tail = rel[(np.abs(b) < min(floors) * mx) & (b != 0)]
+    edges = [0.0, 1e-6, 1e-5, 1e-4, 1e-3, 1e-2, 1e-1, np.inf]
+    out["tail_below_smallest_floor"] = {"n": int(tail.size), "hist_rel_err_decades_from_1e-6": np.histogram(tail, bins=edges)[0].tolist()}
+    nz = int(((b == 0) & (a != 0)).sum())
+    out["nonzero_where_ref_is_zero"] = nz
+    return out
+
+
+# element-wise relative bound asserted on every gradient element with |ref| >= 1e-3 max|ref| (tests/util.py:
+# elementwise_report; measured values in profiles/r05_parity_report.jsonl)
+ELEMENTWISE_FLOOR = 1e-3
+ELEMENTWISE_RTOL = float(__import__("os").environ.get("EG_ELEMENTWISE_RTOL", "1e-3"))
+
+
+def assert_elementwise(got, ref, keys, label, rtol=None):
+    rtol = ELEMENTWISE_RTOL if rtol is None else rtol
+    rep = {k: elementwise_report(got[k], ref[k]) for k in keys}
+    worst = {k: rep[k][f"ge_{ELEMENTWISE_FLOOR:g}"]["max_rel"] for k in keys}
+    for k in keys:
+        assert worst[k] <= rtol, (f"{label} grad {k}: element-wise relative error {worst[k]:.3e} > {rtol} on an element with "
+                                  f"|ref| >= {ELEMENTWISE_FLOOR} max|ref|")
+    return rep
+
+
+def check_grad_step_vs_torch_oracle(sc, view, label, strategy="whole", clean=True):
+    """fused eg_train_step (no Adam) against the dense PyTorch oracle's AUTOGRAD -- a backward derived independently of
+    every hand-written one (the C oracle's backward is hand-derived like the HIP kernels') -- on the same inputs; 1e-4
+    on every element in the norm-wise sense, the element-wise bound of assert_elementwise next to it.  Any size the
+    tile-chunked oracle holds in memory (30 k Gaussians @512x512: ~3 s and 2.4 GB on CPU).  Returns the stopped share."""
+    from edgegaussians_amd import EdgeTrainer
+    from oracle import ref_torch as O
+    sc, fw, border, w, removed = strict_inputs(sc, view, strategy)
+    N = sc.means.shape[0]
+    tr = EdgeTrainer(sc.means, sc.log_scales, sc.quats, sc.logit_opacities, sc.viewmats, sc.Ks, sc.gt,
+                     sc.width, sc.height)
+    tr.ensure_capacity(views=[view])
+    tr.grad_step(view, w.cuda())
+    names = ("means", "quats", "scales", "opac", "absgrad")
+    got = dict(zip(names, [t.clone().cpu() for t in tr.grad_views()] + [tr.grads.view(-1)[11 * N:].clone().cpu()]))
+    loss_g = tr.pop_loss()
+    assert not tr.overflowed()
+    p = [t.clone().requires_grad_(True) for t in (sc.means, sc.quats, sc.log_scales, sc.logit_opacities)]
+    render, alpha, info = O.rasterization(
+        means=p[0], quats=p[1], scales=torch.exp(p[2]), opacities=torch.sigmoid(p[3]).squeeze(-1),
+        colors=torch.ones(N, 3), viewmats=sc.viewmats[view:view + 1], Ks=sc.Ks[view:view + 1], width=sc.width,
+        height=sc.height, packed=False, absgrad=True, rasterize_mode="antialiased")
+    info["means2d"].retain_grad()
+    loss = O.edge_step_loss(render[0, ..., 0], sc.gt[view], w)
+    loss.backward()
+    assert abs(loss_g - float(loss)) <= 1e-4 * abs(float(loss)), (loss_g, float(loss))
+    want = dict(zip(names, [p[0].grad, p[1].grad, p[2].grad, p[3].grad.view(-1), info["means2d"].absgrad[0].norm(dim=-1)]))
+    stopped = float((alpha.detach() > 1 - 1.1e-4).float().mean())
+    errs = {k: rel_err(got[k], want[k]) for k in names}
+    for k in names:
+        assert_close(got[k], want[k], rtol=1e-4, name=f"{label} {k}")
+    rep = assert_elementwise(got, want, names, label)
+    record("fused_grad_step_vs_torch_oracle", scene=label, gaussians=N, removed_borderline_gaussians=removed,
+           borderline_pixels=int(border.sum()), pixels=int(border.numel()), stopped_pixel_frac=stopped, max_rel_err=errs,
+           elementwise=rep)
+    return stopped
+
+
 def filter_fixture(golden_dir):
     """Inputs of the reference's filter_by_projection run (tests/golden/make_golden.py:filter_projection):
     means, float edge images (DexiNed / 255) and the camera dicts of filtering.py:42-56."""
@@ -167,7 +245,9 @@ def check_fused_step_vs_c_oracle(sc, view, strategy, label, trainer_kwargs=None,
     n0 = sc.means.shape[0]
     sc, fw, border, w, removed = strict_inputs(sc, view, strategy)
     N, W, H = sc.means.shape[0], sc.width, sc.height
-    assert removed <= max(3, 0.02 * n0) and float(border.float().mean()) < 0.03, (removed, n0)
+    # (caps at 2x the largest sets measured over the sizes and seeds of profiles/r04_parity_report.jsonl: 0.8 % of the
+    # Gaussians, 0.3 % of the pixels)
+    assert removed <= max(3, 0.016 * n0) and float(border.float().mean()) < 0.006, (removed, n0, float(border.float().mean()))
     loss_o, ref = oracle_raw_grads(sc, fw, w, view)
     sched = LRSchedule(scales_start=0, quats_start=0, opacities_start=0)
     tr = EdgeTrainer(sc.means, sc.log_scales, sc.quats, sc.logit_opacities, sc.viewmats, sc.Ks, sc.gt, W, H,
@@ -189,6 +269,9 @@ def check_fused_step_vs_c_oracle(sc, view, strategy, label, trainer_kwargs=None,
            stopped_pixel_frac=float((torch.from_numpy(fw["alphas"]) > 1 - 1.1e-4).float().mean()))
     for k in keys:
         assert_close(got[k], ref[k], rtol=1e-4, name=f"{label} grad {k}")
+    # ... and element-wise (round 5): every gradient element with |ref| >= 1e-3 max|ref|, the tail below it as a histogram
+    record("fused_grad_step_vs_c_oracle_elementwise", size=label, gaussians=N, floor=ELEMENTWISE_FLOOR, rtol=ELEMENTWISE_RTOL,
+           elementwise=assert_elementwise(got, ref, keys, label))
     if not whole_step:
         return tr, sc, w
     # ---- one whole fused step (forward + loss + backward + absgrad + Adam) against ego_train_step
