@@ -1097,7 +1097,8 @@ __device__ __forceinline__ Walk walk_of(const float4 s0, const float4 s1, int wi
   w.jhi = -1;
   w.thr = w.xoff = w.shear = 0.f;
   const int radius = __float_as_int(s1.w);
-  const float thr = __logf(255.f * s1.y) + kThrMargin;
+  // (the raw v_log_f32: 255 o >= 1 wherever the result is used, no denormal scaling needed; 1 ulp, inside the margin)
+  const float thr = 0.693147180559945f * __builtin_amdgcn_logf(255.f * s1.y) + kThrMargin;
   const float det = s0.z * s1.x - s0.w * s0.w;
   if (radius <= 0 || !(thr > 0.f) || !(det > 0.f) || !(s0.z > 0.f)) return w;
   const int tw = (width + kTile - 1) / kTile, th = (height + kTile - 1) / kTile;
@@ -1150,6 +1151,7 @@ struct Quad {
   float A, B, C;  // log2(e) / 2 * (a, b, c)
   float thr2;     // log2(e) * sigma threshold (> 0)
   float o;        // opacity
+  bool high_o;    // (wave-uniform) some lane of the wave walks a Gaussian of opacity > 0.999
 };
 constexpr float kLog2e = 1.44269504088896341f;
 
@@ -1168,12 +1170,20 @@ __device__ __forceinline__ void footprint_cell(const Quad qd, unsigned g, unsign
   const bool in = __float_as_uint(s2) <= __float_as_uint(qd.thr2);
   bool counts = rec.z > dg;
   const bool tie = rec.z == dg;
-  if (__builtin_amdgcn_ballot_w64(tie) != 0ull) counts |= tie & (rec.y >= g);
+  if (__builtin_amdgcn_ballot_w64(tie) != 0ull) {
+    asm volatile("" ::: "memory");  // (a real branch: if-converted, the id compare would run on every visit)
+    counts |= tie & (rec.y >= g);
+  }
   if (!(gT != 0.f && in && counts)) return;
   const float vis = __builtin_amdgcn_exp2f(-s2);
   const float araw = qd.o * vis;
-  // forward: skip if min(0.999, araw) < 1/255; gsplat's backward: no gradient through a clamped alpha
-  const bool ok = (araw >= kAlphaMin) & (araw <= kAlphaMax);
+  // forward: skip if min(0.999, araw) < 1/255; gsplat's backward: no gradient through a clamped alpha (araw <= o:
+  // only a wave that holds a Gaussian of opacity above 0.999 has to look)
+  bool ok = araw >= kAlphaMin;
+  if (qd.high_o) {
+    asm volatile("" ::: "memory");
+    ok &= araw <= kAlphaMax;
+  }
   const float v_alpha = ok ? gT * __builtin_amdgcn_rcpf(1.f - araw) : 0.f;
   m.v_o += vis * v_alpha;
   const float w = -araw * v_alpha;
@@ -1238,7 +1248,8 @@ __device__ __forceinline__ void footprint_walk(const float4 s0, const float4 s1,
     return p;
   };
   const unsigned ug = (unsigned)g, dg = (unsigned)__float_as_int(s1.z);
-  const Quad qd = {0.5f * kLog2e * s0.z, 0.5f * kLog2e * s0.w, 0.5f * kLog2e * s1.x, kLog2e * thr, s1.y};
+  const Quad qd = {0.5f * kLog2e * s0.z, 0.5f * kLog2e * s0.w, 0.5f * kLog2e * s1.x, kLog2e * thr, s1.y,
+                   __builtin_amdgcn_ballot_w64(s1.y > kAlphaMax) != 0ull};
   int di, dc;
   divmod(n, di, dc);
   int ia, ca;
