@@ -629,7 +629,18 @@ def measure_scenes(name, args, device, S, steps=400, warmup=50, spread=False):
                 vs = [s % n_views for s in ss]
                 tr.train_steps(vs, [ratio(v) if s % 5 == 0 else whole for s, v in zip(ss, vs)])
 
+    native = getattr(args, "scenes_driver", "native") == "native"
+    n_threads = getattr(args, "scenes_threads", 0)
+
     def run_all(k, step0):
+        if native:  # ONE native call per chunk: K steps of every scene, round-robin over the S streams (eg_train_steps_multi)
+            from edgegaussians_amd import train_steps_multi
+            for s0 in range(step0, step0 + k, chunk):
+                ss = range(s0, min(s0 + chunk, step0 + k))
+                vs = [s % n_views for s in ss]
+                train_steps_multi([t[0] for t in trs], [vs] * S,
+                                  [[t[2](v) if s % 5 == 0 else t[1] for s, v in zip(ss, vs)] for t in trs], streams, n_threads)
+            return
         th = [threading.Thread(target=drive, args=(i, k, step0)) for i in range(S)]
         for t in th:
             t.start()
@@ -657,8 +668,10 @@ def measure_scenes(name, args, device, S, steps=400, warmup=50, spread=False):
     return {"scenes_per_gpu": S, "value": n * steps * S / dt, "unit": "Gaussians*views/s", "ms_per_step_per_scene": 1e3 * dt / steps,
             "aggregate_us_per_scene_step": 1e6 * dt / (steps * S), "host_enqueue_ms_per_step": 1e3 * t_enq / steps,
             "steps": steps, "warmup": warmup,
+            "driver": (f"native: eg_train_steps_multi, {n_threads if n_threads > 0 else min(S, 8)} host thread(s) inside the call" if native
+                       else "one interpreter thread per scene, each calling eg_train_steps"),
             "config": {"workload": f"{S} x {name}: {n} Gaussians each (seeds {args.seed}..{args.seed + S - 1}), {n_views} views "
-                                   f"@{w}x{h}, one scene per HIP stream + host thread, no collective (BASELINE config 5 on one GPU)"}}
+                                   f"@{w}x{h}, one scene per HIP stream, no collective (BASELINE config 5 on one GPU)"}}
 
 
 def measure_operator(name, args, device, steps=200, warmup=30, adam="torch"):
@@ -778,6 +791,10 @@ def main():
     ap.add_argument("--path", default="fused", choices=["fused", "operator"],
                     help="operator: time the reference's per-step protocol through the gsplat.rasterization shim + torch "
                          "autograd + 4 torch Adam instead of the fused native step")
+    ap.add_argument("--scenes-driver", choices=["native", "threads"], default="native",
+                    help="--scenes-per-gpu: 'native' = one eg_train_steps_multi call per chunk (host threads inside the library), "
+                         "'threads' = one interpreter thread per scene calling eg_train_steps (round 4's driver)")
+    ap.add_argument("--scenes-threads", type=int, default=0, help="host threads inside eg_train_steps_multi (0: min(S, 8))")
     ap.add_argument("--scenes-per-gpu", type=int, default=0,
                     help="S > 0: S independent scenes side by side on this GPU (one stream + host thread each; BASELINE "
                          "config 5), aggregate throughput")

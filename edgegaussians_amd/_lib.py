@@ -111,6 +111,9 @@ _SIGS = {
     "eg_regulariser_step_fixed": [_i32] + [_vp] * 7 + [_i32, _vp, _i32, _i32, _i32, _i32, _vp, _f, _f, _vp, AdamHyper, _vp, _vp],
     "eg_train_step": [C.POINTER(StepArgs), _vp],
     "eg_train_steps": [C.POINTER(StepArgs), _i32, C.POINTER(_i32), C.POINTER(_vp), _vp, _vp, _vp, _vp],
+    # (S scenes: arrays of S pointers -- args, views [K], weight-map tables [K], viewmats, Ks, gts, streams -- + n_threads)
+    "eg_train_steps_multi": [_i32, C.POINTER(C.POINTER(StepArgs)), _i32, C.POINTER(C.POINTER(_i32)), C.POINTER(C.POINTER(_vp)),
+                             C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), _i32],
     "eg_operator_fwd": [C.POINTER(OperatorArgs), _vp],
     "eg_operator_bwd": [C.POINTER(OperatorArgs), _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "eg_train_steps_dp": [C.POINTER(StepArgs), C.POINTER(AdamHyper), _vp, _i32, C.POINTER(_i32), C.POINTER(_vp), _vp, _vp,

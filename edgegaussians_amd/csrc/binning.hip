@@ -277,6 +277,14 @@ __device__ __forceinline__ unsigned block_reduce_u32(unsigned v, bool take_max, 
 }
 
 constexpr int kMaxBucketFill = 96;  // beyond this a bucket's rank pass degenerates: use the network
+#ifndef EG_SORT_BM
+#define EG_SORT_BM 1
+#endif
+#ifndef EG_SORT_RANK_G
+#define EG_SORT_RANK_G 1
+#endif
+constexpr int kSortBM = EG_SORT_BM;          // buckets per thread of the bucket + rank sort
+constexpr int kSortRankG = EG_SORT_RANK_G;   // keys a thread ranks side by side (their LDS reads in flight together)
 
 // Segmented layout (eg_project_emit): tile t owns keys[t * seg_cap ...), its population sits in
 // cursor[t] and the first of its items (128-Gaussian slices) in item_first[t].  The small variant
@@ -327,6 +335,12 @@ struct SegTable {
   // wave slots at 500 k Gaussians; dispatched after every tile's front they find the dead word set and leave at once.
   const int *item_front = nullptr;
   int middle_out = 0;   // workgroup -> tile assignment of the small sort variant (see the kernel)
+#ifdef EG_SORT_PROF
+  // development builds (-DEG_SORT_PROF): [T][12] per-workgroup phase record of the small variant's last launch --
+  // {wall clock at start / end (100 MHz), n, shader-clock ticks of: loads, range barrier + prefix, histogram, scan,
+  // scatter, rank, store drain} (tools/sort_prof.py)
+  unsigned long long *prof = nullptr;
+#endif
 };
 constexpr int kFrontDefault = 4;  // class boundary of the dispatch order (slices); SegTable::slice_major carries it
 
@@ -358,12 +372,42 @@ tile_sort_kernel(unsigned long long *__restrict__ keys, const int *__restrict__ 
       if (seg.item_rec) seg.item_rec += bv * bt.items;
     }
   }
+  // NB = kSortBM buckets per thread: the rank pass costs a key one dependent LDS read per key of its bucket, so the
+  // fullest tile's workgroup -- which the kernel lasts as long as -- is shortened by thinner buckets
+  constexpr int BM = LARGE ? 1 : kSortBM;  // (the large variant is at the LDS limit)
+  constexpr int NB = THREADS * BM;
   unsigned long long *kout = s;      // [CAP] keys scattered by bucket (the fast path keeps its input in registers)
-  int *hist = (int *)(s + CAP);      // [THREADS] counts -> exclusive starts
-  int *cursor = hist + THREADS;      // [THREADS]
+  int *hist = (int *)(s + CAP);      // [NB] counts -> exclusive starts
+  int *cursor = hist + NB;           // [NB]
   __shared__ unsigned wave_tmp[32], wave_tmp2[32];  // two hops per tile, never the same array twice in a row
 
   const int tid = threadIdx.x;
+#ifdef EG_SORT_PROF
+  // (constant indices only: the record stays in registers; no wait of its own -- a tick reads the clock where the code
+  // has just waited anyway, behind a barrier or a reduction over loaded values)
+  unsigned prof_t[7] = {0u, 0u, 0u, 0u, 0u, 0u, 0u};
+  const unsigned long long prof_wall0 = __builtin_amdgcn_s_memrealtime();
+  long long prof_prev = (long long)__builtin_readcyclecounter();
+#define EG_SP_TICK(k_)                                                           \
+  do {                                                                           \
+    if (!LARGE) {                                                                \
+      const long long now_ = (long long)__builtin_readcyclecounter();            \
+      prof_t[k_] = (unsigned)(now_ - prof_prev);                                 \
+      prof_prev = now_;                                                          \
+    }                                                                            \
+  } while (0)
+#define EG_SP_DONE(n_)                                                           \
+  do {                                                                           \
+    if (!LARGE && seg.prof && tid == 0 && blockIdx.y == 0) {                     \
+      unsigned long long *r_ = seg.prof + (size_t)tile * 12;                     \
+      r_[0] = prof_wall0; r_[1] = __builtin_amdgcn_s_memrealtime(); r_[2] = (unsigned long long)(n_); \
+      r_[3] = prof_t[0]; r_[4] = prof_t[1]; r_[5] = prof_t[2]; r_[6] = prof_t[3]; r_[7] = prof_t[4]; r_[8] = prof_t[5]; r_[9] = prof_t[6]; \
+    }                                                                            \
+  } while (0)
+#else
+#define EG_SP_TICK(k_) do {} while (0)
+#define EG_SP_DONE(n_) do {} while (0)
+#endif
   // The large variant runs a small grid (<= 256 workgroups of 136 KiB LDS) over the tiles that outgrew the small one.
   // Round 4: every workgroup first FINDS them -- all its threads look at the T ranges at once and collect the oversized
   // tiles in LDS (sorted by tile index, so that all workgroups hold the same list) -- and then takes entries blockIdx.x,
@@ -539,6 +583,7 @@ tile_sort_kernel(unsigned long long *__restrict__ keys, const int *__restrict__ 
   const int n = (int)(end - start);
   if (n <= 0 || (LARGE ? (n <= small_cap) : (n > small_cap))) {  // empty, or the other variant owns this tile
     if (prefix_pending) { __syncthreads(); finish_prefix(n); }
+    EG_SP_TICK(0); EG_SP_DONE(n);
     continue;
   }
   unsigned long long *segk = keys + start;
@@ -561,30 +606,36 @@ tile_sort_kernel(unsigned long long *__restrict__ keys, const int *__restrict__ 
         dmax = max(dmax, d);
       }
     }
-    hist[tid] = 0;
-    cursor[tid] = 0;
+#pragma unroll
+    for (int m = 0; m < BM; ++m) { hist[tid + m * THREADS] = 0; cursor[tid + m * THREADS] = 0; }
     // depth range of the tile: both reductions share one LDS hop and one barrier
     constexpr int NW = THREADS / 64;
     const int lane = tid & 63, wv = tid >> 6;
     dmin = (unsigned)wave_scan_dpp((int)dmin, -1, OpMinU());
     dmax = (unsigned)wave_scan_dpp((int)dmax, 0, OpMaxU());
+    EG_SP_TICK(0);  // 0: loads (cursors, keys) + the wave-level reductions
     if (lane == 63) { wave_tmp[wv] = dmin; wave_tmp[16 + wv] = dmax; }
     __syncthreads();
     if (prefix_pending) finish_prefix(n);
+    EG_SP_TICK(1);  // 1: range barrier + prefix tables / item records
 #pragma unroll
     for (int w = 0; w < NW; ++w) { dmin = min(dmin, wave_tmp[w]); dmax = max(dmax, wave_tmp[16 + w]); }
-    const float scale = (float)THREADS / ((float)(dmax - dmin) + 1.f);
+    const float scale = (float)NB / ((float)(dmax - dmin) + 1.f);
 #pragma unroll
     for (int j = 0; j < KPT; ++j)
       if (j * THREADS < n && tid + j * THREADS < n) {
         const unsigned d = (unsigned)(kr[j] >> 32);
-        atomicAdd(&hist[min(THREADS - 1, (int)((float)(d - dmin) * scale))], 1);
+        atomicAdd(&hist[min(NB - 1, (int)((float)(d - dmin) * scale))], 1);
       }
     __syncthreads();
+    EG_SP_TICK(2);  // 2: histogram
     // exclusive scan of the bucket counts and their maximum, again one hop and one barrier
-    const int cnt = hist[tid];
+    // (thread tid owns buckets tid * BM ...: cnt = their sum)
+    int cb[BM], cnt = 0, cmx = 0;
+#pragma unroll
+    for (int m = 0; m < BM; ++m) { cb[m] = hist[tid * BM + m]; cnt += cb[m]; cmx = max(cmx, cb[m]); }
     const int incl = wave_scan_dpp(cnt, 0, OpAdd());
-    const int wmax = wave_scan_dpp(cnt, 0, OpMaxI());
+    const int wmax = wave_scan_dpp(cmx, 0, OpMaxI());
     if (lane == 63) { wave_tmp2[wv] = (unsigned)incl; wave_tmp2[16 + wv] = (unsigned)wmax; }
     __syncthreads();
     int pre = 0;
@@ -595,28 +646,76 @@ tile_sort_kernel(unsigned long long *__restrict__ keys, const int *__restrict__ 
       fill = max(fill, wave_tmp2[16 + w]);
     }
     if (fill <= (unsigned)kMaxBucketFill) {
-      hist[tid] = pre + (incl - cnt);
+      {
+        int run = pre + (incl - cnt);
+#pragma unroll
+        for (int m = 0; m < BM; ++m) { hist[tid * BM + m] = run; run += cb[m]; }
+      }
       __syncthreads();
+      EG_SP_TICK(3);  // 3: scan
 #pragma unroll
       for (int j = 0; j < KPT; ++j)
         if (j * THREADS < n && tid + j * THREADS < n) {
           const unsigned d = (unsigned)(kr[j] >> 32);
-          const int bk = min(THREADS - 1, (int)((float)(d - dmin) * scale));
+          const int bk = min(NB - 1, (int)((float)(d - dmin) * scale));
           kout[hist[bk] + atomicAdd(&cursor[bk], 1)] = kr[j];
         }
       __syncthreads();
-      for (int i = tid; i < n; i += THREADS) {
-        const unsigned long long k = kout[i];
-        const unsigned d = (unsigned)(k >> 32);
-        const int bk = min(THREADS - 1, (int)((float)(d - dmin) * scale));
-        const int b0 = hist[bk], b1 = b0 + cursor[bk];
-        int rank = 0;
-        for (int q = b0; q < b1; ++q) rank += (kout[q] < k) ? 1 : 0;
-        const long long o = start + b0 + rank;
-        const int gid = (int)(unsigned)(k & 0xffffffffull);
-        flatten_ids[o] = gid;
-        if (isect_ids) isect_ids[o] = ((long long)tile << 32) | (long long)(k >> 32);
+      EG_SP_TICK(4);  // 4: scatter
+      if (kSortRankG == 1) {
+        for (int i = tid; i < n; i += THREADS) {
+          const unsigned long long k = kout[i];
+          const unsigned d = (unsigned)(k >> 32);
+          const int bk = min(NB - 1, (int)((float)(d - dmin) * scale));
+          const int b0 = hist[bk], b1 = b0 + cursor[bk];
+          int rank = 0;
+          for (int q = b0; q < b1; ++q) rank += (kout[q] < k) ? 1 : 0;
+          const long long o = start + b0 + rank;
+          const int gid = (int)(unsigned)(k & 0xffffffffull);
+          flatten_ids[o] = gid;
+          if (isect_ids) isect_ids[o] = ((long long)tile << 32) | (long long)(k >> 32);
+        }
+      } else {
+        // kSortRankG keys of a thread step through their buckets side by side: one round trip to LDS per step of all of
+        // them instead of one per key and step (the fullest tile's threads rank CAP / THREADS keys each)
+        constexpr int G = kSortRankG;
+        for (int i0 = tid; i0 < n; i0 += G * THREADS) {
+          unsigned long long k[G];
+          int b0[G], f[G], rank[G], fmax = 0;
+#pragma unroll
+          for (int g = 0; g < G; ++g) {
+            const int i = min(i0 + g * THREADS, n - 1);
+            k[g] = kout[i];
+            const unsigned d = (unsigned)(k[g] >> 32);
+            const int bk = min(NB - 1, (int)((float)(d - dmin) * scale));
+            b0[g] = hist[bk];
+            f[g] = (i0 + g * THREADS < n) ? cursor[bk] : 0;
+            rank[g] = 0;
+            fmax = max(fmax, f[g]);
+          }
+          for (int q = 0; q < fmax; ++q) {
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+              const unsigned long long o_ = kout[min(b0[g] + q, n - 1)];
+              rank[g] += (q < f[g] && o_ < k[g]) ? 1 : 0;
+            }
+          }
+#pragma unroll
+          for (int g = 0; g < G; ++g)
+            if (i0 + g * THREADS < n) {
+              const long long o = start + b0[g] + rank[g];
+              flatten_ids[o] = (int)(unsigned)(k[g] & 0xffffffffull);
+              if (isect_ids) isect_ids[o] = ((long long)tile << 32) | (long long)(k[g] >> 32);
+            }
+        }
       }
+#ifdef EG_SORT_PROF
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      EG_SP_TICK(5);  // 5: rank (issue)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      EG_SP_TICK(6);  // 6: the stores' drain
+      EG_SP_DONE(n);
+#endif
       continue;
     }
     // degenerate depth distribution: bitonic network on the keys (kin := LDS buffer `kout`)
@@ -743,9 +842,24 @@ extern "C" int eg_tile_emit(const float *means2d, const int32_t *radii, const fl
 
 static bool g_sort_attr_set = false;
 
+#ifdef EG_SORT_PROF
+static unsigned long long *g_sort_prof = nullptr;
+static int g_sort_prof_tiles = 0;
+#endif
+
 static int launch_tile_sort(uint64_t *keys, const int32_t *offsets, int32_t T, int64_t capacity,
-                            int32_t *flatten_ids, int64_t *isect_ids, int32_t max_tile_hint, const SegTable seg,
+                            int32_t *flatten_ids, int64_t *isect_ids, int32_t max_tile_hint, const SegTable seg_in,
                             eg_stream_t stream, const Batch &bt = Batch{}, int C = 1) {
+  SegTable seg = seg_in;
+#ifdef EG_SORT_PROF
+  if (!g_sort_prof || g_sort_prof_tiles < T) {
+    if (g_sort_prof) (void)hipFree(g_sort_prof);
+    g_sort_prof_tiles = T;
+    (void)hipMalloc((void **)&g_sort_prof, (size_t)T * 12 * sizeof(unsigned long long));
+  }
+  (void)hipMemsetAsync(g_sort_prof, 0, (size_t)T * 12 * sizeof(unsigned long long), as_stream(stream));
+  seg.prof = g_sort_prof;
+#endif
   // small: 256 threads / buckets, 4096 keys; large: 1024 threads / buckets, 16384 keys
   constexpr int kSmall = 4096, kLarge = 16384;
   constexpr size_t kLargeLds = kLarge * 8 + 2 * 1024 * 4;
@@ -769,11 +883,11 @@ static int launch_tile_sort(uint64_t *keys, const int32_t *offsets, int32_t T, i
   // tile that outgrew the hint is then still sorted correctly, by the slower paths of the small variant.
   const bool small_only = max_tile_hint > 0 && (int64_t)max_tile_hint * 5 / 4 <= kSmall;
   if (wide)
-    tile_sort_kernel<512, kSmall, false><<<dim3(T, C), 512, kSmall * 8 + 2 * 512 * 4, as_stream(stream)>>>(
+    tile_sort_kernel<512, kSmall, false><<<dim3(T, C), 512, kSmall * 8 + 2 * 512 * 4 * kSortBM, as_stream(stream)>>>(
         (unsigned long long *)keys, offsets, T, (long long)capacity, small_only ? 0x7fffffff : kSmall, flatten_ids,
         (long long *)isect_ids, seg, bt);
   else
-    tile_sort_kernel<256, kSmall, false><<<dim3(T, C), 256, kSmall * 8 + 2 * 256 * 4, as_stream(stream)>>>(
+    tile_sort_kernel<256, kSmall, false><<<dim3(T, C), 256, kSmall * 8 + 2 * 256 * 4 * kSortBM, as_stream(stream)>>>(
         (unsigned long long *)keys, offsets, T, (long long)capacity, small_only ? 0x7fffffff : kSmall, flatten_ids,
         (long long *)isect_ids, seg, bt);
   if (!small_only)
@@ -782,6 +896,16 @@ static int launch_tile_sort(uint64_t *keys, const int32_t *offsets, int32_t T, i
         seg, bt);
   return check_launch("tile_sort");
 }
+
+#ifdef EG_SORT_PROF
+// development builds only: the per-workgroup phase records of the last small-variant sort launch ([T][12] words)
+extern "C" int64_t eg_debug_sort_profile(uint64_t *out, int64_t max_tiles) {
+  if (!g_sort_prof || !out) return EG_ERR_ARG;
+  const int64_t n = g_sort_prof_tiles < max_tiles ? g_sort_prof_tiles : max_tiles;
+  if (hipMemcpy(out, g_sort_prof, (size_t)n * 12 * sizeof(uint64_t), hipMemcpyDeviceToHost) != hipSuccess) return EG_ERR_LAUNCH;
+  return n;
+}
+#endif
 
 extern "C" int eg_sort_pairs(uint64_t *keys, const int32_t *offsets, int32_t T, int64_t capacity,
                              int32_t *flatten_ids, int64_t *isect_ids, int32_t max_tile_hint, eg_stream_t stream) {

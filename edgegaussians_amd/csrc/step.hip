@@ -13,8 +13,11 @@
 // instead of ~60 (torch glue + gsplat + CUB passes + 4 unfused Adams).
 #include <dlfcn.h>
 
+#include <array>
 #include <cstdarg>
 #include <cstdio>
+#include <thread>
+#include <vector>
 
 #include "common.h"
 
@@ -155,7 +158,8 @@ extern "C" int eg_train_step(const eg_step_args *a, eg_stream_t stream) {
   // sort kernel writes the forward's item records front slices first -- every projection of such a grid sets the flag)
   const uint32_t flags = EG_FLAG_LOG_SCALES | EG_FLAG_LOGIT_OPACITIES | EG_FLAG_ANTIALIASED | EG_FLAG_TIGHT_TILES |
                          ((T > kPrefixHereMaxTiles && a->seg_cap > 0 && a->ticket) ? EG_FLAG_FRONT_PREFIX : 0u);
-  g_ev_cur = (g_ev && g_ev_next < g_ev_steps) ? &g_ev[(kStages + 1) * g_ev_next] : nullptr;
+  // (written only inside a timing window: eg_train_steps_multi's host threads run this function side by side)
+  if (g_ev || g_ev_cur) g_ev_cur = (g_ev && g_ev_next < g_ev_steps) ? &g_ev[(kStages + 1) * g_ev_next] : nullptr;
   hipStream_t st = as_stream(stream);
 #define EG_MARK(k) timing_mark(k, st)
   int rc;
@@ -248,8 +252,7 @@ extern "C" int eg_train_step(const eg_step_args *a, eg_stream_t stream) {
                         a->v_scales, a->v_opacities, a->absgrads, stream);
   EG_MARK(kMarkProjectBwd);
 #undef EG_MARK
-  if (g_ev_cur) ++g_ev_next;
-  g_ev_cur = nullptr;
+  if (g_ev_cur) { ++g_ev_next; g_ev_cur = nullptr; }
   return rc;
 }
 
@@ -317,37 +320,98 @@ extern "C" int eg_train_step_batched(const eg_step_args *a, int32_t C, const flo
 // with every ACTIVE Adam step count advanced by k (a group whose count is < 0 stays skipped).  Saves the
 // per-step host round trip through the binding (~40 us of Python per step: at the reference's sizes the host,
 // not the GPU, bounds the real training loop).
+// step k of a run of K (see eg_train_steps): the view's inputs, the call tag, the Adam counts and -- inside the run --
+// the projection of view k + 1 fused into step k's last kernel
+static int train_step_of_run(const eg_step_args *a, int k, int K, const int32_t *views_host, const float *const *wmaps_host,
+                             const float *viewmats, const float *Ks, const float *gts, eg_stream_t stream) {
+  const size_t hw = (size_t)a->width * a->height;
+  EG_REQUIRE(views_host[k] >= 0 && wmaps_host[k], "bad view / null weight map");
+  eg_step_args s = *a;
+  eg_adam_hyper h;
+  s.viewmat = viewmats + 16 * (size_t)views_host[k];
+  s.K = Ks + 9 * (size_t)views_host[k];
+  s.gt = gts + hw * (size_t)views_host[k];
+  s.wmap = wmaps_host[k];
+  if (a->ws_tag > 0) s.ws_tag = a->ws_tag + k;  // a fresh tag per step (the caller keeps ws_tag + K - 1 <= EG_MAX_WS_TAG)
+  // inside the run the parameters change only through these steps: step k's last kernel projects view k + 1
+  s.have_projection = (k > 0 && a->adam_host && a->seg_cap > 0) ? 1 : a->have_projection;
+  s.next_viewmat = s.next_K = nullptr;
+  if (k + 1 < K && a->adam_host && a->seg_cap > 0) {
+    s.next_viewmat = viewmats + 16 * (size_t)views_host[k + 1];
+    s.next_K = Ks + 9 * (size_t)views_host[k + 1];
+  }
+  if (a->adam_host) {
+    h = *a->adam_host;
+    h.step += k;
+    for (int i = 0; i < 4; ++i)
+      if (h.group_steps[i] > 0) h.group_steps[i] += k;
+    s.adam_host = &h;
+  }
+  return eg_train_step(&s, stream);
+}
+
 extern "C" int eg_train_steps(const eg_step_args *a, int32_t K, const int32_t *views_host, const float *const *wmaps_host,
                               const float *viewmats /*[V,4,4]*/, const float *Ks /*[V,3,3]*/, const float *gts /*[V,H,W]*/,
                               eg_stream_t stream) {
   EG_REQUIRE(a != nullptr && K >= 0 && (K == 0 || (views_host && wmaps_host)) && viewmats && Ks && gts, "bad arguments");
   EG_REQUIRE(a->ws_tag <= 0 || (int64_t)a->ws_tag + K - 1 <= EG_MAX_WS_TAG, "ws_tag + K - 1 exceeds EG_MAX_WS_TAG: zero the workspace and start over at 1");
-  const size_t hw = (size_t)a->width * a->height;
   for (int k = 0; k < K; ++k) {
-    EG_REQUIRE(views_host[k] >= 0 && wmaps_host[k], "bad view / null weight map");
-    eg_step_args s = *a;
-    eg_adam_hyper h;
-    s.viewmat = viewmats + 16 * (size_t)views_host[k];
-    s.K = Ks + 9 * (size_t)views_host[k];
-    s.gt = gts + hw * (size_t)views_host[k];
-    s.wmap = wmaps_host[k];
-    if (a->ws_tag > 0) s.ws_tag = a->ws_tag + k;  // a fresh tag per step (the caller keeps ws_tag + K - 1 <= EG_MAX_WS_TAG)
-    // inside the run the parameters change only through these steps: step k's last kernel projects view k + 1
-    s.have_projection = (k > 0 && a->adam_host && a->seg_cap > 0) ? 1 : a->have_projection;
-    s.next_viewmat = s.next_K = nullptr;
-    if (k + 1 < K && a->adam_host && a->seg_cap > 0) {
-      s.next_viewmat = viewmats + 16 * (size_t)views_host[k + 1];
-      s.next_K = Ks + 9 * (size_t)views_host[k + 1];
-    }
-    if (a->adam_host) {
-      h = *a->adam_host;
-      h.step += k;
-      for (int i = 0; i < 4; ++i)
-        if (h.group_steps[i] > 0) h.group_steps[i] += k;
-      s.adam_host = &h;
-    }
-    const int rc = eg_train_step(&s, stream);
+    const int rc = train_step_of_run(a, k, K, views_host, wmaps_host, viewmats, Ks, gts, stream);
     if (rc) return rc;
   }
+  return EG_OK;
+}
+
+// ---- S independent scenes side by side on one GPU (BASELINE config 5 on one device): K steps of each, enqueued by ONE
+// native call, scene s on streams[s].  `n_threads` host threads share the scenes (thread j takes scenes j, j + n_threads,
+// ...) and walk them ROUND-ROBIN, step k of all its scenes before step k + 1 of any, so that every stream always has
+// work queued while the others are served; n_threads = 1 enqueues everything from the calling thread.  No Python
+// between the steps and none around the threads (S interpreter threads each calling eg_train_steps pay the interpreter's
+// thread switches on top of the launches: profiles/r04_scenes_per_gpu.txt).  The scenes share nothing: every trainer's
+// result equals its solo run.
+extern "C" int eg_train_steps_multi(int32_t S, const eg_step_args *const *args_host, int32_t K,
+                                    const int32_t *const *views_host, const float *const *const *wmaps_host,
+                                    const float *const *viewmats, const float *const *Ks, const float *const *gts,
+                                    const eg_stream_t *streams, int32_t n_threads) {
+  EG_REQUIRE(S >= 1 && S <= 64 && K >= 0 && args_host && views_host && wmaps_host && viewmats && Ks && gts && streams,
+             "bad arguments");
+  EG_REQUIRE(n_threads >= 1, "n_threads >= 1");
+  EG_REQUIRE(g_ev == nullptr, "eg_train_steps_multi: close the eg_timing_begin window first (its events belong to one stream)");
+  for (int s = 0; s < S; ++s) {
+    const eg_step_args *a = args_host[s];
+    EG_REQUIRE(a && (K == 0 || (views_host[s] && wmaps_host[s])) && viewmats[s] && Ks[s] && gts[s], "null scene argument");
+    EG_REQUIRE(a->ws_tag <= 0 || (int64_t)a->ws_tag + K - 1 <= EG_MAX_WS_TAG, "ws_tag + K - 1 exceeds EG_MAX_WS_TAG");
+    for (int q = 0; q < s; ++q) EG_REQUIRE(streams[q] != streams[s] || args_host[q] != a, "the same scene twice");
+  }
+  const int nt = n_threads < S ? n_threads : S;
+  auto drive = [&](int j, char *msg, size_t msg_len) -> int {
+    for (int k = 0; k < K; ++k)
+      for (int s = j; s < S; s += nt) {
+        const int rc = train_step_of_run(args_host[s], k, K, views_host[s], wmaps_host[s], viewmats[s], Ks[s], gts[s], streams[s]);
+        if (rc) { snprintf(msg, msg_len, "scene %d, step %d: %s", s, k, g_err); return rc; }
+      }
+    return EG_OK;
+  };
+  char msg[512] = "";
+  if (nt == 1) {
+    const int rc = drive(0, msg, sizeof(msg));
+    if (rc) set_error("%s", msg);
+    return rc;
+  }
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { set_error("eg_train_steps_multi: hipGetDevice failed"); return EG_ERR_LAUNCH; }
+  std::vector<std::thread> th;
+  std::vector<int> rcs(nt, EG_OK);
+  std::vector<std::array<char, 512>> msgs(nt);
+  for (int j = 1; j < nt; ++j)
+    th.emplace_back([&, j]() {
+      msgs[j][0] = 0;
+      if (hipSetDevice(dev) != hipSuccess) { snprintf(msgs[j].data(), 512, "hipSetDevice(%d) failed", dev); rcs[j] = EG_ERR_LAUNCH; return; }
+      rcs[j] = drive(j, msgs[j].data(), 512);
+    });
+  rcs[0] = drive(0, msgs[0].data(), 512);
+  for (auto &t : th) t.join();
+  for (int j = 0; j < nt; ++j)
+    if (rcs[j]) { set_error("%s", msgs[j].data()); return rcs[j]; }
   return EG_OK;
 }

@@ -450,6 +450,12 @@ class EdgeTrainer:
         self._steps_raw(views, wmaps)
 
     def _steps_raw(self, views, wmaps) -> None:
+        a, va, wa = self._steps_begin(views, wmaps)
+        call("eg_train_steps", C.byref(a), len(views), va, wa, ptr(self.viewmats), ptr(self.Ks), ptr(self.gt), stream())
+        self._steps_end(len(views))
+
+    def _steps_begin(self, views, wmaps):
+        """Host state of a native run of len(views) steps: (argument block of step 0, view indices, weight-map pointers)."""
         self._drop_projection()
         K = len(views)
         self._advance_all()   # step 0's counts; the native loop advances them by k
@@ -459,7 +465,9 @@ class EdgeTrainer:
         wa = (C.c_void_p * K)(*[w.data_ptr() for w in wmaps])
         for w in wmaps:
             assert w.is_cuda and w.is_contiguous() and w.shape == (self.height, self.width)
-        call("eg_train_steps", C.byref(a), K, va, wa, ptr(self.viewmats), ptr(self.Ks), ptr(self.gt), stream())
+        return a, va, wa
+
+    def _steps_end(self, K: int) -> None:
         for _ in range(K - 1):
             self._advance_all()
         self.absgrads_normalize_factor += K
@@ -1295,3 +1303,41 @@ class EdgeTrainer:
         return {"gauss_params.means": r(self.means).clone(), "gauss_params.scales": r(self.log_scales).clone(),
                 "gauss_params.quats": r(self.quats).clone(),
                 "gauss_params.opacities": r(self.logit_opacities).view(-1, 1).clone()}
+
+
+def train_steps_multi(trainers: List["EdgeTrainer"], views: List[List[int]], wmaps: List[List[Tensor]], streams: List,
+                      n_threads: int = 0) -> None:
+    """K consecutive reference iterations of EACH of S independent scenes, enqueued by ONE native call
+    (`eg_train_steps_multi`): scene s = `trainers[s].train_steps(views[s], wmaps[s])` on `streams[s]` (torch.cuda.Stream
+    objects, all different, none of them the stream a trainer's tensors are still being written on).  The scenes share
+    nothing -- every trainer ends exactly where its solo run ends (tests/test_gpu_parity.py) -- but one GPU runs their
+    launch sequences side by side: BASELINE configs[4] ("115-scan sweep, one scene per GPU") with S scenes per device.
+    n_threads: host threads inside the native call (0: one per scene, at most 8)."""
+    S = len(trainers)
+    assert S >= 1 and len(views) == S and len(wmaps) == S and len(streams) == S
+    K = len(views[0])
+    assert all(len(v) == K for v in views) and all(len(w) == K for w in wmaps), "the same number of steps for every scene"
+    assert len({int(st.cuda_stream) for st in streams}) == S and len({id(t) for t in trainers}) == S
+    if K == 0:
+        return
+    blocks = []
+    for tr, vs, ws, sx in zip(trainers, views, wmaps, streams):
+        with torch.cuda.stream(sx):  # (whatever host-side preparation enqueues -- a tag wrap's zeroing, a snapshot -- goes to the scene's stream)
+            if tr.capacity == 0:
+                tr.ensure_capacity()
+            tr._reserve_tags(K)
+            if tr.replay_on_overflow:
+                if not tr._journal:
+                    tr._snapshot()
+                tr._journal.extend(("1", v, w, tr.epoch, tr.loss_scale) for v, w in zip(vs, ws))
+            blocks.append(tr._steps_begin(vs, ws))
+    args = (C.POINTER(_lib.StepArgs) * S)(*[C.pointer(b[0]) for b in blocks])
+    va = (C.POINTER(C.c_int32) * S)(*[C.cast(b[1], C.POINTER(C.c_int32)) for b in blocks])
+    wa = (C.POINTER(C.c_void_p) * S)(*[C.cast(b[2], C.POINTER(C.c_void_p)) for b in blocks])
+    vm = (C.c_void_p * S)(*[ptr(t.viewmats) for t in trainers])
+    ks = (C.c_void_p * S)(*[ptr(t.Ks) for t in trainers])
+    gt = (C.c_void_p * S)(*[ptr(t.gt) for t in trainers])
+    st = (C.c_void_p * S)(*[int(x.cuda_stream) for x in streams])
+    call("eg_train_steps_multi", S, args, K, va, wa, vm, ks, gt, st, n_threads if n_threads > 0 else min(S, 8))
+    for tr in trainers:
+        tr._steps_end(K)

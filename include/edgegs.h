@@ -477,6 +477,18 @@ int eg_train_steps(const eg_step_args *args_host, int32_t K, const int32_t *view
                    const float *const *wmaps_host, const float *viewmats, const float *Ks, const float *gts,
                    eg_stream_t stream);
 
+/* ---- S independent scenes side by side on ONE GPU (BASELINE configs[4], "one scene per GPU", with S of them sharing
+ * a device: at the reference's sizes a single scene's dependent launches sit at their latency floor and leave most of
+ * the chip idle).  K steps of every scene by one native call: scene s = eg_train_steps(args_host[s], K, views_host[s],
+ * wmaps_host[s], viewmats[s], Ks[s], gts[s]) on streams[s] (distinct streams, distinct buffers: the scenes share
+ * nothing, every scene's result equals its solo run).  n_threads host threads (1 .. S) share the scenes -- thread j
+ * takes scenes j, j + n_threads, ... -- and walk them round-robin, step k of all their scenes before step k + 1 of any.
+ * The reference trains one scene per process (train_gaussians.py:311); this is the throughput form of its 115-scan sweep.
+ * Not inside an eg_timing_begin window.  Returns the first failing scene's code (eg_last_error_string names scene and step). */
+int eg_train_steps_multi(int32_t S, const eg_step_args *const *args_host, int32_t K, const int32_t *const *views_host,
+                         const float *const *const *wmaps_host, const float *const *viewmats, const float *const *Ks,
+                         const float *const *gts, const eg_stream_t *streams, int32_t n_threads);
+
 /* ---- C <= EG_MAX_BATCH views per launch sequence.  `args_host` as for eg_train_step
  * (segmented layout required; its viewmat / K / gt / wmap fields are ignored) with every per-view work buffer
  * holding C consecutive copies: splat, g2d [C,N,8]; tile_counts, offsets, tile_end, item_offsets, item_end [C,T];

@@ -1754,6 +1754,44 @@ def test_scenes_side_by_side_on_streams_and_threads_equal_their_solo_runs(env):
             assert torch.equal(x, y), i
 
 
+@pytest.mark.parametrize("n_threads", [1, 2, 0])
+def test_native_multi_scene_run_equals_the_solo_runs(env, n_threads):
+    """eg_train_steps_multi (BASELINE config 5 with S scenes per GPU, one native call for K steps of every scene, round-robin
+    over S streams from 1 / 2 / S host threads inside the call): every trainer ends bit-identical to its solo run; an
+    argument error of one scene names the scene."""
+    _lib, synth, O = env
+    from edgegaussians_amd import EdgeTrainer, train_steps_multi
+    S, K = 3, 24
+    scs = [_scene(synth, n=2500 + 300 * i, w=160, h=112, views=3, seed=10 + i) for i in range(S)]
+    mk = lambda sc: EdgeTrainer(sc.means, sc.log_scales, sc.quats, sc.logit_opacities, sc.viewmats, sc.Ks, sc.gt,  # noqa: E731
+                                sc.width, sc.height)
+    views = [k % 3 for k in range(K)]
+    wm = [[synth.weight_map("weighted", sc.gt[v]).cuda() for v in range(3)] for sc in scs]
+    solo = []
+    for i, sc in enumerate(scs):
+        tr = mk(sc)
+        for k0 in range(0, K, 8):
+            tr.train_steps(views[k0:k0 + 8], [wm[i][v] for v in views[k0:k0 + 8]])
+        solo.append((tr.pop_loss(), tr))
+    side, streams = [mk(sc) for sc in scs], [torch.cuda.Stream() for _ in scs]
+    torch.cuda.synchronize()
+    for k0 in range(0, K, 8):
+        train_steps_multi(side, [views[k0:k0 + 8]] * S, [[wm[i][v] for v in views[k0:k0 + 8]] for i in range(S)], streams,
+                          n_threads=n_threads)
+    torch.cuda.synchronize()
+    for i in range(S):
+        a, b = solo[i][1], side[i]
+        with torch.cuda.stream(streams[i]):
+            loss = b.pop_loss()
+        assert abs(loss - solo[i][0]) <= 1e-6 * abs(solo[i][0]), (i, loss, solo[i][0])  # (a sum of float atomics)
+        for x, y in ((a.means, b.means), (a.log_scales, b.log_scales), (a.quats, b.quats), (a.logit_opacities, b.logit_opacities),
+                     (a.adam_m, b.adam_m), (a.adam_v, b.adam_v), (a.absgrads, b.absgrads)):
+            assert torch.equal(x, y), i
+    with pytest.raises(RuntimeError, match="scene 1"):  # (view index -1 of scene 1: the native call names it)
+        train_steps_multi(side, [[0], [-1], [0]], [[wm[i][0]] for i in range(S)], streams, n_threads=n_threads)
+    torch.cuda.synchronize()
+
+
 def test_roctx_ranges_do_not_change_a_step(env):
     """eg_roctx_enable(1) wraps the stages of eg_train_step in roctx ranges (SURVEY 5: tracing; rocprofv3 --marker-trace);
     with or without them the step is the same."""
