@@ -402,6 +402,7 @@ tile_sort_kernel(unsigned long long *__restrict__ keys, const int *__restrict__ 
       unsigned long long *r_ = seg.prof + (size_t)tile * 12;                     \
       r_[0] = prof_wall0; r_[1] = __builtin_amdgcn_s_memrealtime(); r_[2] = (unsigned long long)(n_); \
       r_[3] = prof_t[0]; r_[4] = prof_t[1]; r_[5] = prof_t[2]; r_[6] = prof_t[3]; r_[7] = prof_t[4]; r_[8] = prof_t[5]; r_[9] = prof_t[6]; \
+      r_[10] = (unsigned long long)(__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 15); r_[11] = blockIdx.x; /* XCC_ID, workgroup */ \
     }                                                                            \
   } while (0)
 #else

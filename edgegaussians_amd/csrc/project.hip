@@ -720,12 +720,18 @@ __device__ __forceinline__ void emit_body(const Raw &raw, bool live, int g, cons
       }
   } else {
     __syncthreads();
-    for (int t = threadIdx.x; t < T; t += kPE) {
-      const int c = s_hist[t];
-      if (c) {
-        s_base[t] = atomicAdd(&cursor[t], c);  // slots [base, base + c) of tile t's segment
-        s_hist[t] = 0;
-      }
+    // slots [base, base + c) of tile t's segment.  Four tiles per thread and round, their returning atomics all issued
+    // before the first result is stored (round 5): one atomic per round was one round trip to the coherence point per
+    // kPE tiles of the grid, in a row -- 15 of them at 1600 x 1200
+    for (int t0 = threadIdx.x; t0 < T; t0 += 4 * kPE) {
+      int c[4], b[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) c[q] = (t0 + q * kPE < T) ? s_hist[t0 + q * kPE] : 0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) b[q] = c[q] ? atomicAdd(&cursor[t0 + q * kPE], c[q]) : 0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (c[q]) { s_base[t0 + q * kPE] = b[q]; s_hist[t0 + q * kPE] = 0; }
     }
     __syncthreads();
     for (int ty = y0; ty < y1; ++ty)

@@ -9,7 +9,7 @@ run() {  # tag
   for c in $CFGS; do
     cd /tmp; export TMPDIR=/tmp; rm -rf /tmp/ks_$1_$c
     timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/ks_$1_$c -o r -- python $R/bench.py --config $c --steps ${STEPS:-200} --warmup 20 --profile-only > /dev/null 2>&1
-    python $R/tools/rocpd_summary.py /tmp/ks_$1_$c/r_results.db $O/kernel_stats_$1_$c.txt | grep "tile_sort\|composite_wave" | awk -v t="$1 $c" '{printf "%-28s %-26s avg %8s us  min %8s  max %8s\n", t, substr($1,1,26), $4, $5, $6}'
+    python $R/tools/rocpd_summary.py /tmp/ks_$1_$c/r_results.db $O/kernel_stats_$1_$c.txt | grep "tile_sort\|composite_wave" | awk -v t="$1 $c" '{printf "%-24s %-30s avg %s us\n", t, substr($0,1,30), $(NF-3)}'
     cd $R
   done
 }
@@ -20,14 +20,16 @@ leg() {  # tag flags wide
   run $1
 }
 {
+if [ -n "$LEGS" ]; then
+  IFS=';' read -ra L <<< "$LEGS"
+  for l in "${L[@]}"; do tag=${l%%=*}; fl=${l#*=}; leg "$tag" "$fl" ""; done
+else
 leg base "" ""
 leg bm2 "-DEG_SORT_BM=2" ""
-leg bm4 "-DEG_SORT_BM=4" ""
-leg g4 "-DEG_SORT_RANK_G=4" ""
-leg bm2g4 "-DEG_SORT_BM=2 -DEG_SORT_RANK_G=4" ""
-leg narrow "" 0
-leg narrow_bm2g4 "-DEG_SORT_BM=2 -DEG_SORT_RANK_G=4" 0
+leg waves6 "-DEG_SORT_WAVES=6" ""
+leg bm2waves6 "-DEG_SORT_BM=2 -DEG_SORT_WAVES=6" ""
 leg base2 "" ""
+fi
 } 2>&1 | tee $O/summary.txt
 unset EG_SORT_WIDE
 python -m edgegaussians_amd.build --force 2>&1 | tail -1

@@ -60,3 +60,7 @@ for lo, hi in ((0, 0), (1, 64), (65, 512), (513, 1536), (1537, 4096)):
     if m.any():
         print(f"  n in [{lo},{hi}]: {int(m.sum())} tiles, lifetime mean {life[m].mean():.0f} ticks, wall {(en[m] - st[m]).mean():.2f} us | "
               + " ".join(f"{rec[m, 3 + i].mean():6.0f}" for i in range(7)))
+
+xcc, wg = rec[:, 10].astype(int), rec[:, 11].astype(int)
+print(f"  XCC_ID of workgroup b: == b % 8 for {int((xcc == wg % 8).sum())} of {len(wg)} workgroups; per-XCC counts {np.bincount(xcc, minlength=8).tolist()}")
+
