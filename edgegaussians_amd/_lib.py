@@ -127,7 +127,7 @@ EXPORTS = sorted(list(_SIGS) + ["eg_last_error_string", "eg_version", "eg_device
                                  "eg_timing_stage_count", "eg_timing_stage_name", "eg_debug_fwd_profile",
                                  "eg_dp_unique_id", "eg_dp_init", "eg_dp_world", "eg_dp_shutdown", "eg_dp_host_profile", "eg_roctx_enable",
                                  "eg_dp_comm_count", "eg_dp_force_all_reduce", "eg_dp_grad_all_reduces",
-                                 "eg_dp_comm_timing_begin", "eg_dp_comm_timing_end"])
+                                 "eg_dp_comm_timing_begin", "eg_dp_comm_timing_end", "eg_record_xcd_shift"])
 
 _lib: Optional[C.CDLL] = None
 
@@ -166,6 +166,7 @@ def load(require_device: bool = True) -> C.CDLL:
         lib.eg_dp_world.argtypes = []
         lib.eg_dp_shutdown.argtypes = []
         lib.eg_roctx_enable.argtypes = [_i32]
+        lib.eg_record_xcd_shift.argtypes = [_i32]
         lib.eg_dp_comm_count.argtypes = []
         lib.eg_dp_force_all_reduce.argtypes = [_i32]
         lib.eg_dp_grad_all_reduces.argtypes = [C.POINTER(_i64)]

@@ -311,7 +311,7 @@ struct SegTable {
   // launch instead of forming its tail; the tail is made of single-slice and empty tiles, which hand nothing over.
   int rank_order;
   // optional output for the wave-autonomous forward (composite_wave.hip): one 16-byte record per item
-  // {tile, slice | slices << 16, first key of the slice, end of the TILE's keys}
+  // {tile, slice | slices << 16, rec_tag, end of the TILE's keys}   (the slice's first key is tile * seg_cap + 128 slice)
   int4 *item_rec;
   // with `total` and `item_rec`: the records are laid out in DISPATCH order, FRONT SLICES FIRST -- slices 0..3 of every
   // tile (tile by tile, in the order of the item numbering), then the deeper slices of the tiles that have them --
@@ -335,6 +335,20 @@ struct SegTable {
   // wave slots at 500 k Gaussians; dispatched after every tile's front they find the dead word set and leave at once.
   const int *item_front = nullptr;
   int middle_out = 0;   // workgroup -> tile assignment of the small sort variant (see the kernel)
+  // Round 5.  Every record carries the CALL TAG of the forward that will read it in word 2 (the forward validates a
+  // record by its tag: the table may have holes, and a record of an earlier call is not mistaken for this call's).
+  unsigned rec_tag = 0;
+  // with `total`, xcd_shift > 0: XCD-AWARE record placement.  Workgroup b of a launch runs on XCD b % 8 (measured:
+  // profiles/r05_sort_ab.txt); the tiles are dealt to the eight XCDs in square blocks of 2^xcd_shift tiles,
+  // xcd = (block_x + 3 block_y) % 8, and the records of XCD x's tiles are written at indices 8 k + x, k counting
+  // through THAT XCD's list -- front slices [0, slice_major) of its tiles first, tile by tile, then their deeper
+  // slices.  All slices of a tile then run on one XCD (their hand-over stays inside one L2) and the tiles that share
+  // Gaussians share an L2 (the forward's record gather filled every one of the eight L2s with the whole record array).
+  // The lists differ in length: the table has holes at the end of the shorter ones (no record carries the call's tag
+  // there) and spans 8 x the longest list -- beyond max_items the sticky overflow flag goes up.
+  int xcd_shift = 0;
+  int tw = 0;          // tiles per image row (xcd_shift > 0)
+  float inv_tw = 0.f;  // 1 / tw
 #ifdef EG_SORT_PROF
   // development builds (-DEG_SORT_PROF): [T][12] per-workgroup phase record of the small variant's last launch --
   // {wall clock at start / end (100 MHz), n, shader-clock ticks of: loads, range barrier + prefix, histogram, scan,
@@ -342,6 +356,11 @@ struct SegTable {
   unsigned long long *prof = nullptr;
 #endif
 };
+#ifndef EG_XCD_SHIFT_DEFAULT
+#define EG_XCD_SHIFT_DEFAULT 1
+#endif
+constexpr int kXcdMinTiles = 512;  // XCD-aware placement on grids of 512 .. 2048 tiles (the reference's 512 x 512 images: 1024)
+constexpr int kXcdShiftDefault = EG_XCD_SHIFT_DEFAULT;  // XCD-aware record placement: tiles per block side = 2^shift (0 = off)
 constexpr int kFrontDefault = 4;  // class boundary of the dispatch order (slices); SegTable::slice_major carries it
 
 // THREADS = number of buckets; CAP = keys per buffer (two buffers).  n_lo < n handled here.
@@ -374,6 +393,13 @@ tile_sort_kernel(unsigned long long *__restrict__ keys, const int *__restrict__ 
   }
   // NB = kSortBM buckets per thread: the rank pass costs a key one dependent LDS read per key of its bucket, so the
   // fullest tile's workgroup -- which the kernel lasts as long as -- is shortened by thinner buckets
+  // waves of the workgroup that form the tile prefix ("prefix here"): a quarter of them -- with two of eight the 512-thread
+  // variant lost 2.5 us at config 2 to the longer dependent chain per wave (8 tiles per lane), with all of them the
+  // 256-thread variant lost 1.7 us at config 1 to the redundant work
+#ifndef EG_SORT_PREF_WAVES_512
+#define EG_SORT_PREF_WAVES_512 4
+#endif
+  constexpr int kPrefWaves = THREADS >= 512 ? EG_SORT_PREF_WAVES_512 : 2;
   constexpr int BM = LARGE ? 1 : kSortBM;  // (the large variant is at the LDS limit)
   constexpr int NB = THREADS * BM;
   unsigned long long *kout = s;      // [CAP] keys scattered by bucket (the fast path keeps its input in registers)
@@ -454,21 +480,41 @@ tile_sort_kernel(unsigned long long *__restrict__ keys, const int *__restrict__ 
   const int tile = (!LARGE && seg.middle_out) ? ((wg & 1) ? T / 2 - (wg + 1) / 2 : T / 2 + wg / 2) : wg;
   __syncthreads();
   long long start, end;
-  __shared__ int s_pre[5][THREADS / 64];
+  __shared__ int s_pre[6][THREADS / 64];
   bool prefix_pending = false;  // (uniform) the tile prefix still has to be finished: see SegTable::total
   int pop_here = 0;
   // after a barrier: every thread sums the waves' partials; thread 0 writes the tile's table entries (and the
   // totals of the view, if this is the last tile), the first threads the item -> tile map
   auto finish_prefix = [&](int kept_) {
-    int isum = 0, msum = 0, cmax = 0, itot = 0, front = 0;
+    prefix_pending = false;
+    if (tid >= 64) return;  // (the first wave writes the tables and the records: a tile has a few dozen items at most)
+    int isum = 0, msum = 0, cmax = 0, itot = 0, front = 0, deepx = 0;
 #pragma unroll
-    for (int w = 0; w < THREADS / 64; ++w) {
+    for (int w = 0; w < kPrefWaves; ++w) {
       isum += s_pre[0][w]; msum += s_pre[1][w]; cmax = max(cmax, s_pre[2][w]); itot += s_pre[3][w];
-      front += s_pre[4][w];
+      front += s_pre[4][w]; deepx += s_pre[5][w];
     }
-    const int isumf = front & 0xffff, itotf = front >> 16;
+    // of the tiles of THIS tile's XCD (all tiles without the XCD-aware placement): front-class items in front of this
+    // tile / in all, deep-class items in front of this tile
+    const int k0 = front & 0xffff, l0 = front >> 16, k1 = deepx;
     const int first_ = min(isum, seg.max_items);
     const int items_ = min(max(1, (kept_ + 127) >> 7), max(0, seg.max_items - first_));
+    // dispatch index of slice i: class 0 = slices [0, slice_major) of the list's tiles, class 1 = the rest; inside a class
+    // tile by tile in the item numbering's order.  (Every workgroup forms the same sums from the same cursors.)
+    const int myx = seg.xcd_shift > 0 ? xcd_of_tile(tile, seg.tw, seg.inv_tw, seg.xcd_shift) : 0;
+    bool rec_over = false;
+    for (int i = tid; i < items_; i += 64) {
+      seg.item_tile[first_ + i] = tile;
+      if (seg.item_rec) {
+        const int pos = i < seg.slice_major ? k0 + i : l0 + k1 + (i - seg.slice_major);
+        const int disp = seg.xcd_shift > 0 ? 8 * pos + myx : pos;
+        if (disp < seg.max_items)
+          seg.item_rec[disp] = make_int4(tile, i | (items_ << 16), (int)seg.rec_tag, tile * seg.seg_cap + kept_);
+        else
+          rec_over = true;  // (the longest XCD list does not fit the table: the caller grows it and replays)
+      }
+    }
+    if (rec_over) seg.total[1] = 1;
     if (tid == 0) {
       seg.item_first[tile] = first_;
       seg.tile_start[tile] = tile * seg.seg_cap;
@@ -479,21 +525,6 @@ tile_sort_kernel(unsigned long long *__restrict__ keys, const int *__restrict__ 
         if (cmax > seg.seg_cap || itot > seg.max_items) seg.total[1] = 1;  // sticky: only the host clears it
         seg.total[2] = min(itot, seg.max_items);
         seg.total[3] = cmax;
-      }
-    }
-    // dispatch index of slice i: class 0 = slices [0, kFront) of all tiles, class 1 = the rest; inside a class tile by
-    // tile in the item numbering's order.  (Every workgroup forms the same sums from
-    // the same cursors.  Not when the item tables overflow: the truncated tiles would leave holes in the record
-    // table, and a stale record could send a wave looking back on a slice nobody publishes.)
-    const bool front_first = !LARGE && seg.slice_major && itot <= seg.max_items;
-    for (int i = tid; i < items_; i += THREADS) {
-      seg.item_tile[first_ + i] = tile;
-      if (seg.item_rec) {
-        int disp = first_ + i;
-        if (front_first)
-          disp = i < seg.slice_major ? isumf + i : itotf + (isum - isumf) + (i - seg.slice_major);
-        if (disp < seg.max_items)
-          seg.item_rec[disp] = make_int4(tile, i | (items_ << 16), tile * seg.seg_cap + i * 128, tile * seg.seg_cap + kept_);
       }
     }
     prefix_pending = false;
@@ -511,36 +542,54 @@ tile_sort_kernel(unsigned long long *__restrict__ keys, const int *__restrict__ 
         // (they travel with the tile's own cursor and first keys); per-wave partial sums go to LDS and the prefix
         // is finished right after the FIRST barrier the sort takes anyway (finish_prefix below): no barrier of its own
         // (ALL populations, not only those of the tiles in front: the item numbering may follow the populations' rank)
-        int pv[kPrefixHereMaxTiles / THREADS];
-#pragma unroll
-        for (int j = 0; j < kPrefixHereMaxTiles / THREADS; ++j)
-          pv[j] = (tid + j * THREADS < T) ? seg.cursor[tid + j * THREADS] : -1;
+        // Round 5: the sums are formed by the workgroup's FIRST TWO waves only (8 tiles per lane and batch; a grid above
+        // 1024 tiles takes a second batch), not by every wave over T / THREADS tiles each: with the per-XCD class sums the
+        // redundant vector work of the launch (T workgroups x all waves x {per-tile arithmetic + six DPP scans}) cost the
+        // 256-thread variant 1.7 us at config 1.  The other waves do not need the prefix before the first barrier.
+        // Buffer loads on a descriptor of the T cursors: one 32-bit offset per load, a tile beyond T reads 0.
         pop_here = seg.cursor[tile];
         kept = min(pop_here, seg.seg_cap);
-        int isum = 0, msum = 0, cmax = 0, itot = 0;
-        // the same over min(items, kFront): the sum over the tiles in front in the low half, over all tiles in the high
-        // half (at most 2048 * 15 each)
-        int front = 0;
+        if ((tid >> 6) < kPrefWaves) {
+          int isum = 0, msum = 0, cmax = 0, itot = 0;
+          // the same over min(items, kFront): the sum over the tiles in front in the low half, over all tiles in the high
+          // half (at most 2048 * 15 each); deepx: the deeper slices of the tiles in front.  With the XCD-aware placement
+          // both run over the tiles of this tile's XCD only.
+          int front = 0, deepx = 0;
+          const int myx = seg.xcd_shift > 0 ? xcd_of_tile(tile, seg.tw, seg.inv_tw, seg.xcd_shift) : 0;
+          const __amdgpu_buffer_rsrc_t cur_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)seg.cursor, 0, T * 4, 0x00020000);
+          constexpr int NE = kPrefixHereMaxTiles / (2 * 64 * kPrefWaves);
+          auto sums = [&](int j0) {
+            int pv[NE];
 #pragma unroll
-        for (int j = 0; j < kPrefixHereMaxTiles / THREADS; ++j)
-          if (pv[j] >= 0) {
-            const int tj = tid + j * THREADS;
-            const int kk = min(pv[j], seg.seg_cap), it = max(1, (kk + 127) >> 7);
-            const bool before = seg.rank_order ? (pv[j] > pop_here || (pv[j] == pop_here && tj < tile)) : tj < tile;
-            isum += before ? it : 0;
-            itot += it; msum += kk; cmax = max(cmax, pv[j]);
-            const int itf = min(it, seg.slice_major);
-            front += (before ? itf : 0) + (itf << 16);
+            for (int j = 0; j < NE; ++j)
+              pv[j] = (int)__builtin_amdgcn_raw_buffer_load_b32(cur_rsrc, (tid + (j0 + j) * 64 * kPrefWaves) * 4, 0, 0);
+#pragma unroll
+            for (int j = 0; j < NE; ++j) {
+              const int tj = tid + (j0 + j) * 64 * kPrefWaves;
+              const bool ok = tj < T;
+              const int kk = ok ? min(pv[j], seg.seg_cap) : 0, it = ok ? max(1, (kk + 127) >> 7) : 0;
+              const bool before = seg.rank_order ? (pv[j] > pop_here || (pv[j] == pop_here && tj < tile)) : tj < tile;
+              isum += before ? it : 0;
+              itot += it; msum += kk; cmax = max(cmax, ok ? pv[j] : 0);
+              const bool mine = seg.xcd_shift == 0 || xcd_of_tile(tj, seg.tw, seg.inv_tw, seg.xcd_shift) == myx;
+              const int itf = mine ? min(it, seg.slice_major) : 0;
+              front += (before ? itf : 0) + (itf << 16);
+              deepx += (mine && before) ? it - itf : 0;
+            }
+          };
+          sums(0);
+          if (T > kPrefixHereMaxTiles / 2) sums(NE);  // (uniform)
+          // (DPP scans: the totals land in lane 63)
+          isum = wave_scan_dpp(isum, 0, OpAdd());
+          msum = wave_scan_dpp(msum, 0, OpAdd());
+          itot = wave_scan_dpp(itot, 0, OpAdd());
+          cmax = wave_scan_dpp(cmax, 0, OpMaxI());
+          front = wave_scan_dpp(front, 0, OpAdd());
+          deepx = wave_scan_dpp(deepx, 0, OpAdd());
+          if ((tid & 63) == 63) {
+            s_pre[0][tid >> 6] = isum; s_pre[1][tid >> 6] = msum; s_pre[2][tid >> 6] = cmax; s_pre[3][tid >> 6] = itot;
+            s_pre[4][tid >> 6] = front; s_pre[5][tid >> 6] = deepx;
           }
-        // (DPP scans: the totals land in lane 63)
-        isum = wave_scan_dpp(isum, 0, OpAdd());
-        msum = wave_scan_dpp(msum, 0, OpAdd());
-        itot = wave_scan_dpp(itot, 0, OpAdd());
-        cmax = wave_scan_dpp(cmax, 0, OpMaxI());
-        front = wave_scan_dpp(front, 0, OpAdd());
-        if ((tid & 63) == 63) {
-          s_pre[0][tid >> 6] = isum; s_pre[1][tid >> 6] = msum; s_pre[2][tid >> 6] = cmax; s_pre[3][tid >> 6] = itot;
-          s_pre[4][tid >> 6] = front;
         }
         prefix_pending = true;
         first = items = 0;
@@ -566,7 +615,7 @@ tile_sort_kernel(unsigned long long *__restrict__ keys, const int *__restrict__ 
               if (ftot >= 0) disp = i < EG_FRONT_LARGE ? fpre + i : ftot + (first - fpre) + (i - EG_FRONT_LARGE);
             }
             if (disp < seg.max_items)
-              seg.item_rec[disp] = make_int4(tile, i | (items << 16), tile * seg.seg_cap + i * 128, tile * seg.seg_cap + kept);
+              seg.item_rec[disp] = make_int4(tile, i | (items << 16), (int)seg.rec_tag, tile * seg.seg_cap + kept);
           }
         }
       }
@@ -908,6 +957,12 @@ extern "C" int64_t eg_debug_sort_profile(uint64_t *out, int64_t max_tiles) {
 }
 #endif
 
+// the XCD-aware record placement the training step / the operator apply on a grid of n_tiles tiles (one view per launch):
+// tiles per block side = 2^shift, 0 = dense records (include/edgegs.h, eg_step_args::item_rec)
+extern "C" int eg_record_xcd_shift(int32_t n_tiles) {
+  return record_xcd_shift(n_tiles, n_tiles <= kPrefixHereMaxTiles, true, 1);
+}
+
 extern "C" int eg_sort_pairs(uint64_t *keys, const int32_t *offsets, int32_t T, int64_t capacity,
                              int32_t *flatten_ids, int64_t *isect_ids, int32_t max_tile_hint, eg_stream_t stream) {
   EG_REQUIRE(T > 0 && offsets, "bad arguments");
@@ -936,10 +991,21 @@ extern "C" int eg_sort_segments(uint64_t *keys, int32_t *tile_cursor, int32_t T,
 }
 
 namespace eg {
+int record_xcd_shift(int T, bool prefix_here, bool has_item_rec, int C) {
+  // (small grids stay dense: eight lists over a few dozen tiles are not balanced, and nothing there misses an L2)
+  int shift = (prefix_here && has_item_rec && C == 1 && T >= kXcdMinTiles) ? kXcdShiftDefault : 0;
+#ifdef EG_DEV_SWITCHES
+  static const int xcd_env = getenv("EG_XCD_SHIFT") ? atoi(getenv("EG_XCD_SHIFT")) : -1;  // (A/B switch)
+  if (xcd_env >= 0 && shift > 0) shift = xcd_env;
+#endif
+  return shift;
+}
+
 int launch_sort_segments(uint64_t *keys, int32_t *tile_cursor, int32_t T, int32_t seg_cap, int32_t *flatten_ids,
                          int32_t *tile_start, int32_t *tile_end, int32_t *item_first, int32_t *item_end,
                          int32_t *item_tile, int32_t max_items, int32_t max_tile_hint, const Batch &bt, int C,
-                         hipStream_t st, int32_t *total_prefix_here, int32_t *item_rec, const int32_t *item_front) {
+                         hipStream_t st, int32_t *total_prefix_here, int32_t *item_rec, const int32_t *item_front,
+                         uint32_t rec_tag, int32_t tiles_per_row) {
   SegTable seg;
   seg.cursor = tile_cursor; seg.seg_cap = seg_cap;
   seg.tile_start = tile_start; seg.tile_end = tile_end;
@@ -952,6 +1018,12 @@ int launch_sort_segments(uint64_t *keys, int32_t *tile_cursor, int32_t T, int32_
   seg.slice_major = kFrontDefault;
   seg.middle_out = 1;
   seg.item_front = total_prefix_here ? nullptr : item_front;
+  seg.rec_tag = rec_tag;
+  // XCD-aware record placement ("prefix here" grids, one view per launch: the workgroup -> XCD map of a batched launch
+  // depends on max_items % 8): blocks of 2 x 2 tiles
+  seg.tw = tiles_per_row;
+  seg.inv_tw = tiles_per_row > 0 ? 1.f / (float)tiles_per_row : 0.f;
+  seg.xcd_shift = tiles_per_row > 0 ? record_xcd_shift(T, total_prefix_here != nullptr, item_rec != nullptr, C) : 0;
 #ifdef EG_DEV_SWITCHES  // A/B switches of development builds (edgegaussians_amd/build.py, EG_DEV_SWITCHES=1)
   static const int rank_order = getenv("EG_TILE_ORDER") ? atoi(getenv("EG_TILE_ORDER")) : 0;
   static const int front = getenv("EG_FRONT_SLICES") ? atoi(getenv("EG_FRONT_SLICES")) : kFrontDefault;

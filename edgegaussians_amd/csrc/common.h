@@ -48,25 +48,36 @@ int launch_project_emit(const float *means, const float *quats, const float *log
                         const float *viewmat, const float *K, int32_t N, int32_t width, int32_t height, uint32_t flags,
                         float *splat, int32_t *tile_cursor, int32_t seg_cap, uint64_t *keys, int32_t *item_first,
                         int32_t max_items, int32_t *total, int32_t *ticket, const Batch &bt, int C, hipStream_t st);
+// Round 5, XCD-aware item records (binning.hip SegTable::xcd_shift, composite_wave.hip): the XCD a tile's workgroups are
+// meant to run on -- square blocks of 2^shift tiles, dealt (block_x + 3 block_y) % 8.  tile < 2^20: the quotient is exact.
+__device__ __forceinline__ int xcd_of_tile(int tile, int tw, float inv_tw, int shift) {
+  const int ty = (int)(((float)tile + 0.5f) * inv_tw);
+  const int tx = tile - __mul24(ty, tw);  // (24-bit multiplies: full rate)
+  return ((tx >> shift) + __mul24(3, ty >> shift)) & 7;
+}
+
 int launch_sort_segments(uint64_t *keys, int32_t *tile_cursor, int32_t T, int32_t seg_cap, int32_t *flatten_ids,
                          int32_t *tile_start, int32_t *tile_end, int32_t *item_first, int32_t *item_end,
                          int32_t *item_tile, int32_t max_items, int32_t max_tile_hint, const Batch &bt, int C,
                          hipStream_t st, int32_t *total_prefix_here = nullptr, int32_t *item_rec = nullptr,
-                         const int32_t *item_front = nullptr);
+                         const int32_t *item_front = nullptr, uint32_t rec_tag = 0, int32_t tiles_per_row = 0);
 int launch_composite_fwd_segments(const float *splat, const int32_t *tile_start, const int32_t *tile_end,
                                   const int32_t *item_first, const int32_t *item_end, const int32_t *item_tile,
                                   const int32_t *flatten_ids, int32_t width, int32_t height, float loss_scale,
                                   float *loss_out, const int32_t *total, int64_t max_items, void *workspace,
                                   float *gtstop, int32_t rewalk_hint, const Batch &bt, int C, hipStream_t st,
                                   int32_t max_tile_hint, int32_t chain_tag, int32_t *cursor_reset = nullptr,
-                                  const int32_t *item_rec = nullptr);
+                                  const int32_t *item_rec = nullptr, int32_t seg_cap = 0);
 int composite_fwd_segments_hinted(const float *splat, const int32_t *tile_start, const int32_t *tile_end,
                                   const int32_t *item_first, const int32_t *item_end, const int32_t *item_tile,
                                   const int32_t *flatten_ids, int32_t width, int32_t height, float *render, float *alphas,
                                   int32_t *last_ids, const float *gt, const float *wmap, float loss_scale, float *vpix,
                                   float *loss_out, const int32_t *total, int64_t max_items, void *workspace,
                                   float *gtstop, int32_t rewalk_hint, int32_t max_tile_hint, int32_t chain_tag,
-                                  hipStream_t st, int32_t *cursor_reset = nullptr, const int32_t *item_rec = nullptr);
+                                  hipStream_t st, int32_t *cursor_reset = nullptr, const int32_t *item_rec = nullptr,
+                                  int32_t seg_cap = 0);
+// the XCD-aware record placement launch_sort_segments applies ("prefix here" grid with item records, one view): 0 = none
+int record_xcd_shift(int T, bool prefix_here, bool has_item_rec, int C);
 // workspace / max_items / loss_out (all three or none): the compositing workspace whose 64 partial loss sums (left by
 // the wave-autonomous forward) block (0, view) folds into *loss_out
 int launch_footprint_bwd(const float *splat, int32_t N, int32_t width, int32_t height, const float *gtstop, float *g2d,

@@ -19,9 +19,10 @@ struct TileTable {
   // != nullptr (the training step when the sort kernel forms the tile prefix itself, binning.hip): the binning
   // cursors [T], which the first slice workgroup of every tile returns to zero for the next projection
   int *cursor_reset;
-  // optional (training step): the sort kernel's per-item records {tile, slice | slices << 16, first key of the slice,
-  // end of the tile's keys}
+  // optional (training step): the sort kernel's per-item records {tile, slice | slices << 16, call tag, end of the
+  // tile's keys} (binning.hip, SegTable::item_rec / rec_tag)
   const int4 *item_rec;
+  int seg_cap = 0;    // with item_rec: keys per tile segment (a slice's first key is tile * seg_cap + 128 slice)
 };
 
 // pixel of thread `tid` in the slice-parallel kernels: wave w owns the 8x8 quadrant (w & 1, w >> 1)

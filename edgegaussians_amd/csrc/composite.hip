@@ -1617,8 +1617,8 @@ int composite_fwd_segments_hinted(const float *splat, const int32_t *tile_start,
                                   int32_t *last_ids, const float *gt, const float *wmap, float loss_scale, float *vpix,
                                   float *loss_out, const int32_t *total, int64_t max_items, void *workspace,
                                   float *gtstop, int32_t rewalk_hint, int32_t max_tile_hint, int32_t chain_tag,
-                                  hipStream_t st, int32_t *cursor_reset, const int32_t *item_rec) {
-  const TileTable tt = {tile_start, tile_end, item_first, item_end, item_tile, cursor_reset, (const int4 *)item_rec};
+                                  hipStream_t st, int32_t *cursor_reset, const int32_t *item_rec, int32_t seg_cap) {
+  const TileTable tt = {tile_start, tile_end, item_first, item_end, item_tile, cursor_reset, (const int4 *)item_rec, seg_cap};
   return launch_sliced_fwd((const float4 *)splat, tt, 1, flatten_ids, width, height, render, alphas, last_ids, gt, wmap,
                            loss_scale, vpix, loss_out, total, max_items, workspace, gtstop, rewalk_hint, st, Batch{}, 1,
                            max_tile_hint, chain_tag);
@@ -1686,8 +1686,8 @@ int launch_composite_fwd_segments(const float *splat, const int32_t *tile_start,
                                   float *loss_out, const int32_t *total, int64_t max_items, void *workspace,
                                   float *gtstop, int32_t rewalk_hint, const Batch &bt, int C, hipStream_t st,
                                   int32_t max_tile_hint, int32_t chain_tag, int32_t *cursor_reset,
-                                  const int32_t *item_rec) {
-  const TileTable tt = {tile_start, tile_end, item_first, item_end, item_tile, cursor_reset, (const int4 *)item_rec};
+                                  const int32_t *item_rec, int32_t seg_cap) {
+  const TileTable tt = {tile_start, tile_end, item_first, item_end, item_tile, cursor_reset, (const int4 *)item_rec, seg_cap};
   return launch_sliced_fwd((const float4 *)splat, tt, 1, flatten_ids, width, height, nullptr, nullptr, nullptr,
                            bt.gt[0], bt.wmap[0], loss_scale, nullptr, loss_out, total, max_items, workspace, gtstop,
                            rewalk_hint, st, bt, C, max_tile_hint, chain_tag);

@@ -518,6 +518,7 @@ struct WaveArgs {
   float loss_scale;
   int max_anchored;  // tiles of more slices look back over all aggregates (kMaxAnchoredSlices; 0 in an A/B build leg)
   const int *item_first;  // [T]: the tile's first item in the contiguous per-tile numbering (hand-over storage)
+  int seg_cap;            // keys per tile segment: slice s of tile t starts at key t * seg_cap + 128 s
 };
 
 __device__ __forceinline__ int dead_key(unsigned tag, int slice) { return (int)((tag << 15) | (unsigned)(32767 - min(slice, 32767))); }
@@ -565,15 +566,15 @@ __device__ __forceinline__ void wave_fwd_body(WaveArgs a, const Batch &bt, WaveL
   // where this item lives: ONE 16-byte record left by the sort kernel.  Requested together with the item count (the grid
   // covers max_items, the table has max_items entries: a stale record beyond the count is read and dropped) -- one
   // dependent round trip less at the head of every wave.
+  // (round 5: a record is valid iff its word 2 carries THIS call's tag -- the table has holes where an XCD's list ends
+  // before the longest one, and beyond the last record it holds the records of earlier calls; the item count is not needed)
   const int4 ir = a.item_rec[b];
-  const int n_items = a.total[2];
-  // ('|', and a test on the record that never fires: the exit needs BOTH loads, so neither is sunk behind the branch)
-  if ((b >= n_items) | (ir.y < 0)) return;
+  if ((unsigned)ir.z != a.tag) return;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   if (TIMED && lane < 8) my_prof[lane] = lane == 7 ? 1ull : 0ull;
   WaveList &wl = lists[wv];
   const int tile = ir.x, s_me = ir.y & 0xffff, ns = ir.y >> 16;
-  const int start = ir.z, t_end = ir.w, end = min(t_end, start + kSlice);
+  const int start = tile * a.seg_cap + s_me * kSlice, t_end = ir.w, end = min(t_end, start + kSlice);
   // ---- chained mode, DEAD SLICES: the (tile, quadrant)'s "first slice behind every pixel's stop" of THIS call, if a
   // wave in front has found it out already (a non-blocking look: all four words, so that the workgroup can take the
   // decision to leave without talking to itself).  Requested first: the answer is waited for before anything else.
@@ -832,6 +833,11 @@ int launch_wave_fwd(const float4 *splat, const TileTable tt, const int32_t *flat
   a.gt = gt; a.wmap = wmap; a.alphas = alphas; a.gtstop = (StopRec *)gtstop; a.prof = g_prof;
   a.width = width; a.height = height; a.tw = tw; a.n_tiles = tw * th;
   a.tag = tag; a.loss_scale = loss_scale; a.max_anchored = max_anchored; a.item_first = tt.item_first;
+  a.seg_cap = tt.seg_cap;
+  if (tt.seg_cap <= 0) {
+    set_error("composite_fwd(wave): the item records need the segment capacity");
+    return EG_ERR_ARG;
+  }
   // one view: everything is resolved here and the kernel never looks at the batch descriptor
   const bool batched = C > 1;
   if (!batched && bt.gt[0]) { a.gt = bt.gt[0]; a.wmap = bt.wmap[0]; }

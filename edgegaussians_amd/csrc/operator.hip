@@ -64,10 +64,11 @@ extern "C" int eg_operator_fwd(const eg_operator_args *a, eg_stream_t stream) {
   if (rc) return rc;
   rc = launch_sort_segments(a->keys, a->tile_counts, T, a->seg_cap, a->flatten_ids, a->tile_start, a->tile_end, a->item_first,
                             a->item_end, a->item_tile, (int32_t)a->max_items, a->max_tile_hint, Batch{}, 1, st,
-                            prefix_here ? a->total : nullptr, a->item_rec, prefix_here ? nullptr : a->ticket + 1);
+                            prefix_here ? a->total : nullptr, a->item_rec, prefix_here ? nullptr : a->ticket + 1,
+                            (uint32_t)a->ws_tag, tw);
   if (rc) return rc;
   const TileTable tt = {a->tile_start, a->tile_end, a->item_first, a->item_end, a->item_tile,
-                        prefix_here ? a->tile_counts : nullptr, (const int4 *)a->item_rec};
+                        prefix_here ? a->tile_counts : nullptr, (const int4 *)a->item_rec, a->seg_cap};
   rc = launch_wave_fwd((const float4 *)a->splat, tt, a->flatten_ids, a->width, a->height, nullptr, nullptr, 1.f, a->total,
                        a->max_items, a->workspace, a->gtstop, /*chained=*/1, (unsigned)a->ws_tag, a->max_tile_hint, st, Batch{}, 1,
                        a->alphas);

@@ -190,7 +190,7 @@ extern "C" int eg_train_step(const eg_step_args *a, eg_stream_t stream) {
     rc = launch_sort_segments(a->keys, a->tile_counts, T, a->seg_cap, a->flatten_ids, a->offsets, a->tile_end,
                               a->item_offsets, a->item_end, a->item_tile, (int32_t)a->max_items, a->max_tile_hint, Batch{}, 1,
                               st, prefix_here ? a->total : nullptr, a->item_rec,
-                              (flags & EG_FLAG_FRONT_PREFIX) ? a->ticket + 1 : nullptr);
+                              (flags & EG_FLAG_FRONT_PREFIX) ? a->ticket + 1 : nullptr, (uint32_t)max(a->ws_tag, 0), tw);
     }
     if (rc) return rc;
     EG_MARK(kMarkSort);
@@ -202,7 +202,7 @@ extern "C" int eg_train_step(const eg_step_args *a, eg_stream_t stream) {
                                        a->flatten_ids, a->width, a->height, a->render, a->alphas, a->last_ids, a->gt,
                                        a->wmap, a->loss_scale, a->vpix, a->loss, a->total, a->max_items, a->workspace,
                                        a->gtstop, a->rewalk_hint, a->max_tile_hint, a->ws_tag, st,
-                                       prefix_here ? a->tile_counts : nullptr, a->item_rec);
+                                       prefix_here ? a->tile_counts : nullptr, a->item_rec, a->seg_cap);
     if (rc) return rc;
   } else {
   // tile_counts is zero on entry (caller zero-initialises it once): the projection counts it up and its
@@ -298,12 +298,13 @@ extern "C" int eg_train_step_batched(const eg_step_args *a, int32_t C, const flo
   if (rc) return rc;
   rc = launch_sort_segments(a->keys, a->tile_counts, T, a->seg_cap, a->flatten_ids, a->offsets, a->tile_end,
                             a->item_offsets, a->item_end, a->item_tile, (int32_t)a->max_items, a->max_tile_hint, bt, C,
-                            st, prefix_here ? a->total : nullptr, a->item_rec);
+                            st, prefix_here ? a->total : nullptr, a->item_rec, nullptr, (uint32_t)max(a->ws_tag, 0), tw);
   if (rc) return rc;
   rc = launch_composite_fwd_segments(a->splat, a->offsets, a->tile_end, a->item_offsets, a->item_end, a->item_tile,
                                      a->flatten_ids, a->width, a->height, a->loss_scale, a->loss, a->total,
                                      a->max_items, a->workspace, a->gtstop, a->rewalk_hint, bt, C, st,
-                                     a->max_tile_hint, a->ws_tag, prefix_here ? a->tile_counts : nullptr, a->item_rec);
+                                     a->max_tile_hint, a->ws_tag, prefix_here ? a->tile_counts : nullptr, a->item_rec,
+                                     a->seg_cap);
   if (rc) return rc;
   rc = launch_footprint_bwd(a->splat, a->N, a->width, a->height, a->gtstop, a->g2d, bt, C, st, a->workspace, a->max_items,
                             a->loss);

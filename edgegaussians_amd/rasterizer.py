@@ -237,10 +237,15 @@ class _FastBuffers:
         """(Re)allocate the intersection buffers for M = m, largest tile population tile_max (with head-room)."""
         seg = (int(tile_max * 1.5) // 128 + 2) * 128
         cap = int(m * 1.3) + 4096
-        if seg <= self.seg_cap and cap // 128 + self.T <= self.max_items:
+        # (XCD-aware record placement, include/edgegs.h: the record table spans 8 x the longest of eight per-XCD lists --
+        # a quarter on top of the item count covers the imbalance of ordinary views; beyond it the overflow retry grows)
+        items = cap // 128 + self.T
+        if _lib.load().eg_record_xcd_shift(self.T) > 0:
+            items += items // 4
+        if seg <= self.seg_cap and items <= self.max_items:
             return
         self.seg_cap = max(seg, self.seg_cap)
-        self.max_items = max(cap // 128 + self.T, self.max_items)
+        self.max_items = max(items, self.max_items)
         self.max_tile = max(tile_max, self.max_tile)
         i32 = dict(dtype=torch.int32, device=self.dev)
         self.keys = torch.empty(self.T * self.seg_cap, dtype=torch.int64, device=self.dev)
@@ -263,7 +268,8 @@ class _FastBuffers:
 
     def roomy(self, m: int, tile_max: int) -> bool:
         """The last call left at least 30 % of head-room in both capacities (views of a scene differ by less)."""
-        return m * 1.3 <= (self.max_items - self.T) * 128 and tile_max * 1.3 <= self.seg_cap
+        items = self.max_items * 4 // 5 if _lib.load().eg_record_xcd_shift(self.T) > 0 else self.max_items
+        return m * 1.3 <= (items - self.T) * 128 and tile_max * 1.3 <= self.seg_cap
 
     def settle(self) -> None:
         """Looks at the verdicts of a call whose read-back was deferred.  An overflow or non-unit colours there mean that
@@ -295,6 +301,7 @@ class _FastBuffers:
     def next_tag(self) -> int:
         if self.tag >= _lib.MAX_WS_TAG:  # (every 65 534 calls: granules of 2^16 calls ago must not look fresh)
             self.workspace.zero_()
+            self.item_rec.zero_()  # (the records carry the call tag as well)
             self.tag = 0
         self.tag += 1
         return self.tag

@@ -198,7 +198,7 @@ class EdgeTrainer:
         n_keys = max(self.T * self.seg_cap, self.capacity)  # (the staged path always uses the classic layout)
         self.keys = torch.empty(n_keys, dtype=torch.int64, device=self.dev)
         self.flatten_ids = torch.empty(n_keys, dtype=torch.int32, device=self.dev)
-        self.max_items = (self.capacity + 127) // 128 + self.T
+        self.max_items = max((self.capacity + 127) // 128 + self.T, getattr(self, "_rec_need", 0))
         if self.seg_cap:
             self.tile_end = torch.zeros(self.T, dtype=torch.int32, device=self.dev)
             self.item_end = torch.zeros(self.T, dtype=torch.int32, device=self.dev)
@@ -267,25 +267,43 @@ class EdgeTrainer:
              ptr(self.total), stream())
         tot = self.total.tolist()  # one host sync: M, overflow flag, items, largest tile population
         self._last_tile_max = int(tot[3])
+        self._last_rec_span = self._record_span()
         self.tile_counts.zero_()
         return int(tot[0])
+
+    def _record_span(self) -> int:
+        """Entries of the item-record table the view just counted needs (tile_counts holds its populations): the number
+        of items -- or, with the XCD-aware placement (include/edgegs.h, item_rec), 8 x the longest of the eight per-XCD lists."""
+        shift = int(_lib.load().eg_record_xcd_shift(self.T)) if self.segmented else 0
+        if shift == 0:
+            return 0  # (dense records: one per item, and capacity / 128 + T bounds the items)
+        items = torch.clamp((self.tile_counts[:self.T] + 127) // 128, min=1)
+        if getattr(self, "_tile_xcd", None) is None or self._tile_xcd[1] != shift:
+            tw = (self.width + 15) // 16
+            t = torch.arange(self.T, device=self.dev)
+            self._tile_xcd = ((((t % tw) >> shift) + 3 * ((t // tw) >> shift)) % 8, shift)
+        per = torch.bincount(self._tile_xcd[0], weights=items.double(), minlength=8)
+        return 8 * int(per.max().item())
 
     def ensure_capacity(self, slack: float = 1.3, views: Optional[List[int]] = None) -> int:
         """Sizes the isect buffers from a count-only sweep (called at start and after every
         densify / cull event, i.e. whenever N changes -- 22 times in a 400-epoch ABC run)."""
         self._drop_projection()
         views = list(range(self.V)) if views is None else views
-        m_max, tile_max = 0, 0
+        m_max, tile_max, span_max = 0, 0, 0
         for v in views:
             m_max = max(m_max, self.count_intersections(v))
             tile_max = max(tile_max, self._last_tile_max)
+            span_max = max(span_max, self._last_rec_span)
         self.max_tile_seen = tile_max  # launch-shape hint of the tile sort (never affects results)
+        # the item-record table (XCD-aware placement: 8 x the longest per-XCD list) with the same slack as the keys
+        self._rec_need = int(span_max * slack) + 64 if span_max > 0 else 0
         need = int(m_max * slack) + 4096
         seg = (int(tile_max * 1.5) // 128 + 2) * 128 if self.segmented else 0
         if self.T * seg > (1 << 28):  # a few monster tiles would make T fixed segments absurdly large (> 3 GB):
             seg = 0                   # fall back to the count / scan / emit layout for this scene
             self.seg_cap = 0
-        if need > self.capacity or seg > self.seg_cap:
+        if need > self.capacity or seg > self.seg_cap or self._rec_need > self.max_items:
             self._alloc_isect(max(need, self.capacity), max(seg, self.seg_cap))
         self.m_max_seen = m_max
         self._args_cache = {}
@@ -371,6 +389,10 @@ class EdgeTrainer:
         for ws in [self.workspace] + [b["workspace"] for b in self._batches.values()]:
             if ws is not None:
                 ws.zero_()
+        # (the item records carry the call tag too: a record of 2^16 steps ago must not look like this call's)
+        for rec in [getattr(self, "item_rec", None)] + [b.get("item_rec") for b in self._batches.values()]:
+            if rec is not None:
+                rec.zero_()
         self._ws_tag = 0
 
     def _next_tag(self, n: int) -> int:

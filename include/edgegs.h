@@ -449,9 +449,15 @@ typedef struct {
    * eg_train_steps uses ws_tag .. ws_tag + K - 1).  0: the slice / combine / re-walk sequence. */
   int32_t ws_tag;
   /* optional (segmented layout): the sort kernel then also leaves one 16-byte record per item -- item_rec [max_items, 4]
-   * = {tile, slice | slices << 16, first key of the slice, end of the tile's keys}, in the order the forward dispatches
-   * its workgroups in (on tile grids of <= 2048 tiles: slices 0..3 of every tile first, the deeper slices after them;
-   * the record INDEX is not the item number -- the hand-over storage is addressed through item_first) -- and the step
+   * = {tile, slice | slices << 16, ws_tag of this call, end of the tile's keys} (the slice's first key is tile * seg_cap +
+   * 128 * slice), in the order the forward dispatches its workgroups in.  The record INDEX is not the item number -- the
+   * hand-over storage is addressed through item_first -- and the table may have HOLES: the forward takes a record for
+   * this call's iff word 2 equals ws_tag, so the table must be zeroed whenever the workspace is (tag wrap).  Tile grids of
+   * of 512 .. 2048 tiles (eg_record_xcd_shift), one view per launch: XCD-aware placement -- workgroup b of a launch runs on XCD b % 8; the tiles are
+   * dealt to the XCDs in 2 x 2-tile blocks, xcd = (block_x + 3 block_y) % 8, and XCD x's records sit at indices 8 k + x,
+   * slices 0..3 of its tiles first, their deeper slices after them; the table spans 8 x the longest of the eight lists
+   * (beyond max_items: the sticky overflow word).  Larger grids / batched launches: slices [0, 9) resp. [0, 4) of all
+   * tiles first, then the deeper slices, no holes.  The step
    * (no images wanted,
    * ws_tag > 0) runs the wave-autonomous forward, whose hand-over granules carry ws_tag: 1 <= ws_tag <= EG_MAX_WS_TAG,
    * different from the tag of every earlier call on this workspace since the workspace was last zeroed (the WHOLE
@@ -469,6 +475,10 @@ typedef struct {
  * same results; the stand-alone entries eg_project_emit / eg_sort_segments / eg_composite_fwd_segments keep the
  * protocol described with them.) */
 int eg_train_step(const eg_step_args *args_host, eg_stream_t stream);
+
+/* The XCD-aware placement of the item records (eg_step_args::item_rec) on a grid of n_tiles tiles with one view per launch:
+ * tiles per block side = 2^result, 0 = dense records.  A caller sizes max_items for 8 x the longest of the eight lists. */
+int eg_record_xcd_shift(int32_t n_tiles);
 
 /* ---- K consecutive steps by one native call: step k = eg_train_step on view views_host[k] (taken out of the
  * [V,4,4] / [V,3,3] / [V,H,W] arrays) with weight map wmaps_host[k] and every active Adam step count of

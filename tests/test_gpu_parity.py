@@ -2043,21 +2043,27 @@ def test_operator_protocol_with_the_drop_in_adam(env):
         assert_close(x, y, rtol=1e-5, name=name)
 
 
-@pytest.mark.parametrize("size", ["small_grid", "large_grid"])
+@pytest.mark.parametrize("size", ["tiny_grid", "small_grid", "large_grid"])
 def test_item_records_follow_the_dispatch_order_contract(env, size):
-    """What the wave-autonomous forward's look-back relies on (binning.hip, SegTable::slice_major / item_front): the records
-    the sort kernel leaves in `item_rec` are a PERMUTATION of all (tile, slice) pairs; a slice's record comes after the
-    records of every slice in front of it in its tile (workgroups are dispatched in record order and only ever wait for
-    lower records: the decoupled look-back cannot deadlock); the front slices of the multi-slice tiles come before any
-    deeper slice -- on tile grids of <= 2048 tiles slices [0, 4) of every tile first, above that slices [0, 9)
-    first (the projection's scan supplies the prefix: EG_FLAG_FRONT_PREFIX) --; and the item numbering the hand-over
-    storage uses (item_first / item_end / item_tile) stays contiguous per tile."""
+    """What the wave-autonomous forward's look-back relies on (binning.hip, SegTable::slice_major / item_front / xcd_shift):
+    the records the sort kernel leaves in `item_rec` that carry THIS call's tag are exactly the (tile, slice) pairs of the
+    view, each once; a slice's record comes after the records of every slice in front of it in its tile (workgroups are
+    dispatched in record order and only ever wait for lower records: the decoupled look-back cannot deadlock); the front
+    slices come before the deeper ones; and the item numbering the hand-over storage uses (item_first / item_end /
+    item_tile) stays contiguous per tile.
+    Tile grids of <= 2048 tiles (round 5, XCD-aware placement): workgroup b runs on XCD b % 8, tile (tx, ty) belongs to XCD
+    ((tx >> 1) + 3 (ty >> 1)) % 8, and the records of XCD x's tiles sit at indices 8 k + x, k dense from 0 -- slices [0, 4)
+    of its tiles first, tile by tile, then the deeper slices; no other index below max_items carries the call's tag.
+    Larger grids: slices [0, 9) of every tile first (the projection's scan supplies the prefix: EG_FLAG_FRONT_PREFIX), then
+    the deeper slices, indices [0, n_items) without holes."""
     import numpy as np
     _lib, synth, O = env
     from edgegaussians_amd import EdgeTrainer
     # Gaussians three times the usual size: the largest tile holds several thousand (dozens of slices)
-    if size == "small_grid":
-        W, H, n_g, scale = 330, 200, 20_000, 0.012
+    if size == "tiny_grid":
+        W, H, n_g, scale = 330, 200, 20_000, 0.012    # 21 x 13 = 273 tiles: below the XCD-aware placement's 512
+    elif size == "small_grid":
+        W, H, n_g, scale = 528, 400, 40_000, 0.012    # 33 x 25 = 825 tiles
     else:
         W, H, n_g, scale = 1008, 608, 120_000, 0.012  # 63 x 38 = 2394 tiles: the projection kernel scans the tiles
     sc = synth.make_scene(n_g, 2, W, H, seed=1, anisotropy=5.0, spread_opacity=True, scale=scale)
@@ -2067,9 +2073,15 @@ def test_item_records_follow_the_dispatch_order_contract(env, size):
     tr.grad_step(1, w)
     torch.cuda.synchronize()
     n_items = int(tr.total.cpu()[2])
-    T = tr.T
-    assert (T <= 2048) == (size == "small_grid")
-    rec = tr.item_rec.cpu().numpy()[:n_items]
+    T, tw = tr.T, (W + 15) // 16
+    assert (T <= 2048) == (size != "large_grid")
+    xcd_shift = int(_lib.load().eg_record_xcd_shift(T))
+    assert xcd_shift == (1 if size == "small_grid" else 0)
+    table = tr.item_rec.cpu().numpy()
+    valid = table[:, 2] == tr._ws_tag  # (the tag of the call just made)
+    assert int(valid.sum()) == n_items, (int(valid.sum()), n_items)
+    where = np.nonzero(valid)[0]
+    rec = table[valid]
     first, end_ = tr.item_offsets.cpu().numpy()[:T], tr.item_end.cpu().numpy()[:T]
     item_tile = tr.item_tile.cpu().numpy()[:n_items]
     tile, sl, ns = rec[:, 0], rec[:, 1] & 0xffff, rec[:, 1] >> 16
@@ -2081,26 +2093,41 @@ def test_item_records_follow_the_dispatch_order_contract(env, size):
     assert np.array_equal(ns, (end_ - first)[tile]) and (sl < ns).all()
     pairs = tile.astype(np.int64) * 65536 + sl
     assert len(np.unique(pairs)) == n_items
-    assert np.array_equal(rec[:, 2], tile * tr.seg_cap + sl * 128)  # first key of the slice
+    tile_end = tr.tile_end.cpu().numpy()[:T]
+    assert np.array_equal(rec[:, 3], tile_end[tile])  # end of the tile's keys
     # dispatch order: inside a tile by slice
     order = np.lexsort((np.arange(n_items), pairs))
     same_tile = tile[order][1:] == tile[order][:-1]
-    assert (np.diff(order)[same_tile] > 0).all(), "a slice was dispatched before a slice in front of it"
-    if any(k in os.environ for k in ("EG_FRONT_SLICES", "EG_FRONT_LARGE")):
+    assert (np.diff(where[order])[same_tile] > 0).all(), "a slice was dispatched before a slice in front of it"
+    if any(k in os.environ for k in ("EG_FRONT_SLICES", "EG_FRONT_LARGE", "EG_XCD_SHIFT")):
         return
     per_tile = end_ - first
     if size == "small_grid":
-        # two classes (SegTable::slice_major): slices [0, 4) of every tile, tile by tile, then the deeper slices
         front = 4  # kFrontDefault
-        n_a = int(np.minimum(per_tile, front).sum())
-        assert n_a < n_items and (sl[:n_a] < front).all() and (sl[n_a:] >= front).all()
-        assert (np.diff(tile[:n_a]) >= 0).all() and (np.diff(tile[n_a:]) >= 0).all()
+        ty, tx = np.divmod(tile, tw)
+        xcd = ((tx >> 1) + 3 * (ty >> 1)) % 8
+        assert np.array_equal(where % 8, xcd), "a record sits in another XCD's list"
+        assert len(np.unique(xcd)) == 8
+        span = 0
+        for x in range(8):
+            m = xcd == x
+            k = where[m] // 8
+            assert np.array_equal(k, np.arange(m.sum())), "an XCD's list has a hole"
+            span = max(span, 8 * int(m.sum()))
+            slx, tix = sl[m], tile[m]
+            n_a = int((slx < front).sum())
+            # two classes (SegTable::slice_major): slices [0, 4) of the list's tiles, tile by tile, then the deeper slices
+            assert n_a < m.sum() and (slx[:n_a] < front).all() and (slx[n_a:] >= front).all()
+            assert (np.diff(tix[:n_a]) >= 0).all() and (np.diff(tix[n_a:]) >= 0).all()
+        assert span <= tr.max_items and where.max() < span
     else:
-        front = 9  # EG_FRONT_LARGE
+        assert np.array_equal(where, np.arange(n_items))  # no holes
+        front = 9 if size == "large_grid" else 4  # EG_FRONT_LARGE / kFrontDefault
         n_a = int(np.minimum(per_tile, front).sum())
         assert n_a < n_items and (sl[:n_a] < front).all() and (sl[n_a:] >= front).all()
         assert (np.diff(tile[:n_a]) >= 0).all() and (np.diff(tile[n_a:]) >= 0).all()  # tile by tile inside a class
-        # the prefix the projection's scan left behind (ticket[1 .. T + 1])
-        fp = tr.ticket.cpu().numpy()
-        assert fp[0] == 0 and np.array_equal(fp[1:T + 1], np.concatenate([[0], np.cumsum(np.minimum(per_tile, front))[:-1]]))
-        assert fp[T + 1] == n_a
+        if size == "large_grid":
+            # the prefix the projection's scan left behind (ticket[1 .. T + 1])
+            fp = tr.ticket.cpu().numpy()
+            assert fp[0] == 0 and np.array_equal(fp[1:T + 1], np.concatenate([[0], np.cumsum(np.minimum(per_tile, front))[:-1]]))
+            assert fp[T + 1] == n_a
