@@ -21,6 +21,7 @@
 #include <cstdlib>
 
 #include "common.h"
+#include "composite.h"  // (carve_workspace: where the forward keeps its partial loss sums)
 
 namespace eg {
 
@@ -305,11 +306,6 @@ struct SegTable {
   // the compositing kernel returns them to zero -- and the last tile's workgroup leaves the totals
   // [4]: M, sticky overflow flag, items, largest tile population.
   int *total;
-  // with `total`: number the items HEAVIEST TILE FIRST (rank by population, ties by tile index) instead of in tile
-  // order.  The compositing kernels take one workgroup per item in item order: the many-slice tiles, whose slices hand
-  // their products over to one another, are then dispatched first and their hand-over chains run under the rest of the
-  // launch instead of forming its tail; the tail is made of single-slice and empty tiles, which hand nothing over.
-  int rank_order;
   // optional output for the wave-autonomous forward (composite_wave.hip): one 16-byte record per item
   // {tile, slice | slices << 16, rec_tag, end of the TILE's keys}   (the slice's first key is tile * seg_cap + 128 slice)
   int4 *item_rec;
@@ -347,7 +343,17 @@ struct SegTable {
   // The lists differ in length: the table has holes at the end of the shorter ones (no record carries the call's tag
   // there) and spans 8 x the longest list -- beyond max_items the sticky overflow flag goes up.
   int xcd_shift = 0;
-  int tw = 0;          // tiles per image row (xcd_shift > 0)
+  int tw = 0;          // tiles per image row (xcd_shift > 0 / skip_empty)
+  // Round 5, with `total` and `item_rec` when the caller's forward is the wave-autonomous one with the fused loss: an EMPTY
+  // tile gets no record.  57 % of the 512 x 512 grid's tiles hold nothing at the reference's sizes; their forward workgroups
+  // -- a fifth of the launch's waves -- only added the background's loss term sum_p w_p |gt_p| and wrote records the footprint
+  // backward never reads (no Gaussian's footprint reaches an empty tile: the exact tile test is conservative).  The tile's
+  // sort workgroup, which has nothing to sort, adds that term instead (to the forward's 64 partial sums) and leaves before the prefix scans and the barrier; the item numbering still counts the tile's one empty item
+  // (nothing else changes), its table entries are not written.  The LAST tile keeps the full path (it leaves the totals).
+  const float *gt = nullptr, *wmap = nullptr;  // [H,W] of the view (batched: Batch::gt / wmap)
+  float *loss_part = nullptr;                  // the forward's 64 partial loss sums (batched: + view * Batch::ws_bytes)
+  int width = 0, height = 0;
+  int skip_empty = 0;
   float inv_tw = 0.f;  // 1 / tw
 #ifdef EG_SORT_PROF
   // development builds (-DEG_SORT_PROF): [T][12] per-workgroup phase record of the small variant's last launch --
@@ -389,17 +395,14 @@ tile_sort_kernel(unsigned long long *__restrict__ keys, const int *__restrict__ 
       seg.item_first += bv * bt.tiles; seg.item_end += bv * bt.tiles; seg.item_tile += bv * bt.items;
       if (seg.total) seg.total += 4 * bv;
       if (seg.item_rec) seg.item_rec += bv * bt.items;
+      if (seg.skip_empty && gridDim.y > 1) {
+        seg.gt = bt.gt[bv]; seg.wmap = bt.wmap[bv];
+        seg.loss_part = (float *)((char *)seg.loss_part + bv * bt.ws_bytes);
+      }
     }
   }
   // NB = kSortBM buckets per thread: the rank pass costs a key one dependent LDS read per key of its bucket, so the
   // fullest tile's workgroup -- which the kernel lasts as long as -- is shortened by thinner buckets
-  // waves of the workgroup that form the tile prefix ("prefix here"): a quarter of them -- with two of eight the 512-thread
-  // variant lost 2.5 us at config 2 to the longer dependent chain per wave (8 tiles per lane), with all of them the
-  // 256-thread variant lost 1.7 us at config 1 to the redundant work
-#ifndef EG_SORT_PREF_WAVES_512
-#define EG_SORT_PREF_WAVES_512 4
-#endif
-  constexpr int kPrefWaves = THREADS >= 512 ? EG_SORT_PREF_WAVES_512 : 2;
   constexpr int BM = LARGE ? 1 : kSortBM;  // (the large variant is at the LDS limit)
   constexpr int NB = THREADS * BM;
   unsigned long long *kout = s;      // [CAP] keys scattered by bucket (the fast path keeps its input in registers)
@@ -480,7 +483,7 @@ tile_sort_kernel(unsigned long long *__restrict__ keys, const int *__restrict__ 
   const int tile = (!LARGE && seg.middle_out) ? ((wg & 1) ? T / 2 - (wg + 1) / 2 : T / 2 + wg / 2) : wg;
   __syncthreads();
   long long start, end;
-  __shared__ int s_pre[6][THREADS / 64];
+  __shared__ int s_pre[4][THREADS / 64];
   bool prefix_pending = false;  // (uniform) the tile prefix still has to be finished: see SegTable::total
   int pop_here = 0;
   // after a barrier: every thread sums the waves' partials; thread 0 writes the tile's table entries (and the
@@ -488,15 +491,12 @@ tile_sort_kernel(unsigned long long *__restrict__ keys, const int *__restrict__ 
   auto finish_prefix = [&](int kept_) {
     prefix_pending = false;
     if (tid >= 64) return;  // (the first wave writes the tables and the records: a tile has a few dozen items at most)
-    int isum = 0, msum = 0, cmax = 0, itot = 0, front = 0, deepx = 0;
+    int isum = 0, front = 0;
 #pragma unroll
-    for (int w = 0; w < kPrefWaves; ++w) {
-      isum += s_pre[0][w]; msum += s_pre[1][w]; cmax = max(cmax, s_pre[2][w]); itot += s_pre[3][w];
-      front += s_pre[4][w]; deepx += s_pre[5][w];
-    }
-    // of the tiles of THIS tile's XCD (all tiles without the XCD-aware placement): front-class items in front of this
-    // tile / in all, deep-class items in front of this tile
-    const int k0 = front & 0xffff, l0 = front >> 16, k1 = deepx;
+    for (int w = 0; w < THREADS / 64; ++w) { isum += s_pre[0][w]; front += s_pre[1][w]; }
+    // of the tiles of THIS tile's XCD (all tiles without the XCD-aware placement): front-class items in front of this tile;
+    // front-class items in all + deep-class items in front of this tile
+    const int k0 = front & 0xffff, l0k1 = front >> 16;
     const int first_ = min(isum, seg.max_items);
     const int items_ = min(max(1, (kept_ + 127) >> 7), max(0, seg.max_items - first_));
     // dispatch index of slice i: class 0 = slices [0, slice_major) of the list's tiles, class 1 = the rest; inside a class
@@ -506,7 +506,7 @@ tile_sort_kernel(unsigned long long *__restrict__ keys, const int *__restrict__ 
     for (int i = tid; i < items_; i += 64) {
       seg.item_tile[first_ + i] = tile;
       if (seg.item_rec) {
-        const int pos = i < seg.slice_major ? k0 + i : l0 + k1 + (i - seg.slice_major);
+        const int pos = i < seg.slice_major ? k0 + i : l0k1 + (i - seg.slice_major);
         const int disp = seg.xcd_shift > 0 ? 8 * pos + myx : pos;
         if (disp < seg.max_items)
           seg.item_rec[disp] = make_int4(tile, i | (items_ << 16), (int)seg.rec_tag, tile * seg.seg_cap + kept_);
@@ -520,7 +520,11 @@ tile_sort_kernel(unsigned long long *__restrict__ keys, const int *__restrict__ 
       seg.tile_start[tile] = tile * seg.seg_cap;
       seg.tile_end[tile] = tile * seg.seg_cap + kept_;
       seg.item_end[tile] = first_ + items_;
-      if (tile == T - 1) {  // (every workgroup has summed ALL tiles: this one leaves the totals of the view)
+      if (tile == T - 1) {  // (the last tile's workgroup has summed the view's totals as well)
+        int msum = 0, cmax = 0;
+#pragma unroll
+        for (int w = 0; w < THREADS / 64; ++w) { msum += s_pre[2][w]; cmax = max(cmax, s_pre[3][w]); }
+        const int itot = isum + max(1, (kept_ + 127) >> 7);  // (the tiles in front + this one: all of them)
         seg.total[0] = msum;
         if (cmax > seg.seg_cap || itot > seg.max_items) seg.total[1] = 1;  // sticky: only the host clears it
         seg.total[2] = min(itot, seg.max_items);
@@ -542,53 +546,79 @@ tile_sort_kernel(unsigned long long *__restrict__ keys, const int *__restrict__ 
         // (they travel with the tile's own cursor and first keys); per-wave partial sums go to LDS and the prefix
         // is finished right after the FIRST barrier the sort takes anyway (finish_prefix below): no barrier of its own
         // (ALL populations, not only those of the tiles in front: the item numbering may follow the populations' rank)
-        // Round 5: the sums are formed by the workgroup's FIRST TWO waves only (8 tiles per lane and batch; a grid above
-        // 1024 tiles takes a second batch), not by every wave over T / THREADS tiles each: with the per-XCD class sums the
-        // redundant vector work of the launch (T workgroups x all waves x {per-tile arithmetic + six DPP scans}) cost the
-        // 256-thread variant 1.7 us at config 1.  The other waves do not need the prefix before the first barrier.
-        // Buffer loads on a descriptor of the T cursors: one 32-bit offset per load, a tile beyond T reads 0.
+        // Round 5.  What a workgroup needs of the other tiles is TWO sums -- the items of the tiles in front (the tile's first
+        // item) and, over the tiles of its XCD's list (all tiles without the XCD-aware placement), the packed pair {front-class
+        // items in front | front-class items in all + deep-class items in front} -- and only the LAST tile's workgroup needs
+        // the view's totals (M, the largest population; the item count is its own prefix + its own items).  Round 4 formed
+        // five sums in every wave of every workgroup; the per-workgroup phase record (profiles/r05_sort_phases_config2.txt,
+        // r05_sort_ab.txt) prices the dependent vector chain in front of the first barrier at ~500 cycles per tile and lane and
+        // ~240 per DPP scan with four waves per SIMD doing the same -- the launch's floor, since 57 % of its workgroups do
+        // nothing else.  The first batch of populations is asked for together with the tile's own: buffer loads on a
+        // descriptor of the T cursors, a tile beyond T reads 0 without a clamp.
         pop_here = seg.cursor[tile];
         kept = min(pop_here, seg.seg_cap);
-        if ((tid >> 6) < kPrefWaves) {
-          int isum = 0, msum = 0, cmax = 0, itot = 0;
-          // the same over min(items, kFront): the sum over the tiles in front in the low half, over all tiles in the high
-          // half (at most 2048 * 15 each); deepx: the deeper slices of the tiles in front.  With the XCD-aware placement
-          // both run over the tiles of this tile's XCD only.
-          int front = 0, deepx = 0;
-          const int myx = seg.xcd_shift > 0 ? xcd_of_tile(tile, seg.tw, seg.inv_tw, seg.xcd_shift) : 0;
-          const __amdgpu_buffer_rsrc_t cur_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)seg.cursor, 0, T * 4, 0x00020000);
-          constexpr int NE = kPrefixHereMaxTiles / (2 * 64 * kPrefWaves);
-          auto sums = [&](int j0) {
-            int pv[NE];
+        const __amdgpu_buffer_rsrc_t cur_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)seg.cursor, 0, T * 4, 0x00020000);
+        constexpr int NE = kPrefixHereMaxTiles / (2 * THREADS);  // tiles per lane and batch: a batch covers 1024 tiles
+        int pv0[NE];
 #pragma unroll
-            for (int j = 0; j < NE; ++j)
-              pv[j] = (int)__builtin_amdgcn_raw_buffer_load_b32(cur_rsrc, (tid + (j0 + j) * 64 * kPrefWaves) * 4, 0, 0);
+        for (int j = 0; j < NE; ++j) pv0[j] = (int)__builtin_amdgcn_raw_buffer_load_b32(cur_rsrc, (tid + j * THREADS) * 4, 0, 0);
+        // (skip_empty: the background's loss term of this tile, asked for with everything else -- used only if the tile
+        // turns out empty; thread t of the first four waves takes pixel (t >> 4, t & 15) of the tile: four half lines per
+        // wave and array)
+        float l_bg = 0.f;
+        if (seg.skip_empty && tid < kTilePix) {
+          const int ty_ = (int)(((float)tile + 0.5f) * seg.inv_tw), tx_ = tile - __mul24(ty_, seg.tw);
+          const int pi = ty_ * kTile + (tid >> 4), pj = tx_ * kTile + (tid & 15);
+          if (pi < seg.height && pj < seg.width) {
+            const int pp = pi * seg.width + pj;
+            l_bg = seg.wmap[pp] * fabsf(seg.gt[pp]);  // w_p |clamp(1 - T_final) - gt_p| with T_final = 1
+          }
+        }
+        if (seg.skip_empty && pop_here == 0 && tile != T - 1) {  // (uniform) nothing to sort, no record, no table entry
+          if (tid < kTilePix) {
+            l_bg = wave_sum_dpp_f(l_bg);  // (total in lane 63)
+            if ((tid & 63) == 63 && l_bg != 0.f) unsafeAtomicAdd(&seg.loss_part[(tile * 4 + (tid >> 6)) & 63], l_bg);
+          }
+          EG_SP_TICK(0); EG_SP_DONE(0);
+          continue;
+        }
+        {
+          int isum = 0, front = 0, msum = 0, cmax = 0;
+          const bool last_tile = tile == T - 1;  // (uniform)
+          const int myx = seg.xcd_shift > 0 ? xcd_of_tile(tile, seg.tw, seg.inv_tw, seg.xcd_shift) : 0;
+          auto sums = [&](const int (&pv)[NE], int j0) {
 #pragma unroll
             for (int j = 0; j < NE; ++j) {
-              const int tj = tid + (j0 + j) * 64 * kPrefWaves;
-              const bool ok = tj < T;
-              const int kk = ok ? min(pv[j], seg.seg_cap) : 0, it = ok ? max(1, (kk + 127) >> 7) : 0;
-              const bool before = seg.rank_order ? (pv[j] > pop_here || (pv[j] == pop_here && tj < tile)) : tj < tile;
+              const int tj = tid + (j0 + j) * THREADS;
+              const bool ok = tj < T, before = tj < tile;
+              const int kk = min(pv[j], seg.seg_cap), it = ok ? max(1, (kk + 127) >> 7) : 0;
               isum += before ? it : 0;
-              itot += it; msum += kk; cmax = max(cmax, ok ? pv[j] : 0);
-              const bool mine = seg.xcd_shift == 0 || xcd_of_tile(tj, seg.tw, seg.inv_tw, seg.xcd_shift) == myx;
+              // (records: an empty tile other than the last one has none with skip_empty; the numbering above still counts it)
+              const bool mine = (seg.xcd_shift == 0 || xcd_of_tile(tj, seg.tw, seg.inv_tw, seg.xcd_shift) == myx) &&
+                                !(seg.skip_empty && kk == 0 && tj != T - 1);
               const int itf = mine ? min(it, seg.slice_major) : 0;
-              front += (before ? itf : 0) + (itf << 16);
-              deepx += (mine && before) ? it - itf : 0;
+              front += (before ? itf : 0) + ((itf + ((mine && before) ? it - itf : 0)) << 16);
+              if (last_tile) { msum += kk; cmax = max(cmax, pv[j]); }
             }
           };
-          sums(0);
-          if (T > kPrefixHereMaxTiles / 2) sums(NE);  // (uniform)
+          sums(pv0, 0);
+          if (T > kPrefixHereMaxTiles / 2) {  // (uniform) a grid above 1024 tiles takes a second round trip
+            int pv1[NE];
+#pragma unroll
+            for (int j = 0; j < NE; ++j)
+              pv1[j] = (int)__builtin_amdgcn_raw_buffer_load_b32(cur_rsrc, (tid + (NE + j) * THREADS) * 4, 0, 0);
+            sums(pv1, NE);
+          }
           // (DPP scans: the totals land in lane 63)
           isum = wave_scan_dpp(isum, 0, OpAdd());
-          msum = wave_scan_dpp(msum, 0, OpAdd());
-          itot = wave_scan_dpp(itot, 0, OpAdd());
-          cmax = wave_scan_dpp(cmax, 0, OpMaxI());
           front = wave_scan_dpp(front, 0, OpAdd());
-          deepx = wave_scan_dpp(deepx, 0, OpAdd());
+          if (last_tile) {
+            msum = wave_scan_dpp(msum, 0, OpAdd());
+            cmax = wave_scan_dpp(cmax, 0, OpMaxI());
+          }
           if ((tid & 63) == 63) {
-            s_pre[0][tid >> 6] = isum; s_pre[1][tid >> 6] = msum; s_pre[2][tid >> 6] = cmax; s_pre[3][tid >> 6] = itot;
-            s_pre[4][tid >> 6] = front; s_pre[5][tid >> 6] = deepx;
+            s_pre[0][tid >> 6] = isum; s_pre[1][tid >> 6] = front;
+            if (last_tile) { s_pre[2][tid >> 6] = msum; s_pre[3][tid >> 6] = cmax; }
           }
         }
         prefix_pending = true;
@@ -984,7 +1014,6 @@ extern "C" int eg_sort_segments(uint64_t *keys, int32_t *tile_cursor, int32_t T,
   seg.item_first = const_cast<int32_t *>(item_first); seg.item_end = item_end;  // (read only: total == nullptr)
   seg.item_tile = item_tile; seg.max_items = max_items;
   seg.total = nullptr;
-  seg.rank_order = 0;
   seg.item_rec = nullptr;
   seg.slice_major = 0;
   return launch_tile_sort(keys, nullptr, T, (int64_t)T * seg_cap, flatten_ids, nullptr, max_tile_hint, seg, stream);
@@ -1005,7 +1034,8 @@ int launch_sort_segments(uint64_t *keys, int32_t *tile_cursor, int32_t T, int32_
                          int32_t *tile_start, int32_t *tile_end, int32_t *item_first, int32_t *item_end,
                          int32_t *item_tile, int32_t max_items, int32_t max_tile_hint, const Batch &bt, int C,
                          hipStream_t st, int32_t *total_prefix_here, int32_t *item_rec, const int32_t *item_front,
-                         uint32_t rec_tag, int32_t tiles_per_row) {
+                         uint32_t rec_tag, int32_t tiles_per_row, const float *gt, const float *wmap, void *workspace,
+                         int32_t width, int32_t height) {
   SegTable seg;
   seg.cursor = tile_cursor; seg.seg_cap = seg_cap;
   seg.tile_start = tile_start; seg.tile_end = tile_end;
@@ -1013,7 +1043,6 @@ int launch_sort_segments(uint64_t *keys, int32_t *tile_cursor, int32_t T, int32_
   seg.item_tile = item_tile; seg.max_items = max_items;
   seg.total = total_prefix_here;
   // the forward's dispatch order (SegTable): front slices first; tiles taken middle-out
-  seg.rank_order = 0;
   seg.item_rec = (int4 *)item_rec;
   seg.slice_major = kFrontDefault;
   seg.middle_out = 1;
@@ -1023,12 +1052,22 @@ int launch_sort_segments(uint64_t *keys, int32_t *tile_cursor, int32_t T, int32_
   // depends on max_items % 8): blocks of 2 x 2 tiles
   seg.tw = tiles_per_row;
   seg.inv_tw = tiles_per_row > 0 ? 1.f / (float)tiles_per_row : 0.f;
+  // the empty tiles' loss terms are added here (SegTable::skip_empty): the caller hands over the view's target / weights and
+  // the compositing workspace exactly when its forward is the wave-autonomous one with the fused loss
+  if (total_prefix_here && item_rec && tiles_per_row > 0 && workspace && width > 0 && height > 0 &&
+      (C > 1 ? bt.gt[0] && bt.wmap[0] : gt && wmap)) {
+    seg.skip_empty = 1;
+    seg.gt = gt; seg.wmap = wmap; seg.width = width; seg.height = height;
+    seg.loss_part = carve_workspace(workspace, max_items, T).loss_part;
+#ifdef EG_DEV_SWITCHES
+    static const int skip_env = getenv("EG_SKIP_EMPTY") ? atoi(getenv("EG_SKIP_EMPTY")) : 1;  // (A/B switch)
+    seg.skip_empty = skip_env;
+#endif
+  }
   seg.xcd_shift = tiles_per_row > 0 ? record_xcd_shift(T, total_prefix_here != nullptr, item_rec != nullptr, C) : 0;
 #ifdef EG_DEV_SWITCHES  // A/B switches of development builds (edgegaussians_amd/build.py, EG_DEV_SWITCHES=1)
-  static const int rank_order = getenv("EG_TILE_ORDER") ? atoi(getenv("EG_TILE_ORDER")) : 0;
   static const int front = getenv("EG_FRONT_SLICES") ? atoi(getenv("EG_FRONT_SLICES")) : kFrontDefault;
   static const int middle_out = getenv("EG_SORT_MIDDLE_OUT") ? atoi(getenv("EG_SORT_MIDDLE_OUT")) : 1;
-  seg.rank_order = rank_order;
   seg.slice_major = front < 0 ? 0 : (front > 15 ? 15 : front);
   seg.middle_out = middle_out;
   static const int front_large = getenv("EG_FRONT_LARGE") ? atoi(getenv("EG_FRONT_LARGE")) : 1;

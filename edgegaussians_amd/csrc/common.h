@@ -60,7 +60,11 @@ int launch_sort_segments(uint64_t *keys, int32_t *tile_cursor, int32_t T, int32_
                          int32_t *tile_start, int32_t *tile_end, int32_t *item_first, int32_t *item_end,
                          int32_t *item_tile, int32_t max_items, int32_t max_tile_hint, const Batch &bt, int C,
                          hipStream_t st, int32_t *total_prefix_here = nullptr, int32_t *item_rec = nullptr,
-                         const int32_t *item_front = nullptr, uint32_t rec_tag = 0, int32_t tiles_per_row = 0);
+                         const int32_t *item_front = nullptr, uint32_t rec_tag = 0, int32_t tiles_per_row = 0,
+                         const float *gt = nullptr, const float *wmap = nullptr, void *workspace = nullptr, int32_t width = 0,
+                         int32_t height = 0);
+bool wave_forward_selected(int channels, const void *render, const void *alphas, const void *last_ids, const void *vpix,
+                           const void *gtstop, const void *wmap, const void *item_rec, int chain_tag);
 int launch_composite_fwd_segments(const float *splat, const int32_t *tile_start, const int32_t *tile_end,
                                   const int32_t *item_first, const int32_t *item_end, const int32_t *item_tile,
                                   const int32_t *flatten_ids, int32_t width, int32_t height, float loss_scale,

@@ -1529,8 +1529,7 @@ static int launch_sliced_fwd(const float4 *splat, const TileTable tt, int channe
 #endif
   // The training step (no images wanted, fused loss, segmented tables): the wave-autonomous forward of
   // composite_wave.hip -- speculative while no pixel reaches the transmittance stop, chained (exact stop inside) otherwise
-  if (!old_fwd && channels == 1 && !render && !alphas && !last_ids && !vpix && gtstop && wmap && tt.item_rec &&
-      chain_tag > 0)
+  if (!old_fwd && wave_forward_selected(channels, render, alphas, last_ids, vpix, gtstop, wmap, tt.item_rec, chain_tag))
     return launch_wave_fwd(splat, tt, flatten_ids, width, height, gt, wmap, loss_scale, total, max_items, workspace, gtstop,
                            !skip, (unsigned)chain_tag, max_tile_hint, s, bt, C);
   // (rewalk_hint == 0 without speculation -- a caller without a journal, e.g. the data-parallel leg, that has seen no
@@ -1609,6 +1608,19 @@ extern "C" int eg_composite_fwd(const float *splat, const float *colors, int32_t
 #undef EG_LAUNCH_FWD
   return check_launch("composite_fwd");
 }
+
+namespace eg {
+// the training step's case -- no images wanted, fused loss, item records, a call tag -- takes the wave-autonomous forward
+// (composite_wave.hip); step.hip asks the same question to let the sort kernel skip the empty tiles (binning.hip, skip_empty)
+bool wave_forward_selected(int channels, const void *render, const void *alphas, const void *last_ids, const void *vpix,
+                           const void *gtstop, const void *wmap, const void *item_rec, int chain_tag) {
+#ifdef EG_DEV_SWITCHES
+  static const bool old_fwd = getenv("EG_FWD_OLD") && atoi(getenv("EG_FWD_OLD")) != 0;
+  if (old_fwd) return false;
+#endif
+  return channels == 1 && !render && !alphas && !last_ids && !vpix && gtstop && wmap && item_rec && chain_tag > 0;
+}
+}  // namespace eg
 
 namespace eg {
 int composite_fwd_segments_hinted(const float *splat, const int32_t *tile_start, const int32_t *tile_end,

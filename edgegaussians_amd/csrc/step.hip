@@ -187,10 +187,14 @@ extern "C" int eg_train_step(const eg_step_args *a, eg_stream_t stream) {
     EG_MARK(kMarkEmit);
     {
     RoctxRange range("eg:tile_sort");
+    // (the wave-autonomous forward with the fused loss follows: the sort kernel adds the empty tiles' loss terms and gives them no record)
+    const bool wave_fwd = wave_forward_selected(1, a->render, a->alphas, a->last_ids, a->vpix, a->gtstop, a->wmap, a->item_rec, a->ws_tag);
     rc = launch_sort_segments(a->keys, a->tile_counts, T, a->seg_cap, a->flatten_ids, a->offsets, a->tile_end,
                               a->item_offsets, a->item_end, a->item_tile, (int32_t)a->max_items, a->max_tile_hint, Batch{}, 1,
                               st, prefix_here ? a->total : nullptr, a->item_rec,
-                              (flags & EG_FLAG_FRONT_PREFIX) ? a->ticket + 1 : nullptr, (uint32_t)max(a->ws_tag, 0), tw);
+                              (flags & EG_FLAG_FRONT_PREFIX) ? a->ticket + 1 : nullptr, (uint32_t)max(a->ws_tag, 0), tw,
+                              wave_fwd ? a->gt : nullptr, wave_fwd ? a->wmap : nullptr, wave_fwd ? a->workspace : nullptr, a->width,
+                              a->height);
     }
     if (rc) return rc;
     EG_MARK(kMarkSort);
@@ -296,9 +300,12 @@ extern "C" int eg_train_step_batched(const eg_step_args *a, int32_t C, const flo
                                a->item_offsets, (int32_t)a->max_items, a->total, prefix_here ? nullptr : a->ticket, bt,
                                C, st);
   if (rc) return rc;
+  const bool wave_fwd_b = wave_forward_selected(1, nullptr, nullptr, nullptr, nullptr, a->gtstop, bt.wmap[0], a->item_rec, a->ws_tag);
   rc = launch_sort_segments(a->keys, a->tile_counts, T, a->seg_cap, a->flatten_ids, a->offsets, a->tile_end,
                             a->item_offsets, a->item_end, a->item_tile, (int32_t)a->max_items, a->max_tile_hint, bt, C,
-                            st, prefix_here ? a->total : nullptr, a->item_rec, nullptr, (uint32_t)max(a->ws_tag, 0), tw);
+                            st, prefix_here ? a->total : nullptr, a->item_rec, nullptr, (uint32_t)max(a->ws_tag, 0), tw,
+                            wave_fwd_b ? bt.gt[0] : nullptr, wave_fwd_b ? bt.wmap[0] : nullptr, wave_fwd_b ? a->workspace : nullptr,
+                            a->width, a->height);
   if (rc) return rc;
   rc = launch_composite_fwd_segments(a->splat, a->offsets, a->tile_end, a->item_offsets, a->item_end, a->item_tile,
                                      a->flatten_ids, a->width, a->height, a->loss_scale, a->loss, a->total,

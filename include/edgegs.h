@@ -457,7 +457,11 @@ typedef struct {
    * dealt to the XCDs in 2 x 2-tile blocks, xcd = (block_x + 3 block_y) % 8, and XCD x's records sit at indices 8 k + x,
    * slices 0..3 of its tiles first, their deeper slices after them; the table spans 8 x the longest of the eight lists
    * (beyond max_items: the sticky overflow word).  Larger grids / batched launches: slices [0, 9) resp. [0, 4) of all
-   * tiles first, then the deeper slices, no holes.  The step
+   * tiles first, then the deeper slices, no holes.  Grids of <= 2048 tiles, fused loss (wmap != NULL, no images wanted): an
+   * EMPTY tile other than the last one has NO record -- its sort workgroup adds the background's loss term
+   * sum_p wmap_p |gt_p| to the forward's partial sums and leaves; its gtstop pixels and its tile / item table entries are
+   * not written (no Gaussian's footprint reaches them: the exact tile test is conservative), its one empty item stays in the
+   * numbering.  The step
    * (no images wanted,
    * ws_tag > 0) runs the wave-autonomous forward, whose hand-over granules carry ws_tag: 1 <= ws_tag <= EG_MAX_WS_TAG,
    * different from the tag of every earlier call on this workspace since the workspace was last zeroed (the WHOLE

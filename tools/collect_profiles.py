@@ -16,7 +16,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EV = os.path.join(ROOT, "gpurun_out", "ev")
 OUT = os.path.join(ROOT, "profiles")
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r04"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r05"
 VALU_PEAK = 256 * 4 * 2.4e9 / 2.0  # (2 cycles per wave64 instruction: MI355X_MICROARCH.md, tools/microbench/issue_rates.hip)
 
 
@@ -48,7 +48,9 @@ def main():
               "bench_config2_operator_native_adam.json": "bench_config2_operator_native_adam.json"}
     copies.update({"fwd_wave_phases_config4.txt": "fwd_wave_phases_config4.txt", "roctx_ranges_config2.txt": "roctx_ranges_config2.txt",
                    "bench_config1_scenes1.json": "bench_config1_scenes1.json", "bench_config1_scenes2.json": "bench_config1_scenes2.json",
-                   "bench_config1_scenes4.json": "bench_config1_scenes4.json"})
+                   "bench_config1_scenes4.json": "bench_config1_scenes4.json", "bench_config1_scenes8.json": "bench_config1_scenes8.json",
+                   "bench_config1_scenes8_threads.json": "bench_config1_scenes8_threads.json",
+                   "bench_config2_scenes4.json": "bench_config2_scenes4.json"})
     for c in ("config1", "config2", "config2i", "config3", "config4"):
         copies[f"kernel_stats_{c}.txt"] = f"kernel_stats_{c}.txt"
         copies[f"timeline_gaps_{c}.txt"] = f"timeline_gaps_{c}.txt"

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Full evidence run on the GPU box (round 4): parity tests + report, bench lines (headline with same-run PMC traffic,
+# Full evidence run on the GPU box (round 5): parity tests + report, bench lines (headline with same-run PMC traffic,
 # config1, trained-like, batched views, operator path, config3/4), rocprofv3 kernel stats + launch gaps, SQ counters.
 #   gpurun --timeout 3000 -- 'bash tools/run_gpu_suite.sh'
 # Everything lands in gpurun_out/ev/; copy what should be judged into profiles/ (tools/collect_profiles.py).
@@ -22,7 +22,9 @@ tools/microbench/issue_rates > $O/issue_rates.txt 2>&1
 EG_FWD_PROF=1 python tools/fwd_prof.py config2 --spread 2>/dev/null | grep -v "^RCCL\|^HIP\|amdgpu.ids" > $O/fwd_wave_phases_config2.txt
 EG_FWD_PROF=1 python tools/fwd_prof.py config2 2>/dev/null | grep -v "^RCCL\|^HIP\|amdgpu.ids" >> $O/fwd_wave_phases_config2.txt
 EG_FWD_PROF=1 python tools/fwd_prof.py config4 --spread 2>/dev/null | grep -v "^RCCL\|^HIP\|amdgpu.ids" > $O/fwd_wave_phases_config4.txt
-for S in 1 2 4; do timeout 300 python bench.py --config config1 --scenes-per-gpu $S 2>/dev/null | tail -1 > $O/bench_config1_scenes$S.json; done
+for S in 1 2 4 8; do timeout 300 python bench.py --config config1 --scenes-per-gpu $S 2>/dev/null | tail -1 > $O/bench_config1_scenes$S.json; done
+timeout 300 python bench.py --config config1 --scenes-per-gpu 8 --scenes-driver threads 2>/dev/null | tail -1 > $O/bench_config1_scenes8_threads.json
+timeout 300 python bench.py --config config2 --scenes-per-gpu 4 2>/dev/null | tail -1 > $O/bench_config2_scenes4.json
 timeout 300 python bench.py --force-dp --no-cpu-baseline --no-traffic --no-extra 2>/dev/null | tail -1 > $O/bench_config2_force_dp.json
 timeout 300 python tools/bench_regularizers.py 2>/dev/null | tail -1 > $O/regularizers_timing.json
 timeout 300 python tools/operator_profile.py config2 2>/dev/null | grep -v "^RCCL\|^HIP\|amdgpu.ids" > $O/operator_profile_config2.txt
