@@ -638,8 +638,11 @@ def measure_scenes(name, args, device, S, steps=400, warmup=50, spread=False):
             for s0 in range(step0, step0 + k, chunk):
                 ss = range(s0, min(s0 + chunk, step0 + k))
                 vs = [s % n_views for s in ss]
-                train_steps_multi([t[0] for t in trs], [vs] * S,
-                                  [[t[2](v) if s % 5 == 0 else t[1] for s, v in zip(ss, vs)] for t in trs], streams, n_threads)
+                wl = []
+                for i, t in enumerate(trs):  # (every scene's weight maps are drawn on ITS stream, like its steps)
+                    with torch.cuda.stream(streams[i]):
+                        wl.append([t[2](v) if s % 5 == 0 else t[1] for s, v in zip(ss, vs)])
+                train_steps_multi([t[0] for t in trs], [vs] * S, wl, streams, n_threads)
             return
         th = [threading.Thread(target=drive, args=(i, k, step0)) for i in range(S)]
         for t in th:

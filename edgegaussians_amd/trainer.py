@@ -181,7 +181,11 @@ class EdgeTrainer:
         self.ticket = torch.zeros(self.T + 2, dtype=torch.int32, device=d)
         img = (lambda **k: torch.zeros(H, W, device=d, **k)) if self.keep_images else (lambda **k: None)
         self.render, self.alphas, self.vpix = img(), img(), img()
-        self.gtstop = torch.zeros(H, W, 3, device=d)  # {vpix * T_final, stop id, stop depth bits} for the fused backward
+        # {vpix * T_final, stop id, stop depth bits} for the fused backward, initialised to "nothing contributed, no stop"
+        # {0, -1, all ones}: on grids of <= 2048 tiles the fused forward does not write the pixels of EMPTY tiles (no
+        # footprint reaches them; include/edgegs.h, item_rec), which keep what they held
+        self.gtstop = torch.zeros(H, W, 3, device=d)
+        self.gtstop.view(torch.int32)[..., 1:] = -1
         self.last_ids = img(dtype=torch.int32)
         # running projection-loss sum (what the step kernels add to) + the parked sums of the epochs marked since the
         # last read-back (mark_epoch); one buffer: one device->host copy reads them all

@@ -109,6 +109,18 @@ def test_chained_forward_stop_records_vs_c_oracle(n, W, H, real):
     stop_id = rec[..., 1].contiguous().view(torch.int32).numpy()
     stopped_o = CO.stopped_pixels(fw)
     ok = ~border.numpy()
+    # Round 5: on grids of <= 2048 tiles the fused forward leaves the pixels of EMPTY tiles (no item record) alone -- the
+    # claim behind it, checked here against the oracle's per-pixel walk: nothing contributes to any pixel of such a tile
+    tab = tr.item_rec.cpu().numpy()
+    tiles_with_records = np.unique(tab[tab[:, 2] == tr._ws_tag][:, 0])
+    tw_ = (W + 15) // 16
+    has = np.zeros(tr.T, bool)
+    has[tiles_with_records] = True
+    pix_has = np.repeat(np.repeat(has.reshape(-1, tw_), 16, axis=0), 16, axis=1)[:H, :W]
+    if tr.T <= 2048:
+        assert not has.all(), "the scene must have empty tiles"
+        assert (fw["alphas"][~pix_has] == 0).all() and not stopped_o[~pix_has].any(), "an empty tile's pixel is covered"
+        ok = ok & pix_has
     T_o = 1.0 - fw["alphas"].astype(np.float64)
     covered = fw["alphas"] > 0
     # T_final (the record holds 0 where nothing contributed: T == 1)
