@@ -1226,6 +1226,39 @@ def test_overflow_between_capacity_sweeps_is_replayed(env):
     assert tb.adam_step == ta.adam_step and tb.step == ta.step and tb.absgrads_normalize_factor == ta.absgrads_normalize_factor
 
 
+def test_record_table_overflow_of_an_unbalanced_view_is_replayed(env):
+    """Round 5, XCD-aware item records: the record table spans 8 x the LONGEST of the eight per-XCD lists.  An object that
+    covers a few 2 x 2-tile blocks only puts its slices into a few lists: the span is a multiple of the item count.  The
+    count sweep sizes the table for it (`_record_span`); with the table cut back to the item count the sort kernel raises the
+    sticky overflow word, the read-back grows the buffers and replays -- same result as the properly sized run."""
+    _lib, synth, O = env
+    from edgegaussians_amd import EdgeTrainer, LRSchedule
+    W, H = 528, 400  # 33 x 25 = 825 tiles: XCD-aware placement
+    sc = synth.make_scene(40_000, 2, W, H, seed=3, anisotropy=3.0, spread_opacity=True, scale=0.006)
+    sc.means.mul_(0.15)  # the object shrinks to a few tiles around the image centre (~790 records spanning ~4300 entries)
+    sched = LRSchedule(scales_start=0, quats_start=0, opacities_start=0)
+    mk = lambda: EdgeTrainer(sc.means, sc.log_scales, sc.quats, sc.logit_opacities, sc.viewmats, sc.Ks, sc.gt,  # noqa: E731
+                             W, H, schedule=sched)
+    ta, tb = mk(), mk()
+    assert _lib.load().eg_record_xcd_shift(ta.T) == 1
+    ta.ensure_capacity()
+    tb.ensure_capacity()
+    tb._rec_need = 0
+    tb._alloc_isect(tb.capacity, tb.seg_cap)  # the record table as if every list were as long as the average
+    assert tb.max_items < ta._rec_need <= ta.max_items
+    w = [synth.weight_map("weighted", sc.gt[v]).cuda() for v in range(2)]
+    for t in (ta, tb):
+        for s in range(4):
+            t.train_step(s % 2, w[s % 2])
+    assert tb.overflowed() and not ta.overflowed()
+    la, lb = ta.pop_loss(), tb.pop_loss()
+    assert tb.overflow_events >= 1 and ta.overflow_events == 0 and not tb.overflowed()
+    assert abs(la - lb) <= 1e-6 * abs(la)
+    for k, v in ta.state_dict().items():
+        assert_close(tb.state_dict()[k], v, rtol=1e-6, name=k)
+    assert_close(tb.absgrads, ta.absgrads, rtol=1e-6, name="absgrads")
+
+
 def test_rewalk_speculation_miss_is_replayed(env):
     """While no pixel has reached the transmittance stop the trainer does not even launch the exact-stop re-walk
     (EG_REWALK_SPECULATE).  Opacities jump to 0.97 between two read-backs: the first stopping pixel raises the sticky
