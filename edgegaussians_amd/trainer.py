@@ -524,6 +524,7 @@ class EdgeTrainer:
                  ticket=torch.zeros(Cn, **i32), gtstop=torch.zeros(Cn, self.height, self.width, 3, device=d),
                  workspace=ws, ws_stride=stride, rewalk_hint=-1)
         b["item_rec"] = torch.zeros(Cn, self.max_items, 4, **i32)
+        b["gtstop"].view(torch.int32)[..., 1:] = -1  # (the neutral record: see _alloc_pixels)
         a = StepArgs()
         a.means, a.quats = ptr(self.means), ptr(self.quats)
         a.log_scales, a.logit_opacities = ptr(self.log_scales), ptr(self.logit_opacities)
