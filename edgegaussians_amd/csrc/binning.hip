@@ -562,19 +562,28 @@ tile_sort_kernel(unsigned long long *__restrict__ keys, const int *__restrict__ 
         int pv0[NE];
 #pragma unroll
         for (int j = 0; j < NE; ++j) pv0[j] = (int)__builtin_amdgcn_raw_buffer_load_b32(cur_rsrc, (tid + j * THREADS) * 4, 0, 0);
-        // (skip_empty: the background's loss term of this tile, asked for with everything else -- used only if the tile
-        // turns out empty; thread t of the first four waves takes pixel (t >> 4, t & 15) of the tile: four half lines per
-        // wave and array)
-        float l_bg = 0.f;
-        if (seg.skip_empty && tid < kTilePix) {
-          const int ty_ = (int)(((float)tile + 0.5f) * seg.inv_tw), tx_ = tile - __mul24(ty_, seg.tw);
-          const int pi = ty_ * kTile + (tid >> 4), pj = tx_ * kTile + (tid & 15);
-          if (pi < seg.height && pj < seg.width) {
-            const int pp = pi * seg.width + pj;
-            l_bg = seg.wmap[pp] * fabsf(seg.gt[pp]);  // w_p |clamp(1 - T_final) - gt_p| with T_final = 1
+        // (skip_empty: the background's loss term of this tile; thread t of the first four waves takes pixel (t >> 4, t & 15)
+        // of the tile: four half lines per wave and array.  The 512-thread variant -- two rounds of workgroups, the empty
+        // border tiles last -- asks for it WITH everything else and uses it only if the tile turns out empty; the
+        // 256-thread variant, whose workgroups all start together, asks once it knows: requested by every tile's
+        // workgroup the term cost that launch 0.6 us at config 1, profiles/r05_skip_empty_ab.txt)
+        constexpr bool kBgEarly = THREADS >= 512;
+        auto bg_term = [&]() -> float {
+          float l = 0.f;
+          if (tid < kTilePix) {
+            const int ty_ = (int)(((float)tile + 0.5f) * seg.inv_tw), tx_ = tile - __mul24(ty_, seg.tw);
+            const int pi = ty_ * kTile + (tid >> 4), pj = tx_ * kTile + (tid & 15);
+            if (pi < seg.height && pj < seg.width) {
+              const int pp = pi * seg.width + pj;
+              l = seg.wmap[pp] * fabsf(seg.gt[pp]);  // w_p |clamp(1 - T_final) - gt_p| with T_final = 1
+            }
           }
-        }
+          return l;
+        };
+        float l_bg = 0.f;
+        if (kBgEarly && seg.skip_empty) l_bg = bg_term();
         if (seg.skip_empty && pop_here == 0 && tile != T - 1) {  // (uniform) nothing to sort, no record, no table entry
+          if (!kBgEarly) l_bg = bg_term();
           if (tid < kTilePix) {
             l_bg = wave_sum_dpp_f(l_bg);  // (total in lane 63)
             if ((tid & 63) == 63 && l_bg != 0.f) unsafeAtomicAdd(&seg.loss_part[(tile * 4 + (tid >> 6)) & 63], l_bg);

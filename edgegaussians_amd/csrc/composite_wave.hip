@@ -6,7 +6,8 @@
 // the path of the general C ABI (render / alphas / last_ids outputs, arbitrary colours, re-walk list).
 //
 //   wave (slice = one 128-Gaussian item of a tile's depth-sorted list, quadrant = 8x8 pixels of the tile)
-//     head    : ONE 16-byte item record left by the sort kernel {tile, item | items << 16, first key, end of the tile}
+//     head    : ONE 16-byte item record left by the sort kernel {tile, item | items << 16, call tag, end of the tile} -- valid iff
+//               it carries this call's tag (round 5: XCD-aware placement with holes, no record for an empty tile: binning.hip)
 //     stage   : every thread of the workgroup gathers one half record of the slice into the workgroup's LDS copy (ONE
 //               barrier, the only one of the kernel), then every wave tests all 128 Gaussians against ITS quadrant (the
 //               exact ellipse-vs-rectangle test) and ballot-compacts the hits into its OWN list in LDS, in slice order

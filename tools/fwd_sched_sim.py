@@ -25,10 +25,11 @@ cap = tr.max_items * 4
 buf = np.zeros((cap, 8), np.uint64)
 n = lib.eg_debug_fwd_profile(buf.ctypes.data, cap)
 rec = buf[:n].astype(np.float64).reshape(-1, 4, 8)
-n_items = int(tr.total.cpu()[2])
-rec = rec[:n_items]
+tab = tr.item_rec.cpu().numpy()[:len(rec)]
+valid = tab[:, 2] == tr._ws_tag                       # (round 5: the records of the last call; the table has holes)
+rec, ir = rec[valid], tab[valid]
+n_items = len(ir)
 life = rec[:, :, :7].sum(axis=2).max(axis=1)          # a workgroup holds its slot until its last wave is done
-ir = tr.item_rec.cpu().numpy()[:n_items]
 sl, ns = ir[:, 1] & 0xffff, ir[:, 1] >> 16
 def makespan(order, slots=2048):
     h = [0.0] * slots; heapq.heapify(h); end = 0.0
