@@ -1044,7 +1044,7 @@ int launch_sort_segments(uint64_t *keys, int32_t *tile_cursor, int32_t T, int32_
                          int32_t *item_tile, int32_t max_items, int32_t max_tile_hint, const Batch &bt, int C,
                          hipStream_t st, int32_t *total_prefix_here, int32_t *item_rec, const int32_t *item_front,
                          uint32_t rec_tag, int32_t tiles_per_row, const float *gt, const float *wmap, void *workspace,
-                         int32_t width, int32_t height) {
+                         int32_t width, int32_t height, int32_t front_slices) {
   SegTable seg;
   seg.cursor = tile_cursor; seg.seg_cap = seg_cap;
   seg.tile_start = tile_start; seg.tile_end = tile_end;
@@ -1053,7 +1053,10 @@ int launch_sort_segments(uint64_t *keys, int32_t *tile_cursor, int32_t T, int32_
   seg.total = total_prefix_here;
   // the forward's dispatch order (SegTable): front slices first; tiles taken middle-out
   seg.item_rec = (int4 *)item_rec;
-  seg.slice_major = kFrontDefault;
+  // the class boundary of the dispatch order: the caller's (the step passes 9 when its forward runs in chained mode --
+  // under the XCD-aware placement 30.6 against 31.7 us at config 2, 21.1 against 22.1 with the initial opacities -- and 4
+  // in speculative mode: 17.7 against 17.9; profiles/r05_front_slices_ab.txt), 4 by default
+  seg.slice_major = front_slices > 0 ? min(front_slices, 15) : kFrontDefault;
   seg.middle_out = 1;
   seg.item_front = total_prefix_here ? nullptr : item_front;
   seg.rec_tag = rec_tag;
@@ -1075,9 +1078,9 @@ int launch_sort_segments(uint64_t *keys, int32_t *tile_cursor, int32_t T, int32_
   }
   seg.xcd_shift = tiles_per_row > 0 ? record_xcd_shift(T, total_prefix_here != nullptr, item_rec != nullptr, C) : 0;
 #ifdef EG_DEV_SWITCHES  // A/B switches of development builds (edgegaussians_amd/build.py, EG_DEV_SWITCHES=1)
-  static const int front = getenv("EG_FRONT_SLICES") ? atoi(getenv("EG_FRONT_SLICES")) : kFrontDefault;
+  static const int front = getenv("EG_FRONT_SLICES") ? atoi(getenv("EG_FRONT_SLICES")) : -2;  // (-2: not set)
   static const int middle_out = getenv("EG_SORT_MIDDLE_OUT") ? atoi(getenv("EG_SORT_MIDDLE_OUT")) : 1;
-  seg.slice_major = front < 0 ? 0 : (front > 15 ? 15 : front);
+  if (front != -2) seg.slice_major = front < 0 ? 0 : (front > 15 ? 15 : front);
   seg.middle_out = middle_out;
   static const int front_large = getenv("EG_FRONT_LARGE") ? atoi(getenv("EG_FRONT_LARGE")) : 1;
   if (!front_large) seg.item_front = nullptr;

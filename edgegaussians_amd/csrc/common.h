@@ -62,7 +62,7 @@ int launch_sort_segments(uint64_t *keys, int32_t *tile_cursor, int32_t T, int32_
                          hipStream_t st, int32_t *total_prefix_here = nullptr, int32_t *item_rec = nullptr,
                          const int32_t *item_front = nullptr, uint32_t rec_tag = 0, int32_t tiles_per_row = 0,
                          const float *gt = nullptr, const float *wmap = nullptr, void *workspace = nullptr, int32_t width = 0,
-                         int32_t height = 0);
+                         int32_t height = 0, int32_t front_slices = 0);
 bool wave_forward_selected(int channels, const void *render, const void *alphas, const void *last_ids, const void *vpix,
                            const void *gtstop, const void *wmap, const void *item_rec, int chain_tag);
 int launch_composite_fwd_segments(const float *splat, const int32_t *tile_start, const int32_t *tile_end,
@@ -82,6 +82,7 @@ int composite_fwd_segments_hinted(const float *splat, const int32_t *tile_start,
                                   int32_t seg_cap = 0);
 // the XCD-aware record placement launch_sort_segments applies ("prefix here" grid with item records, one view): 0 = none
 int record_xcd_shift(int T, bool prefix_here, bool has_item_rec, int C);
+constexpr int kFrontChained = 9;  // class boundary of the forward's dispatch order when it runs in chained mode (binning.hip)
 // workspace / max_items / loss_out (all three or none): the compositing workspace whose 64 partial loss sums (left by
 // the wave-autonomous forward) block (0, view) folds into *loss_out
 int launch_footprint_bwd(const float *splat, int32_t N, int32_t width, int32_t height, const float *gtstop, float *g2d,

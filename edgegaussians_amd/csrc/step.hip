@@ -194,7 +194,7 @@ extern "C" int eg_train_step(const eg_step_args *a, eg_stream_t stream) {
                               st, prefix_here ? a->total : nullptr, a->item_rec,
                               (flags & EG_FLAG_FRONT_PREFIX) ? a->ticket + 1 : nullptr, (uint32_t)max(a->ws_tag, 0), tw,
                               wave_fwd ? a->gt : nullptr, wave_fwd ? a->wmap : nullptr, wave_fwd ? a->workspace : nullptr, a->width,
-                              a->height);
+                              a->height, (wave_fwd && a->rewalk_hint != EG_REWALK_SPECULATE) ? kFrontChained : 0);
     }
     if (rc) return rc;
     EG_MARK(kMarkSort);

@@ -2086,7 +2086,8 @@ def test_item_records_follow_the_dispatch_order_contract(env, size):
     item_tile) stays contiguous per tile.
     Tile grids of <= 2048 tiles (round 5, XCD-aware placement): workgroup b runs on XCD b % 8, tile (tx, ty) belongs to XCD
     ((tx >> 1) + 3 (ty >> 1)) % 8, and the records of XCD x's tiles sit at indices 8 k + x, k dense from 0 -- slices [0, 4)
-    of its tiles first, tile by tile, then the deeper slices; no other index below max_items carries the call's tag.
+    of its tiles first (slices [0, 9) when the forward runs in chained mode), tile by tile, then the deeper slices; no other
+    index below max_items carries the call's tag.
     Larger grids: slices [0, 9) of every tile first (the projection's scan supplies the prefix: EG_FLAG_FRONT_PREFIX), then
     the deeper slices, indices [0, n_items) without holes."""
     import numpy as np
@@ -2150,8 +2151,10 @@ def test_item_records_follow_the_dispatch_order_contract(env, size):
     assert (np.diff(where[order])[same_tile] > 0).all(), "a slice was dispatched before a slice in front of it"
     if any(k in os.environ for k in ("EG_FRONT_SLICES", "EG_FRONT_LARGE", "EG_XCD_SHIFT")):
         return
+    # (the class boundary: 9 when the step's forward runs in chained mode -- a grad_step without a journal does --, 4 otherwise)
+    front_small = 9 if tr._rewalk_arg(False) != -2 else 4
     if size == "small_grid":
-        front = 4  # kFrontDefault
+        front = front_small  # kFrontChained / kFrontDefault
         ty, tx = np.divmod(tile, tw)
         xcd = ((tx >> 1) + 3 * (ty >> 1)) % 8
         assert np.array_equal(where % 8, xcd), "a record sits in another XCD's list"
@@ -2170,7 +2173,7 @@ def test_item_records_follow_the_dispatch_order_contract(env, size):
         assert span <= tr.max_items and where.max() < span
     else:
         assert np.array_equal(where, np.arange(len(rec)))  # no holes
-        front = 9 if size == "large_grid" else 4  # EG_FRONT_LARGE / kFrontDefault
+        front = 9 if size == "large_grid" else front_small  # EG_FRONT_LARGE / the step's class boundary
         n_a = int(np.minimum(per_tile, front)[has_rec].sum())
         assert n_a < n_items and (sl[:n_a] < front).all() and (sl[n_a:] >= front).all()
         assert (np.diff(tile[:n_a]) >= 0).all() and (np.diff(tile[n_a:]) >= 0).all()  # tile by tile inside a class
