@@ -545,7 +545,6 @@ tile_sort_kernel(unsigned long long *__restrict__ keys, const int *__restrict__ 
         // The populations of the tiles before this one are REQUESTED by all threads before anything is waited for
         // (they travel with the tile's own cursor and first keys); per-wave partial sums go to LDS and the prefix
         // is finished right after the FIRST barrier the sort takes anyway (finish_prefix below): no barrier of its own
-        // (ALL populations, not only those of the tiles in front: the item numbering may follow the populations' rank)
         // Round 5.  What a workgroup needs of the other tiles is TWO sums -- the items of the tiles in front (the tile's first
         // item) and, over the tiles of its XCD's list (all tiles without the XCD-aware placement), the packed pair {front-class
         // items in front | front-class items in all + deep-class items in front} -- and only the LAST tile's workgroup needs
