@@ -279,7 +279,7 @@ __device__ __forceinline__ unsigned block_reduce_u32(unsigned v, bool take_max, 
 
 constexpr int kMaxBucketFill = 96;  // beyond this a bucket's rank pass degenerates: use the network
 #ifndef EG_SORT_BM
-#define EG_SORT_BM 1
+#define EG_SORT_BM 2  // (round 5, final kernel, same box: 7.81 / 11.45 / 31.07 -> 7.59 / 11.22 / 30.14 us at configs 1 / 2 / 3; 4: config 3 36.3)
 #endif
 #ifndef EG_SORT_RANK_G
 #define EG_SORT_RANK_G 1
