@@ -7,7 +7,10 @@ namespace eg {
 
 constexpr int kWaveSlice = 256;               // most Gaussians one wave of the wave-autonomous forward stages at a time
 constexpr unsigned kGranuleTagMask = 0xffffu;  // its hand-over granules carry a 16-bit call tag (composite_wave.hip)
-constexpr int kAnchorShift = 3;               // every 8th slice of a tile publishes an inclusive granule (composite_wave.hip)
+#ifndef EG_ANCHOR_SHIFT
+#define EG_ANCHOR_SHIFT 3
+#endif
+constexpr int kAnchorShift = EG_ANCHOR_SHIFT;  // every 8th slice of a tile publishes an inclusive granule (composite_wave.hip)
 constexpr int kSlice = 128;  // Gaussians per item (half the LDS of 256 => 8 workgroups/CU, 2x the items)
 
 // Where a tile's sorted ids and its items (128-Gaussian slices) live.  Classic layout: start = offsets,
