@@ -1339,7 +1339,9 @@ def train_steps_multi(trainers: List["EdgeTrainer"], views: List[List[int]], wma
     objects, all different, none of them the stream a trainer's tensors are still being written on).  The scenes share
     nothing -- every trainer ends exactly where its solo run ends (tests/test_gpu_parity.py) -- but one GPU runs their
     launch sequences side by side: BASELINE configs[4] ("115-scan sweep, one scene per GPU") with S scenes per device.
-    n_threads: host threads inside the native call (0: one per scene, at most 8)."""
+    n_threads: host threads inside the native call (0: one per scene, at most 8).  The weight maps must have been produced on
+    the scene's stream (or before a synchronisation).  After a failure of the native call the trainers' states are undefined
+    (some scenes have enqueued more steps than others): restore them from checkpoints."""
     S = len(trainers)
     assert S >= 1 and len(views) == S and len(wmaps) == S and len(streams) == S
     K = len(views[0])
@@ -1347,6 +1349,9 @@ def train_steps_multi(trainers: List["EdgeTrainer"], views: List[List[int]], wma
     assert len({int(st.cuda_stream) for st in streams}) == S and len({id(t) for t in trainers}) == S
     if K == 0:
         return
+    for tr, vs, ws in zip(trainers, views, wmaps):  # (checked BEFORE any trainer's host state moves)
+        for w in ws:
+            assert w.is_cuda and w.is_contiguous() and w.shape == (tr.height, tr.width), "weight maps: contiguous [H, W] device tensors"
     blocks = []
     for tr, vs, ws, sx in zip(trainers, views, wmaps, streams):
         with torch.cuda.stream(sx):  # (whatever host-side preparation enqueues -- a tag wrap's zeroing, a snapshot -- goes to the scene's stream)
