@@ -1275,6 +1275,9 @@ __device__ __forceinline__ void footprint_walk(const float4 s0, const float4 s1,
   }
 }
 
+#ifndef EG_FP_SHARED_WALK
+#define EG_FP_SHARED_WALK 1  // (round 5, same box: 8.78 / 20.67 / 158.1 / 188.4 -> 8.24 / 19.7 / 157.7 / 186.3 us at configs 1-4; 0 = sized per wave)
+#endif
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8)))
 footprint_bwd_kernel(const float4 *__restrict__ splat, int N, int width, int height,
                      const StopRec *__restrict__ gtstop, float *__restrict__ g2d, const Batch bt,
@@ -1293,21 +1296,47 @@ footprint_bwd_kernel(const float4 *__restrict__ splat, int N, int width, int hei
   }
   const int wave = blockIdx.x * 4 + wv;
   const int gbase = wave * 8;
+#if EG_FP_SHARED_WALK
+  // Round 5: the workgroup's 32 footprints are sized ONCE, one Gaussian per lane of the first wave's lower half, and handed
+  // to the four waves through LDS -- sized in the home phase of every wave, eight lanes per Gaussian, the same arithmetic
+  // ran four times per workgroup: ~150 of the ~1000 vector instructions a wave of this kernel issues at config 2.
+  __shared__ __attribute__((aligned(16))) int s_walk[32][12];  // i0 fh pw jlo | jhi cells thr xoff | shear - - -
+  if (threadIdx.x < 32) {
+    const int hg = blockIdx.x * 32 + (int)threadIdx.x;
+    Walk w = walk_of(make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f), width, height);
+    if (hg < N) w = walk_of(splat[2 * hg], splat[2 * hg + 1], width, height);
+    int4 *dst = (int4 *)s_walk[threadIdx.x];
+    dst[0] = make_int4(w.i0, w.fh, w.pw, w.jlo);
+    dst[1] = make_int4(w.jhi, w.cells, __float_as_int(w.thr), __float_as_int(w.xoff));
+    dst[2] = make_int4(__float_as_int(w.shear), 0, 0, 0);
+  }
+  __syncthreads();  // (the only barrier of the kernel: in front of the whole-wave exits)
+#endif
   if (gbase >= N) return;  // whole waves leave; there is no workgroup barrier below
   // descriptor of this view's record image, built from uniform values only
   const __amdgpu_buffer_rsrc_t rec_rsrc =
       __builtin_amdgcn_make_buffer_rsrc((void *)gtstop, 0, width * height * (int)sizeof(StopRec), 0x00020000);
 
-  // (Eight Gaussians per wave is the measured optimum at the reference's sizes: what precedes and follows the walk costs
+  // (Eight Gaussians per wave is the measured optimum at the reference's sizes: what precedes and follows the walk cost
   // a wave ~400 VALU instructions whatever it holds -- a third of the kernel's issue slots at config 2 -- but sixteen
   // Gaussians per wave lose more to the coarser lane dealing than they save, +13 % at config 2 and +47 % at
   // 1600 x 1200; four per wave gain 8 % at 1600 x 1200 and lose 15 % at config 2.)
   // home phase: the 8 lanes of group k all size the footprint of Gaussian gbase + k
+#if EG_FP_SHARED_WALK
+  Walk h;
+  {
+    const int4 *src = (const int4 *)s_walk[wv * 8 + (lane >> 3)];
+    const int4 a = src[0], b = src[1];
+    h.i0 = a.x; h.fh = a.y; h.pw = a.z; h.jlo = a.w; h.jhi = b.x; h.cells = b.y;
+    h.thr = __int_as_float(b.z); h.xoff = __int_as_float(b.w); h.shear = __int_as_float(src[2].x);
+  }
+#else
   Walk h = walk_of(make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f), width, height);
   {
     const int hg = gbase + (lane >> 3);
     if (hg < N) h = walk_of(splat[2 * hg], splat[2 * hg + 1], width, height);
   }
+#endif
   // Lanes per Gaussian, computed group-parallel: one lane for every live footprint, the other
   // 64 - live in proportion to the cell counts (rounded down), the slack (<= live) one each to the
   // first live groups.  A footprint of any size is handled here: a screen-filling Gaussian simply
@@ -1345,9 +1374,19 @@ footprint_bwd_kernel(const float4 *__restrict__ splat, int N, int width, int hei
     const int cells = r < n ? __shfl(h.cells, src, 64) : 0;
     s0 = splat[2 * g];
     s1 = splat[2 * g + 1];
+#if EG_FP_SHARED_WALK
+    {  // (the walk of the lane's Gaussian: three 16-byte LDS reads instead of nine lane shuffles)
+      const int4 *wk = (const int4 *)s_walk[wv * 8 + k];
+      const int4 a = wk[0], b = wk[1];
+      const float shear_k = __int_as_float(wk[2].x);
+      footprint_walk(s0, s1, g, r, n, a.x, cells > 0 ? a.y : 0, max(a.z, 1), a.w, b.x, __int_as_float(b.z),
+                     __int_as_float(b.w), shear_k, width, rec_rsrc, m);
+    }
+#else
     footprint_walk(s0, s1, g, r, n, __shfl(h.i0, src, 64), cells > 0 ? __shfl(h.fh, src, 64) : 0,
                    max(__shfl(h.pw, src, 64), 1), __shfl(h.jlo, src, 64), __shfl(h.jhi, src, 64), __shfl(h.thr, src, 64),
                    __shfl(h.xoff, src, 64), __shfl(h.shear, src, 64), width, rec_rsrc, m);
+#endif
   }
   // partial g2d record of this lane: vx vy |vx| |vy| va vb vc vo
   float *mine = &red[wv][lane * 8];
