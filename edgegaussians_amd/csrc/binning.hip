@@ -483,7 +483,7 @@ tile_sort_kernel(unsigned long long *__restrict__ keys, const int *__restrict__ 
   const int tile = (!LARGE && seg.middle_out) ? ((wg & 1) ? T / 2 - (wg + 1) / 2 : T / 2 + wg / 2) : wg;
   __syncthreads();
   long long start, end;
-  __shared__ int s_pre[4][THREADS / 64];
+  __shared__ int s_pre[5][THREADS / 64];
   bool prefix_pending = false;  // (uniform) the tile prefix still has to be finished: see SegTable::total
   int pop_here = 0;
   // after a barrier: every thread sums the waves' partials; thread 0 writes the tile's table entries (and the
@@ -491,12 +491,13 @@ tile_sort_kernel(unsigned long long *__restrict__ keys, const int *__restrict__ 
   auto finish_prefix = [&](int kept_) {
     prefix_pending = false;
     if (tid >= 64) return;  // (the first wave writes the tables and the records: a tile has a few dozen items at most)
-    int isum = 0, front = 0;
+    int isum = 0, k0 = 0, l0k1 = 0;
 #pragma unroll
-    for (int w = 0; w < THREADS / 64; ++w) { isum += s_pre[0][w]; front += s_pre[1][w]; }
-    // of the tiles of THIS tile's XCD (all tiles without the XCD-aware placement): front-class items in front of this tile;
-    // front-class items in all + deep-class items in front of this tile
-    const int k0 = front & 0xffff, l0k1 = front >> 16;
+    for (int w = 0; w < THREADS / 64; ++w) { isum += s_pre[0][w]; k0 += s_pre[1][w]; l0k1 += s_pre[4][w]; }
+    // of the tiles of THIS tile's XCD (all tiles without the XCD-aware placement): k0 = front-class items in front of this
+    // tile; l0k1 = front-class items in all + deep-class items in front of this tile.  (Two full ints: round 5 packed them
+    // into 16-bit halves of one, and a list of >= 32768 items turned `l0k1` negative -- a negative dispatch index still
+    // passed `disp < max_items`.)
     const int first_ = min(isum, seg.max_items);
     const int items_ = min(max(1, (kept_ + 127) >> 7), max(0, seg.max_items - first_));
     // dispatch index of slice i: class 0 = slices [0, slice_major) of the list's tiles, class 1 = the rest; inside a class
@@ -508,7 +509,7 @@ tile_sort_kernel(unsigned long long *__restrict__ keys, const int *__restrict__ 
       if (seg.item_rec) {
         const int pos = i < seg.slice_major ? k0 + i : l0k1 + (i - seg.slice_major);
         const int disp = seg.xcd_shift > 0 ? 8 * pos + myx : pos;
-        if (disp < seg.max_items)
+        if (disp >= 0 && disp < seg.max_items)
           seg.item_rec[disp] = make_int4(tile, i | (items_ << 16), (int)seg.rec_tag, tile * seg.seg_cap + kept_);
         else
           rec_over = true;  // (the longest XCD list does not fit the table: the caller grows it and replays)
@@ -591,7 +592,7 @@ tile_sort_kernel(unsigned long long *__restrict__ keys, const int *__restrict__ 
           continue;
         }
         {
-          int isum = 0, front = 0, msum = 0, cmax = 0;
+          int isum = 0, front = 0, deep = 0, msum = 0, cmax = 0;
           const bool last_tile = tile == T - 1;  // (uniform)
           const int myx = seg.xcd_shift > 0 ? xcd_of_tile(tile, seg.tw, seg.inv_tw, seg.xcd_shift) : 0;
           auto sums = [&](const int (&pv)[NE], int j0) {
@@ -605,7 +606,8 @@ tile_sort_kernel(unsigned long long *__restrict__ keys, const int *__restrict__ 
               const bool mine = (seg.xcd_shift == 0 || xcd_of_tile(tj, seg.tw, seg.inv_tw, seg.xcd_shift) == myx) &&
                                 !(seg.skip_empty && kk == 0 && tj != T - 1);
               const int itf = mine ? min(it, seg.slice_major) : 0;
-              front += (before ? itf : 0) + ((itf + ((mine && before) ? it - itf : 0)) << 16);
+              front += before ? itf : 0;
+              deep += itf + ((mine && before) ? it - itf : 0);
               if (last_tile) { msum += kk; cmax = max(cmax, pv[j]); }
             }
           };
@@ -620,12 +622,13 @@ tile_sort_kernel(unsigned long long *__restrict__ keys, const int *__restrict__ 
           // (DPP scans: the totals land in lane 63)
           isum = wave_scan_dpp(isum, 0, OpAdd());
           front = wave_scan_dpp(front, 0, OpAdd());
+          deep = wave_scan_dpp(deep, 0, OpAdd());
           if (last_tile) {
             msum = wave_scan_dpp(msum, 0, OpAdd());
             cmax = wave_scan_dpp(cmax, 0, OpMaxI());
           }
           if ((tid & 63) == 63) {
-            s_pre[0][tid >> 6] = isum; s_pre[1][tid >> 6] = front;
+            s_pre[0][tid >> 6] = isum; s_pre[1][tid >> 6] = front; s_pre[4][tid >> 6] = deep;
             if (last_tile) { s_pre[2][tid >> 6] = msum; s_pre[3][tid >> 6] = cmax; }
           }
         }

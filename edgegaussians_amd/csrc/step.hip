@@ -389,7 +389,12 @@ extern "C" int eg_train_steps_multi(int32_t S, const eg_step_args *const *args_h
     const eg_step_args *a = args_host[s];
     EG_REQUIRE(a && (K == 0 || (views_host[s] && wmaps_host[s])) && viewmats[s] && Ks[s] && gts[s], "null scene argument");
     EG_REQUIRE(a->ws_tag <= 0 || (int64_t)a->ws_tag + K - 1 <= EG_MAX_WS_TAG, "ws_tag + K - 1 exceeds EG_MAX_WS_TAG");
-    for (int q = 0; q < s; ++q) EG_REQUIRE(streams[q] != streams[s] || args_host[q] != a, "the same scene twice");
+    // (distinct streams AND distinct buffers, as the header promises: the same argument block -- or another block over the
+    // same parameters / workspace -- on a second stream would have two host threads race on one scene)
+    for (int q = 0; q < s; ++q)
+      EG_REQUIRE(streams[q] != streams[s] && args_host[q] != a && args_host[q]->means != a->means &&
+                     args_host[q]->workspace != a->workspace,
+                 "the same scene (or the same stream) twice");
   }
   const int nt = n_threads < S ? n_threads : S;
   auto drive = [&](int j, char *msg, size_t msg_len) -> int {

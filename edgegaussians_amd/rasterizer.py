@@ -233,8 +233,12 @@ class _FastBuffers:
         a.tile_counts, a.tile_start, a.tile_end = ptr(self.tile_counts), ptr(self.tile_start), ptr(self.tile_end)
         a.item_first, a.item_end, a.total, a.ticket = ptr(self.item_first), ptr(self.item_end), ptr(self.total), ptr(self.ticket)
 
-    def size(self, m: int, tile_max: int) -> None:
-        """(Re)allocate the intersection buffers for M = m, largest tile population tile_max (with head-room)."""
+    def size(self, m: int, tile_max: int, overflowed: bool = False) -> None:
+        """(Re)allocate the intersection buffers for M = m, largest tile population tile_max (with head-room).
+        `overflowed`: the call that reported (m, tile_max) raised the sticky overflow flag WITH the current buffers --
+        grow from what is there (the record table doubles whatever m says: under the XCD-aware placement it spans
+        8 x the longest per-XCD list, which m does not bound; the segments double when the largest tile outgrew them),
+        so that repeated attempts are cumulative."""
         seg = (int(tile_max * 1.5) // 128 + 2) * 128
         cap = int(m * 1.3) + 4096
         # (XCD-aware record placement, include/edgegs.h: the record table spans 8 x the longest of eight per-XCD lists --
@@ -242,6 +246,10 @@ class _FastBuffers:
         items = cap // 128 + self.T
         if _lib.load().eg_record_xcd_shift(self.T) > 0:
             items += items // 4
+        if overflowed and self.max_items:
+            items = max(items, 2 * self.max_items)
+            if tile_max > self.seg_cap:
+                seg = max(seg, 2 * self.seg_cap)
         if seg <= self.seg_cap and items <= self.max_items:
             return
         self.seg_cap = max(seg, self.seg_cap)
@@ -290,6 +298,8 @@ class _FastBuffers:
         if overflow or not unit:
             self.confident = 0
             self.reset()
+            if overflow:  # (the caller's next call -- after catching this -- finds grown buffers: growth is cumulative)
+                self.size(2 * max(m, 1), 2 * max(tile_max, 1), overflowed=True)
             raise RuntimeError(
                 "rasterization (fast path, deferred read-back): the previous call " +
                 ("overflowed its intersection buffers" if overflow else "was given colours that are not all ones") +
@@ -419,7 +429,7 @@ class _UnitRasterization(torch.autograd.Function):
                     fb.confident = fb.confident + 1 if (unit and fb.roomy(m, tile_max)) else 0
                 break
             fb.reset()
-            fb.size(2 * max(m, 1), 2 * max(tile_max, 1))  # the scene outgrew the cached buffers: grow, run again
+            fb.size(2 * max(m, 1), 2 * max(tile_max, 1), overflowed=True)  # outgrew the cached buffers: grow (cumulatively), run again
         else:
             raise RuntimeError("rasterization: the intersection buffers still overflow after six doublings")
         fb.max_tile = max(fb.max_tile, tile_max)

@@ -380,6 +380,10 @@ class EdgeTrainer:
         and before their arguments are built.  (A replay reserves the tags of its whole journal before it starts,
         _recover_from_overflow: inside one this function never wraps.)"""
         assert 0 < n <= _lib.MAX_WS_TAG, n
+        # (a replay draws up to two fresh tags per journalled entry and reserves them all up front: the journal is read
+        # back -- flushed -- before it grows past half the tag range, whatever the forward's mode)
+        if self._journal and not self._replaying and 2 * (len(self._journal) + n) > _lib.MAX_WS_TAG:
+            self.flush()
         if self.chained_forward and self._ws_tag + n > _lib.MAX_WS_TAG:
             assert not self._replaying, "a replay reserves its tags up front"
             if self._journal:
@@ -624,6 +628,9 @@ class EdgeTrainer:
         seg = int(self.seg_cap * factor) // 128 * 128 if self.seg_cap else 0
         if self.T * seg > (1 << 28):
             seg = 0  # absurd fixed segments: the count / scan / emit layout takes over
+        # (the record table of the XCD-aware placement spans 8 x the longest per-XCD list, which `capacity` does not
+        # bound: an overflow raised there is only cured by growing the table itself)
+        self._rec_need = int(getattr(self, "_rec_need", 0) * factor)
         self._alloc_isect(int(self.capacity * factor), seg)
 
     def _recover_from_overflow(self) -> None:
@@ -737,13 +744,22 @@ class EdgeTrainer:
                     total += t.numel() * t.element_size()
         return total
 
+    def _scene_stream(self):
+        """Context of the stream this trainer's steps were last enqueued on by `train_steps_multi` (a no-op context for a
+        trainer that only ever ran on the current stream): read-backs and replays must follow the scene's own work."""
+        import contextlib
+        st = getattr(self, "_bound_stream", None)
+        return torch.cuda.stream(st) if st is not None else contextlib.nullcontext()
+
     def flush(self) -> None:
         """Drain the stream, verify that no step since the last read-back overflowed (repairing it if one
-        did) and forget the journal.  Every operation that changes the state outside train_step calls it."""
-        r = self._read_words()
-        if r["overflow"] or r["missed"]:
-            self._recover_from_overflow()
-        self._journal.clear()
+        did) and forget the journal.  Every operation that changes the state outside train_step calls it.
+        (A trainer driven by `train_steps_multi` does this on the scene's stream.)"""
+        with self._scene_stream():
+            r = self._read_words()
+            if r["overflow"] or r["missed"]:
+                self._recover_from_overflow()
+            self._journal.clear()
 
     # ------------------------------------------------------------------ epoch marks (no host sync)
     def _mark_raw(self, k: int) -> None:
@@ -1028,6 +1044,10 @@ class EdgeTrainer:
                 "seen": seen, "batch_seen": batch_seen, "missed": missed != 0}
 
     def _sync_state(self) -> Dict:
+        with self._scene_stream():  # (train_steps_multi: on the scene's stream)
+            return self._sync_state_here()
+
+    def _sync_state_here(self) -> Dict:
         """The read-back between runs of steps: checks the sticky flags (replaying the journalled steps when one is
         raised), forgets the journal, zeroes the loss sums and refreshes launch-shape hints and buffer sizes."""
         r = self._read_words()
@@ -1340,7 +1360,9 @@ def train_steps_multi(trainers: List["EdgeTrainer"], views: List[List[int]], wma
     nothing -- every trainer ends exactly where its solo run ends (tests/test_gpu_parity.py) -- but one GPU runs their
     launch sequences side by side: BASELINE configs[4] ("115-scan sweep, one scene per GPU") with S scenes per device.
     n_threads: host threads inside the native call (0: one per scene, at most 8).  The weight maps must have been produced on
-    the scene's stream (or before a synchronisation).  After a failure of the native call the trainers' states are undefined
+    the scene's stream (or before a synchronisation).  The trainer remembers `streams[s]`: its later read-backs (`flush`,
+    `pop_loss`, `pop_losses`) and an overflow replay of these steps run on that stream whatever stream is current; any OTHER
+    call on the trainer (densify, single steps) must be made under `torch.cuda.stream(streams[s])` or after a synchronisation.  After a failure of the native call the trainers' states are undefined
     (some scenes have enqueued more steps than others): restore them from checkpoints."""
     S = len(trainers)
     assert S >= 1 and len(views) == S and len(wmaps) == S and len(streams) == S
@@ -1363,6 +1385,7 @@ def train_steps_multi(trainers: List["EdgeTrainer"], views: List[List[int]], wma
                     tr._snapshot()
                 tr._journal.extend(("1", v, w, tr.epoch, tr.loss_scale) for v, w in zip(vs, ws))
             blocks.append(tr._steps_begin(vs, ws))
+        tr._bound_stream = sx  # (flush / pop_loss / a replay of these steps run on the scene's stream from now on)
     args = (C.POINTER(_lib.StepArgs) * S)(*[C.pointer(b[0]) for b in blocks])
     va = (C.POINTER(C.c_int32) * S)(*[C.cast(b[1], C.POINTER(C.c_int32)) for b in blocks])
     wa = (C.POINTER(C.c_void_p) * S)(*[C.cast(b[2], C.POINTER(C.c_void_p)) for b in blocks])
