@@ -37,6 +37,10 @@ CONFIGS = {
     "config2": (100_000, 50, 512, 512),
     "config3": (200_000, 49, 1600, 1200),
     "config4": (500_000, 200, 1200, 680),
+    # SURVEY 0.4 "additional config": the scan at its NATIVE size -- data/ABC-NEF_Edge/data/00004926/meta_data.json:
+    # 800 x 800, the 50 real poses with their own intrinsics -- against the scan's real DexiNed maps (the four committed
+    # in tests/golden/edges_00004926.npz, cycled over the views), config 1's Gaussian count
+    "abc800": (30_000, 50, 800, 800),
 }
 LR_SCALE = 1e-3
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (~6.3 TB/s achievable)
@@ -59,16 +63,38 @@ def algorithmic_bytes(n, m, hw):
 
 
 REAL_POSES = os.path.join(ROOT, "tests", "golden", "cameras_00004926.npz")  # the scan's 50 cameras (data fixture)
+REAL_EDGES = os.path.join(ROOT, "tests", "golden", "edges_00004926.npz")    # four of its DexiNed edge maps, 800 x 800
+
+
+def real_edge_maps(n_views, width, height):
+    """[n_views, H, W] in [0, 1]: the scan's committed DexiNed maps (sparse idx / val fixtures at the native 800 x 800)
+    cycled over the views.  A map is an INPUT of the step; which view it is paired with does not change the work."""
+    import numpy as np
+    e = np.load(REAL_EDGES)
+    keep = [int(k) for k in e["views"]]
+    assert (height, width) == (800, 800), "the fixtures are the scan's native 800 x 800 maps"
+    maps = torch.zeros(len(keep), height * width)
+    for i, k in enumerate(keep):
+        maps[i][torch.from_numpy(e[f"idx_{k}"]).long()] = torch.from_numpy(e[f"val_{k}"]).float() / 255.0
+    return maps.view(len(keep), height, width)[[v % len(keep) for v in range(n_views)]].contiguous(), keep
 
 
 def build_trainer(name, seed, device, spread_opacity=False):
     from edgegaussians_amd import EdgeTrainer, LRSchedule, synth
     n, v, w, h = CONFIGS[name]
+    n = int(os.environ.get("EG_BENCH_GAUSSIANS", n))  # (development legs: another Gaussian count on the same views)
     # SURVEY 8(d): configs 1 and 2 run on the 50 REAL poses of scan 00004926 (intrinsics rescaled 800 -> 512);
     # configs 3 / 4 name data sets that are not in the reference tree: synthetic look-at poses, stated as such
-    real = name in ("config1", "config2") and os.path.exists(REAL_POSES) and not os.environ.get("EG_SYNTH_POSES")
+    real = name in ("config1", "config2", "abc800") and os.path.exists(REAL_POSES) and not os.environ.get("EG_SYNTH_POSES")
     sc = synth.make_scene(n, v, w, h, seed=seed, anisotropy=5.0, spread_opacity=spread_opacity,
                           cameras_npz=REAL_POSES if real else None)
+    edges = "synthetic wireframe edge maps"
+    if name == "abc800":
+        assert real and os.path.exists(REAL_EDGES), "abc800 needs the scan's fixtures under tests/golden/"
+        gt, keep = real_edge_maps(v, w, h)
+        import dataclasses
+        sc = dataclasses.replace(sc, gt=gt)
+        edges = f"the scan's REAL DexiNed edge maps (views {keep} of tests/golden/edges_00004926.npz, cycled)"
     # All four optimizers live (as after epoch 30 of the reference schedule) with the reference's
     # learning rates scaled by LR_SCALE: Adam does its full arithmetic and memory traffic, but the
     # random synthetic scene stays (practically) stationary, so warm-up, the timed window, the
@@ -87,16 +113,23 @@ def build_trainer(name, seed, device, spread_opacity=False):
     # the `bg_edge_ratio` sample is DRAWN inside the loop, like the real one (train_loop.py: one eg_ratio_wmap_seeded
     # launch on every 5th step), not precomputed
     ratio = lambda view: tr.weight_map(view, "bg_edge_ratio", 1.0)  # noqa: E731
-    return tr, sc, whole, ratio, ("real poses of scan 00004926 (intrinsics 800->512)" if real else "synthetic look-at poses")
+    poses = "synthetic look-at poses"
+    if real:
+        poses = "real poses of scan 00004926 (intrinsics " + ("as recorded, 800x800" if w == 800 else f"800->{w}") + ")"
+    return tr, sc, whole, ratio, poses + "; " + edges
 
 
+FUSED_BWD_STAGE = "footprint_bwd+project_bwd_adam+next_project_bin"
 # kernel name (as rocprofv3 reports it) -> stage of eg_train_step
 STAGE_OF = {"composite_wave_fwd_kernel": "composite_slice_fwd", "composite_wave2_fwd_kernel": "composite_slice_fwd", "project_emit_kernel": "project_bwd_adam+next_project_bin", "project_bwd_emit_kernel": "project_bwd_adam+next_project_bin",
             "tile_emit_kernel": "tile_emit",
             "tile_sort_kernel": "tile_sort", "composite_slice_fwd_kernel": "composite_slice_fwd",
             "composite_chained_fwd_kernel": "composite_slice_fwd",  # (the pre-warm window runs before the first read-back)
             "composite_rewalk_fwd_kernel": "composite_rewalk_fwd", "footprint_bwd_kernel": "footprint_bwd",
-            "project_bwd_kernel": "project_bwd_adam+next_project_bin"}
+            "project_bwd_kernel": "project_bwd_adam+next_project_bin",
+            # round 6: the per-Gaussian backward as ONE kernel (csrc/backward_fused.hip) -- footprint backward, projection
+            # backward + Adam, the next view's projection + binning
+            "gaussian_bwd_fused_kernel": FUSED_BWD_STAGE}
 
 
 def measure_traffic(config, spread, steps=40):
@@ -327,6 +360,7 @@ def measure(name, args, device, rank, world, backend, spread=False, steps=None, 
     steps = args.steps if steps is None else steps
     warmup = args.warmup if warmup is None else warmup
     n, n_views, w, h = CONFIGS[name]
+    n = int(os.environ.get("EG_BENCH_GAUSSIANS", n))
     # --replicas (BASELINE config 5: one scene per GPU): every rank trains its OWN scene (seed + rank), no collective
     tr, sc, whole, ratio, poses = build_trainer(name, args.seed + (rank if args.replicas else 0), device, spread)
     tr.ensure_capacity()
@@ -458,7 +492,7 @@ def measure(name, args, device, rank, world, backend, spread=False, steps=None, 
         "value": n * steps * world * vps / dt, "ms_per_step": 1e3 * dt / steps, "steps": steps, "warmup": warmup,
         "config": {"workload": f"{name}: {n} Gaussians (5:1 anisotropic, scale 0.004, opacity "
                                f"{'U(0.05,0.9)' if spread else '0.08'}), {n_views} views @{w}x{h}, {poses}, "
-                               f"synthetic wireframe edge maps, loss whole/bg_edge_ratio 4:1",
+                               f"loss whole/bg_edge_ratio 4:1",
                    "n_gaussians": n, "views": n_views, "width": w, "height": h, "lr_scale": LR_SCALE, "poses": poses,
                    "tile_intersections_M": m_timed, "tile_intersections_M_is": "mean over the views of the timed window (this rank's)",
                    "tile_intersections_M_all_views": m_all, "tile_intersections_M_last_view": m_last, "tile_intersections_M_min_max": [min(m_by_view), max(m_by_view)],
@@ -578,6 +612,12 @@ def measure(name, args, device, rank, world, backend, spread=False, steps=None, 
                 stage_us[key] = stage_us.pop("project_bwd_adam") + stage_us.pop("project_bin")
                 for x in (ab, ab_all):
                     x[key] = x.pop("project_bwd_adam") + x.pop("project_bin")
+                if tr.fused_backward_active():
+                    # ... and (round 6) the footprint backward is the same kernel's first phase: one stage, the bytes of
+                    # both minus the g2d record's round trip (64 N: written by one, read by the other -- it stays in LDS)
+                    stage_us[FUSED_BWD_STAGE] = stage_us.pop(key) + stage_us.pop("footprint_bwd")
+                    for x in (ab, ab_all):
+                        x[FUSED_BWD_STAGE] = x.pop(key) + x.pop("footprint_bwd") - 64 * n
             # the wave-autonomous forward resolves the exact stop inside the one kernel: the re-walk stage's pair of
             # events brackets NOTHING -- what it measures is what a pair of event records costs on this queue
             wave_fwd = tr.segmented and os.environ.get("EG_FWD_OLD", "0") in ("", "0")
@@ -586,7 +626,8 @@ def measure(name, args, device, rank, world, backend, spread=False, steps=None, 
             achieved = ab[dom] / (stage_us[dom] * 1e-6) / 1e9
             symbol = {"composite_slice_fwd": "composite_wave_fwd_kernel" if wave_fwd else "composite_slice_fwd_kernel",
                       "footprint_bwd": "footprint_bwd_kernel", "tile_sort": "tile_sort_kernel",
-                      "project_bwd_adam+next_project_bin": "project_bwd_emit_kernel"}.get(dom, dom)
+                      "project_bwd_adam+next_project_bin": "project_bwd_emit_kernel",
+                      FUSED_BWD_STAGE: "gaussian_bwd_fused_kernel"}.get(dom, dom)
             res["roofline"] = {"bound": "hbm", "kernel": dom, "kernel_symbol": symbol, "achieved": achieved,
                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                                "algorithmic_bytes_per_launch": ab[dom], "avg_launch_us": stage_us[dom],
@@ -600,6 +641,32 @@ def measure(name, args, device, rank, world, backend, spread=False, steps=None, 
             ab_t = algorithmic_bytes(n, m_timed, w * h)["step_total"]  # (the contract window's own views)
             res["step_roofline"] = {"algorithmic_bytes_per_step": ab_t, "achieved_GBps": ab_t / (dt / steps) / 1e9,
                                     "frac": ab_t / (dt / steps) / 1e9 / HBM_PEAK_GBS}
+    if dp is not None and not args.profile_only:
+        # LAST (the replicas diverge from here on): the same enqueue path with the gradient collective left out on every
+        # rank -- t_no_collective / t is the share of the step that is NOT the wire (RCCL latency + its stream stalls), so
+        # that a scaling curve says what it lost to the collective and what to everything else
+        kk = max(min(steps, 200), 1)
+        with dp.no_collective():
+            run(min(kk, 50), warmup + 4 * steps)  # (settle)
+            barrier()
+            t1 = time.perf_counter()
+            run(kk, warmup + 4 * steps + 50)
+            barrier()
+            d3 = time.perf_counter() - t1
+        if world > 1:
+            t = torch.tensor([d3], device=device if backend == "nccl" else "cpu", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            d3 = float(t.item())
+        try:
+            tr.pop_loss()
+        except Exception as e:  # noqa: BLE001 -- diverged replicas may disagree on a replay: the timing above stands
+            print(f"[bench] read-back after the no-collective window: {e!r}", file=sys.stderr)
+        res["ms_per_step_no_collective"] = 1e3 * d3 / kk
+        res["no_collective_leg"] = {"steps": kk, "what": "the timed window's enqueue path with the [12 N] gradient all-reduce left out on "
+                                    "every rank (eg_dp_force_all_reduce(-1) / DataParallelStep.no_collective): MEASUREMENT ONLY, run "
+                                    "last -- the replicas diverge in it",
+                                    "collective_cost_us_per_step": 1e3 * (res["ms_per_step_median"] - 1e3 * d3 / kk),
+                                    "non_collective_share_of_step": (1e3 * d3 / kk) / res["ms_per_step_median"]}
     res["_scene"] = sc
     return res
 
@@ -805,6 +872,10 @@ def main():
                     help="wrap the stages of every step in roctx ranges (eg_roctx_enable; for rocprofv3 --marker-trace)")
     ap.add_argument("--no-extra", action="store_true",
                     help="only the headline workload (skip the config1 and trained-like lines under other_workloads)")
+    ap.add_argument("--extra-set", default="all", choices=["all", "target"],
+                    help="which siblings ride on the line: 'all', or 'target' = only north_star's named configuration as a full "
+                         "citizen (config 1 with its own roofline, traffic and CPU baseline) and the scan at its native 800x800 "
+                         "against its real edge maps")
     args = ap.parse_args()
 
     from edgegaussians_amd import dist as egdist
@@ -900,6 +971,7 @@ def main():
         # north_star's stated target is config 1 (~30 k Gaussians, the scan's 50 views @512x512): measured in this
         # same run, next to a trained-like variant of the headline (opacities U(0.05, 0.9): transmittance stops)
         extra = {}
+        sc_config1 = None
         other = "init_opacity" if args.spread_opacity else "trained_like"
         for key, name, spread, vps in (("config1", "config1", False, 1),
                                        (f"{args.config}_{other}", args.config, not args.spread_opacity, 1),
@@ -907,21 +979,32 @@ def main():
                                        (f"{args.config}_4_views_per_step", args.config, args.spread_opacity, 4)):
             if name == args.config and spread == args.spread_opacity and vps == args.views_per_step:
                 continue
+            if args.extra_set == "target" and key != "config1":
+                continue
             # (siblings, not the contract window: never shorter than 200 steps whatever --steps says -- a 20-step window
             # of config 1 lasts under a millisecond and read 15 % slow on the driver's box)
             r = measure(name, args, device, rank, world, backend, spread=spread, vps=vps,
                         steps=max(args.steps, 200) // vps, warmup=max(args.warmup // vps, 5))
-            r.pop("_scene")
+            sc_extra = r.pop("_scene")
+            if key == "config1":
+                sc_config1 = sc_extra
             r["unit"] = "Gaussians*views/s"
             extra[key] = r
-        for name in ("config1", args.config):  # the drop-in operator path (train_gaussians.py unchanged)
+        # SURVEY 0.4's additional config: the scan at its native 800 x 800 (2500 tiles) against its REAL DexiNed maps
+        if os.path.exists(REAL_EDGES) and os.path.exists(REAL_POSES):
+            r = measure("abc800", args, device, rank, world, backend, spread=False, steps=max(args.steps, 200), warmup=max(args.warmup, 5))
+            r.pop("_scene")
+            r["unit"] = "Gaussians*views/s"
+            extra["abc800_real_edges"] = r
+        for name in (("config1", args.config) if args.extra_set == "all" else ()):  # the drop-in operator path (train_gaussians.py unchanged)
             extra[f"{name}_operator_path"] = measure_operator(name, args, device)
-        # ... and with the drop-in optimizer class as well (train_utils.py:50-59 edited to build it)
-        extra[f"{args.config}_operator_path_native_adam"] = measure_operator(args.config, args, device, adam="native")
-        # BASELINE config 5 (one scene per GPU, 115 scans): S scenes side by side on ONE GPU, aggregate throughput
-        extra["config1_scenes_per_gpu"] = {str(S): {k: v for k, v in measure_scenes("config1", args, device, S).items()
-                                                    if k in ("value", "ms_per_step_per_scene", "aggregate_us_per_scene_step",
-                                                             "host_enqueue_ms_per_step")} for S in (1, 2, 4)}
+        if args.extra_set == "all":
+            # ... and with the drop-in optimizer class as well (train_utils.py:50-59 edited to build it)
+            extra[f"{args.config}_operator_path_native_adam"] = measure_operator(args.config, args, device, adam="native")
+            # BASELINE config 5 (one scene per GPU, 115 scans): S scenes side by side on ONE GPU, aggregate throughput
+            extra["config1_scenes_per_gpu"] = {str(S): {k: v for k, v in measure_scenes("config1", args, device, S).items()
+                                                        if k in ("value", "ms_per_step_per_scene", "aggregate_us_per_scene_step",
+                                                                 "host_enqueue_ms_per_step")} for S in (1, 2, 4)}
         out["other_workloads"] = extra
         if "config1" in extra:
             # north_star quotes its target on config 1 (~30 k Gaussians, 50 views @512x512): carried at the top level next
@@ -935,6 +1018,24 @@ def main():
             out["value_config1"] = c1["config"]["n_gaussians"] / (c1["ms_per_step_median"] * 1e-3)
             out["ms_per_step_windows_config1"] = c1["ms_per_step_windows"]
             out["roofline_config1"] = c1.get("roofline")
+            # ... a full citizen of the line (round 6): its dominant kernel's HBM traffic from the same-run PMC passes, and
+            # the CPU restatement timed on ITS scene (N = 30 k) -- north_star names this configuration and a CPU path beside it
+            if out["roofline_config1"] is not None and not args.no_traffic:
+                st1, src1 = measure_traffic("config1", False)
+                out["roofline_config1"]["traffic"] = st1.get(out["roofline_config1"]["kernel"]) if st1 else None
+                out["roofline_config1"]["traffic_source"] = src1
+                if st1:
+                    out["traffic_bytes_per_step_by_stage_config1"] = st1
+            if sc_config1 is not None and not args.no_cpu_baseline:
+                out["cpu_baseline_config1"] = cpu_baseline(sc_config1, min(args.cpu_budget, 8.0), args.cpu_oracle)
+    if world > 1 and not args.replicas and args.views_per_step == 1 and not args.no_extra:
+        # the overlapped mode of the data-parallel step (dist.py: two half batches per rank and step, the first half's
+        # all-reduce hidden behind the second half's rasterisation): a sibling on the same line, every rank runs it
+        r2 = measure(args.config, args, device, rank, world, backend, spread=args.spread_opacity, vps=2,
+                     steps=max(args.steps, 200) // 2, warmup=max(args.warmup // 2, 5), stages=False)
+        r2.pop("_scene")
+        r2["unit"] = "Gaussians*views/s"
+        out["views_per_step_2"] = r2
     if single and rank == 0 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(sc, args.cpu_budget, args.cpu_oracle)
     if world > 1 or args.force_dp:

@@ -55,7 +55,7 @@ class StepArgs(C.Structure):
         ("v_means", _vp), ("v_quats", _vp), ("v_scales", _vp), ("v_opacities", _vp),
         ("adam_host", C.POINTER(AdamHyper)),
         ("next_viewmat", _vp), ("next_K", _vp), ("have_projection", _i32), ("ws_tag", _i32),
-        ("item_rec", _vp),
+        ("item_rec", _vp), ("two_kernel_backward", _i32),
     ]
 
 
@@ -127,7 +127,8 @@ EXPORTS = sorted(list(_SIGS) + ["eg_last_error_string", "eg_version", "eg_device
                                  "eg_timing_stage_count", "eg_timing_stage_name", "eg_debug_fwd_profile",
                                  "eg_dp_unique_id", "eg_dp_init", "eg_dp_world", "eg_dp_shutdown", "eg_dp_host_profile", "eg_roctx_enable",
                                  "eg_dp_comm_count", "eg_dp_force_all_reduce", "eg_dp_grad_all_reduces",
-                                 "eg_dp_comm_timing_begin", "eg_dp_comm_timing_end", "eg_record_xcd_shift"])
+                                 "eg_dp_comm_timing_begin", "eg_dp_comm_timing_end", "eg_record_xcd_shift",
+                                 "eg_backward_is_fused"])
 
 _lib: Optional[C.CDLL] = None
 
@@ -167,6 +168,7 @@ def load(require_device: bool = True) -> C.CDLL:
         lib.eg_dp_shutdown.argtypes = []
         lib.eg_roctx_enable.argtypes = [_i32]
         lib.eg_record_xcd_shift.argtypes = [_i32]
+        lib.eg_backward_is_fused.argtypes = [_i32, _i32]
         lib.eg_dp_comm_count.argtypes = []
         lib.eg_dp_force_all_reduce.argtypes = [_i32]
         lib.eg_dp_grad_all_reduces.argtypes = [C.POINTER(_i64)]

@@ -18,7 +18,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libedgegs.so")
 OBJ = os.path.join(HERE, "csrc", "_obj")
-SOURCES = ["project.hip", "binning.hip", "composite.hip", "composite_wave.hip", "densify.hip", "knn.hip", "step.hip", "dp.hip", "operator.hip"]
+SOURCES = ["project.hip", "binning.hip", "composite.hip", "composite_wave.hip", "densify.hip", "knn.hip", "step.hip", "dp.hip", "operator.hip", "backward_fused.hip"]
 # -fno-slp-vectorize: the SLP pass pairs scalar fp32 operations into v_pk_*_f32, which gfx950's vector pipe issues at
 # exactly the cost of the two plain instructions (tools/microbench/issue_rates.hip: 5.6 vs 2 x 2.8 cycles) -- and the
 # pairs need their operands in adjacent registers: v_mov shuffles and s_nop hazards on top.  Measured on the whole step
@@ -48,7 +48,7 @@ def _stale() -> bool:
     if not os.path.exists(STAMP) or open(STAMP).read() != " ".join(FLAGS):
         return True  # (built with other flags, e.g. a development build with EG_DEV_SWITCHES)
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in SOURCES + ["common.h", "composite.h"]]
+    deps = [os.path.join(CSRC, f) for f in SOURCES + ["common.h", "composite.h", "project_dev.h", "footprint_dev.h"]]
     deps.append(os.path.join(HERE, "..", "include", "edgegs.h"))
     return any(os.path.getmtime(d) > t for d in deps)
 

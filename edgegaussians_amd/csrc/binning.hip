@@ -306,6 +306,7 @@ struct SegTable {
   // the compositing kernel returns them to zero -- and the last tile's workgroup leaves the totals
   // [4]: M, sticky overflow flag, items, largest tile population.
   int *total;
+  int *total_flag = nullptr;   // the view's [4] totals for a kernel that does not form them (`total` == nullptr): only [1], the sticky overflow flag, is raised
   // optional output for the wave-autonomous forward (composite_wave.hip): one 16-byte record per item
   // {tile, slice | slices << 16, rec_tag, end of the TILE's keys}   (the slice's first key is tile * seg_cap + 128 slice)
   int4 *item_rec;
@@ -330,6 +331,9 @@ struct SegTable {
   // dispatched right behind its front ones and sat waiting for their anchor's inclusive granule, half of the forward's
   // wave slots at 500 k Gaussians; dispatched after every tile's front they find the dead word set and leave at once.
   const int *item_front = nullptr;
+  // round 6, without `total`, xcd_shift > 0 (and item_front, total_flag): the XCD-aware placement on grids above 2048 tiles --
+  // tiles dealt to the XCDs in bands of 2^xcd_shift tile ROWS, xcd = (ty >> xcd_shift) & 7, positions from the two prefixes the
+  // projection's scan leaves anyway (see the kernel); class boundary EG_FRONT_LARGE; every tile has a record (no skip_empty)
   int middle_out = 0;   // workgroup -> tile assignment of the small sort variant (see the kernel)
   // Round 5.  Every record carries the CALL TAG of the forward that will read it in word 2 (the forward validates a
   // record by its tag: the table may have holes, and a record of an earlier call is not mistaken for this call's).
@@ -367,6 +371,10 @@ struct SegTable {
 #endif
 constexpr int kXcdMinTiles = 512;  // XCD-aware placement on grids of 512 .. 2048 tiles (the reference's 512 x 512 images: 1024)
 constexpr int kXcdShiftDefault = EG_XCD_SHIFT_DEFAULT;  // XCD-aware record placement: tiles per block side = 2^shift (0 = off)
+#ifndef EG_SORT_GRID_DIV
+#define EG_SORT_GRID_DIV 1
+#endif
+constexpr int kSortGridDiv = EG_SORT_GRID_DIV;  // tiles per workgroup of the small sort variant (launch_tile_sort)
 constexpr int kFrontDefault = 4;  // class boundary of the dispatch order (slices); SegTable::slice_major carries it
 
 // THREADS = number of buckets; CAP = keys per buffer (two buffers).  n_lo < n handled here.
@@ -638,27 +646,69 @@ tile_sort_kernel(unsigned long long *__restrict__ keys, const int *__restrict__ 
         kept = min(seg.cursor[tile], seg.seg_cap);  // every thread reads it; reset after the barrier
         first = seg.item_first[tile];
         items = min(max(1, (kept + 127) >> 7), max(0, seg.max_items - first));
+        // Round 6: XCD-aware record placement above 2048 tiles, WITHOUT another scan.  The tiles are dealt to the XCDs in
+        // BANDS of 2^xcd_shift tile rows, xcd = (ty >> shift) & 7: a band is a contiguous run of tile indices, a list is
+        // every eighth band, and the projection's scan already left the two exclusive prefixes over ALL tiles -- F (front-class
+        // items: item_front) and A (items: item_first).  Tile t's place in its list follows from their values at t and at the
+        // boundaries of the list's bands -- a dozen loads that travel with the tile's own, summed by the first wave:
+        //   k0   = sum over the list's bands in front of (F(end) - F(start)) + F(t) - F(start of t's band)
+        //   l0k1 = the list's front total + the same sums of G = A - F (deep-class items)
+        // (2 x 2 blocks dealt round-robin, as on the small grids, need a prefix per list: sixteen more sums in the projection
+        // kernel's serial tail measured +1.7 / +4.3 us per step at 800 x 800 / 1600 x 1200 -- profiles/r06_xcd_large_ab.txt.)
+        int k0 = 0, l0k1 = 0, myx = -1;
+        if (seg.xcd_shift > 0 && seg.item_front && seg.item_rec && seg.total_flag) {
+          const int ftot = seg.item_front[T];
+          if (ftot >= 0) {  // (< 0: the view overflowed the item capacity -- item order, see below)
+            const int band_tiles = seg.tw << seg.xcd_shift, nb = (T + band_tiles - 1) / band_tiles;
+            const int b = (int)(((float)tile + 0.5f) * seg.inv_tw) >> seg.xcd_shift;
+            myx = b & 7;
+            if (tid < 64) {
+              int fb = 0, gb = 0, ft = 0;
+              for (int bj = myx + 8 * tid; bj < nb; bj += 8 * 64) {
+                const int s0 = bj * band_tiles, e0 = min(T, s0 + band_tiles);
+                const int Fs = seg.item_front[s0], Fe = seg.item_front[e0];
+                const int As = seg.item_first[s0], Ae = e0 < T ? seg.item_first[e0] : seg.total_flag[2];
+                const int df = Fe - Fs, dg = (Ae - As) - df;
+                ft += df;
+                if (bj < b) { fb += df; gb += dg; }
+              }
+              fb = wave_scan_dpp(fb, 0, OpAdd()); gb = wave_scan_dpp(gb, 0, OpAdd()); ft = wave_scan_dpp(ft, 0, OpAdd());
+              if (tid == 63) {
+                const int s0 = b * band_tiles;
+                const int Ft = seg.item_front[tile], Fs = seg.item_front[s0], As = seg.item_first[s0];
+                s_pre[0][0] = fb + (Ft - Fs);
+                s_pre[1][0] = ft + gb + ((first - Ft) - (As - Fs));
+              }
+            }
+          }
+        }
         __syncthreads();
+        if (myx >= 0) { k0 = s_pre[0][0]; l0k1 = s_pre[1][0]; }
         if (tid == 0) {
           seg.cursor[tile] = 0;  // ready for the next step
           seg.tile_start[tile] = tile * seg.seg_cap;
           seg.tile_end[tile] = tile * seg.seg_cap + kept;
           seg.item_end[tile] = first + items;
         }
+        bool rec_over = false;
         for (int i = tid; i < items; i += THREADS) {
           seg.item_tile[first + i] = tile;
           if (seg.item_rec) {
             int disp = first + i;
-            if (seg.item_front) {
+            if (myx >= 0) {
+              disp = 8 * (i < EG_FRONT_LARGE ? k0 + i : l0k1 + (i - EG_FRONT_LARGE)) + myx;
+              if (disp >= seg.max_items) rec_over = true;  // (the longest list does not fit the table: grow + replay)
+            } else if (seg.item_front) {
               // (ftot < 0: the view overflowed the item capacity and the projection's scan said so -- item order, which
               // has no holes when tiles are truncated; the caller grows the buffers and replays)
               const int fpre = seg.item_front[tile], ftot = seg.item_front[T];
               if (ftot >= 0) disp = i < EG_FRONT_LARGE ? fpre + i : ftot + (first - fpre) + (i - EG_FRONT_LARGE);
             }
-            if (disp < seg.max_items)
+            if (disp >= 0 && disp < seg.max_items)
               seg.item_rec[disp] = make_int4(tile, i | (items << 16), (int)seg.rec_tag, tile * seg.seg_cap + kept);
           }
         }
+        if (rec_over) seg.total_flag[1] = 1;  // sticky: only the host clears it
       }
       start = (long long)tile * seg.seg_cap;
       end = start + kept;
@@ -973,12 +1023,20 @@ static int launch_tile_sort(uint64_t *keys, const int32_t *offsets, int32_t T, i
   // LDS that would all find nothing to do: ~3 us) is skipped and the small variant owns EVERY tile -- a
   // tile that outgrew the hint is then still sorted correctly, by the slower paths of the small variant.
   const bool small_only = max_tile_hint > 0 && (int64_t)max_tile_hint * 5 / 4 <= kSmall;
+  // workgroups of the small variant: one per tile -- or (grid_div > 1) one per grid_div tiles, which the kernel's
+  // grid-stride loop pairs middle-out rank b with rank b + T / grid_div: a central tile and a border tile
+  int grid_div = kSortGridDiv;
+#ifdef EG_DEV_SWITCHES
+  static const int div_env = getenv("EG_SORT_GRID_DIV") ? atoi(getenv("EG_SORT_GRID_DIV")) : 0;  // (A/B switch)
+  if (div_env > 0) grid_div = div_env;
+#endif
+  const int grid_x = cdiv(T, grid_div);
   if (wide)
-    tile_sort_kernel<512, kSmall, false><<<dim3(T, C), 512, kSmall * 8 + 2 * 512 * 4 * kSortBM, as_stream(stream)>>>(
+    tile_sort_kernel<512, kSmall, false><<<dim3(grid_x, C), 512, kSmall * 8 + 2 * 512 * 4 * kSortBM, as_stream(stream)>>>(
         (unsigned long long *)keys, offsets, T, (long long)capacity, small_only ? 0x7fffffff : kSmall, flatten_ids,
         (long long *)isect_ids, seg, bt);
   else
-    tile_sort_kernel<256, kSmall, false><<<dim3(T, C), 256, kSmall * 8 + 2 * 256 * 4 * kSortBM, as_stream(stream)>>>(
+    tile_sort_kernel<256, kSmall, false><<<dim3(grid_x, C), 256, kSmall * 8 + 2 * 256 * 4 * kSortBM, as_stream(stream)>>>(
         (unsigned long long *)keys, offsets, T, (long long)capacity, small_only ? 0x7fffffff : kSmall, flatten_ids,
         (long long *)isect_ids, seg, bt);
   if (!small_only)
@@ -1033,7 +1091,12 @@ extern "C" int eg_sort_segments(uint64_t *keys, int32_t *tile_cursor, int32_t T,
 namespace eg {
 int record_xcd_shift(int T, bool prefix_here, bool has_item_rec, int C) {
   // (small grids stay dense: eight lists over a few dozen tiles are not balanced, and nothing there misses an L2)
-  int shift = (prefix_here && has_item_rec && C == 1 && T >= kXcdMinTiles) ? kXcdShiftDefault : 0;
+  // (round 6: grids above 2048 tiles too -- there in bands of tile rows, see tile_sort_kernel)
+  int shift = (has_item_rec && C == 1 && T >= kXcdMinTiles) ? kXcdShiftDefault : 0;
+#ifdef EG_DEV_SWITCHES
+  static const int xcd_large = getenv("EG_XCD_LARGE") ? atoi(getenv("EG_XCD_LARGE")) : 1;  // (A/B switch)
+  if (!prefix_here && !xcd_large) shift = 0;
+#endif
 #ifdef EG_DEV_SWITCHES
   static const int xcd_env = getenv("EG_XCD_SHIFT") ? atoi(getenv("EG_XCD_SHIFT")) : -1;  // (A/B switch)
   if (xcd_env >= 0 && shift > 0) shift = xcd_env;
@@ -1046,8 +1109,9 @@ int launch_sort_segments(uint64_t *keys, int32_t *tile_cursor, int32_t T, int32_
                          int32_t *item_tile, int32_t max_items, int32_t max_tile_hint, const Batch &bt, int C,
                          hipStream_t st, int32_t *total_prefix_here, int32_t *item_rec, const int32_t *item_front,
                          uint32_t rec_tag, int32_t tiles_per_row, const float *gt, const float *wmap, void *workspace,
-                         int32_t width, int32_t height, int32_t front_slices) {
+                         int32_t width, int32_t height, int32_t front_slices, int32_t *total_flag) {
   SegTable seg;
+  seg.total_flag = total_flag;
   seg.cursor = tile_cursor; seg.seg_cap = seg_cap;
   seg.tile_start = tile_start; seg.tile_end = tile_end;
   seg.item_first = item_first; seg.item_end = item_end;
@@ -1079,6 +1143,10 @@ int launch_sort_segments(uint64_t *keys, int32_t *tile_cursor, int32_t T, int32_
 #endif
   }
   seg.xcd_shift = tiles_per_row > 0 ? record_xcd_shift(T, total_prefix_here != nullptr, item_rec != nullptr, C) : 0;
+  if (!total_prefix_here) {
+    // above 2048 tiles the placement works from the projection scan's two prefixes (item_first, item_front: EG_FLAG_FRONT_PREFIX)
+    if (!(seg.xcd_shift > 0 && item_front && total_flag)) seg.xcd_shift = 0;
+  }
 #ifdef EG_DEV_SWITCHES  // A/B switches of development builds (edgegaussians_amd/build.py, EG_DEV_SWITCHES=1)
   static const int front = getenv("EG_FRONT_SLICES") ? atoi(getenv("EG_FRONT_SLICES")) : -2;  // (-2: not set)
   static const int middle_out = getenv("EG_SORT_MIDDLE_OUT") ? atoi(getenv("EG_SORT_MIDDLE_OUT")) : 1;

@@ -62,7 +62,7 @@ int launch_sort_segments(uint64_t *keys, int32_t *tile_cursor, int32_t T, int32_
                          hipStream_t st, int32_t *total_prefix_here = nullptr, int32_t *item_rec = nullptr,
                          const int32_t *item_front = nullptr, uint32_t rec_tag = 0, int32_t tiles_per_row = 0,
                          const float *gt = nullptr, const float *wmap = nullptr, void *workspace = nullptr, int32_t width = 0,
-                         int32_t height = 0, int32_t front_slices = 0);
+                         int32_t height = 0, int32_t front_slices = 0, int32_t *total_flag = nullptr);
 bool wave_forward_selected(int channels, const void *render, const void *alphas, const void *last_ids, const void *vpix,
                            const void *gtstop, const void *wmap, const void *item_rec, int chain_tag);
 int launch_composite_fwd_segments(const float *splat, const int32_t *tile_start, const int32_t *tile_end,
@@ -98,6 +98,18 @@ int launch_project_bwd_emit(float *means, float *quats, float *scales, float *op
                             float *m, float *v, const eg_adam_hyper &hyper, int32_t *tile_cursor, int32_t seg_cap,
                             uint64_t *keys, int32_t *item_first, int32_t max_items, int32_t *total, int32_t *ticket,
                             hipStream_t st);
+#ifndef EG_FUSED_BWD_MAX_GAUSSIANS
+#define EG_FUSED_BWD_MAX_GAUSSIANS 32768
+#endif
+constexpr int kFusedBwdMaxGaussians = EG_FUSED_BWD_MAX_GAUSSIANS;  // (see step.hip fused_backward_pays)
+// round 6 (backward_fused.hip): footprint backward + projection backward + Adam + the next view's projection and binning
+// in ONE kernel, tile grids of <= kPrefixHereMaxTiles tiles; g2d optional (the record stays in LDS)
+int launch_gaussian_bwd_fused(float *means, float *quats, float *scales, float *opacities, const float *viewmat,
+                              const float *K, const float *next_viewmat, const float *next_K, int32_t N, int32_t width,
+                              int32_t height, float eps2d, uint32_t flags, float *splat, const float *gtstop, float *g2d,
+                              float *absgrads, float *m, float *v, const eg_adam_hyper &hyper, int32_t *tile_cursor,
+                              int32_t seg_cap, uint64_t *keys, void *workspace, int64_t max_items, float *loss_out,
+                              hipStream_t st);
 int launch_project_bwd_batched(float *means, float *quats, float *scales, float *opacities, int32_t N, int32_t width,
                                int32_t height, float eps2d, uint32_t flags, const float *splat, const float *g2d,
                                float *v_means, float *v_quats, float *v_scales, float *v_opacities, float *absgrads,

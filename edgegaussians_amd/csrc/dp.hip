@@ -124,7 +124,7 @@ extern "C" int eg_dp_comm_count(void) {
 }
 
 extern "C" int eg_dp_force_all_reduce(int32_t on) {
-  g_force_all_reduce = on ? 1 : 0;
+  g_force_all_reduce = on > 0 ? 1 : (on < 0 ? -1 : 0);
   return EG_OK;
 }
 
@@ -241,7 +241,7 @@ extern "C" int eg_train_steps_dp(const eg_step_args *a, const eg_adam_hyper *hyp
     // (a sum over ONE rank is the identity: RCCL implements a one-rank allReduce through the copy engine -- fill + copy
     // blits with ~90 us of stream stalls, profiles/r04_timeline_gaps_config2_dp_native.txt -- which a one-GPU run of this
     // leg would measure instead of the leg; eg_dp_all_reduce still goes through RCCL whatever the size)
-    if (g_world > 1 || g_force_all_reduce) {
+    if ((g_world > 1 && g_force_all_reduce >= 0) || g_force_all_reduce > 0) {
       const bool timed = g_comm_ev && g_comm_ev_n < g_comm_ev_cap;
       if (timed) (void)hipEventRecord(g_comm_ev[2 * g_comm_ev_n], as_stream(stream));
       rc = nccl_check(p_all_reduce(g, g, 12 * (size_t)a->N, kNcclFloat, kNcclSum, g_comm, as_stream(stream)), "ncclAllReduce");

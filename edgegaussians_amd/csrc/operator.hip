@@ -65,7 +65,7 @@ extern "C" int eg_operator_fwd(const eg_operator_args *a, eg_stream_t stream) {
   rc = launch_sort_segments(a->keys, a->tile_counts, T, a->seg_cap, a->flatten_ids, a->tile_start, a->tile_end, a->item_first,
                             a->item_end, a->item_tile, (int32_t)a->max_items, a->max_tile_hint, Batch{}, 1, st,
                             prefix_here ? a->total : nullptr, a->item_rec, prefix_here ? nullptr : a->ticket + 1,
-                            (uint32_t)a->ws_tag, tw, nullptr, nullptr, nullptr, 0, 0, kFrontChained);
+                            (uint32_t)a->ws_tag, tw, nullptr, nullptr, nullptr, 0, 0, kFrontChained, a->total);
   if (rc) return rc;
   const TileTable tt = {a->tile_start, a->tile_end, a->item_first, a->item_end, a->item_tile,
                         prefix_here ? a->tile_counts : nullptr, (const int4 *)a->item_rec, a->seg_cap};

@@ -149,6 +149,14 @@ extern "C" int eg_timing_end(float *stage_us /*[kStages] host*/, int32_t *n_step
   return EG_OK;
 }
 
+// where the one-kernel backward (backward_fused.hip) is the faster form: see launch_gaussian_bwd_fused
+static bool fused_backward_pays(int n_gaussians, int n_tiles) {
+  return n_tiles <= kPrefixHereMaxTiles && n_gaussians <= kFusedBwdMaxGaussians;
+}
+extern "C" int eg_backward_is_fused(int32_t n_gaussians, int32_t n_tiles) {
+  return (n_gaussians > 0 && n_tiles > 0 && fused_backward_pays(n_gaussians, n_tiles)) ? 1 : 0;
+}
+
 extern "C" int eg_train_step(const eg_step_args *a, eg_stream_t stream) {
   EG_REQUIRE(a != nullptr, "null args");
   EG_REQUIRE(a->N > 0 && a->width > 0 && a->height > 0 && a->capacity > 0, "bad sizes");
@@ -194,7 +202,7 @@ extern "C" int eg_train_step(const eg_step_args *a, eg_stream_t stream) {
                               st, prefix_here ? a->total : nullptr, a->item_rec,
                               (flags & EG_FLAG_FRONT_PREFIX) ? a->ticket + 1 : nullptr, (uint32_t)max(a->ws_tag, 0), tw,
                               wave_fwd ? a->gt : nullptr, wave_fwd ? a->wmap : nullptr, wave_fwd ? a->workspace : nullptr, a->width,
-                              a->height, (wave_fwd && a->rewalk_hint != EG_REWALK_SPECULATE) ? kFrontChained : 0);
+                              a->height, (wave_fwd && a->rewalk_hint != EG_REWALK_SPECULATE) ? kFrontChained : 0, a->total);
     }
     if (rc) return rc;
     EG_MARK(kMarkSort);
@@ -231,6 +239,23 @@ extern "C" int eg_train_step(const eg_step_args *a, eg_stream_t stream) {
   // (slice / re-walk marks are recorded inside eg_composite_fwd)
   // backward: footprint compositing VJP, then projection VJP + absgrad (+ Adam)
   EG_REQUIRE(a->splat && a->gtstop && a->g2d, "null pointer");
+  if (a->adam_host && a->next_viewmat && a->next_K && a->seg_cap > 0 && fused_backward_pays(a->N, T) && !a->two_kernel_backward) {
+    // round 6: both in ONE kernel (backward_fused.hip) -- the projection chain of a workgroup's 64 Gaussians runs in its
+    // first wave while the other workgroups' footprint walks fill the issue slots; the g2d record stays in LDS
+    RoctxRange range("eg:gaussian_bwd_fused");
+    rc = launch_gaussian_bwd_fused(a->means, a->quats, a->log_scales, a->logit_opacities, a->viewmat, a->K, a->next_viewmat,
+                                   a->next_K, a->N, a->width, a->height, 0.3f, flags, a->splat, a->gtstop,
+#ifdef EG_BF_PROF
+                                   a->g2d,  // (development: the kernel's phase stamps land here)
+#else
+                                   nullptr,
+#endif
+                                   a->absgrads, a->adam_m, a->adam_v, *a->adam_host, a->tile_counts, a->seg_cap, a->keys,
+                                   a->workspace, a->max_items, a->loss, st);
+    EG_MARK(kMarkProjectBwd);
+    if (g_ev_cur) { ++g_ev_next; g_ev_cur = nullptr; }
+    return rc;
+  }
   {
   RoctxRange range("eg:footprint_bwd");
   rc = launch_footprint_bwd(a->splat, a->N, a->width, a->height, a->gtstop, a->g2d, Batch{}, 1, st,

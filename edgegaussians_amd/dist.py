@@ -121,6 +121,7 @@ class DataParallelStep:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.time_comm = time_comm
+        self.skip_collective = False  # measurement only: see no_collective()
         self._ev: List = []
         # EdgeTrainer keeps the journal: (grad_step, all-reduce, apply_adam) triples are journalled like its own steps,
         # its read-backs merge the sticky overflow / missed-stop words over the ranks (max) so that ALL ranks replay the
@@ -128,6 +129,30 @@ class DataParallelStep:
         self._journals = hasattr(worker, "attach_dp")
         if self._journals:
             worker.attach_dp(self)
+
+    def no_collective(self):
+        """Context manager, MEASUREMENT ONLY (bench.py's `ms_per_step_no_collective`): inside it the gradient all-reduce of
+        `step` / `steps` is left out on every rank -- the Python driver's torch.distributed call and the native run's
+        ncclAllReduce (eg_dp_force_all_reduce(-1)) alike -- so that the same launch sequence is timed without the wire.
+        Every rank then steps on its own view's gradient: the replicas DIVERGE, whatever follows is not the reference's
+        data-parallel training any more.  The small control collectives (read-back words, loss sums) stay."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def cm():
+            from . import _lib
+            lib = _lib.load()
+            native = lib.eg_dp_world() >= 1
+            self.skip_collective = True
+            if native:
+                lib.eg_dp_force_all_reduce(-1)
+            try:
+                yield self
+            finally:
+                self.skip_collective = False
+                if native:
+                    lib.eg_dp_force_all_reduce(0)
+        return cm()
 
     def reduce_words(self, ints, floats):
         """(element-wise max of `ints`, element-wise sum of `floats`) over the ranks, as Python lists."""
@@ -164,8 +189,8 @@ class DataParallelStep:
         return t
 
     # ------------------------------------------------------------------ the collective
-    def _all_reduce(self, t: torch.Tensor, async_op: bool = False):
-        if self.world <= 1:
+    def _all_reduce(self, t: torch.Tensor, async_op: bool = False, gradient: bool = False):
+        if self.world <= 1 or (gradient and self.skip_collective):
             return None
         if t.is_cuda and dist.get_backend(self.group) == "gloo":
             # test mode only (several ranks sharing one GPU, RCCL refuses that): stage through the host
@@ -241,7 +266,7 @@ class DataParallelStep:
         if isinstance(view, int):
             grads = self.worker.grad_step(view, wmap, **j)
             e0 = self._mark()
-            self._all_reduce(grads)
+            self._all_reduce(grads, gradient=True)
             e1 = self._mark()
             if e0 is not None:
                 self._ev.append((e0, e1))
@@ -254,7 +279,7 @@ class DataParallelStep:
         if len(views) == 1 or self.world <= 1:
             grads = self.worker.grad_step_batched(views, wmaps, **j)
             e0 = self._mark()
-            self._all_reduce(grads)
+            self._all_reduce(grads, gradient=True)
             e1 = self._mark()
             if e0 is not None:
                 self._ev.append((e0, e1))
@@ -262,10 +287,10 @@ class DataParallelStep:
             return
         h = (len(views) + 1) // 2  # odd C: the larger half first, its collective is the hidden one
         ga = self.worker.grad_step_batched(views[:h], wmaps[:h], slot=1, **j)   # first half -> second buffer
-        work = self._all_reduce(ga, async_op=True)                              # ... reduced on RCCL's stream while
+        work = self._all_reduce(ga, async_op=True, gradient=True)                              # ... reduced on RCCL's stream while
         gb = self.worker.grad_step_batched(views[h:], wmaps[h:], slot=0, **j)   # the second half is rasterised
         e0 = self._mark()
-        self._all_reduce(gb)
+        self._all_reduce(gb, gradient=True)
         if work is not None:
             work.wait()  # the compute stream waits (no host block)
         e1 = self._mark()

@@ -99,6 +99,10 @@ class EdgeTrainer:
         self._ws_tag = 0       # tags of the chained forward (eg_step_args.ws_tag): one fresh value per enqueued step
         self._replaying = False  # inside _recover_from_overflow's replay of the journal
         self.chained_forward = bool(int(os.environ.get("EG_CHAINED", "1")))
+        # round 6: inside a native run of steps on a tile grid of <= 2048 tiles the backward is ONE kernel
+        # (csrc/backward_fused.hip); True (development: EG_TWO_KERNEL_BACKWARD=1) keeps the footprint backward and the
+        # projection backward as two launches -- the same parameters bit for bit (tests/test_gpu_parity.py)
+        self.two_kernel_backward = bool(int(os.environ.get("EG_TWO_KERNEL_BACKWARD", "0")))
         # noise of duplicate() comes from a dedicated generator seeded with (seed, event number): identical
         # on every data-parallel rank whatever else the ranks drew (edge_gs.py:462-467 uses the global RNG)
         self.seed = int(seed)
@@ -285,7 +289,10 @@ class EdgeTrainer:
         if getattr(self, "_tile_xcd", None) is None or self._tile_xcd[1] != shift:
             tw = (self.width + 15) // 16
             t = torch.arange(self.T, device=self.dev)
-            self._tile_xcd = ((((t % tw) >> shift) + 3 * ((t // tw) >> shift)) % 8, shift)
+            if self.T <= _lib.PREFIX_HERE_MAX_TILES:  # 2 x 2-tile blocks dealt round-robin
+                self._tile_xcd = ((((t % tw) >> shift) + 3 * ((t // tw) >> shift)) % 8, shift)
+            else:                                      # (round 6) above 2048 tiles: bands of 2^shift tile rows
+                self._tile_xcd = (((t // tw) >> shift) % 8, shift)
         per = torch.bincount(self._tile_xcd[0], weights=items.double(), minlength=8)
         return 8 * int(per.max().item())
 
@@ -350,6 +357,7 @@ class EdgeTrainer:
         a.loss_scale = self.loss_scale
         a.rewalk_hint = self._rewalk_arg(fused_adam)
         a.ws_tag = self._next_tag(n_tags) if self.chained_forward else 0
+        a.two_kernel_backward = 1 if self.two_kernel_backward else 0
         if fused_adam:
             a.absgrads = ptr(self.absgrads)
             a.adam_host = self._args_cache["hyper_ptr"]
@@ -631,6 +639,8 @@ class EdgeTrainer:
         # (the record table of the XCD-aware placement spans 8 x the longest per-XCD list, which `capacity` does not
         # bound: an overflow raised there is only cured by growing the table itself)
         self._rec_need = int(getattr(self, "_rec_need", 0) * factor)
+        if self.segmented and _lib.load().eg_record_xcd_shift(self.T) > 0:
+            self._rec_need = max(self._rec_need, int(self.max_items * factor))  # (whatever it was sized from: the table itself grows)
         self._alloc_isect(int(self.capacity * factor), seg)
 
     def _recover_from_overflow(self) -> None:
@@ -1121,6 +1131,11 @@ class EdgeTrainer:
         self.total[1:2].zero_()
         for b in self._batches.values():
             b["total"][:, 1].zero_()
+
+    def fused_backward_active(self) -> bool:
+        """Inside a native run of steps (`train_steps`) the backward of a step is ONE kernel (csrc/backward_fused.hip)."""
+        return bool(self.segmented and self.seg_cap > 0 and not self.two_kernel_backward
+                    and _lib.load().eg_backward_is_fused(self.N, self.T))
 
     def last_m(self) -> int:
         return self._totals()[0]

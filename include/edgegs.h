@@ -470,6 +470,13 @@ typedef struct {
    * and raises bit 1 of control word 3 of the workspace (sticky, next to bit 0 = "a pixel stopped in speculative
    * mode"): the results of that call are void and the caller must say so.  Batched step: [C, max_items, 4]. */
   int32_t *item_rec;
+  /* Round 6.  Inside a run of steps (adam_host, next_viewmat, segmented layout) on a tile grid of <= 2048 tiles the
+   * step's backward is ONE kernel: every workgroup walks the footprints of its 64 Gaussians (compositing VJP), then its
+   * first wave runs their projection VJP, absgrads, Adam and the next view's projection + binning -- the same functions,
+   * the same arithmetic per Gaussian, bit-identical parameters; the g2d record stays on chip (args.g2d is not written).
+   * != 0: the two kernels of rounds 1-5 (footprint backward, then projection backward + Adam + next projection), g2d
+   * written.  Everywhere else the field is ignored (the two kernels run). */
+  int32_t two_kernel_backward;
 } eg_step_args;
 #define EG_MAX_WS_TAG 0xfffe
 
@@ -479,6 +486,11 @@ typedef struct {
  * same results; the stand-alone entries eg_project_emit / eg_sort_segments / eg_composite_fwd_segments keep the
  * protocol described with them.) */
 int eg_train_step(const eg_step_args *args_host, eg_stream_t stream);
+
+/* 1 when a step of a run (adam_host, next_viewmat, segmented layout, two_kernel_backward == 0) on a scene of n_gaussians
+ * and a grid of n_tiles tiles runs its backward as the ONE kernel described at eg_step_args.two_kernel_backward, else 0:
+ * what a caller labels its measurements with (bench.py). */
+int eg_backward_is_fused(int32_t n_gaussians, int32_t n_tiles);
 
 /* The XCD-aware placement of the item records (eg_step_args::item_rec) on a grid of n_tiles tiles with one view per launch:
  * tiles per block side = 2^result, 0 = dense records.  A caller sizes max_items for 8 x the longest of the eight lists. */
@@ -563,9 +575,12 @@ int eg_dp_shutdown(void);
 /* the communicator's size as RCCL reports it (ncclCommCount): what bench.py puts on its line as the proof that RCCL saw
  * N ranks; 0 without a communicator, negative on an error */
 int eg_dp_comm_count(void);
-/* test switch: on != 0 makes eg_train_steps_dp issue its [12 N] ncclAllReduce through a ONE-rank communicator too (a sum
- * over one rank is the identity, the run skips it by default: RCCL does it with copy-engine blits that stall the
- * stream).  Reset by eg_dp_shutdown. */
+/* test / measurement switch.  on > 0 makes eg_train_steps_dp issue its [12 N] ncclAllReduce through a ONE-rank
+ * communicator too (a sum over one rank is the identity, the run skips it by default: RCCL does it with copy-engine blits
+ * that stall the stream).  on < 0 (round 6, MEASUREMENT ONLY): the collective is left out with N ranks as well -- every
+ * rank then steps on its own view's gradient, the replicas DIVERGE and the run is no longer the reference's data-parallel
+ * step; bench.py times one such window after all its valid ones ("step time with the collective compiled out") so that a
+ * scaling curve separates RCCL's latency from everything else.  0: default.  Reset by eg_dp_shutdown. */
 int eg_dp_force_all_reduce(int32_t on);
 /* [12 N] gradient collectives issued by eg_train_steps_dp since eg_dp_init (and the floats they carried) */
 int64_t eg_dp_grad_all_reduces(int64_t *floats_out_host /*NULL ok*/);

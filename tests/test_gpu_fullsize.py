@@ -36,6 +36,27 @@ def test_fused_step_vs_c_oracle_full_size(name):
 REAL_POSES = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cameras_00004926.npz")
 
 
+@pytest.mark.parametrize("name", ["config1", "config2_real_poses", "config2_real_poses_init", "config3", "config4"])
+def test_inside_the_borderline_sets_full_size(name):
+    """Round 6.  The tests above remove the integer-borderline Gaussians and zero-weight the
+    borderline pixels on BOTH sides; here the fused step runs on the UNCLEANED scene with the UNMASKED weight map: every
+    Gaussian without a borderline pixel meets the plain 1e-4 tolerance, radius / cull decisions differ from the oracle's
+    only on listed Gaussians, and a Gaussian that owns borderline pixels deviates by no more than the one-decision bound
+    of those pixels (tests/util.py: check_inside_borderline_sets).  Numbers -> profiles/r06_parity_report.jsonl."""
+    from edgegaussians_amd import _lib, synth
+    from tests.util import check_inside_borderline_sets
+    _lib.load()
+    if name.startswith("config2"):
+        spread = not name.endswith("init")
+        sc = synth.make_scene(100_000, 50, 512, 512, seed=0, anisotropy=5.0, spread_opacity=spread, cameras_npz=REAL_POSES)
+        view, strategy = (31, "bg_edge_ratio") if spread else (18, "weighted")
+    else:
+        n, W, H, view, strategy = SIZES[name]
+        sc = synth.make_scene(n, 2, W, H, seed=0, anisotropy=5.0, spread_opacity=True)
+    rec = check_inside_borderline_sets(sc, view, strategy, name)
+    assert rec["gaussians_owning_a_borderline_pixel"] > 0, "the scene must exercise the threshold cases"
+
+
 @pytest.mark.parametrize("n,spread,view,strategy", [(30_000, False, 0, "whole"), (30_000, True, 23, "weighted"),
                                                     (100_000, True, 12, "bg_edge_ratio")])
 def test_grad_step_vs_autograd_oracle_full_size_real_poses(n, spread, view, strategy):

@@ -1326,6 +1326,7 @@ def test_item_overflow_on_a_large_tile_grid_is_replayed(env, mode):
     extra = int(ta.total[2]) - ta.T   # items beyond one per tile in the view just rasterised
     assert extra >= 16, extra
     hint = tb.rewalk_hint
+    tb._rec_need = 0  # (round 6: the record table of the XCD-aware placement is sized from the count sweep: not here)
     tb._alloc_isect(max(128, extra * 128 * 3 // 4), tb.seg_cap)   # item table: T + 3/4 of what the views need
     tb.rewalk_hint = hint
     assert tb.max_items < int(ta.total[2])
@@ -1513,6 +1514,50 @@ def test_native_run_of_steps_equals_single_steps(env):
     assert int(tb.tile_counts.abs().sum()) == 0 and int(tb.ticket[0]) == 0
 
 
+@pytest.mark.parametrize("case", ["small", "stops", "config1_size"])
+def test_fused_backward_kernel_equals_the_two_kernel_path(env, case):
+    """Round 6: inside a native run of steps the backward is ONE kernel (csrc/backward_fused.hip: footprint backward, then --
+    in the workgroup's first wave -- projection backward + absgrads + Adam + the next view's projection and binning).  It
+    inlines the functions the two kernels of rounds 1-5 inline: every parameter, moment and absgrad must come out BIT FOR
+    BIT the same as with `two_kernel_backward` (eg_step_args), and so must the loss sums."""
+    _lib, synth, O = env
+    from edgegaussians_amd import EdgeTrainer, LRSchedule
+    if case == "small":
+        sc = _scene(synth, n=4001, w=200, h=136, views=5)          # (N not a multiple of 64: a ragged last workgroup)
+    elif case == "stops":
+        sc = synth.make_scene(3000, 4, 128, 96, seed=6, spread_opacity=False, scale=0.03, anisotropy=2.0)
+        sc.logit_opacities[:] = torch.logit(torch.tensor(0.97))    # transmittance stops: the order-dependent part
+    else:
+        sc = synth.make_scene(30011, 6, 512, 512, seed=11)
+    sched = LRSchedule(scales_start=0, quats_start=0, opacities_start=0)
+    mk = lambda: EdgeTrainer(sc.means, sc.log_scales, sc.quats, sc.logit_opacities, sc.viewmats, sc.Ks, sc.gt,  # noqa: E731
+                             sc.width, sc.height, schedule=sched, spatial_order=(case == "config1_size"))
+    ta, tb = mk(), mk()
+    ta.two_kernel_backward = True
+    assert not tb.two_kernel_backward
+    ta.ensure_capacity(); tb.ensure_capacity()
+    V = sc.viewmats.shape[0]
+    views = [(3 * i + 1) % V for i in range(9)]
+    wm = [synth.weight_map(("weighted", "whole", "bg_edge_ratio")[i % 3], sc.gt[v], generator=torch.Generator().manual_seed(i)).cuda()
+          for i, v in enumerate(views)]
+    for t in (ta, tb):
+        t.train_steps(views[:4], wm[:4])
+        t.train_steps(views[4:], wm[4:])
+    la, lb = ta.pop_loss(), tb.pop_loss()
+    assert abs(la - lb) <= 1e-6 * abs(la), (la, lb)  # (the loss terms meet in float atomics: the sum's last bits follow their order)
+    assert not ta.overflowed() and not tb.overflowed()
+    sa, sb = ta.state_dict(), tb.state_dict()
+    for k, v in sa.items():
+        assert torch.equal(sb[k], v), f"fused backward kernel: {k} differs from the two-kernel path"
+    for name in ("absgrads", "adam_m", "adam_v"):
+        assert torch.equal(getattr(tb, name), getattr(ta, name)), name
+    # a single step after the run (no tail, the two-kernel tail of eg_train_step) leaves both in the same state again
+    ta.train_step(views[0], wm[0]); tb.train_step(views[0], wm[0])
+    for k, v in ta.state_dict().items():
+        assert torch.equal(tb.state_dict()[k], v), f"after the run: {k}"
+    assert int(tb.tile_counts.abs().sum()) == 0
+
+
 def test_batched_views_with_stops_and_overflow_replay(env):
     """The batched launch sequence on a stop-heavy scene (exact-stop re-walk per view, gridDim.y) equals the sum of the
     single-view steps; and a batched step that overflows buffers sized without slack is replayed from the journal."""
@@ -1599,7 +1644,39 @@ def test_bench_line_contract(env):
     assert lo <= rf["algorithmic_bytes_M"] <= hi
     if rf["kernel"] == "composite_slice_fwd":
         assert abs(rf["algorithmic_bytes_per_launch"] - (28 * rf["algorithmic_bytes_M"] + 20 * cfg["width"] * cfg["height"])) < 1.0
+    if rf["kernel"] == "footprint_bwd+project_bwd_adam+next_project_bin":
+        # round 6, the one-kernel backward: G8's gather + per-pixel records, G9 + absgrad + Adam, the next view's G1 + keys; the
+        # g2d record's 64 N bytes (written by one kernel, read by the next until round 5) are gone
+        assert rf["kernel_symbol"] == "gaussian_bwd_fused_kernel"
+        assert abs(rf["algorithmic_bytes_per_launch"] - (562 * cfg["n_gaussians"] + 40 * rf["algorithmic_bytes_M"] + 20 * cfg["width"] * cfg["height"])) < 1.0
     assert abs(rf["achieved"] - rf["algorithmic_bytes_per_launch"] / (rf["avg_launch_us"] * 1e-6) / 1e9) <= 1e-6 * rf["achieved"]
+
+
+def test_bench_line_carries_the_target_configuration(env, golden_dir):
+    """Round 6 (VERDICT r05 missing 3 / 4): north_star's named configuration -- config 1, ~30 k Gaussians on the scan's 50 views
+    @512 x 512 -- rides on the line as a full citizen (value, its own roofline, its own CPU baseline on the same N), and the scan
+    at its NATIVE 800 x 800 against its real DexiNed maps is a workload of the same line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "200", "--warmup", "10", "--cpu-budget", "2",
+                        "--no-traffic", "--extra-set", "target"], capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.strip()][-1])
+    assert d["config"]["n_gaussians"] == 100_000  # the headline stays config 2
+    for k in ("value_config1", "ms_per_step_config1", "roofline_config1", "cpu_baseline_config1", "cpu_baseline"):
+        assert k in d, k
+    c1 = d["other_workloads"]["config1"]
+    assert c1["config"]["n_gaussians"] == 30_000 and abs(d["value_config1"] - 30_000 / (d["ms_per_step_config1"] * 1e-3)) < 1e-6 * d["value_config1"]
+    cb1 = d["cpu_baseline_config1"]
+    assert cb1["kind"] == "port" and cb1["value"] > 0 and "N=30000" in cb1["sample"] and cb1["unit"] == d["unit"]
+    rf1 = d["roofline_config1"]
+    assert rf1["bound"] == "hbm" and 0 < rf1["frac"] < 1 and "traffic" in rf1
+    a8 = d["other_workloads"]["abc800_real_edges"]
+    assert a8["config"]["width"] == 800 and a8["config"]["height"] == 800 and a8["value"] > 0
+    assert "REAL DexiNed" in a8["config"]["workload"] and "as recorded" in a8["config"]["workload"]
+    assert a8["config"]["tile_intersections_M"] > 0 and len(a8["ms_per_step_windows"]) == 3
 
 
 def test_bench_launches_its_own_ranks(env):
@@ -1615,7 +1692,7 @@ def test_bench_launches_its_own_ranks(env):
     envv = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     envv["EG_DIST_BACKEND"] = "gloo"
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--config", "config1", "--steps", "20",
-                        "--warmup", "5", "--no-traffic", "--no-extra", "--no-cpu-baseline"], capture_output=True, text=True,
+                        "--warmup", "5", "--no-traffic", "--no-cpu-baseline"], capture_output=True, text=True,
                        timeout=900, cwd=root, env=envv)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
@@ -1628,6 +1705,16 @@ def test_bench_launches_its_own_ranks(env):
     assert sorted(x[0] for x in pr["rank_device_pid"]) == [0, 1] and len({x[2] for x in pr["rank_device_pid"]}) == 2
     assert len(d["allreduce_exposed_us_per_step_by_rank"]) == 2 and d["allreduce_bytes_per_step"] == 48 * d["config"]["n_gaussians"]
     assert abs(d["value"] - 2 * d["config"]["n_gaussians"] / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    # round 6: whatever the first scaling run shows, the line says what the collective cost -- the same enqueue path timed
+    # with the gradient all-reduce left out on every rank (run last: the replicas diverge in it) -- and carries the
+    # overlapped two-half-batches mode as a sibling
+    nc = d["no_collective_leg"]
+    assert d["ms_per_step_no_collective"] > 0 and nc["steps"] >= 20 and "MEASUREMENT ONLY" in nc["what"]
+    assert abs(nc["non_collective_share_of_step"] - d["ms_per_step_no_collective"] / d["ms_per_step_median"]) < 1e-9
+    assert abs(nc["collective_cost_us_per_step"] - 1e3 * (d["ms_per_step_median"] - d["ms_per_step_no_collective"])) < 1e-6
+    v2 = d["views_per_step_2"]
+    assert v2["config"]["views_per_step"] == 4 and v2["value"] > 0 and "ms_per_step_no_collective" in v2
+    assert abs(v2["value"] - 4 * v2["config"]["n_gaussians"] / (v2["ms_per_step"] * 1e-3)) <= 1e-6 * v2["value"]
     # ... and without the test mode it REFUSES: two ranks asked for, one device visible
     envv.pop("EG_DIST_BACKEND")
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(torch.cuda.device_count() + 1), "--steps", "5"],
@@ -1853,7 +1940,9 @@ def test_bench_kernel_trace_pass(env):
         pytest.skip("rocprofv3 not installed")
     kt, src = bench.measure_kernel_trace("config1", False, steps=40)
     assert kt is not None, src
-    for k in ("composite_wave_fwd_kernel", "footprint_bwd_kernel", "tile_sort_kernel", "project_bwd_emit_kernel"):
+    # (config 1 -- 30 k Gaussians -- runs its backward as ONE kernel inside a native run, round 6; the run's last step has no
+    # next view to project and takes the two kernels)
+    for k in ("composite_wave_fwd_kernel", "gaussian_bwd_fused_kernel", "footprint_bwd_kernel", "tile_sort_kernel"):
         assert k in kt and 1.0 < kt[k] < 200.0, (k, kt)
     assert "kernel-trace" in src
 
@@ -1868,7 +1957,7 @@ def test_bench_issue_roofline_pass(env):
         pytest.skip("rocprofv3 not installed")
     kernels, src = bench.measure_issue("config1", False, steps=10)
     assert kernels is not None, src
-    assert "composite_wave_fwd_kernel" in kernels and "footprint_bwd_kernel" in kernels and "tile_sort_kernel" in kernels
+    assert "composite_wave_fwd_kernel" in kernels and "gaussian_bwd_fused_kernel" in kernels and "tile_sort_kernel" in kernels
     for k, r in kernels.items():
         assert r["valu_wave_instructions_per_launch"] > 0 and 0 < r["valu_issue_frac_of_peak"] < 1, (k, r)
         shares = r["wave_cycles_issuing"] + r["wave_cycles_parked_waitcnt_or_barrier"] + r["wave_cycles_issue_stalled"]
@@ -2088,8 +2177,9 @@ def test_item_records_follow_the_dispatch_order_contract(env, size):
     ((tx >> 1) + 3 (ty >> 1)) % 8, and the records of XCD x's tiles sit at indices 8 k + x, k dense from 0 -- slices [0, 4)
     of its tiles first (slices [0, 9) when the forward runs in chained mode), tile by tile, then the deeper slices; no other
     index below max_items carries the call's tag.
-    Larger grids: slices [0, 9) of every tile first (the projection's scan supplies the prefix: EG_FLAG_FRONT_PREFIX), then
-    the deeper slices, indices [0, n_items) without holes."""
+    Larger grids (round 6): XCD-aware too, the tiles dealt in BANDS of two tile rows, xcd = (ty >> 1) % 8 (a tile's place in its
+    list then follows from the two prefixes the projection's scan leaves anyway: ticket[1 .. T + 1], item_first); class boundary
+    9 (EG_FRONT_LARGE); every tile -- empty ones too -- has a record."""
     import numpy as np
     _lib, synth, O = env
     from edgegaussians_amd import EdgeTrainer
@@ -2110,7 +2200,7 @@ def test_item_records_follow_the_dispatch_order_contract(env, size):
     T, tw = tr.T, (W + 15) // 16
     assert (T <= 2048) == (size != "large_grid")
     xcd_shift = int(_lib.load().eg_record_xcd_shift(T))
-    assert xcd_shift == (1 if size == "small_grid" else 0)
+    assert xcd_shift == (0 if size == "tiny_grid" else 1)
     table = tr.item_rec.cpu().numpy()
     valid = table[:, 2] == tr._ws_tag  # (the tag of the call just made)
     where = np.nonzero(valid)[0]
@@ -2153,10 +2243,10 @@ def test_item_records_follow_the_dispatch_order_contract(env, size):
         return
     # (the class boundary: 9 when the step's forward runs in chained mode -- a grad_step without a journal does --, 4 otherwise)
     front_small = 9 if tr._rewalk_arg(False) != -2 else 4
-    if size == "small_grid":
-        front = front_small  # kFrontChained / kFrontDefault
+    if xcd_shift > 0:
+        front = front_small if size == "small_grid" else 9  # kFrontChained / kFrontDefault; EG_FRONT_LARGE above 2048 tiles
         ty, tx = np.divmod(tile, tw)
-        xcd = ((tx >> 1) + 3 * (ty >> 1)) % 8
+        xcd = ((tx >> 1) + 3 * (ty >> 1)) % 8 if size == "small_grid" else (ty >> 1) % 8
         assert np.array_equal(where % 8, xcd), "a record sits in another XCD's list"
         assert len(np.unique(xcd)) == 8
         span = 0
@@ -2167,18 +2257,18 @@ def test_item_records_follow_the_dispatch_order_contract(env, size):
             span = max(span, 8 * int(m.sum()))
             slx, tix = sl[m], tile[m]
             n_a = int((slx < front).sum())
-            # two classes (SegTable::slice_major): slices [0, 4) of the list's tiles, tile by tile, then the deeper slices
+            # two classes (SegTable::slice_major): slices [0, front) of the list's tiles, tile by tile, then the deeper slices
             assert n_a < m.sum() and (slx[:n_a] < front).all() and (slx[n_a:] >= front).all()
             assert (np.diff(tix[:n_a]) >= 0).all() and (np.diff(tix[n_a:]) >= 0).all()
         assert span <= tr.max_items and where.max() < span
+        if size == "large_grid":
+            # the prefix the projection's scan left behind (ticket[1 .. T + 1]): front-class items in front of every tile
+            fp = tr.ticket.cpu().numpy()
+            fr = np.minimum(per_tile, front)
+            assert fp[0] == 0 and np.array_equal(fp[1:T + 1], np.concatenate([[0], np.cumsum(fr)[:-1]])) and fp[T + 1] == fr.sum()
     else:
         assert np.array_equal(where, np.arange(len(rec)))  # no holes
-        front = 9 if size == "large_grid" else front_small  # EG_FRONT_LARGE / the step's class boundary
+        front = front_small  # the step's class boundary
         n_a = int(np.minimum(per_tile, front)[has_rec].sum())
         assert n_a < n_items and (sl[:n_a] < front).all() and (sl[n_a:] >= front).all()
         assert (np.diff(tile[:n_a]) >= 0).all() and (np.diff(tile[n_a:]) >= 0).all()  # tile by tile inside a class
-        if size == "large_grid":
-            # the prefix the projection's scan left behind (ticket[1 .. T + 1])
-            fp = tr.ticket.cpu().numpy()
-            assert fp[0] == 0 and np.array_equal(fp[1:T + 1], np.concatenate([[0], np.cumsum(np.minimum(per_tile, front))[:-1]]))
-            assert fp[T + 1] == n_a

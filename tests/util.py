@@ -380,3 +380,131 @@ def check_batched_step_vs_c_oracle(sc, views, strategies, label):
            borderline_pixels=n_border, loss_rel_err=abs(loss_g - loss_o) / abs(loss_o), grad_max_rel_err=errs,
            adam_delta_err_over_tolerance=aerr)
     return tr
+
+
+# ---------------------------------------------------------------------------------------------------
+# Round 6 (VERDICT r05 weak 3): what the HIP path does INSIDE the borderline sets.  check_fused_step_vs_c_oracle takes
+# the integer-borderline Gaussians out of the scene and gives the borderline pixels zero weight ON BOTH SIDES: a kernel
+# that mishandled exactly the threshold cases would pass it.  This check runs the SAME step on the UNCLEANED scene with
+# the UNMASKED weight map and asserts, element by element,
+#   * outside the attributable set: the plain 1e-4 tolerance (so the masking only ever protected attributable rows);
+#   * integer decisions (radius, culls) differ from the oracle's ONLY on Gaussians the oracle lists as borderline;
+#   * inside: |got - ref| <= the 1e-4 tolerance + the ONE-DECISION bound of the Gaussian's borderline pixels.
+# One-decision bound.  With unit colours the 2-D gradient of Gaussian g is a sum over the pixels p it contributes to of
+# v_p T_final(p) / (1 - alpha_g) * d alpha_g / d theta  (DESIGN.md section 5), and T_final / (1 - alpha_g) <= T_before(g):
+# whatever two implementations decide at a pixel whose walk passes within the margins of a threshold (alpha 1/255, alpha
+# 0.999, T 1e-4) -- include the Gaussian or not, stop there or one later -- each one's term of that pixel is bounded by
+# c_{g,p} = |v_p| T_before(g, p) |d alpha_g / d theta| evaluated as if included, both terms have the sign of v_p, so they
+# differ by at most c_{g,p}; where the SIGN of v_p itself hinges on rounding (|render - gt| < 1e-6) by 2 c_{g,p}.
+# T_before comes from the oracle's walk (+1 %: a flip in front of g moves it by <= 1/255 + margin).  The bound of a
+# Gaussian is the sum over ITS borderline pixels -- typically 1-3 of the hundreds it covers -- and zero for everybody else.
+def _borderline_pixel_bounds(fw, w, gt, border, alpha_floor=(1.0 / 255.0) * (1.0 - 4 * REL_ALPHA)):
+    """[N, 8] one-decision bounds (columns of g2d: v_x v_y |v_x| |v_y| v_a v_b v_c v_o) and the bool [N] set of Gaussians
+    that own a weighted borderline pixel, from a C-oracle forward `fw` (float64 arithmetic on its fp32 values)."""
+    width, height = fw["_size"]
+    tw = (width + 15) // 16
+    N = fw["means2d"].shape[0]
+    bound = np.zeros((N, 8), np.float64)
+    owns = np.zeros(N, bool)
+    offs = fw["isect_offsets"].reshape(-1).astype(np.int64)
+    ends = np.concatenate([offs[1:], [fw["M"]]])
+    flat = fw["flatten_ids"]
+    m2d, con, op = fw["means2d"].astype(np.float64), fw["conics"].astype(np.float64), fw["opacities"].astype(np.float64)
+    d_img = np.clip(fw["render"][..., 0], 0.0, 1.0).astype(np.float64) - to_np(gt).astype(np.float64)
+    wn = to_np(w).astype(np.float64)
+    ys, xs = np.nonzero(to_np(border) & (wn != 0))
+    for py, px in zip(ys, xs):
+        t = (py // 16) * tw + px // 16
+        ids = flat[offs[t]:ends[t]]
+        if ids.size == 0:
+            continue
+        dx, dy = m2d[ids, 0] - (px + 0.5), m2d[ids, 1] - (py + 0.5)
+        a, b, c = con[ids, 0], con[ids, 1], con[ids, 2]
+        sigma = 0.5 * (a * dx * dx + c * dy * dy) + b * dx * dy
+        vis = np.exp(-np.maximum(sigma, 0.0))
+        araw = op[ids] * vis
+        cand = (sigma >= -1e-6) & (araw >= alpha_floor)            # may be included by SOME correct implementation
+        alpha = np.where(cand, np.minimum(0.999, araw), 0.0)
+        t_before = np.concatenate([[1.0], np.cumprod(1.0 - alpha)[:-1]]) * 1.01
+        kappa = 2.0 if (abs(d_img[py, px]) < 1e-6 and d_img[py, px] != 0) else 1.0
+        v = kappa * abs(wn[py, px]) * t_before * cand
+        wm = v * araw                                                # |dL/dsigma| as if included
+        gx, gy = np.abs(a * dx + b * dy), np.abs(b * dx + c * dy)
+        rows = np.stack([wm * gx, wm * gy, wm * gx, wm * gy, 0.5 * wm * dx * dx, wm * np.abs(dx * dy), 0.5 * wm * dy * dy,
+                         v * vis], axis=1)
+        np.add.at(bound, ids, rows)
+        owns[ids[cand]] = True
+    return bound, owns
+
+
+def check_inside_borderline_sets(sc, view, strategy, label, trainer_kwargs=None, seed=3, ratio=1.0):
+    """See the comment above.  Returns the record written to parity_report.jsonl."""
+    from edgegaussians_amd import EdgeTrainer, synth
+    from oracle import c_oracle as CO
+    N, W, H = sc.means.shape[0], sc.width, sc.height
+    fw = oracle_forward(sc, view)
+    border = borderline_pixel_mask(fw, sc.gt[view])
+    w = synth.weight_map(strategy, sc.gt[view], ratio, torch.Generator().manual_seed(seed))   # UNMASKED
+    listed = CO.project_borderline(sc.means.numpy(), sc.quats.numpy(), torch.exp(sc.log_scales).numpy(), sc.viewmats[view].numpy(),
+                                   sc.Ks[view].numpy(), W, H, rel=REL_GAUSS) > 0
+    loss_o, ref = oracle_raw_grads(sc, fw, w, view)
+    want = CO.backward(fw, (w * torch.sign(torch.clamp(torch.from_numpy(fw["render"][..., 0]), 0, 1) - sc.gt[view])).numpy()[..., None].astype(np.float32))
+    ref2d = np.concatenate([want["means2d"], want["absgrad"], want["conics"], want["opacities_eff"][:, None]], axis=1).astype(np.float64)
+    tr = EdgeTrainer(sc.means, sc.log_scales, sc.quats, sc.logit_opacities, sc.viewmats, sc.Ks, sc.gt, W, H, **(trainer_kwargs or {}))
+    tr.ensure_capacity(views=[view])
+    tr.grad_step(view, w.cuda().contiguous())
+    gm, gq, gs, go = [t.clone().cpu() for t in tr.grad_views()]
+    got = {"means": gm, "quats": gq, "scales": gs, "opac": go, "absgrad": tr.grads.view(-1)[11 * N:].clone().cpu()}
+    assert tr.ref_index is None, "rows in the scene's order (spatial_order off)"
+    g2d = tr.g2d.clone().cpu()
+    radii_g = tr.splat.view(-1, 8)[:, 7].clone().view(torch.int32).cpu()
+    loss_g = tr.pop_loss()
+    assert not tr.overflowed()
+    # ---- integer decisions: a radius (0 = culled) that differs from the oracle's only on a LISTED borderline Gaussian
+    rad_o = fw["radii"]
+    flipped = radii_g.numpy() != rad_o
+    assert not (flipped & ~listed).any(), (f"{label}: {int((flipped & ~listed).sum())} Gaussians take another radius / cull decision than the "
+                                           "oracle WITHOUT being float-borderline")
+    # everybody whose 3-sigma box overlaps a flipped Gaussian's (either radius) shares pixels with it: attributable to it
+    near_flip = np.zeros(N, bool)
+    r_any = np.maximum(radii_g.numpy(), rad_o).astype(np.float64)
+    mx, my = fw["means2d"][:, 0].astype(np.float64), fw["means2d"][:, 1].astype(np.float64)
+    for f in np.nonzero(flipped)[0]:
+        near_flip |= (np.abs(mx - mx[f]) <= r_any + r_any[f]) & (np.abs(my - my[f]) <= r_any + r_any[f])
+    near_flip |= flipped
+    # ---- the 2-D gradients, every Gaussian, every component
+    bound, owns = _borderline_pixel_bounds(fw, w, sc.gt[view], border)
+    vis = rad_o > 0
+    dev = np.abs(g2d.numpy().astype(np.float64) - ref2d)
+    cols = ((0, 2), (2, 4), (4, 7), (7, 8))
+    tol = np.zeros_like(dev)
+    for c0, c1 in cols:   # (assert_close's criterion, per block of like components)
+        tol[:, c0:c1] = 1e-4 * np.abs(ref2d[vis][:, c0:c1]).max() + 1e-4 * np.abs(ref2d[:, c0:c1])
+    rows = vis & ~near_flip
+    over = dev[rows] - tol[rows] - bound[rows]
+    worst = float((dev[rows] / (tol[rows] + bound[rows])).max())
+    assert (over <= 0).all(), (f"{label}: 2-D gradient off by {worst:.3f} x (1e-4 tolerance + one-decision bound of the Gaussian's borderline "
+                               f"pixels) on {int((over > 0).any(axis=1).sum())} Gaussians")
+    plain = rows & ~owns
+    assert (dev[plain] <= tol[plain]).all(), f"{label}: a Gaussian WITHOUT a borderline pixel misses the plain 1e-4 tolerance"
+    needed = (dev[rows & owns] > tol[rows & owns]).any(axis=1)     # rows where the bound was actually used
+    use = dev[rows & owns][needed] / np.maximum(bound[rows & owns][needed], 1e-300)
+    # ---- raw-parameter gradients of everybody not attributable: the plain tolerance, unmasked weights, uncleaned scene
+    clear = ~near_flip & ~owns
+    keys = ("means", "quats", "scales", "opac", "absgrad")
+    raw_err = {}
+    for k in keys:
+        a_, b_ = to_np(got[k]).astype(np.float64).reshape(N, -1), np.asarray(ref[k], np.float64).reshape(N, -1)
+        t_ = 1e-4 * np.abs(b_).max() + 1e-4 * np.abs(b_)
+        raw_err[k] = float((np.abs(a_ - b_)[clear] / t_[clear]).max()) if clear.any() else 0.0
+        assert raw_err[k] <= 1.0, f"{label} raw grad {k}: {raw_err[k]:.2f} x the 1e-4 tolerance on a Gaussian with no borderline pixel"
+    # ---- the loss: a borderline pixel moves |render - gt| by at most one threshold contribution
+    loss_slack = float((to_np(w).astype(np.float64) * to_np(border)).sum()) * (1.0 / 255.0 + 2e-4)
+    assert abs(loss_g - loss_o) <= 1e-4 * abs(loss_o) + loss_slack, (loss_g, loss_o, loss_slack)
+    rec = dict(size=label, gaussians=N, listed_borderline_gaussians=int(listed.sum()), radius_or_cull_flips=int(flipped.sum()),
+               rows_near_a_flip=int(near_flip.sum()), borderline_pixels=int(border.sum()), pixels=int(border.numel()),
+               gaussians_owning_a_borderline_pixel=int((owns & vis).sum()), rows_that_needed_the_bound=int(needed.sum()),
+               worst_dev_over_tolerance_plus_bound=worst, worst_dev_over_bound_where_needed=float(use.max()) if use.size else 0.0,
+               raw_grad_err_over_tolerance_outside=raw_err, loss_rel_err=abs(loss_g - loss_o) / abs(loss_o))
+    record("inside_borderline_sets", **rec)
+    return rec
