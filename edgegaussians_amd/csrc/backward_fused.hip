@@ -58,6 +58,160 @@ struct FusedBwdArgs {
   float *loss_part, *loss_out;                    // the forward's 64 partial loss sums -> the caller's accumulator
 };
 
+// Phase 2 of the fused kernel: projection VJP + absgrads + Adam of Gaussian g of
+// view k, then the projection + exact tile binning of the NEXT view with the updated parameters still in registers; one
+// Gaussian per lane of ONE wave, no workgroup barrier.  raw / ag0 / mm / vv: the Gaussian's parameters, absgrad accumulator
+// and Adam moments as loaded by the caller (EG_BF_HOIST) or to be loaded here; ga / gb: its g2d record.  s_hist [T] zeroed,
+// s_base [T], s_touched [kBFTouched], s_ntouched zeroed: the wave's LDS.
+struct TailLds {
+  int *hist, *base, *touched, *ntouched;
+};
+#ifdef EG_BF_PROF
+#define EG_BF_STAMP2(k_)                                                           \
+  do {                                                                             \
+    if (prof_rec) {                                                                \
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                  \
+      const unsigned long long t_ = __builtin_amdgcn_s_memrealtime();              \
+      if (lane == 0) prof_rec[k_] = t_;                                            \
+    }                                                                              \
+  } while (0)
+#else
+#define EG_BF_STAMP2(k_) do {} while (0)
+#endif
+__device__ __forceinline__ void gaussian_tail(const FusedBwdArgs &a, const int g, const int lane, Raw raw, const float ag0,
+                                              float (&mm)[11], float (&vv)[11], const float4 ga, const float4 gb,
+                                              const TailLds lds, unsigned long long *prof_rec) {
+  const int width = a.width, height = a.height, N = a.N;
+  const int tw = (width + kTile - 1) / kTile, th = (height + kTile - 1) / kTile, T = tw * th;
+  const float4 *splat = a.splat;
+  int *s_hist = lds.hist, *s_base = lds.base, *s_touched = lds.touched;
+  int &s_ntouched = *lds.ntouched;
+  const bool alive = g < N;
+  if (alive) {
+#if !EG_BF_HOIST
+    raw = load_raw(a.means, a.quats, a.scales, a.opacities, g);
+#endif
+    const int radius = __float_as_int(splat[2 * g + 1].w);
+    const size_t oM = 0, oS = 3 * (size_t)N, oQ = 6 * (size_t)N, oO = 10 * (size_t)N;
+    const Cam cam = load_cam(a.viewmat, a.K);
+    Grads gr;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) gr.mean[k] = gr.scale[k] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) gr.quat[k] = 0.f;
+    gr.opac = 0.f;
+    if (radius > 0) {
+#if EG_BF_HOIST
+      const float ag = ag0;
+#else
+      const float ag = a.absgrads ? a.absgrads[g] : 0.f;
+#endif
+      Fwd f;
+      forward_geom(cam, raw, width, height, -3.0e38f, 3.0e38f, a.eps2d, a.flags, f);
+      backward_geom(cam, f, a.eps2d, a.flags, ga, gb, false, 0.f, 0.f, gr);
+      if (a.absgrads) a.absgrads[g] = ag + sqrtf(ga.z * ga.z + ga.w * ga.w);
+    }
+    EG_BF_STAMP2(3);  // parameters loaded, forward recomputed, projection VJP
+#if !EG_BF_HOIST
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      mm[k] = a.am[oM + 3 * g + k]; vv[k] = a.av[oM + 3 * g + k];
+      mm[3 + k] = a.am[oS + 3 * g + k]; vv[3 + k] = a.av[oS + 3 * g + k];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { mm[6 + k] = a.am[oQ + 4 * g + k]; vv[6 + k] = a.av[oQ + 4 * g + k]; }
+    mm[10] = a.am[oO + g]; vv[10] = a.av[oO + g];
+#endif
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      adam1(raw.m[k], gr.mean[k], mm[k], vv[k], 0, a.hyper);
+      a.means[3 * g + k] = raw.m[k]; a.am[oM + 3 * g + k] = mm[k]; a.av[oM + 3 * g + k] = vv[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      adam1(raw.s[k], gr.scale[k], mm[3 + k], vv[3 + k], 1, a.hyper);
+      a.scales[3 * g + k] = raw.s[k]; a.am[oS + 3 * g + k] = mm[3 + k]; a.av[oS + 3 * g + k] = vv[3 + k];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      adam1(raw.q[k], gr.quat[k], mm[6 + k], vv[6 + k], 2, a.hyper);
+      a.quats[4 * g + k] = raw.q[k]; a.am[oQ + 4 * g + k] = mm[6 + k]; a.av[oQ + 4 * g + k] = vv[6 + k];
+    }
+    adam1(raw.o, gr.opac, mm[10], vv[10], 3, a.hyper);
+    a.opacities[g] = raw.o; a.am[oO + g] = mm[10]; a.av[oO + g] = vv[10];
+  }
+
+  EG_BF_STAMP2(4);  // moments loaded, Adam, parameters and moments stored
+  // the next view with the updated parameters (emit_body of project.hip, by ONE wave)
+  const Cam ncam = load_cam(a.next_viewmat, a.next_K);
+  Fwd f;
+  int radius = 0;
+  if (alive && forward_geom(ncam, raw, width, height, 0.01f, 1e10f, 0.3f, a.flags, f))
+    radius = radius_of(f, width, height, 0.f);
+  const bool aa = a.flags & EG_FLAG_ANTIALIASED;
+  float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+  if (radius > 0) {
+    s0 = make_float4(f.u, f.v, f.a, f.b);
+    s1 = make_float4(f.c, aa ? f.o * f.comp : f.o, f.z, __int_as_float(radius));
+  }
+  if (alive) {
+    a.splat[2 * g] = s0;
+    a.splat[2 * g + 1] = s1;
+  }
+  int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
+  if (radius > 0) tile_box_tight(s0.x, s0.y, radius, s0.z, s0.w, s1.x, s1.y, tw, th, x0, y0, x1, y1);
+  const int bw = x1 - x0;
+  const bool small_box = (y1 - y0) * bw <= 32;
+  unsigned mask = 0u;
+  {
+    int bit = 0;
+    for (int ty = y0; ty < y1; ++ty)
+      for (int tx = x0; tx < x1; ++tx, ++bit) {
+        if (!splat_hits_tile(s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, tx, ty)) continue;
+        if (small_box) mask |= 1u << bit;
+        const int t = ty * tw + tx;
+        if (atomicAdd(&s_hist[t], 1) == 0) {  // the tile's first hit in this workgroup: list it
+          const int idx = atomicAdd(&s_ntouched, 1);
+          if (idx < kBFTouched) s_touched[idx] = t;
+        }
+      }
+  }
+  EG_BF_STAMP2(5);  // next view projected, exact tile tests, LDS histogram
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  // slots [base, base + c) of every touched tile's segment: one returning global atomic per tile
+  const int nt = s_ntouched;
+  if (nt <= kBFTouched) {
+    for (int i = lane; i < nt; i += 64) {
+      const int t = s_touched[i];
+      const int c = s_hist[t];
+      s_base[t] = atomicAdd(&a.cursor[t], c);
+      s_hist[t] = 0;
+    }
+  } else {  // (a workgroup whose Gaussians touch more tiles than the list holds: the whole histogram)
+    for (int t = lane; t < T; t += 64) {
+      const int c = s_hist[t];
+      if (c) { s_base[t] = atomicAdd(&a.cursor[t], c); s_hist[t] = 0; }
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  EG_BF_STAMP2(6);  // slots reserved (returning global atomics)
+  const unsigned long long key = ((unsigned long long)(unsigned)__float_as_int(s1.z) << 32) | (unsigned)g;
+  for (int ty = y0; ty < y1; ++ty)
+    for (int tx = x0; tx < x1; ++tx) {
+      const bool hit = small_box ? ((mask >> ((ty - y0) * bw + (tx - x0))) & 1u) != 0u
+                                 : splat_hits_tile(s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, tx, ty);
+      if (!hit) continue;
+      const int t = ty * tw + tx;
+      const int slot = s_base[t] + atomicAdd(&s_hist[t], 1);
+      if (slot < a.seg_cap) a.keys[(size_t)t * a.seg_cap + slot] = key;
+    }
+  EG_BF_STAMP2(7);  // keys stored
+}
+
 __global__ void __launch_bounds__(64 * kBFWaves) __attribute__((amdgpu_waves_per_eu(EG_BF_WAVES_PER_EU, EG_BF_WAVES_PER_EU)))
 gaussian_bwd_fused_kernel(const FusedBwdArgs a) {
   // LDS: a workgroup keeps its allocation until its LAST wave ends, i.e. through phase 2, where one wave of eight is left:
@@ -219,132 +373,16 @@ gaussian_bwd_fused_kernel(const FusedBwdArgs a) {
   if (lane == 0) s_ntouched = 0;
 
   // ---------------------------------------------------------------- phase 2: one Gaussian per lane of the first wave
-  const int g = g2;
-  const bool alive = g < N;
-  if (alive) {
-#if !EG_BF_HOIST
-    raw = load_raw(a.means, a.quats, a.scales, a.opacities, g);
-#endif
-    const int radius = __float_as_int(splat[2 * g + 1].w);
-    const size_t oM = 0, oS = 3 * (size_t)N, oQ = 6 * (size_t)N, oO = 10 * (size_t)N;
-    const Cam cam = load_cam(a.viewmat, a.K);
-    Grads gr;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) gr.mean[k] = gr.scale[k] = 0.f;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) gr.quat[k] = 0.f;
-    gr.opac = 0.f;
-    if (radius > 0) {
-      const float4 ga = *(const float4 *)&s_g2d[8 * lane], gb = *(const float4 *)&s_g2d[8 * lane + 4];
-#if EG_BF_HOIST
-      const float ag = ag0;
-#else
-      const float ag = a.absgrads ? a.absgrads[g] : 0.f;
-#endif
-      Fwd f;
-      forward_geom(cam, raw, width, height, -3.0e38f, 3.0e38f, a.eps2d, a.flags, f);
-      backward_geom(cam, f, a.eps2d, a.flags, ga, gb, false, 0.f, 0.f, gr);
-      if (a.absgrads) a.absgrads[g] = ag + sqrtf(ga.z * ga.z + ga.w * ga.w);
-    }
-    EG_BF_STAMP(3);  // parameters loaded, forward recomputed, projection VJP
-#if !EG_BF_HOIST
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      mm[k] = a.am[oM + 3 * g + k]; vv[k] = a.av[oM + 3 * g + k];
-      mm[3 + k] = a.am[oS + 3 * g + k]; vv[3 + k] = a.av[oS + 3 * g + k];
-    }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { mm[6 + k] = a.am[oQ + 4 * g + k]; vv[6 + k] = a.av[oQ + 4 * g + k]; }
-    mm[10] = a.am[oO + g]; vv[10] = a.av[oO + g];
-#endif
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      adam1(raw.m[k], gr.mean[k], mm[k], vv[k], 0, a.hyper);
-      a.means[3 * g + k] = raw.m[k]; a.am[oM + 3 * g + k] = mm[k]; a.av[oM + 3 * g + k] = vv[k];
-    }
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      adam1(raw.s[k], gr.scale[k], mm[3 + k], vv[3 + k], 1, a.hyper);
-      a.scales[3 * g + k] = raw.s[k]; a.am[oS + 3 * g + k] = mm[3 + k]; a.av[oS + 3 * g + k] = vv[3 + k];
-    }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      adam1(raw.q[k], gr.quat[k], mm[6 + k], vv[6 + k], 2, a.hyper);
-      a.quats[4 * g + k] = raw.q[k]; a.am[oQ + 4 * g + k] = mm[6 + k]; a.av[oQ + 4 * g + k] = vv[6 + k];
-    }
-    adam1(raw.o, gr.opac, mm[10], vv[10], 3, a.hyper);
-    a.opacities[g] = raw.o; a.am[oO + g] = mm[10]; a.av[oO + g] = vv[10];
-  }
-
-  EG_BF_STAMP(4);  // moments loaded, Adam, parameters and moments stored
-  // the next view with the updated parameters (emit_body of project.hip, by ONE wave)
-  const Cam ncam = load_cam(a.next_viewmat, a.next_K);
-  Fwd f;
-  int radius = 0;
-  if (alive && forward_geom(ncam, raw, width, height, 0.01f, 1e10f, 0.3f, a.flags, f))
-    radius = radius_of(f, width, height, 0.f);
-  const bool aa = a.flags & EG_FLAG_ANTIALIASED;
-  float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
-  if (radius > 0) {
-    s0 = make_float4(f.u, f.v, f.a, f.b);
-    s1 = make_float4(f.c, aa ? f.o * f.comp : f.o, f.z, __int_as_float(radius));
-  }
-  if (alive) {
-    a.splat[2 * g] = s0;
-    a.splat[2 * g + 1] = s1;
-  }
-  int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
-  if (radius > 0) tile_box_tight(s0.x, s0.y, radius, s0.z, s0.w, s1.x, s1.y, tw, th, x0, y0, x1, y1);
-  const int bw = x1 - x0;
-  const bool small_box = (y1 - y0) * bw <= 32;
-  unsigned mask = 0u;
   {
-    int bit = 0;
-    for (int ty = y0; ty < y1; ++ty)
-      for (int tx = x0; tx < x1; ++tx, ++bit) {
-        if (!splat_hits_tile(s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, tx, ty)) continue;
-        if (small_box) mask |= 1u << bit;
-        const int t = ty * tw + tx;
-        if (atomicAdd(&s_hist[t], 1) == 0) {  // the tile's first hit in this workgroup: list it
-          const int idx = atomicAdd(&s_ntouched, 1);
-          if (idx < kBFTouched) s_touched[idx] = t;
-        }
-      }
+    const float4 ga = *(const float4 *)&s_g2d[8 * lane], gb = *(const float4 *)&s_g2d[8 * lane + 4];
+    const TailLds lds = {s_hist, s_base, s_touched, &s_ntouched};
+#ifdef EG_BF_PROF
+    unsigned long long *pr = a.g2d ? prof_rec : nullptr;
+#else
+    unsigned long long *pr = nullptr;
+#endif
+    gaussian_tail(a, g2, lane, raw, ag0, mm, vv, ga, gb, lds, pr);
   }
-  EG_BF_STAMP(5);  // next view projected, exact tile tests, LDS histogram
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  // slots [base, base + c) of every touched tile's segment: one returning global atomic per tile
-  const int nt = s_ntouched;
-  if (nt <= kBFTouched) {
-    for (int i = lane; i < nt; i += 64) {
-      const int t = s_touched[i];
-      const int c = s_hist[t];
-      s_base[t] = atomicAdd(&a.cursor[t], c);
-      s_hist[t] = 0;
-    }
-  } else {  // (a workgroup whose Gaussians touch more tiles than the list holds: the whole histogram)
-    for (int t = lane; t < T; t += 64) {
-      const int c = s_hist[t];
-      if (c) { s_base[t] = atomicAdd(&a.cursor[t], c); s_hist[t] = 0; }
-    }
-  }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  EG_BF_STAMP(6);  // slots reserved (returning global atomics)
-  const unsigned long long key = ((unsigned long long)(unsigned)__float_as_int(s1.z) << 32) | (unsigned)g;
-  for (int ty = y0; ty < y1; ++ty)
-    for (int tx = x0; tx < x1; ++tx) {
-      const bool hit = small_box ? ((mask >> ((ty - y0) * bw + (tx - x0))) & 1u) != 0u
-                                 : splat_hits_tile(s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, tx, ty);
-      if (!hit) continue;
-      const int t = ty * tw + tx;
-      const int slot = s_base[t] + atomicAdd(&s_hist[t], 1);
-      if (slot < a.seg_cap) a.keys[(size_t)t * a.seg_cap + slot] = key;
-    }
-  EG_BF_STAMP(7);  // keys stored
 }
 
 int launch_gaussian_bwd_fused(float *means, float *quats, float *scales, float *opacities, const float *viewmat, const float *K,

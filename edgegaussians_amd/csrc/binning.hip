@@ -1091,12 +1091,18 @@ extern "C" int eg_sort_segments(uint64_t *keys, int32_t *tile_cursor, int32_t T,
 namespace eg {
 int record_xcd_shift(int T, bool prefix_here, bool has_item_rec, int C) {
   // (small grids stay dense: eight lists over a few dozen tiles are not balanced, and nothing there misses an L2)
-  // (round 6: grids above 2048 tiles too -- there in bands of tile rows, see tile_sort_kernel)
+  // Round 6 built the placement for grids ABOVE 2048 tiles as well (bands of tile rows: tile_sort_kernel) and measured it
+  // (profiles/r06_xcd_large_ab.txt): the forward's fabric traffic falls from 3.4x / 3.1x to 1.6x / 1.4x of the algorithmic
+  // bytes at 1600 x 1200 / 1200 x 680 -- and the forward takes 138 / 126 us instead of 133 / 116 (eight lists of unequal work;
+  // with 2 x 2 blocks and a per-list scan in the projection's tail 134 / 117 and +4 us in that tail): the launch is not
+  // traffic-bound.  OFF there; EG_XCD_LARGE=1 in a development build turns it on.
   int shift = (has_item_rec && C == 1 && T >= kXcdMinTiles) ? kXcdShiftDefault : 0;
+  int xcd_large = 0;
 #ifdef EG_DEV_SWITCHES
-  static const int xcd_large = getenv("EG_XCD_LARGE") ? atoi(getenv("EG_XCD_LARGE")) : 1;  // (A/B switch)
-  if (!prefix_here && !xcd_large) shift = 0;
+  static const int xcd_large_env = getenv("EG_XCD_LARGE") ? atoi(getenv("EG_XCD_LARGE")) : 0;  // (A/B switch)
+  xcd_large = xcd_large_env;
 #endif
+  if (!prefix_here && !xcd_large) shift = 0;
 #ifdef EG_DEV_SWITCHES
   static const int xcd_env = getenv("EG_XCD_SHIFT") ? atoi(getenv("EG_XCD_SHIFT")) : -1;  // (A/B switch)
   if (xcd_env >= 0 && shift > 0) shift = xcd_env;

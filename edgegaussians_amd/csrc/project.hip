@@ -11,6 +11,8 @@
 //   t = Rv mu + tv;  W = Rv R(q) diag(s);  P = J W (2x3);  cov2d = P P^T;  B = cov2d + eps I
 //   conic = B^-1;  comp = sqrt(max(0, det cov2d / det B));  o_eff = o * comp
 // and the reverse sweep through the same chain.
+#include <cstdlib>
+
 #include "common.h"
 #include "project_dev.h"
 

@@ -99,10 +99,10 @@ class EdgeTrainer:
         self._ws_tag = 0       # tags of the chained forward (eg_step_args.ws_tag): one fresh value per enqueued step
         self._replaying = False  # inside _recover_from_overflow's replay of the journal
         self.chained_forward = bool(int(os.environ.get("EG_CHAINED", "1")))
-        # round 6: inside a native run of steps on a tile grid of <= 2048 tiles the backward is ONE kernel
-        # (csrc/backward_fused.hip); True (development: EG_TWO_KERNEL_BACKWARD=1) keeps the footprint backward and the
-        # projection backward as two launches -- the same parameters bit for bit (tests/test_gpu_parity.py)
-        self.two_kernel_backward = bool(int(os.environ.get("EG_TWO_KERNEL_BACKWARD", "0")))
+        # round 6 (eg_step_args.two_kernel_backward): inside a native run of steps on a tile grid of <= 2048 tiles the backward of
+        # a scene of <= 32768 Gaussians is ONE kernel (csrc/backward_fused.hip); != 0 (development: EG_TWO_KERNEL_BACKWARD=1)
+        # keeps the two kernels of rounds 1-5 -- the same parameters bit for bit (tests/test_gpu_parity.py)
+        self.two_kernel_backward = int(os.environ.get("EG_TWO_KERNEL_BACKWARD", "0"))  # eg_step_args.two_kernel_backward
         # noise of duplicate() comes from a dedicated generator seeded with (seed, event number): identical
         # on every data-parallel rank whatever else the ranks drew (edge_gs.py:462-467 uses the global RNG)
         self.seed = int(seed)
@@ -357,7 +357,7 @@ class EdgeTrainer:
         a.loss_scale = self.loss_scale
         a.rewalk_hint = self._rewalk_arg(fused_adam)
         a.ws_tag = self._next_tag(n_tags) if self.chained_forward else 0
-        a.two_kernel_backward = 1 if self.two_kernel_backward else 0
+        a.two_kernel_backward = int(self.two_kernel_backward)
         if fused_adam:
             a.absgrads = ptr(self.absgrads)
             a.adam_host = self._args_cache["hyper_ptr"]

@@ -470,12 +470,13 @@ typedef struct {
    * and raises bit 1 of control word 3 of the workspace (sticky, next to bit 0 = "a pixel stopped in speculative
    * mode"): the results of that call are void and the caller must say so.  Batched step: [C, max_items, 4]. */
   int32_t *item_rec;
-  /* Round 6.  Inside a run of steps (adam_host, next_viewmat, segmented layout) on a tile grid of <= 2048 tiles the
-   * step's backward is ONE kernel: every workgroup walks the footprints of its 64 Gaussians (compositing VJP), then its
-   * first wave runs their projection VJP, absgrads, Adam and the next view's projection + binning -- the same functions,
-   * the same arithmetic per Gaussian, bit-identical parameters; the g2d record stays on chip (args.g2d is not written).
-   * != 0: the two kernels of rounds 1-5 (footprint backward, then projection backward + Adam + next projection), g2d
-   * written.  Everywhere else the field is ignored (the two kernels run). */
+  /* Round 6.  Inside a run of steps (adam_host, next_viewmat, segmented layout) on a tile grid of <= 2048 tiles a scene of
+   * up to 32768 Gaussians (eg_backward_is_fused) runs the step's backward as ONE kernel: every workgroup walks the
+   * footprints of its 64 Gaussians (compositing VJP), then its first wave runs their projection VJP, absgrads, Adam and the
+   * next view's projection + binning -- the same functions, the same arithmetic per Gaussian, bit-identical parameters; the
+   * g2d record stays on chip (args.g2d is not written).  != 0: the two kernels of rounds 1-5 (footprint backward, then
+   * projection backward + Adam + next projection), g2d written.  Everywhere else -- larger scenes, larger grids, no next
+   * view, the gradient form -- the field is ignored (the two kernels run). */
   int32_t two_kernel_backward;
 } eg_step_args;
 #define EG_MAX_WS_TAG 0xfffe

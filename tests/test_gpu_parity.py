@@ -1516,10 +1516,11 @@ def test_native_run_of_steps_equals_single_steps(env):
 
 @pytest.mark.parametrize("case", ["small", "stops", "config1_size"])
 def test_fused_backward_kernel_equals_the_two_kernel_path(env, case):
-    """Round 6: inside a native run of steps the backward is ONE kernel (csrc/backward_fused.hip: footprint backward, then --
-    in the workgroup's first wave -- projection backward + absgrads + Adam + the next view's projection and binning).  It
-    inlines the functions the two kernels of rounds 1-5 inline: every parameter, moment and absgrad must come out BIT FOR
-    BIT the same as with `two_kernel_backward` (eg_step_args), and so must the loss sums."""
+    """Round 6: inside a native run of steps the backward of a scene of <= 32768 Gaussians is ONE kernel (csrc/backward_fused.hip:
+    footprint backward, then -- in the workgroup's first wave -- projection backward + absgrads + Adam + the next view's
+    projection and binning).  It inlines the functions the two kernels of rounds 1-5 inline: every parameter, moment and
+    absgrad must come out BIT FOR BIT the same as with eg_step_args.two_kernel_backward, the loss sums to the order of their
+    float atomics."""
     _lib, synth, O = env
     from edgegaussians_amd import EdgeTrainer, LRSchedule
     if case == "small":
@@ -1533,9 +1534,10 @@ def test_fused_backward_kernel_equals_the_two_kernel_path(env, case):
     mk = lambda: EdgeTrainer(sc.means, sc.log_scales, sc.quats, sc.logit_opacities, sc.viewmats, sc.Ks, sc.gt,  # noqa: E731
                              sc.width, sc.height, schedule=sched, spatial_order=(case == "config1_size"))
     ta, tb = mk(), mk()
-    ta.two_kernel_backward = True
-    assert not tb.two_kernel_backward
+    ta.two_kernel_backward = 1   # rounds 1-5: footprint backward, then projection backward with 512 Gaussians per workgroup
+    assert not tb.two_kernel_backward and tb.N <= 32768 and tb.T <= 2048
     ta.ensure_capacity(); tb.ensure_capacity()
+    assert tb.fused_backward_active() and not ta.fused_backward_active()
     V = sc.viewmats.shape[0]
     views = [(3 * i + 1) % V for i in range(9)]
     wm = [synth.weight_map(("weighted", "whole", "bg_edge_ratio")[i % 3], sc.gt[v], generator=torch.Generator().manual_seed(i)).cuda()
@@ -1551,7 +1553,7 @@ def test_fused_backward_kernel_equals_the_two_kernel_path(env, case):
         assert torch.equal(sb[k], v), f"fused backward kernel: {k} differs from the two-kernel path"
     for name in ("absgrads", "adam_m", "adam_v"):
         assert torch.equal(getattr(tb, name), getattr(ta, name)), name
-    # a single step after the run (no tail, the two-kernel tail of eg_train_step) leaves both in the same state again
+    # a single step after the run (no next view: the footprint backward + project_bwd_adam) leaves both in the same state again
     ta.train_step(views[0], wm[0]); tb.train_step(views[0], wm[0])
     for k, v in ta.state_dict().items():
         assert torch.equal(tb.state_dict()[k], v), f"after the run: {k}"
@@ -2177,9 +2179,10 @@ def test_item_records_follow_the_dispatch_order_contract(env, size):
     ((tx >> 1) + 3 (ty >> 1)) % 8, and the records of XCD x's tiles sit at indices 8 k + x, k dense from 0 -- slices [0, 4)
     of its tiles first (slices [0, 9) when the forward runs in chained mode), tile by tile, then the deeper slices; no other
     index below max_items carries the call's tag.
-    Larger grids (round 6): XCD-aware too, the tiles dealt in BANDS of two tile rows, xcd = (ty >> 1) % 8 (a tile's place in its
-    list then follows from the two prefixes the projection's scan leaves anyway: ticket[1 .. T + 1], item_first); class boundary
-    9 (EG_FRONT_LARGE); every tile -- empty ones too -- has a record."""
+    Larger grids: slices [0, 9) of every tile first (the projection's scan supplies the prefix: EG_FLAG_FRONT_PREFIX), then the
+    deeper slices, indices [0, n_items) without holes.  (Round 6 built the XCD-aware placement for them as well -- bands of two
+    tile rows, xcd = (ty >> 1) % 8 -- and measured the forward slower with it: off, profiles/r06_xcd_large_ab.txt; the branch
+    above checks it when a development build turns it on.)"""
     import numpy as np
     _lib, synth, O = env
     from edgegaussians_amd import EdgeTrainer
@@ -2200,7 +2203,7 @@ def test_item_records_follow_the_dispatch_order_contract(env, size):
     T, tw = tr.T, (W + 15) // 16
     assert (T <= 2048) == (size != "large_grid")
     xcd_shift = int(_lib.load().eg_record_xcd_shift(T))
-    assert xcd_shift == (0 if size == "tiny_grid" else 1)
+    assert xcd_shift == (1 if size == "small_grid" else 0)  # (above 2048 tiles: built, measured, off -- profiles/r06_xcd_large_ab.txt)
     table = tr.item_rec.cpu().numpy()
     valid = table[:, 2] == tr._ws_tag  # (the tag of the call just made)
     where = np.nonzero(valid)[0]
@@ -2268,7 +2271,12 @@ def test_item_records_follow_the_dispatch_order_contract(env, size):
             assert fp[0] == 0 and np.array_equal(fp[1:T + 1], np.concatenate([[0], np.cumsum(fr)[:-1]])) and fp[T + 1] == fr.sum()
     else:
         assert np.array_equal(where, np.arange(len(rec)))  # no holes
-        front = front_small  # the step's class boundary
+        front = 9 if size == "large_grid" else front_small  # EG_FRONT_LARGE / the step's class boundary
         n_a = int(np.minimum(per_tile, front)[has_rec].sum())
         assert n_a < n_items and (sl[:n_a] < front).all() and (sl[n_a:] >= front).all()
         assert (np.diff(tile[:n_a]) >= 0).all() and (np.diff(tile[n_a:]) >= 0).all()  # tile by tile inside a class
+        if size == "large_grid":
+            # the prefix the projection's scan left behind (ticket[1 .. T + 1])
+            fp = tr.ticket.cpu().numpy()
+            assert fp[0] == 0 and np.array_equal(fp[1:T + 1], np.concatenate([[0], np.cumsum(np.minimum(per_tile, front))[:-1]]))
+            assert fp[T + 1] == n_a
