@@ -36,7 +36,7 @@ namespace eg {
 #define EG_BF_WAVES_PER_EU 4
 #endif
 #ifndef EG_BF_HOIST
-#define EG_BF_HOIST 1
+#define EG_BF_HOIST 0  // (1: phase 2's loads requested before the walks -- measured 17.8 against 17.5 us at config 1, profiles/r06_misc_ab.txt)
 #endif
 constexpr int kBFWaves = 8;                 // waves per workgroup
 constexpr int kBFGauss = 8 * kBFWaves;      // Gaussians per workgroup = lanes of the phase-2 wave
@@ -247,9 +247,9 @@ gaussian_bwd_fused_kernel(const FusedBwdArgs a) {
 #define EG_BF_STAMP(k_) do {} while (0)
 #endif
   EG_BF_STAMP(0);
-  // What phase 2 reads of its Gaussian -- 11 parameters, the absgrad accumulator, 22 Adam moments -- is requested HERE by the
-  // wave that will run it, before the walks: 35 registers held through phase 1 (the kernel is built for four waves per SIMD:
-  // phase 2 needs 104 registers, phase 1 sixty), and the ~1.5 us round trip leaves the chain at the launch's tail.
+  // (EG_BF_HOIST: what phase 2 reads of its Gaussian -- 11 parameters, the absgrad accumulator, 22 Adam moments -- requested
+  // HERE by the wave that will run it, before the walks, 35 registers held through phase 1.  Built and measured: no gain,
+  // the round trip hides behind the other waves' walks anyway; off.)
   const int g2 = blockIdx.x * kBFGauss + lane;  // phase 2's Gaussian of this lane (first wave)
   Raw raw = {};
   float ag0 = 0.f, mm[11], vv[11];

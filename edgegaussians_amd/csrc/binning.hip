@@ -1024,7 +1024,9 @@ static int launch_tile_sort(uint64_t *keys, const int32_t *offsets, int32_t T, i
   // tile that outgrew the hint is then still sorted correctly, by the slower paths of the small variant.
   const bool small_only = max_tile_hint > 0 && (int64_t)max_tile_hint * 5 / 4 <= kSmall;
   // workgroups of the small variant: one per tile -- or (grid_div > 1) one per grid_div tiles, which the kernel's
-  // grid-stride loop pairs middle-out rank b with rank b + T / grid_div: a central tile and a border tile
+  // grid-stride loop pairs middle-out rank b with rank b + T / grid_div: a central tile and a border tile.  Round 6 measured
+  // 2 ("one workgroup retires a run of empty tiles"): 7.7 -> 10.1 us at config 1, 11.8 -> 12.4 at config 2
+  // (profiles/r06_misc_ab.txt) -- the second tile's round trip to memory starts after the first tile's sort; stays 1
   int grid_div = kSortGridDiv;
 #ifdef EG_DEV_SWITCHES
   static const int div_env = getenv("EG_SORT_GRID_DIV") ? atoi(getenv("EG_SORT_GRID_DIV")) : 0;  // (A/B switch)

@@ -58,14 +58,17 @@ def elementwise_report(a, b, floors=(1e-1, 1e-2, 1e-3)):
 
 # The element-wise statement of the tolerance, asserted next to the norm-wise one on every gradient comparison: the
 # RELATIVE error of an element is bounded by a tier that follows its size against the largest element of its tensor --
-#     |ref| >= 0.1   max|ref| : 1e-4   (north_star's figure holds element by element here; measured <= 8e-5)
-#     |ref| >= 0.01  max|ref| : 1e-3   (measured <= 4.5e-4)
-#     |ref| >= 0.001 max|ref| : 1e-2   (measured <= 3.8e-3)
+#     |ref| >= 0.1   max|ref| : 1e-4   (north_star's figure holds element by element here; measured <= 8.2e-5)
+#     |ref| >= 0.01  max|ref| : 6e-4   (measured <= 4.5e-4; round 5 allowed 1e-3)
+#     |ref| >= 0.001 max|ref| : 5e-3   (measured <= 3.8e-3; round 5 allowed 1e-2)
 # i.e. an ABSOLUTE error of ~1e-5 max|ref| (measured <= 8e-6), ten times tighter than assert_close's 1e-4 max|ref|: a
 # gradient element is a sum of ~10^3 signed fp32 terms of the size of the large elements, and one that cancels to 1e-3
-# of them has lost three digits in both implementations.  Below 1e-3 max|ref| the relative errors are reported as a
-# histogram (profiles/r05_parity_report.jsonl), not bounded.  EG_ELEMENTWISE_SCALE loosens all tiers (recording runs).
-ELEMENTWISE_TIERS = ((1e-1, 1e-4), (1e-2, 1e-3), (1e-3, 1e-2))
+# of them has lost three digits in both implementations.  Round 6 tightened the two lower tiers to what three rounds of
+# measurements support (worst cases: the quaternion gradient at 200 k Gaussians @1600x1200, profiles/r06_parity_report.jsonl);
+# 1e-4 at 0.01 max|ref| is NOT supported by them (4.5e-4 measured), which is the cancellation above, not a defect: the same
+# elements agree to 8e-6 of the maximum.  Below 1e-3 max|ref| the relative errors are reported as a histogram, not bounded.
+# EG_ELEMENTWISE_SCALE loosens all tiers (recording runs).
+ELEMENTWISE_TIERS = ((1e-1, 1e-4), (1e-2, 6e-4), (1e-3, 5e-3))
 _EW_SCALE = float(__import__("os").environ.get("EG_ELEMENTWISE_SCALE", "1"))
 
 

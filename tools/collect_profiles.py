@@ -16,7 +16,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EV = os.path.join(ROOT, "gpurun_out", "ev")
 OUT = os.path.join(ROOT, "profiles")
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r05"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r06"
 VALU_PEAK = 256 * 4 * 2.4e9 / 2.0  # (2 cycles per wave64 instruction: MI355X_MICROARCH.md, tools/microbench/issue_rates.hip)
 
 
@@ -51,7 +51,8 @@ def main():
                    "bench_config1_scenes4.json": "bench_config1_scenes4.json", "bench_config1_scenes8.json": "bench_config1_scenes8.json",
                    "bench_config1_scenes8_threads.json": "bench_config1_scenes8_threads.json",
                    "bench_config2_scenes4.json": "bench_config2_scenes4.json"})
-    for c in ("config1", "config2", "config2i", "config3", "config4"):
+    copies.update({"bench_abc800.json": "bench_abc800_real_edges.json", "bench_driver_window.json": "bench_driver_window_20_steps.json"})
+    for c in ("config1", "config2", "config2i", "config3", "config4", "abc800"):
         copies[f"kernel_stats_{c}.txt"] = f"kernel_stats_{c}.txt"
         copies[f"timeline_gaps_{c}.txt"] = f"timeline_gaps_{c}.txt"
         copies[f"sq_counters_{c}.txt"] = f"pmc_sq_counters_{c}.txt"
