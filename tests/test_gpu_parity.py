@@ -1514,7 +1514,7 @@ def test_native_run_of_steps_equals_single_steps(env):
     assert int(tb.tile_counts.abs().sum()) == 0 and int(tb.ticket[0]) == 0
 
 
-@pytest.mark.parametrize("case", ["small", "stops", "config1_size"])
+@pytest.mark.parametrize("case", ["small", "stops", "config1_size", "tiny", "wide_footprints"])
 def test_fused_backward_kernel_equals_the_two_kernel_path(env, case):
     """Round 6: inside a native run of steps the backward of a scene of <= 32768 Gaussians is ONE kernel (csrc/backward_fused.hip:
     footprint backward, then -- in the workgroup's first wave -- projection backward + absgrads + Adam + the next view's
@@ -1528,6 +1528,12 @@ def test_fused_backward_kernel_equals_the_two_kernel_path(env, case):
     elif case == "stops":
         sc = synth.make_scene(3000, 4, 128, 96, seed=6, spread_opacity=False, scale=0.03, anisotropy=2.0)
         sc.logit_opacities[:] = torch.logit(torch.tensor(0.97))    # transmittance stops: the order-dependent part
+    elif case == "tiny":
+        sc = synth.make_scene(37, 4, 33, 17, seed=3, scale=0.05)    # one partial workgroup, 3 x 2 tiles
+    elif case == "wide_footprints":
+        # 100 Gaussians that each cover most of a 45 x 25-tile grid: a workgroup's 64 Gaussians touch more tiles than the
+        # touched list holds (512) -- the wave sweeps the whole histogram instead
+        sc = synth.make_scene(100, 4, 720, 400, seed=4, scale=0.25, anisotropy=1.5, spread_opacity=True)
     else:
         sc = synth.make_scene(30011, 6, 512, 512, seed=11)
     sched = LRSchedule(scales_start=0, quats_start=0, opacities_start=0)
@@ -1558,6 +1564,8 @@ def test_fused_backward_kernel_equals_the_two_kernel_path(env, case):
     for k, v in ta.state_dict().items():
         assert torch.equal(tb.state_dict()[k], v), f"after the run: {k}"
     assert int(tb.tile_counts.abs().sum()) == 0
+    if case == "wide_footprints":
+        assert tb.last_m() > 512 * 2, "the scene must touch more tiles per workgroup than the touched list holds"
 
 
 def test_batched_views_with_stops_and_overflow_replay(env):
