@@ -357,7 +357,7 @@ class EdgeTrainer:
         a.loss_scale = self.loss_scale
         a.rewalk_hint = self._rewalk_arg(fused_adam)
         a.ws_tag = self._next_tag(n_tags) if self.chained_forward else 0
-        a.two_kernel_backward = int(self.two_kernel_backward)
+        a.two_kernel_backward = 1 if (self.two_kernel_backward or getattr(self, "_side_by_side", False)) else 0
         if fused_adam:
             a.absgrads = ptr(self.absgrads)
             a.adam_host = self._args_cache["hyper_ptr"]
@@ -1390,6 +1390,11 @@ def train_steps_multi(trainers: List["EdgeTrainer"], views: List[List[int]], wma
         for w in ws:
             assert w.is_cuda and w.is_contiguous() and w.shape == (tr.height, tr.width), "weight maps: contiguous [H, W] device tensors"
     blocks = []
+    # (round 6: several scenes side by side keep the two-kernel backward -- the one-kernel form is built for four waves per
+    # SIMD, which is what a lone 30 k-Gaussian scene wants and what eight scenes sharing the chip do not: 1.49 against 1.32 G
+    # Gaussians*views/s at S = 8, profiles/r06_scenes_per_gpu.txt; same parameters either way)
+    for tr in trainers:
+        tr._side_by_side = S >= 2
     for tr, vs, ws, sx in zip(trainers, views, wmaps, streams):
         with torch.cuda.stream(sx):  # (whatever host-side preparation enqueues -- a tag wrap's zeroing, a snapshot -- goes to the scene's stream)
             if tr.capacity == 0:
@@ -1408,6 +1413,10 @@ def train_steps_multi(trainers: List["EdgeTrainer"], views: List[List[int]], wma
     ks = (C.c_void_p * S)(*[ptr(t.Ks) for t in trainers])
     gt = (C.c_void_p * S)(*[ptr(t.gt) for t in trainers])
     st = (C.c_void_p * S)(*[int(x.cuda_stream) for x in streams])
-    call("eg_train_steps_multi", S, args, K, va, wa, vm, ks, gt, st, n_threads if n_threads > 0 else min(S, 8))
+    try:
+        call("eg_train_steps_multi", S, args, K, va, wa, vm, ks, gt, st, n_threads if n_threads > 0 else min(S, 8))
+    finally:
+        for tr in trainers:
+            tr._side_by_side = False
     for tr in trainers:
         tr._steps_end(K)
