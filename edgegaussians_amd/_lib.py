@@ -119,6 +119,14 @@ _SIGS = {
     "eg_train_steps_dp": [C.POINTER(StepArgs), C.POINTER(AdamHyper), _vp, _i32, C.POINTER(_i32), C.POINTER(_vp), _vp, _vp,
                           _vp, _i32, _vp],
     "eg_dp_all_reduce": [_vp, _i64, _vp],
+    "eg_project_fwd_cams": [_vp] * 6 + [_i32, _i32, _i32, _i32, _f, _f, _f, _f, _u32] + [_vp] * 8 + [_vp],
+    "eg_project_bwd_cams": [_vp] * 6 + [_i32, _i32, _i32, _i32, _f, _u32] + [_vp] * 7 + [_vp],
+    "eg_tile_offsets_cams": [_vp, _i32, _i32, _i64, _vp, _vp, _vp, _vp],
+    "eg_tile_emit_sort_cams": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, C.POINTER(_i64), C.POINTER(_vp), C.POINTER(_vp),
+                               C.POINTER(_vp), C.POINTER(_i32), _vp],
+    "eg_composite_fwd_cams": [_i32, _vp, _i32, _vp, _i32, _i32, C.POINTER(_vp), C.POINTER(_vp), _i32, _i32, _vp, _vp, _vp,
+                              C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_i64), C.POINTER(_vp), _vp, _vp],
+    "eg_composite_bwd_footprint_cams": [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp],
     "eg_train_step_batched": [C.POINTER(StepArgs), _i32, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), _vp],
 }
 EXPORTS = sorted(list(_SIGS) + ["eg_last_error_string", "eg_version", "eg_device_count",

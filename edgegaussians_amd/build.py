@@ -18,7 +18,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libedgegs.so")
 OBJ = os.path.join(HERE, "csrc", "_obj")
-SOURCES = ["project.hip", "binning.hip", "composite.hip", "composite_wave.hip", "densify.hip", "knn.hip", "step.hip", "dp.hip", "operator.hip", "backward_fused.hip"]
+SOURCES = ["project.hip", "binning.hip", "composite.hip", "composite_wave.hip", "densify.hip", "knn.hip", "step.hip", "dp.hip", "operator.hip", "backward_fused.hip", "cams.hip"]
 # -fno-slp-vectorize: the SLP pass pairs scalar fp32 operations into v_pk_*_f32, which gfx950's vector pipe issues at
 # exactly the cost of the two plain instructions (tools/microbench/issue_rates.hip: 5.6 vs 2 x 2.8 cycles) -- and the
 # pairs need their operands in adjacent registers: v_mov shuffles and s_nop hazards on top.  Measured on the whole step

@@ -178,11 +178,19 @@ project_bwd_kernel(float *__restrict__ means, float *__restrict__ quats, float *
     absgrads[g] = 0.f;
   }
   if (!ADAM) {
+    if (flags & EG_FLAG_GRAD_ACCUM) {  // (the sum over the cameras of eg_project_bwd_cams: camera 0 wrote, this one adds)
 #pragma unroll
-    for (int k = 0; k < 3; ++k) { v_means[3 * g + k] = gr.mean[k]; v_scales[3 * g + k] = gr.scale[k]; }
+      for (int k = 0; k < 3; ++k) { v_means[3 * g + k] += gr.mean[k]; v_scales[3 * g + k] += gr.scale[k]; }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) v_quats[4 * g + k] = gr.quat[k];
-    if (v_opacities) v_opacities[g] = gr.opac;
+      for (int k = 0; k < 4; ++k) v_quats[4 * g + k] += gr.quat[k];
+      if (v_opacities) v_opacities[g] += gr.opac;
+    } else {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { v_means[3 * g + k] = gr.mean[k]; v_scales[3 * g + k] = gr.scale[k]; }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v_quats[4 * g + k] = gr.quat[k];
+      if (v_opacities) v_opacities[g] = gr.opac;
+    }
   } else {
     // moment layout: [means 3N | scales 3N | quats 4N | opacities N]
     const size_t oM = 0, oS = 3 * (size_t)N, oQ = 6 * (size_t)N, oO = 10 * (size_t)N;

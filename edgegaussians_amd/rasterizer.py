@@ -61,11 +61,10 @@ class _Projection(torch.autograd.Function):
         tpg = torch.empty(Cn, N, dtype=torch.int32, device=dev)
         counts = torch.zeros(Cn, tw * th, dtype=torch.int32, device=dev)
         flags = _lib.FLAG_ANTIALIASED if antialiased else 0
-        for c in range(Cn):
-            call("eg_project_fwd", ptr(means_c), ptr(quats_c), ptr(scales_c), ptr(opac_c), ptr(vm[c]), ptr(Kc[c]),
-                 N, width, height, near_plane, far_plane, eps2d, radius_clip, flags,
-                 ptr(splat[c]), ptr(radii[c]), ptr(means2d[c]), ptr(depths[c]), ptr(conics[c]), ptr(comps[c]),
-                 ptr(tpg[c]), ptr(counts[c]), None, stream())
+        # (round 6: the C cameras by ONE native call -- csrc/cams.hip loops over the per-camera launcher)
+        call("eg_project_fwd_cams", ptr(means_c), ptr(quats_c), ptr(scales_c), ptr(opac_c), ptr(vm), ptr(Kc), N, Cn, width, height,
+             near_plane, far_plane, eps2d, radius_clip, flags, ptr(splat), ptr(radii), ptr(means2d), ptr(depths), ptr(conics),
+             ptr(comps), ptr(tpg), ptr(counts), stream())
         ctx.save_for_backward(means_c, quats_c, scales_c, opac_c, vm, Kc, splat)
         ctx.cfg = (width, height, eps2d, flags)
         ctx.mark_non_differentiable(radii, tpg, counts, splat)
@@ -94,17 +93,10 @@ class _Projection(torch.autograd.Function):
         v_means = torch.empty(N, 3, device=dev)
         v_quats = torch.empty(N, 4, device=dev)
         v_scales = torch.empty(N, 3, device=dev)
-        tm, tq, ts = (v_means, v_quats, v_scales) if Cn == 1 else (torch.empty_like(v_means), torch.empty_like(v_quats),
-                                                                  torch.empty_like(v_scales))
-        for c in range(Cn):
-            call("eg_project_bwd", ptr(means), ptr(quats), ptr(scales), ptr(opac), ptr(vm[c]), ptr(Kc[c]),
-                 N, width, height, eps2d, flags, ptr(splat[c]), ptr(g2d[c]), ptr(vcomp[c]),
-                 ptr(vdep[c]) if vdep is not None else None, ptr(tm), ptr(tq), ptr(ts), None, None, stream())
-            if Cn > 1:
-                if c == 0:
-                    v_means.copy_(tm); v_quats.copy_(tq); v_scales.copy_(ts)
-                else:
-                    v_means += tm; v_quats += tq; v_scales += ts
+        # (one native call: camera 0 writes, the others add -- EG_FLAG_GRAD_ACCUM -- in the order of the loop this replaces)
+        call("eg_project_bwd_cams", ptr(means), ptr(quats), ptr(scales), ptr(opac), ptr(vm), ptr(Kc), N, Cn, width, height, eps2d,
+             flags, ptr(splat), ptr(g2d), ptr(vcomp), ptr(vdep) if vdep is not None else None, ptr(v_means), ptr(v_quats),
+             ptr(v_scales), stream())
         return (v_means, v_quats, v_scales) + (None,) * 10
 
 
@@ -128,15 +120,15 @@ class _Compositing(torch.autograd.Function):
         # order-independent footprint backward reads (deterministic, no atomics, no zero-fill of the gradients)
         sliced = unit_colors and all(n > 0 for n in n_items)
         gtstop = torch.empty(Cn, height, width, 3, device=dev) if sliced else None
-        for c in range(Cn):
-            col = None if unit_colors else ptr(colors_c[c] if colors_c.dim() == 3 else colors_c)
-            ws = None
-            if unit_colors and n_items[c] > 0:  # slice-parallel forward needs its scratch
-                ws = _lib.composite_workspace(n_items[c], offsets[c].shape[0] - 1, dev)
-            call("eg_composite_fwd", ptr(splat[c]), col, D, ptr(offsets[c]), ptr(flatten_ids[c]), width, height,
-                 ptr(render[c]), ptr(alphas[c]), ptr(last_ids[c]), None, None, 1.0, None, None,
-                 ptr(item_offsets[c]) if ws is not None else None, ptr(totals[c]) if ws is not None else None,
-                 n_items[c], ptr(ws), ptr(gtstop[c]) if sliced else None, -1, stream())
+        # (round 6: ONE native call for the C cameras; the arrays whose sizes differ per camera go as host arrays of pointers)
+        T = offsets[0].shape[0] - 1
+        ws = [(_lib.composite_workspace(n_items[c], T, dev) if (unit_colors and n_items[c] > 0) else None) for c in range(Cn)]
+        PV = C.c_void_p * Cn
+        call("eg_composite_fwd_cams", Cn, ptr(splat), N, None if unit_colors else ptr(colors_c), 1 if colors_c.dim() == 3 else 0, D,
+             PV(*[ptr(o) for o in offsets]), PV(*[ptr(f) for f in flatten_ids]), width, height, ptr(render), ptr(alphas),
+             ptr(last_ids), PV(*[ptr(t) if w is not None else None for t, w in zip(item_offsets, ws)]),
+             PV(*[ptr(t) if w is not None else None for t, w in zip(totals, ws)]),
+             (C.c_int64 * Cn)(*[int(n) for n in n_items]), PV(*[ptr(w) for w in ws]), ptr(gtstop) if sliced else None, stream())
         ctx.save_for_backward(means2d, splat, colors_c, alphas, last_ids, *offsets, *flatten_ids, *item_offsets,
                               *totals)
         ctx.gtstop = gtstop
@@ -160,8 +152,7 @@ class _Compositing(torch.autograd.Function):
             rec = ctx.gtstop.clone()
             rec[..., 0] *= (v_render.sum(-1) + v_alphas[..., 0])
             g2d = torch.empty(Cn, N, 8, device=dev)
-            for c in range(Cn):
-                call("eg_composite_bwd_footprint", ptr(splat[c]), N, width, height, ptr(rec[c]), ptr(g2d[c]), stream())
+            call("eg_composite_bwd_footprint_cams", ptr(splat), N, Cn, width, height, ptr(rec), ptr(g2d), stream())
             if absgrad:
                 means2d.absgrad = g2d[..., 2:4].contiguous()
             # views of the one [C,N,8] record: the projection backward recognises them and skips the re-pack
@@ -578,6 +569,36 @@ def isect_tiles_and_sort(means2d: Tensor, radii: Tensor, depths: Tensor, counts:
     return offsets, flat[:M], (ids[:M] if ids is not None else None), M, item_offsets, total, n_items
 
 
+def isect_tiles_and_sort_cams(means2d: Tensor, radii: Tensor, depths: Tensor, counts: Tensor, width: int, height: int,
+                              extra_flag: Optional[Tensor] = None):
+    """`isect_tiles_and_sort` for the C cameras of one call ([C, N, ...] inputs, `counts` [C, T]) by THREE native calls and
+    ONE host read-back (round 6: it was three calls and one read-back PER CAMERA): the C tile scans, then -- the M_c known --
+    key emission + per-tile sort of every camera (csrc/cams.hip).  Returns per-camera lists
+    (offsets, flat, ids, M, item_offsets, total, n_items) and the value of `extra_flag`."""
+    dev = means2d.device
+    Cn, N = means2d.shape[0], means2d.shape[1]
+    T = counts.shape[1]
+    offsets = torch.empty(Cn, T + 1, dtype=torch.int32, device=dev)
+    item_offsets = torch.empty(Cn, T + 1, dtype=torch.int32, device=dev)
+    total = torch.zeros(Cn, 4, dtype=torch.int32, device=dev)  # total[:, 1] (overflow) is sticky: start from zero
+    call("eg_tile_offsets_cams", ptr(counts), T, Cn, 1 << 40, ptr(offsets), ptr(item_offsets), ptr(total), stream())
+    words = total.reshape(-1) if extra_flag is None else torch.cat([total.reshape(-1), extra_flag.to(torch.int32).reshape(1)])
+    vals = words.tolist()  # the one read-back of the call (gsplat has one too: the cumsum total before allocating)
+    extra = int(vals[4 * Cn]) if extra_flag is not None else None
+    Ms = [int(vals[4 * c]) for c in range(Cn)]
+    n_items = [int(vals[4 * c + 2]) for c in range(Cn)]
+    nmax = [int(vals[4 * c + 3]) for c in range(Cn)]
+    keys = [torch.empty(max(m, 1), dtype=torch.int64, device=dev) for m in Ms]
+    flat = [torch.empty(max(m, 1), dtype=torch.int32, device=dev) for m in Ms]
+    ids = [torch.empty(max(m, 1), dtype=torch.int64, device=dev) for m in Ms]
+    PV = C.c_void_p * Cn
+    call("eg_tile_emit_sort_cams", ptr(means2d), ptr(radii), ptr(depths), N, Cn, width, height, ptr(offsets), ptr(counts),
+         (C.c_int64 * Cn)(*Ms), PV(*[ptr(k) for k in keys]), PV(*[ptr(f) for f in flat]), PV(*[ptr(i) for i in ids]),
+         (C.c_int32 * Cn)(*nmax), stream())
+    return ([offsets[c] for c in range(Cn)], [flat[c][:Ms[c]] for c in range(Cn)], [ids[c][:Ms[c]] for c in range(Cn)], Ms,
+            [item_offsets[c] for c in range(Cn)], [total[c] for c in range(Cn)], n_items, extra)
+
+
 def rasterization(
     means: Tensor, quats: Tensor, scales: Tensor, opacities: Tensor, colors: Tensor,
     viewmats: Tensor, Ks: Tensor, width: int, height: int,
@@ -640,20 +661,17 @@ def rasterization(
     # "unit colours" on the device and read the verdict back with M (the one host sync gsplat also has)
     unit_flag = None if colors.requires_grad else (colors == 1).all()
     with torch.no_grad():
+        o_l, f_l, i_l, Ms, item_l, tot_l, nit_l, extra = isect_tiles_and_sort_cams(
+            means2d.contiguous(), radii, depths.contiguous(), counts, width, height, extra_flag=unit_flag)
         for c in range(Cn):
-            offsets, flat, ids, M, item_offsets, total, n_items = isect_tiles_and_sort(
-                means2d[c], radii[c], depths[c], counts[c], width, height, extra_flag=unit_flag if c == 0 else None)
-            item_l.append(item_offsets)
-            tot_l.append(total)
-            nit_l.append(n_items)
-            offs_l.append(offsets)
-            flat_l.append(flat if M > 0 else torch.zeros(1, dtype=torch.int32, device=means.device))
-            ids_l.append((ids | (c << (32 + tile_bits)), flat + c * N, M))
-            info_offsets.append((offsets[:-1] + m_base).reshape(th, tw))
-            m_base += M
+            offs_l.append(o_l[c])
+            flat_l.append(f_l[c] if Ms[c] > 0 else torch.zeros(1, dtype=torch.int32, device=means.device))
+            ids_l.append((i_l[c] | (c << (32 + tile_bits)), f_l[c] + c * N, Ms[c]))
+            info_offsets.append((o_l[c][:-1] + m_base).reshape(th, tw))
+            m_base += Ms[c]
 
     # ... and take the order-independent unit-colour kernels when that is what we were given
-    unit = unit_flag is not None and bool(isect_tiles_and_sort.last_extra)
+    unit = unit_flag is not None and bool(extra)
     render, alphas, last_ids = _Compositing.apply(
         means2d, conics, colors, opac.contiguous(), width, height, tuple(offs_l), tuple(flat_l), bool(absgrad),
         unit, tuple(item_l), tuple(tot_l), tuple(nit_l), _splat)

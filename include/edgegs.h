@@ -55,6 +55,8 @@ typedef void *eg_stream_t; /* hipStream_t */
                                       also leaves ticket[1 + t] = sum over the tiles before t of min(items, EG_FRONT_LARGE)  \
                                       and ticket[1 + T] = that sum over all tiles (dispatch classes of the forward on tile   \
                                       grids above 2048 tiles: the sort kernel then writes the item records front slices first) */
+#define EG_FLAG_GRAD_ACCUM 64u       /* eg_project_bwd: v_means / v_quats / v_scales / v_opacities += instead of = (the sum over the \
+                                      cameras of eg_project_bwd_cams) */
 #define EG_FRONT_LARGE 9
 #define EG_FLAG_TIGHT_TILES 8u     /* bin with the opacity-aware tile box (subset of gsplat's box that \
                                       drops only (Gaussian, tile) pairs contributing exactly nothing) */
@@ -530,6 +532,39 @@ int64_t eg_batched_workspace_stride(int64_t max_items, int64_t n_tiles);
 int eg_train_step_batched(const eg_step_args *args_host, int32_t C, const float *const *viewmats,
                           const float *const *Ks, const float *const *gts, const float *const *wmaps,
                           eg_stream_t stream);
+
+/* ---- C cameras per native call for the GENERAL operator path (gsplat.rasterization takes viewmats [C,4,4]; the reference
+ * itself calls it with one camera, edge_gs.py:250-268).  Native loops over the per-camera entries above -- the same kernels,
+ * the same results -- with the cameras' arrays as [C, ...] blocks, or as HOST arrays of C device pointers where the sizes
+ * differ per camera (the binning arrays of M_c entries).  One native call per stage, one host read-back for all totals. */
+int eg_project_fwd_cams(const float *means, const float *quats, const float *scales, const float *opacities,
+                        const float *viewmats /*[C,4,4]*/, const float *Ks /*[C,3,3]*/, int32_t N, int32_t C, int32_t width,
+                        int32_t height, float near_plane, float far_plane, float eps2d, float radius_clip, uint32_t flags,
+                        float *splat /*[C,N,8]*/, int32_t *radii, float *means2d, float *depths, float *conics,
+                        float *compensations, int32_t *tiles_per_gauss /*[C,N] each, NULL ok*/,
+                        int32_t *tile_counts /*[C,T]*/, eg_stream_t stream);
+/* v_means [N,3], v_quats [N,4], v_scales [N,3] = SUM over the cameras (camera 0 writes, the others add) */
+int eg_project_bwd_cams(const float *means, const float *quats, const float *scales, const float *opacities,
+                        const float *viewmats, const float *Ks, int32_t N, int32_t C, int32_t width, int32_t height, float eps2d,
+                        uint32_t flags, const float *splat /*[C,N,8]*/, const float *g2d /*[C,N,8]*/,
+                        const float *v_comps_ext /*[C,N]*/, const float *v_depths_ext /*[C,N] or NULL*/, float *v_means,
+                        float *v_quats, float *v_scales, eg_stream_t stream);
+int eg_tile_offsets_cams(const int32_t *tile_counts /*[C,T]*/, int32_t T, int32_t C, int64_t capacity,
+                         int32_t *offsets /*[C,T+1]*/, int32_t *item_offsets /*[C,T+1]*/, int32_t *total /*[C,4]*/,
+                         eg_stream_t stream);
+int eg_tile_emit_sort_cams(const float *means2d /*[C,N,2]*/, const int32_t *radii /*[C,N]*/, const float *depths /*[C,N]*/,
+                           int32_t N, int32_t C, int32_t width, int32_t height, const int32_t *offsets /*[C,T+1]*/,
+                           int32_t *tile_counts /*[C,T], returned to zero*/, const int64_t *M_host /*[C]*/,
+                           uint64_t *const *keys, int32_t *const *flatten_ids, int64_t *const *isect_ids /*NULL ok*/,
+                           const int32_t *max_tile_host /*[C] or NULL*/, eg_stream_t stream);
+int eg_composite_fwd_cams(int32_t C, const float *splat /*[C,N,8]*/, int32_t N, const float *colors, int32_t colors_per_camera,
+                          int32_t channels, const int32_t *const *offsets, const int32_t *const *flatten_ids, int32_t width,
+                          int32_t height, float *render /*[C,H,W,channels]*/, float *alphas /*[C,H,W]*/,
+                          int32_t *last_ids /*[C,H,W]*/, const int32_t *const *item_offsets, const int32_t *const *total,
+                          const int64_t *max_items_host, void *const *workspace, float *gtstop /*[C,H,W,3] or NULL*/,
+                          eg_stream_t stream);
+int eg_composite_bwd_footprint_cams(const float *splat /*[C,N,8]*/, int32_t N, int32_t C, int32_t width, int32_t height,
+                                    const float *gtstop /*[C,H,W,3]*/, float *g2d /*[C,N,8]*/, eg_stream_t stream);
 
 /* ---- the drop-in operator's fast path in two calls (edgegaussians_amd/rasterizer.py: the reference's own call of
  * gsplat.rasterization -- one camera, colours == 1 without grad, edge_gs.py:247-279 -- and its autograd backward).
