@@ -383,6 +383,10 @@ def measure(name, args, device, rank, world, backend, spread=False, steps=None, 
     def wmap_for(step, view):
         return ratio(view) if step % 5 == 0 else whole  # configs/ABC_DexiNed.json:85-92
 
+    def wmaps_for(ss, vs):
+        # (a run's maps by one native call: the same draws as wmap_for one by one -- EdgeTrainer.weight_maps, round 6)
+        return tr.weight_maps(list(vs), ["bg_edge_ratio" if s % 5 == 0 else "whole" for s in ss], 1.0)
+
     chunk = max(1, args.chunk)
 
     def run(k, step0):
@@ -392,13 +396,13 @@ def measure(name, args, device, rank, world, backend, spread=False, steps=None, 
             for s0 in range(step0, step0 + k, chunk):
                 ss = range(s0, min(s0 + chunk, step0 + k))
                 vs = [s % n_views for s in ss]
-                tr.train_steps(vs, [wmap_for(s, v) for s, v in zip(ss, vs)])
+                tr.train_steps(vs, wmaps_for(ss, vs))
             return
         if native_dp and not dp.time_comm and chunk > 1:
             for s0 in range(step0, step0 + k, chunk):
                 ss = range(s0, min(s0 + chunk, step0 + k))
                 vs = [egdist.view_for(s, rank, world, n_views) for s in ss]
-                dp.steps(vs, [wmap_for(s, v) for s, v in zip(ss, vs)],
+                dp.steps(vs, wmaps_for(ss, vs),
                          next_view=egdist.view_for(ss[-1] + 1, rank, world, n_views))
             return
         for s in range(step0, step0 + k):

@@ -100,6 +100,8 @@ _SIGS = {
     "eg_append_rows": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _f, _vp, _vp],
     "eg_ratio_wmap": [_vp, _f, _i32, _vp, _i32, _i32, _vp, _vp],
     "eg_ratio_wmap_seeded": [_vp, _f, _i32, _i32, _i32, C.c_uint64, _i32, _vp, _vp],
+    "eg_ratio_wmaps_seeded": [_i32, C.POINTER(_vp), _f, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32), C.POINTER(C.c_uint64),
+                              _i32, _vp, _vp],
     "eg_project_hits": [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _vp, _vp],
     "eg_project_visibility": [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _vp, _vp],
     "eg_knn": [_vp, _i32, _i32, C.POINTER(_f), _f, C.POINTER(_i32), _vp, _vp, _vp, _vp, _vp, _vp, _vp],

@@ -236,3 +236,17 @@ extern "C" int eg_ratio_wmap_seeded(const float *gt, float thr, int32_t n_edge, 
       n_sel > 0 ? 1.f / (float)n_sel : 0.f, (uint32_t)seed, (uint32_t)(seed >> 32), half_bits, HW, out);
   return check_launch("ratio_wmap_seeded");
 }
+
+// C such maps by one native call (round 6: a run of steps draws one map per fifth step BEFORE it is enqueued -- 13 us of
+// host time per draw through the binding, with the GPU idle behind a read-back at the head of a window): map c from
+// gts[c] with (n_edge[c], n_bg[c], n_sel[c], seeds[c]) into out + c * HW.  Host arrays; the same kernel, the same maps.
+extern "C" int eg_ratio_wmaps_seeded(int32_t C, const float *const *gts, float thr, const int32_t *n_edge, const int32_t *n_bg,
+                                     const int32_t *n_sel, const uint64_t *seeds, int32_t HW, float *out, eg_stream_t stream) {
+  EG_REQUIRE(C >= 0 && HW > 0 && (C == 0 || (gts && n_edge && n_bg && n_sel && seeds && out)), "bad arguments");
+  for (int c = 0; c < C; ++c) {
+    const int rc = eg_ratio_wmap_seeded(gts[c], thr, n_edge[c], n_bg[c], n_sel[c], seeds[c], HW, out + (size_t)HW * c, stream);
+    if (rc) return rc;
+  }
+  return EG_OK;
+}
+

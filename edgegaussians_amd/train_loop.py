@@ -76,7 +76,13 @@ def train_epoch(tr: EdgeTrainer, views: Iterable[int], epoch: int, num_epochs: i
 
     def flush_steps():
         if pend_v:
-            tr.train_steps(list(pend_v), list(pend_w))
+            if generator is not None:
+                maps = list(pend_w)
+            elif hasattr(tr, "weight_maps"):  # (strategies were parked: the run's maps by ONE native call -- same draws, same order)
+                maps = tr.weight_maps(list(pend_v), list(pend_w), ratio, edge_threshold)
+            else:
+                maps = [tr.weight_map(v, st, ratio, None, edge_threshold) for v, st in zip(pend_v, pend_w)]
+            tr.train_steps(list(pend_v), maps)
             pend_v.clear()
             pend_w.clear()
 
@@ -84,7 +90,9 @@ def train_epoch(tr: EdgeTrainer, views: Iterable[int], epoch: int, num_epochs: i
         if alternate:
             strategy = projection_cfg["less_freq_loss"] if step_no % period == 0 else projection_cfg["more_freq_loss"]
         pend_v.append(int(idx))
-        pend_w.append(tr.weight_map(idx, strategy, ratio, generator, edge_threshold))
+        # (device-side draws: park the strategy, flush_steps draws the run's maps together; a host generator -- the
+        # reference's CPU randperm -- is advanced by drawing, so it draws here)
+        pend_w.append(strategy if generator is None else tr.weight_map(idx, strategy, ratio, generator, edge_threshold))
         n += 1
         step_no += 1
         if (apply_dir or apply_ratio) and step_no % 5 == 0:

@@ -403,6 +403,10 @@ int eg_ratio_wmap(const float *gt /*[H*W]*/, float thr, int32_t n_edge, const in
  * network + cycle walking): exactly n_sel distinct pixels, uniformly distributed; a new seed gives a new sample. */
 int eg_ratio_wmap_seeded(const float *gt /*[H*W]*/, float thr, int32_t n_edge, int32_t n_bg, int32_t n_sel,
                          uint64_t seed, int32_t HW, float *out /*[H*W]*/, eg_stream_t stream);
+/* C of them by one native call: map c from gts[c] with (n_edge[c], n_bg[c], n_sel[c], seeds[c]) into out + c * HW (host
+ * arrays; the same kernel, the same maps). */
+int eg_ratio_wmaps_seeded(int32_t C, const float *const *gts, float thr, const int32_t *n_edge, const int32_t *n_bg,
+                          const int32_t *n_sel, const uint64_t *seeds, int32_t HW, float *out /*[C,H*W]*/, eg_stream_t stream);
 
 /* ---- whole training step for one view, enqueued from native code (train_gaussians.py:81-106):
  * project+count -> offsets -> emit -> sort -> composite+loss -> composite bwd -> project bwd

@@ -1538,6 +1538,15 @@ def test_device_weight_maps_match_the_host_construction(env):
     s2 = tr.weight_map(1, "bg_edge_ratio", 1.0).cpu().view(-1) - edge.float().view(-1) / n_e > 0.5 / n_e
     both, expect = int((s1 & s2).sum()), n_e * n_e / n_bg
     assert abs(both - expect) < 6 * math.sqrt(expect) + 3, (both, expect)
+    # round 6: a run's maps by ONE native call (weight_maps -> eg_ratio_wmaps_seeded) = the same maps, the same draw sequence
+    mk = lambda: EdgeTrainer(sc.means, sc.log_scales, sc.quats, sc.logit_opacities, sc.viewmats, sc.Ks, sc.gt, sc.width, sc.height)  # noqa: E731
+    t1, t2 = mk(), mk()
+    vs, st = [1, 0, 0, 1, 1, 0], ["bg_edge_ratio", "whole", "bg_edge_ratio", "weighted", "bg_edge_ratio", "bg_edge_ratio"]
+    one_by_one = [t1.weight_map(v, k, 0.7) for v, k in zip(vs, st)]
+    batch = t2.weight_maps(vs, st, 0.7)
+    for x, y in zip(one_by_one, batch):
+        assert y.is_contiguous() and y.shape == (sc.height, sc.width) and torch.equal(x, y)
+    assert t1._wmap_draws == t2._wmap_draws == 4 and torch.equal(t1.weight_map(0, "bg_edge_ratio"), t2.weight_maps([0], ["bg_edge_ratio"])[0])
 
 
 def test_native_run_of_steps_equals_single_steps(env):
