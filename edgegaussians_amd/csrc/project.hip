@@ -390,13 +390,20 @@ struct SegOut {
   int *item_front;  // optional [T + 1] (EG_FLAG_FRONT_PREFIX): exclusive scan of min(items, EG_FRONT_LARGE), total at [T]
 };
 
-constexpr int kPE = 512;  // threads per workgroup: 512 halves the per-workgroup histogram sweeps and cursor atomics of 256 (config2 16.6 -> 14.6 us, config3 48 -> 33); 1024 loses that again to the longer barriers
+// Threads (= Gaussians) per workgroup of the projection + binning kernels: 512 halves the per-workgroup histogram sweeps and
+// cursor atomics of 256 (config 2 16.6 -> 14.6 us, config 3 48 -> 33 in round 3; 61 against 47 us at config 3 in round 6);
+// 1024 loses that again to the longer barriers.  Round 6: SMALL scenes take 256 -- at 30 k Gaussians 59 workgroups of 512
+// leave three quarters of the CUs without one and every barrier waits for the slowest of eight waves: project_bwd_emit
+// 12.5 -> 10.7 us at config 1, equal at 100 k (profiles/r06_wg_ab.txt).
+constexpr int kPE = 512, kPESmall = 256;
+constexpr int kPESmallMaxGaussians = 65536;
+__host__ __device__ constexpr bool pe_small(int N) { return N <= kPESmallMaxGaussians; }
 
 // Projection of Gaussian g (raw parameters in registers) for camera `cam`, packed record, exact tile hits, key
 // emission into the fixed per-tile segments, and -- in the last workgroup of the view -- the scan over the tiles.
 // Shared by project_emit_kernel and by the tail of project_bwd_emit_kernel (which projects the NEXT view with
 // the parameters Adam has just updated).  s_mem: 2 T ints of LDS when LDS_HIST.
-template <bool LDS_HIST>
+template <bool LDS_HIST, int PE>
 __device__ __forceinline__ void emit_body(const Raw &raw, bool live, int g, const Cam &cam, int width, int height,
                                           uint32_t flags, float4 *__restrict__ splat, int *__restrict__ cursor,
                                           int seg_cap, unsigned long long *__restrict__ keys, const SegOut &out,
@@ -404,7 +411,7 @@ __device__ __forceinline__ void emit_body(const Raw &raw, bool live, int g, cons
   const int tw = (width + kTile - 1) / kTile, th = (height + kTile - 1) / kTile, T = tw * th;
   int *s_hist = s_mem, *s_base = s_mem + T;
   if (LDS_HIST) {
-    for (int t = threadIdx.x; t < T; t += kPE) s_hist[t] = 0;
+    for (int t = threadIdx.x; t < T; t += PE) s_hist[t] = 0;
     __syncthreads();
   }
   Fwd f;
@@ -452,16 +459,16 @@ __device__ __forceinline__ void emit_body(const Raw &raw, bool live, int g, cons
     __syncthreads();
     // slots [base, base + c) of tile t's segment.  Four tiles per thread and round, their returning atomics all issued
     // before the first result is stored (round 5): one atomic per round was one round trip to the coherence point per
-    // kPE tiles of the grid, in a row -- 15 of them at 1600 x 1200
-    for (int t0 = threadIdx.x; t0 < T; t0 += 4 * kPE) {
+    // PE tiles of the grid, in a row -- 15 of them at 1600 x 1200
+    for (int t0 = threadIdx.x; t0 < T; t0 += 4 * PE) {
       int c[4], b[4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) c[q] = (t0 + q * kPE < T) ? s_hist[t0 + q * kPE] : 0;
+      for (int q = 0; q < 4; ++q) c[q] = (t0 + q * PE < T) ? s_hist[t0 + q * PE] : 0;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) b[q] = c[q] ? atomicAdd(&cursor[t0 + q * kPE], c[q]) : 0;
+      for (int q = 0; q < 4; ++q) b[q] = c[q] ? atomicAdd(&cursor[t0 + q * PE], c[q]) : 0;
 #pragma unroll
       for (int q = 0; q < 4; ++q)
-        if (c[q]) { s_base[t0 + q * kPE] = b[q]; s_hist[t0 + q * kPE] = 0; }
+        if (c[q]) { s_base[t0 + q * PE] = b[q]; s_hist[t0 + q * PE] = 0; }
     }
     __syncthreads();
     for (int ty = y0; ty < y1; ++ty)
@@ -481,7 +488,7 @@ __device__ __forceinline__ void emit_body(const Raw &raw, bool live, int g, cons
   // here"): this kernel ends with its last key store instead of ~3 us of barrier, ticket, cursor loads and scan
   if (out.ticket == nullptr) return;
   __shared__ int s_last;
-  __shared__ int s_tmp[kPE / 64];
+  __shared__ int s_tmp[PE / 64];
   // (every cursor atomic of this workgroup is a RETURNING atomic whose value has been consumed above, i.e. it has
   // been performed; the key / parameter stores still in flight need not be waited for: the scan reads cursors only)
   __syncthreads();
@@ -490,9 +497,9 @@ __device__ __forceinline__ void emit_body(const Raw &raw, bool live, int g, cons
   if (!s_last) return;
   // stage the T populations in LDS with coalesced, independent loads; every thread then owns a
   // contiguous run of tiles (the scan needs runs, the memory system wants strides)
-  const int per = (T + kPE - 1) / kPE, t0 = threadIdx.x * per, t1 = min(T, t0 + per);
+  const int per = (T + PE - 1) / PE, t0 = threadIdx.x * per, t1 = min(T, t0 + per);
   if (LDS_HIST) {
-    for (int t = threadIdx.x; t < T; t += kPE)
+    for (int t = threadIdx.x; t < T; t += PE)
       s_hist[t] = __hip_atomic_load(&cursor[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
   }
@@ -503,10 +510,10 @@ __device__ __forceinline__ void emit_body(const Raw &raw, bool live, int g, cons
     isum += it; msum += kept; cmax = max(cmax, pop); fsum += min(it, EG_FRONT_LARGE);
   }
   int itot, mtot, ftot = 0;
-  int ie = block_excl_scan<kPE>(isum, s_tmp, itot);
-  (void)block_excl_scan<kPE>(msum, s_tmp, mtot);
+  int ie = block_excl_scan<PE>(isum, s_tmp, itot);
+  (void)block_excl_scan<PE>(msum, s_tmp, mtot);
   // (dispatch classes of the forward on large tile grids: where the front slices of the tiles before this one end)
-  int fe = out.item_front ? block_excl_scan<kPE>(fsum, s_tmp, ftot) : 0;
+  int fe = out.item_front ? block_excl_scan<PE>(fsum, s_tmp, ftot) : 0;
   for (int t = t0; t < t1; ++t) {
     const int pop = LDS_HIST ? s_hist[t] : __hip_atomic_load(&cursor[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (LDS_HIST) s_base[t] = ie; else out.item_first[t] = min(ie, out.max_items);
@@ -519,7 +526,7 @@ __device__ __forceinline__ void emit_body(const Raw &raw, bool live, int g, cons
   if (out.item_front && threadIdx.x == 0) out.item_front[T] = itot > out.max_items ? -1 : ftot;
   if (LDS_HIST) {
     __syncthreads();
-    for (int t = threadIdx.x; t < T; t += kPE) out.item_first[t] = min(s_base[t], out.max_items);
+    for (int t = threadIdx.x; t < T; t += PE) out.item_first[t] = min(s_base[t], out.max_items);
   }
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) cmax = max(cmax, __shfl_xor(cmax, d, 64));
@@ -528,7 +535,7 @@ __device__ __forceinline__ void emit_body(const Raw &raw, bool live, int g, cons
   __syncthreads();
   if (threadIdx.x == 0) {
     int m = 0;
-    for (int w = 0; w < kPE / 64; ++w) m = max(m, s_tmp[w]);
+    for (int w = 0; w < PE / 64; ++w) m = max(m, s_tmp[w]);
     out.total[0] = mtot;
     if (m > seg_cap || itot > out.max_items) out.total[1] = 1;  // sticky: only the host clears it
     out.total[2] = min(itot, out.max_items);
@@ -537,8 +544,8 @@ __device__ __forceinline__ void emit_body(const Raw &raw, bool live, int g, cons
   }
 }
 
-template <bool LDS_HIST>
-__global__ void __launch_bounds__(kPE)
+template <bool LDS_HIST, int PE>
+__global__ void __launch_bounds__(PE)
 project_emit_kernel(const float *__restrict__ means, const float *__restrict__ quats,
                     const float *__restrict__ scales, const float *__restrict__ opacities,
                     const float *__restrict__ viewmat, const float *__restrict__ K, int N, int width, int height,
@@ -556,14 +563,14 @@ project_emit_kernel(const float *__restrict__ means, const float *__restrict__ q
   const bool live = g < N;
   Raw raw = {};
   if (live) raw = load_raw(means, quats, scales, opacities, g);
-  emit_body<LDS_HIST>(raw, live, g, load_cam(viewmat, K), width, height, flags, splat, cursor, seg_cap, keys, out, s_mem);
+  emit_body<LDS_HIST, PE>(raw, live, g, load_cam(viewmat, K), width, height, flags, splat, cursor, seg_cap, keys, out, s_mem);
 }
 
 // Tail fusion across the step boundary (single-view training, consecutive steps enqueued natively): the
 // projection backward + absgrad + Adam of view k and -- with the parameters still in registers -- the projection,
 // binning and tile scan of view k + 1.  One launch and one read of the parameters instead of two.
-template <bool LDS_HIST, bool HOIST>
-__global__ void __launch_bounds__(kPE)
+template <bool LDS_HIST, bool HOIST, int PE>
+__global__ void __launch_bounds__(PE)
 project_bwd_emit_kernel(float *__restrict__ means, float *__restrict__ quats, float *__restrict__ scales,
                         float *__restrict__ opacities, const float *__restrict__ viewmat, const float *__restrict__ K,
                         const float *__restrict__ next_viewmat, const float *__restrict__ next_K, int N, int width,
@@ -641,7 +648,7 @@ project_bwd_emit_kernel(float *__restrict__ means, float *__restrict__ quats, fl
     opacities[g] = raw.o; am[oO + g] = mm[10]; av[oO + g] = vv[10];
   }
   // the next view, with the updated parameters still in registers (this thread's splat row of view k is dead now)
-  emit_body<LDS_HIST>(raw, live, g, load_cam(next_viewmat, next_K), width, height, flags, splat, cursor, seg_cap, keys,
+  emit_body<LDS_HIST, PE>(raw, live, g, load_cam(next_viewmat, next_K), width, height, flags, splat, cursor, seg_cap, keys,
                       out, s_mem);
 }
 
@@ -649,8 +656,8 @@ project_bwd_emit_kernel(float *__restrict__ means, float *__restrict__ quats, fl
 // and -- with the updated parameters still in registers -- the projection, binning and tile scan of the view this
 // rank rasterises NEXT (the body of project_emit_kernel): the tail fusion of the single-GPU step for the
 // data-parallel leg, one launch and one read of the parameters instead of two.
-template <bool LDS_HIST>
-__global__ void __launch_bounds__(kPE)
+template <bool LDS_HIST, int PE>
+__global__ void __launch_bounds__(PE)
 adam_emit_kernel(float *__restrict__ means, float *__restrict__ scales, float *__restrict__ quats,
                  float *__restrict__ opacities, const float *__restrict__ g_means, const float *__restrict__ g_scales,
                  const float *__restrict__ g_quats, const float *__restrict__ g_opacities, float *__restrict__ am,
@@ -691,7 +698,7 @@ adam_emit_kernel(float *__restrict__ means, float *__restrict__ scales, float *_
       opacities[g] = raw.o; am[oO + g] = m; av[oO + g] = v;
     }
   }
-  emit_body<LDS_HIST>(raw, live, g, load_cam(next_viewmat, next_K), width, height, flags, splat, cursor, seg_cap, keys,
+  emit_body<LDS_HIST, PE>(raw, live, g, load_cam(next_viewmat, next_K), width, height, flags, splat, cursor, seg_cap, keys,
                       out, s_mem);
 }
 
@@ -754,15 +761,18 @@ int launch_project_emit(const float *means, const float *quats, const float *log
   out.item_first = item_first; out.max_items = max_items;
   out.total = total; out.ticket = ticket;
   out.item_front = (ticket && (flags & EG_FLAG_FRONT_PREFIX)) ? ticket + 1 : nullptr;
-  const dim3 grid(cdiv(N, kPE), C);
-  if (2 * T <= 16384)
-    project_emit_kernel<true><<<grid, kPE, sizeof(int) * 2 * T, st>>>(
-        means, quats, log_scales, logit_opacities, viewmat, K, N, width, height, flags, (float4 *)splat, tile_cursor,
-        seg_cap, (unsigned long long *)keys, out, bt);
-  else
-    project_emit_kernel<false><<<grid, kPE, 0, st>>>(
-        means, quats, log_scales, logit_opacities, viewmat, K, N, width, height, flags, (float4 *)splat, tile_cursor,
-        seg_cap, (unsigned long long *)keys, out, bt);
+#define EG_EMIT(LDS, PE_, SMEM)                                                                                        \
+  project_emit_kernel<LDS, PE_><<<dim3(cdiv(N, PE_), C), PE_, SMEM, st>>>(                                              \
+      means, quats, log_scales, logit_opacities, viewmat, K, N, width, height, flags, (float4 *)splat, tile_cursor,     \
+      seg_cap, (unsigned long long *)keys, out, bt)
+  // (C views per launch multiply the workgroups: the batched step keeps 512)
+  const bool small = pe_small(N) && C == 1;
+  if (2 * T <= 16384) {
+    if (small) EG_EMIT(true, kPESmall, sizeof(int) * 2 * T); else EG_EMIT(true, kPE, sizeof(int) * 2 * T);
+  } else {
+    if (small) EG_EMIT(false, kPESmall, 0); else EG_EMIT(false, kPE, 0);
+  }
+#undef EG_EMIT
   return check_launch("project_emit");
 }
 }  // namespace eg
@@ -829,15 +839,17 @@ int launch_project_bwd_emit(float *means, float *quats, float *scales, float *op
   out.total = total; out.ticket = ticket;
   out.item_front = (ticket && (flags & EG_FLAG_FRONT_PREFIX)) ? ticket + 1 : nullptr;
   const bool hoist = N <= 160000;  // up to ~2.5 waves of these threads per SIMD
-#define EG_BWD_EMIT(LDS, HO, SMEM)                                                                                  \
-  project_bwd_emit_kernel<LDS, HO><<<cdiv(N, kPE), kPE, SMEM, st>>>(                                               \
+#define EG_BWD_EMIT(LDS, HO, PE_, SMEM)                                                                             \
+  project_bwd_emit_kernel<LDS, HO, PE_><<<cdiv(N, PE_), PE_, SMEM, st>>>(                                          \
       means, quats, scales, opacities, viewmat, K, next_viewmat, next_K, N, width, height, eps2d, flags,           \
       (float4 *)splat, (const float4 *)g2d, absgrads, m, v, make_adamk(hyper), tile_cursor, seg_cap,               \
       (unsigned long long *)keys, out)
-  if (2 * T <= 16384) {
-    if (hoist) EG_BWD_EMIT(true, true, sizeof(int) * 2 * T); else EG_BWD_EMIT(true, false, sizeof(int) * 2 * T);
+  if (pe_small(N)) {  // (small scenes: hoisted loads, 256 Gaussians per workgroup)
+    if (2 * T <= 16384) EG_BWD_EMIT(true, true, kPESmall, sizeof(int) * 2 * T); else EG_BWD_EMIT(false, true, kPESmall, 0);
+  } else if (2 * T <= 16384) {
+    if (hoist) EG_BWD_EMIT(true, true, kPE, sizeof(int) * 2 * T); else EG_BWD_EMIT(true, false, kPE, sizeof(int) * 2 * T);
   } else {
-    if (hoist) EG_BWD_EMIT(false, true, 0); else EG_BWD_EMIT(false, false, 0);
+    if (hoist) EG_BWD_EMIT(false, true, kPE, 0); else EG_BWD_EMIT(false, false, kPE, 0);
   }
 #undef EG_BWD_EMIT
   return check_launch("project_bwd_emit");
@@ -959,16 +971,17 @@ extern "C" int eg_adam_emit(float *means, float *scales, float *quats, float *op
   out.total = total; out.ticket = ticket;
   out.item_front = (ticket && (flags & EG_FLAG_FRONT_PREFIX)) ? ticket + 1 : nullptr;
   hipStream_t st = as_stream(stream);
-  if (2 * T <= 16384)
-    adam_emit_kernel<true><<<cdiv(N, kPE), kPE, sizeof(int) * 2 * T, st>>>(
-        means, scales, quats, opacities, g_means, g_scales, g_quats, g_opacities, m, v, N, make_adamk(hyper),
-        absgrad_inc, absgrads, next_viewmat, next_K, width, height, flags, (float4 *)splat, tile_cursor, seg_cap,
-        (unsigned long long *)keys, out);
-  else
-    adam_emit_kernel<false><<<cdiv(N, kPE), kPE, 0, st>>>(
-        means, scales, quats, opacities, g_means, g_scales, g_quats, g_opacities, m, v, N, make_adamk(hyper),
-        absgrad_inc, absgrads, next_viewmat, next_K, width, height, flags, (float4 *)splat, tile_cursor, seg_cap,
-        (unsigned long long *)keys, out);
+#define EG_ADAM_EMIT(LDS, PE_, SMEM)                                                                                    \
+  adam_emit_kernel<LDS, PE_><<<cdiv(N, PE_), PE_, SMEM, st>>>(                                                          \
+      means, scales, quats, opacities, g_means, g_scales, g_quats, g_opacities, m, v, N, make_adamk(hyper), absgrad_inc, \
+      absgrads, next_viewmat, next_K, width, height, flags, (float4 *)splat, tile_cursor, seg_cap,                     \
+      (unsigned long long *)keys, out)
+  if (2 * T <= 16384) {
+    if (pe_small(N)) EG_ADAM_EMIT(true, kPESmall, sizeof(int) * 2 * T); else EG_ADAM_EMIT(true, kPE, sizeof(int) * 2 * T);
+  } else {
+    if (pe_small(N)) EG_ADAM_EMIT(false, kPESmall, 0); else EG_ADAM_EMIT(false, kPE, 0);
+  }
+#undef EG_ADAM_EMIT
   return check_launch("adam_emit");
 }
 
