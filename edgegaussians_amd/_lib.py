@@ -27,7 +27,7 @@ FLAG_ANTIALIASED = 4
 FLAG_TIGHT_TILES = 8
 FLAG_ABSGRAD_WRITE = 16
 FLAG_FRONT_PREFIX = 32   # EG_FLAG_FRONT_PREFIX (tile grids above PREFIX_HERE_MAX_TILES: `ticket` is [T + 2])
-PREFIX_HERE_MAX_TILES = 2048
+PREFIX_HERE_MAX_TILES = 2560  # kPrefixHereMaxTiles (csrc/common.h)
 REWALK_SPECULATE = -2  # EG_REWALK_SPECULATE
 MAX_WS_TAG = 0xfffe      # EG_MAX_WS_TAG
 

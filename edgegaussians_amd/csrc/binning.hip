@@ -378,7 +378,9 @@ constexpr int kSortGridDiv = EG_SORT_GRID_DIV;  // tiles per workgroup of the sm
 constexpr int kFrontDefault = 4;  // class boundary of the dispatch order (slices); SegTable::slice_major carries it
 
 // THREADS = number of buckets; CAP = keys per buffer (two buffers).  n_lo < n handled here.
-template <int THREADS, int CAP, bool LARGE>
+template <int THREADS, int CAP, bool LARGE, bool PREFIX3 = false>
+// (PREFIX3, round 6: "prefix here" on grids of 2049 .. 2560 tiles -- the reference's native 800 x 800 is 2500 -- takes a third batch
+// of cursor loads; an instantiation of its own: the branch alone cost the 1024-tile launches of configs 1 / 2 0.3-0.4 us)
 // (512-thread variant: two workgroups per CU need 4 waves per SIMD, i.e. at most 128 VGPRs; the 256-thread variant at
 // 128 VGPRs -- three dwords spilled -- fits FOUR workgroups per CU instead of three: config 3's 7500 tiles 36.9 -> 29.4 us.
 // Pushing either further -- 6 or 8 waves per SIMD -- spills the keys and costs 5-12 us: measured)
@@ -566,7 +568,7 @@ tile_sort_kernel(unsigned long long *__restrict__ keys, const int *__restrict__ 
         pop_here = seg.cursor[tile];
         kept = min(pop_here, seg.seg_cap);
         const __amdgpu_buffer_rsrc_t cur_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)seg.cursor, 0, T * 4, 0x00020000);
-        constexpr int NE = kPrefixHereMaxTiles / (2 * THREADS);  // tiles per lane and batch: a batch covers 1024 tiles
+        constexpr int NE = kPrefixBatchTiles / THREADS;  // tiles per lane and batch: a batch covers 1024 tiles
         int pv0[NE];
 #pragma unroll
         for (int j = 0; j < NE; ++j) pv0[j] = (int)__builtin_amdgcn_raw_buffer_load_b32(cur_rsrc, (tid + j * THREADS) * 4, 0, 0);
@@ -620,12 +622,21 @@ tile_sort_kernel(unsigned long long *__restrict__ keys, const int *__restrict__ 
             }
           };
           sums(pv0, 0);
-          if (T > kPrefixHereMaxTiles / 2) {  // (uniform) a grid above 1024 tiles takes a second round trip
+          if (T > kPrefixBatchTiles) {  // (uniform) a grid above 1024 tiles takes a second round trip
             int pv1[NE];
 #pragma unroll
             for (int j = 0; j < NE; ++j)
               pv1[j] = (int)__builtin_amdgcn_raw_buffer_load_b32(cur_rsrc, (tid + (NE + j) * THREADS) * 4, 0, 0);
             sums(pv1, NE);
+          }
+          // (round 6: ... and the reference's native 800 x 800 -- 2500 tiles -- a third.  Requesting all three batches before the
+          // first is summed costs the 256-thread variant six spilled registers: 15.9 against 14.5 us at 800 x 800)
+          if (PREFIX3 && T > 2 * kPrefixBatchTiles) {
+            int pv2[NE];
+#pragma unroll
+            for (int j = 0; j < NE; ++j)
+              pv2[j] = (int)__builtin_amdgcn_raw_buffer_load_b32(cur_rsrc, (tid + (2 * NE + j) * THREADS) * 4, 0, 0);
+            sums(pv2, 2 * NE);
           }
           // (DPP scans: the totals land in lane 63)
           isum = wave_scan_dpp(isum, 0, OpAdd());
@@ -1033,14 +1044,14 @@ static int launch_tile_sort(uint64_t *keys, const int32_t *offsets, int32_t T, i
   if (div_env > 0) grid_div = div_env;
 #endif
   const int grid_x = cdiv(T, grid_div);
-  if (wide)
-    tile_sort_kernel<512, kSmall, false><<<dim3(grid_x, C), 512, kSmall * 8 + 2 * 512 * 4 * kSortBM, as_stream(stream)>>>(
-        (unsigned long long *)keys, offsets, T, (long long)capacity, small_only ? 0x7fffffff : kSmall, flatten_ids,
-        (long long *)isect_ids, seg, bt);
-  else
-    tile_sort_kernel<256, kSmall, false><<<dim3(grid_x, C), 256, kSmall * 8 + 2 * 256 * 4 * kSortBM, as_stream(stream)>>>(
-        (unsigned long long *)keys, offsets, T, (long long)capacity, small_only ? 0x7fffffff : kSmall, flatten_ids,
-        (long long *)isect_ids, seg, bt);
+#define EG_SORT_SMALL(TH_, P3_)                                                                                          \
+  tile_sort_kernel<TH_, kSmall, false, P3_><<<dim3(grid_x, C), TH_, kSmall * 8 + 2 * TH_ * 4 * kSortBM, as_stream(stream)>>>( \
+      (unsigned long long *)keys, offsets, T, (long long)capacity, small_only ? 0x7fffffff : kSmall, flatten_ids,            \
+      (long long *)isect_ids, seg, bt)
+  const bool prefix3 = seg.total != nullptr && T > 2 * kPrefixBatchTiles;
+  if (wide) { if (prefix3) EG_SORT_SMALL(512, true); else EG_SORT_SMALL(512, false); }
+  else      { if (prefix3) EG_SORT_SMALL(256, true); else EG_SORT_SMALL(256, false); }
+#undef EG_SORT_SMALL
   if (!small_only)
     tile_sort_kernel<1024, kLarge, true><<<dim3(min(T, 256), C), 1024, kLargeLds, as_stream(stream)>>>(
         (unsigned long long *)keys, offsets, T, (long long)capacity, kSmall, flatten_ids, (long long *)isect_ids,

@@ -31,7 +31,12 @@ void timing_mark(int mark, hipStream_t stream);
 // single-view launch: blockIdx.y is 0 and the kernels use their own view arguments.
 // largest tile grid for which the sort kernel forms the tile prefix itself (every tile's workgroup reads the
 // cursors of the tiles before it: O(T^2 / 2) loads in all)
-constexpr int kPrefixHereMaxTiles = 2048;
+// (round 6: 2048 -> 2560, so that the reference's NATIVE image size -- 800 x 800 = 2500 tiles, data/ABC-NEF_Edge/.../meta_data.json --
+// takes this path with everything that hangs on it: no scan tail in the projection kernels, empty tiles without a record or a
+// forward workgroup, XCD-aware records, the one-kernel backward)
+constexpr int kPrefixHereMaxTiles = 2560;
+constexpr int kPrefixBatchTiles = 1024;  // cursors one batch of the sort kernel's prefix loads covers (<= 3 batches)
+static_assert(kPrefixHereMaxTiles <= 3 * kPrefixBatchTiles, "tile_sort_kernel forms the prefix in at most three batches");
 constexpr int kMaxBatch = EG_MAX_BATCH;
 struct Batch {
   long long splat4 = 0;    // splat / g2d: float4 units (2 N)

@@ -964,7 +964,7 @@ extern "C" int eg_adam_emit(float *means, float *scales, float *quats, float *op
   const int T = cdiv(width, kTile) * cdiv(height, kTile);
   // (ticket == NULL: no scan tail -- for a following eg_train_step on a tile grid of <= 2048 tiles, whose sort kernel
   // forms the tile prefix itself)
-  EG_REQUIRE(ticket || T <= kPrefixHereMaxTiles, "ticket may be NULL only on tile grids of <= 2048 tiles");
+  EG_REQUIRE(ticket || T <= kPrefixHereMaxTiles, "ticket may be NULL only on tile grids of <= 2560 tiles");
   EG_REQUIRE((int64_t)T * seg_cap < (1ll << 31), "T * seg_cap must fit 31 bits");
   SegOut out;
   out.item_first = item_first; out.max_items = max_items;

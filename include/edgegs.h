@@ -54,7 +54,7 @@ typedef void *eg_stream_t; /* hipStream_t */
 #define EG_FLAG_FRONT_PREFIX 32u     /* eg_project_emit & co.: `ticket` is [T + 2] int32 and the scan of the last workgroup    \
                                       also leaves ticket[1 + t] = sum over the tiles before t of min(items, EG_FRONT_LARGE)  \
                                       and ticket[1 + T] = that sum over all tiles (dispatch classes of the forward on tile   \
-                                      grids above 2048 tiles: the sort kernel then writes the item records front slices first) */
+                                      grids above 2560 tiles: the sort kernel then writes the item records front slices first) */
 #define EG_FLAG_GRAD_ACCUM 64u       /* eg_project_bwd: v_means / v_quats / v_scales / v_opacities += instead of = (the sum over the \
                                       cameras of eg_project_bwd_cams) */
 #define EG_FRONT_LARGE 9
@@ -425,7 +425,7 @@ typedef struct {
   int32_t *tile_counts, *offsets, *item_offsets, *total; /* [T], [T+1], [T+1], [4] */
   uint32_t *tile_mask;                                   /* [N] */
   int32_t *ticket;                                       /* [T + 2], zero-initialised once ([0]: the scan's ticket; [1..T+1]:
-                                                            see EG_FLAG_FRONT_PREFIX, used on tile grids above 2048 tiles) */
+                                                            see EG_FLAG_FRONT_PREFIX, used on tile grids above 2560 tiles) */
   void *workspace;   /* eg_composite_workspace_bytes(max_items, T) bytes, control prefix zeroed at allocation */
   int64_t max_items; /* >= ceil(capacity/128) + T */
   uint64_t *keys;
@@ -459,11 +459,11 @@ typedef struct {
    * 128 * slice), in the order the forward dispatches its workgroups in.  The record INDEX is not the item number -- the
    * hand-over storage is addressed through item_first -- and the table may have HOLES: the forward takes a record for
    * this call's iff word 2 equals ws_tag, so the table must be zeroed whenever the workspace is (tag wrap).  Tile grids of
-   * of 512 .. 2048 tiles (eg_record_xcd_shift), one view per launch: XCD-aware placement -- workgroup b of a launch runs on XCD b % 8; the tiles are
+   * of 512 .. 2560 tiles (eg_record_xcd_shift), one view per launch: XCD-aware placement -- workgroup b of a launch runs on XCD b % 8; the tiles are
    * dealt to the XCDs in 2 x 2-tile blocks, xcd = (block_x + 3 block_y) % 8, and XCD x's records sit at indices 8 k + x,
    * slices 0..3 of its tiles first, their deeper slices after them; the table spans 8 x the longest of the eight lists
    * (beyond max_items: the sticky overflow word).  Larger grids / batched launches: slices [0, 9) resp. [0, 4) of all
-   * tiles first, then the deeper slices, no holes.  Grids of <= 2048 tiles, fused loss (wmap != NULL, no images wanted): an
+   * tiles first, then the deeper slices, no holes.  Grids of <= 2560 tiles, fused loss (wmap != NULL, no images wanted): an
    * EMPTY tile other than the last one has NO record -- its sort workgroup adds the background's loss term
    * sum_p wmap_p |gt_p| to the forward's partial sums and leaves; its gtstop pixels and its tile / item table entries are
    * not written (no Gaussian's footprint reaches them: the exact tile test is conservative), its one empty item stays in the
@@ -476,7 +476,7 @@ typedef struct {
    * and raises bit 1 of control word 3 of the workspace (sticky, next to bit 0 = "a pixel stopped in speculative
    * mode"): the results of that call are void and the caller must say so.  Batched step: [C, max_items, 4]. */
   int32_t *item_rec;
-  /* Round 6.  Inside a run of steps (adam_host, next_viewmat, segmented layout) on a tile grid of <= 2048 tiles a scene of
+  /* Round 6.  Inside a run of steps (adam_host, next_viewmat, segmented layout) on a tile grid of <= 2560 tiles (round 6: 2048 -> 2560, the reference's native 800 x 800 = 2500 tiles included) a scene of
    * up to 32768 Gaussians (eg_backward_is_fused) runs the step's backward as ONE kernel: every workgroup walks the
    * footprints of its 64 Gaussians (compositing VJP), then its first wave runs their projection VJP, absgrads, Adam and the
    * next view's projection + binning -- the same functions, the same arithmetic per Gaussian, bit-identical parameters; the
@@ -487,7 +487,7 @@ typedef struct {
 } eg_step_args;
 #define EG_MAX_WS_TAG 0xfffe
 
-/* (Segmented layout, tile grids of <= 2048 tiles: eg_train_step / eg_train_steps / eg_train_step_batched run the
+/* (Segmented layout, tile grids of <= 2560 tiles: eg_train_step / eg_train_steps / eg_train_step_batched run the
  * projection kernels without their ticket + scan tail -- `ticket` is then unused -- let every tile's sort workgroup
  * form its item prefix from the cursors, and have the compositing kernel return the cursors to zero.  Same tables,
  * same results; the stand-alone entries eg_project_emit / eg_sort_segments / eg_composite_fwd_segments keep the

@@ -1364,7 +1364,7 @@ def test_item_overflow_on_a_large_tile_grid_is_replayed(env, mode):
     overflow's.  Both forward modes: same result as a run that was oversized from the start."""
     _lib, synth, O = env
     from edgegaussians_amd import EdgeTrainer, LRSchedule
-    W, H = 1024, 640   # 64 x 40 = 2560 tiles > kPrefixHereMaxTiles
+    W, H = 1056, 640   # 66 x 40 = 2640 tiles > kPrefixHereMaxTiles (2560 since round 6)
     # (speculative: opacity 0.08 and thin footprints, ~20 layers per pixel -- no pixel reaches the transmittance stop)
     sc = synth.make_scene(40000, 2, W, H, seed=8, anisotropy=5.0, spread_opacity=(mode == "chained"),
                           scale=0.01 if mode == "chained" else 0.004)
@@ -1372,7 +1372,7 @@ def test_item_overflow_on_a_large_tile_grid_is_replayed(env, mode):
     mk = lambda: EdgeTrainer(sc.means, sc.log_scales, sc.quats, sc.logit_opacities, sc.viewmats, sc.Ks, sc.gt,  # noqa: E731
                              sc.width, sc.height, schedule=sched)
     ta, tb = mk(), mk()
-    assert ta.T == 2560
+    assert ta.T == 2640 and ta.T > _lib.PREFIX_HERE_MAX_TILES
     w = [synth.weight_map("weighted", sc.gt[v]).cuda() for v in range(2)]
     for t in (ta, tb):
         t.ensure_capacity(slack=2.0)
@@ -1582,7 +1582,7 @@ def test_native_run_of_steps_equals_single_steps(env):
     assert int(tb.tile_counts.abs().sum()) == 0 and int(tb.ticket[0]) == 0
 
 
-@pytest.mark.parametrize("case", ["small", "stops", "config1_size", "tiny", "wide_footprints"])
+@pytest.mark.parametrize("case", ["small", "stops", "config1_size", "tiny", "wide_footprints", "native_800"])
 def test_fused_backward_kernel_equals_the_two_kernel_path(env, case):
     """Round 6: inside a native run of steps the backward of a scene of <= 32768 Gaussians is ONE kernel (csrc/backward_fused.hip:
     footprint backward, then -- in the workgroup's first wave -- projection backward + absgrads + Adam + the next view's
@@ -1598,6 +1598,8 @@ def test_fused_backward_kernel_equals_the_two_kernel_path(env, case):
         sc.logit_opacities[:] = torch.logit(torch.tensor(0.97))    # transmittance stops: the order-dependent part
     elif case == "tiny":
         sc = synth.make_scene(37, 4, 33, 17, seed=3, scale=0.05)    # one partial workgroup, 3 x 2 tiles
+    elif case == "native_800":
+        sc = synth.make_scene(9000, 4, 800, 800, seed=12, spread_opacity=True)   # the reference's native size: 2500 tiles
     elif case == "wide_footprints":
         # 100 Gaussians that each cover most of a 45 x 25-tile grid: a workgroup's 64 Gaussians touch more tiles than the
         # touched list holds (512) -- the wave sweeps the whole histogram instead
@@ -1609,7 +1611,7 @@ def test_fused_backward_kernel_equals_the_two_kernel_path(env, case):
                              sc.width, sc.height, schedule=sched, spatial_order=(case == "config1_size"))
     ta, tb = mk(), mk()
     ta.two_kernel_backward = 1   # rounds 1-5: footprint backward, then projection backward with 512 Gaussians per workgroup
-    assert not tb.two_kernel_backward and tb.N <= 32768 and tb.T <= 2048
+    assert not tb.two_kernel_backward and tb.N <= 32768 and tb.T <= 2560
     ta.ensure_capacity(); tb.ensure_capacity()
     assert tb.fused_backward_active() and not ta.fused_backward_active()
     V = sc.viewmats.shape[0]
@@ -2075,9 +2077,11 @@ def test_bench_issue_roofline_pass(env):
     assert bench.VALU_ISSUE_PEAK == 256 * 4 * 2.4e9 / 2.0
 
 
-@pytest.mark.parametrize("W,H,n", [(1024, 512, 8000), (1040, 512, 8000), (2048, 16, 3000), (33, 17, 500), (721, 403, 6000)])
+@pytest.mark.parametrize("W,H,n", [(1024, 512, 8000), (1040, 512, 8000), (1280, 512, 8000), (1296, 512, 8000), (800, 800, 8000),
+                                   (2048, 16, 3000), (33, 17, 500), (721, 403, 6000)])
 def test_tile_grid_shapes_around_the_prefix_switch(env, W, H, n):
-    """Tile grids on either side of kPrefixHereMaxTiles (2048 tiles: the sort kernel forms the tile prefix and the
+    """Tile grids on either side of kPrefixHereMaxTiles (2560 tiles since round 6 -- the prefix in one, two or three batches of
+    1024 cursors; 800 x 800 is the reference's native size: the sort kernel forms the tile prefix and the
     compositing kernel returns the cursors to zero; above it the projection kernel's last workgroup scans), strips one
     tile high / wide, and sizes that are not multiples of 16: one fused step against the plain-C oracle, then a
     native run of steps (tail fusion across the step boundary) that must leave every cursor at zero."""
@@ -2300,7 +2304,7 @@ def test_item_records_follow_the_dispatch_order_contract(env, size):
     elif size == "small_grid":
         W, H, n_g, scale = 528, 400, 40_000, 0.012    # 33 x 25 = 825 tiles
     else:
-        W, H, n_g, scale = 1008, 608, 120_000, 0.012  # 63 x 38 = 2394 tiles: the projection kernel scans the tiles
+        W, H, n_g, scale = 1056, 640, 130_000, 0.012  # 66 x 40 = 2640 tiles: the projection kernel scans the tiles
     sc = synth.make_scene(n_g, 2, W, H, seed=1, anisotropy=5.0, spread_opacity=True, scale=scale)
     tr = EdgeTrainer(sc.means, sc.log_scales, sc.quats, sc.logit_opacities, sc.viewmats, sc.Ks, sc.gt, W, H)
     tr.ensure_capacity()
@@ -2309,7 +2313,7 @@ def test_item_records_follow_the_dispatch_order_contract(env, size):
     torch.cuda.synchronize()
     n_items = int(tr.total.cpu()[2])
     T, tw = tr.T, (W + 15) // 16
-    assert (T <= 2048) == (size != "large_grid")
+    assert (T <= _lib.PREFIX_HERE_MAX_TILES) == (size != "large_grid")
     xcd_shift = int(_lib.load().eg_record_xcd_shift(T))
     assert xcd_shift == (1 if size == "small_grid" else 0)  # (above 2048 tiles: built, measured, off -- profiles/r06_xcd_large_ab.txt)
     table = tr.item_rec.cpu().numpy()
