@@ -1711,6 +1711,7 @@ def test_bench_line_contract(env):
     assert "untuned" in cb["sample"].lower()  # (a stated baseline, not a speed-up denominator)
     # round 3: what happened before and around the timed window is on the line
     assert d["prewarm_steps"] >= 400 and len(d["ms_per_step_windows"]) == 3
+    assert d["rehearsal_steps"] == 5 + 200  # (round 6: an untimed window of the timed one's shape runs in front of it)
     assert d["ms_per_step_windows"][0] == d["ms_per_step"]  # `value` is the contract's window, the repeats are extra
     assert d["ms_per_step_min"] == min(d["ms_per_step_windows"]) and d["ms_per_step_median"] in d["ms_per_step_windows"]
     assert d["config"]["forward_mode"].startswith(("speculative", "chained")) and "opacity" in d["config"]["workload"]
