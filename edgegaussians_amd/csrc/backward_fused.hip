@@ -1,6 +1,6 @@
 // G8 + G9 + Adam + the next view's G1 / G2-4 in ONE kernel (round 6): the per-Gaussian backward of the training step.
 //
-// Replaces, inside a native run of steps on tile grids of <= 2048 tiles, the pair
+// Replaces, inside a native run of steps on tile grids of <= 2560 tiles and for scenes of <= 32768 Gaussians, the pair
 //   footprint_bwd_kernel      (composite.hip: gsplat's rasterize_to_pixels_bwd, order-independent form)
 //   project_bwd_emit_kernel   (project.hip: fully_fused_projection_bwd + update_absgrads + 4x Adam.step -- SURVEY a3.G9,
 //                              a6, a7; edge_gs.py:250-268, :607-613, train_gaussians.py:104-106 -- and the NEXT view's
@@ -22,6 +22,12 @@
 // Morton order touch a dozen tiles, so this kernel keeps a TOUCHED LIST next to the (zero-initialised) histogram: the
 // first hit of a tile appends it, the wave reserves slots with one returning global atomic per LISTED tile and hands them
 // out from LDS.  Same keys, same segments; the order inside a segment is as unspecified as before (the sort fixes it).
+//
+// Where it pays (profiles/r06_fused_backward_ab.txt): phase 2 needs 104 VGPRs, phase 1 sixty -- built for 8 waves per SIMD phase 2
+// spills 49 registers (14.6 us per wave instead of 9), built for 4 the walks lose half their occupancy; so the kernel is built
+// for 4 and taken where ONE round of workgroups covers the scene (2 per CU x 256 CUs x 64 Gaussians = 32768): 40.1 -> 36.8 us
+// per step at 30 k Gaussians, 42.7 -> 44.2 at 40 k, 77.6 -> 81.9 at 100 k (step.hip: fused_backward_pays).  A workgroup keeps
+// its LDS through phase 2, so phase 2 REUSES phase 1's storage (13.3 KB per workgroup; 32 KB measured 45 us at 100 k).
 //
 // Results: phase 1 and phase 2 inline the very functions the two kernels inline (forward_geom, backward_geom, adam1,
 // footprint_walk ...), every Gaussian's arithmetic is the same sequence: a step through this kernel is bit-identical to
